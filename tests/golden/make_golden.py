@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REFERENCE implementation on CPU.
+
+Run in the build container only (needs /root/reference, which never travels to the GPU box):
+
+    python tests/golden/make_golden.py
+
+It imports /root/reference/video_nmn/module_net.py::VideoNMN and utils/program_parser.py, loads the
+deterministic synthetic weights of stair_amd.synth into the reference model through load_state_dict,
+runs every program form of stair_amd.synth.CORPUS and writes *data only* (inputs are re-creatable
+from the generator; outputs are stored):
+
+    tests/golden/tiny_conv.npz    H=64 V=128 A=16 max_video_length=40, T=40   (Conv1d Temporal)
+    tests/golden/tiny_conv_t24.npz same model, T=24 (< max_video_length)
+    tests/golden/tiny_linear.npz  H=64 V=128 A=16 max_video_length=8,  T=8    (Linear Temporal)
+    tests/golden/full.npz         H=512 V=2048 A=172 max_video_length=64, T=64 (logits etc. only)
+    tests/golden/programs.json    parse_program / stat_module_levels / get_childrens_and_parents
+
+h5py and nltk (imported at the top of the reference's dataset.py, used only by its data loader) are
+not installed in this image; empty stand-in modules are registered so the *model* file imports.
+Nothing from the reference is copied into the fixtures except its numerical outputs.
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+from stair_amd import spec, synth  # noqa: E402
+
+CONFIGS = {
+    'tiny_conv': dict(hidden_size=64, video_size=128, text_size=300, dropout=0.25, answer_vocab_length=16,
+                      max_video_length=40, init_method='default', layer_norm=1, have_pretrain_head=True,
+                      object_types=10),
+    'tiny_linear': dict(hidden_size=64, video_size=128, text_size=300, dropout=0.25, answer_vocab_length=16,
+                        max_video_length=8, init_method='default', layer_norm=1, have_pretrain_head=True,
+                        object_types=10),
+    'full': dict(spec.DEFAULT_CONFIG),
+}
+PRETRAIN_MODULES = {'Exists', 'Xor', 'Equals', 'Filter', 'ToAction', 'FilterFrame', 'ExistsFrame',
+                    'Superlative', 'Localize', 'Temporal', 'decoder'}     # train_module.py:36-48 keys
+SEED = 0
+
+AGQA_PROGRAM_STRINGS = {
+    # P0: /root/reference/utils/scene_graphs.py:586; P1-P7: SURVEY.md Appendix B (AGQA grammar)
+    'P0': 'XOR(Exists(food, Iterate(Localize(between, [grasping onto a doorknob, drinking from a cup]), Filter(frame, [relation, holding, objects]))), Exists(Query(class, OnlyItem(Iterate(video, Filter(frame, [relations, opening, objects])))), Iterate(Localize(between, [grasping onto a doorknob, drinking from a cup]), Filter(frame, [relation, holding, objects]))))',
+    'P1': 'Exists(dish, Iterate(video, Filter(frame, [objects])))',
+    'P2': 'Query(class, OnlyItem(IterateUntil(forward, Localize(after, eating a sandwich), HasItem(Iterate(frame, Filter(frame, [relations, holding, objects]))), Iterate(frame, Filter(frame, [relations, holding, objects])))))',
+    'P3': 'Superlative(max, Filter(video, [actions]), Subtract(Query(end, action), Query(start, action)))',
+    'P4': 'Equals(Query(class, OnlyItem(Iterate(video, Filter(frame, [relations, holding, objects])))), Query(class, OnlyItem(Iterate(video, Filter(frame, [relations, touching, objects])))))',
+    'P5': 'Compare([before, after], Exists(eating a sandwich, Iterate(Localize(temporal tag, opening a door), Filter(frame, [actions]))))',
+    'P6': 'Choose(dish, blanket, Iterate(Localize(while, holding a dish), Filter(frame, [relations, holding, objects])))',
+    'P7': 'AND(Exists(ToAction(holding, dish), Filter(video, [actions])), Exists(door, Iterate(video, Filter(frame, [objects]))))',
+}
+
+
+def import_reference():
+    sys.path.insert(0, '/root/reference')
+    for name in ('h5py', 'nltk', 'nltk.corpus', 'nltk.tokenize'):
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules['nltk.corpus'].stopwords = type('S', (), {'words': lambda self, l: []})()
+    sys.modules['nltk.tokenize'].word_tokenize = str.split
+    sys.modules['nltk'].corpus, sys.modules['nltk'].tokenize = sys.modules['nltk.corpus'], sys.modules['nltk.tokenize']
+    from video_nmn.module_net import VideoNMN
+    from utils import program_parser
+    return VideoNMN, program_parser
+
+
+def to_np(x):
+    if isinstance(x, torch.Tensor):
+        return x.detach().cpu().numpy()
+    return x
+
+
+def build_model(VideoNMN, config):
+    import contextlib
+    import io
+    cfg = dict(config)
+    cfg['dropout'] = 0.0
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = VideoNMN(cfg, pretrain_modules=set(PRETRAIN_MODULES))
+    weights = synth.make_weights(config, SEED)
+    sd = {k: torch.from_numpy(weights[k].copy()) for k in spec.state_dict_keys(config)}
+    assert list(model.state_dict().keys()) == list(sd.keys()), 'state_dict key order differs from spec'
+    for k, v in model.state_dict().items():
+        assert tuple(v.shape) == tuple(sd[k].shape), (k, v.shape, sd[k].shape)
+    model.load_state_dict(sd)
+    model.eval()
+    return model
+
+
+def run_question(model, config, qid, form, T, full_dump):
+    d = synth.make_question(config, SEED, qid, form=form, T=T)
+    data = {
+        'question': torch.from_numpy(d['question']), 'video_features': torch.from_numpy(d['video_features']),
+        'prog_str_to_question_tokens': d['prog_str_to_question_tokens'],
+        'nmn_program_list': d['nmn_program_list'], 'nmn_program_idx': d['nmn_program_idx'],
+    }
+    out = {}
+    with torch.no_grad():
+        r = model(data, return_res_by_step=True, return_result_of_each_step=False, test_mode=True)
+        key = 'q%d/' % qid
+        out[key + 'logits'] = to_np(r['logits'])
+        for idx, (prog, val) in r['res_by_step'].items():
+            out[key + 'head%d' % idx] = to_np(val)
+        if full_dump:
+            # raw module results (no pretrain heads): run again with an empty pretrain set
+            saved = model.pretrain_modules
+            model.pretrain_modules = set()
+            r2 = model(data, return_res_by_step=False, return_result_of_each_step=True, test_mode=True)
+            model.pretrain_modules = saved
+            for i, (params, res) in enumerate(r2['result_of_each_step']):
+                if isinstance(res, torch.Tensor):
+                    out[key + 'step%d' % i] = to_np(res)
+            out[key + 'video_feat'] = to_np(model.encode_video(data['video_features']))
+            tok, sent = model.encode_question(data['question'])
+            out[key + 'token_feature'], out[key + 'question_feature'] = to_np(tok), to_np(sent)
+        else:
+            tok, sent = model.encode_question(data['question'])
+            out[key + 'question_feature'] = to_np(sent)
+    return out, d
+
+
+def main():
+    VideoNMN, pp = import_reference()
+    torch.manual_seed(0)
+    torch.set_num_threads(4)
+
+    # ---- (iv) program front-end outputs ----
+    progs = {}
+    for name, s in AGQA_PROGRAM_STRINGS.items():
+        nmn, more = pp.parse_program(s)
+        assert pp.program_is_valid(nmn)
+        ch, pa = pp.get_childrens_and_parents(nmn)
+        progs[name] = {'string': s, 'nmn': nmn, 'idx': more['idx_list'], 'levels': pp.stat_module_levels(nmn),
+                       'childrens': ch, 'parents': pa}
+        assert (nmn, more['idx_list']) == tuple(synth.CORPUS[name]), name
+    for name in synth.ALL_FORMS:
+        if name in progs:
+            continue
+        nmn, idx = synth.CORPUS[name]
+        assert pp.program_is_valid(nmn), name
+        ch, pa = pp.get_childrens_and_parents(nmn)
+        progs[name] = {'string': None, 'nmn': nmn, 'idx': idx, 'levels': pp.stat_module_levels(nmn),
+                       'childrens': ch, 'parents': pa}
+    progs['_nary_mappings'] = dict(pp.nary_mappings)
+    with open(os.path.join(HERE, 'programs.json'), 'w') as f:
+        json.dump(progs, f, indent=1)
+
+    # ---- (i) tiny configs: everything ----
+    jobs = [('tiny_conv', 'tiny_conv', 40, synth.ALL_FORMS), ('tiny_conv_t24', 'tiny_conv', 24, ['P0', 'P2', 'P5', 'C0', 'C1']),
+            ('tiny_linear', 'tiny_linear', 8, synth.ALL_FORMS)]
+    for fname, cname, T, forms in jobs:
+        config = CONFIGS[cname]
+        model = build_model(VideoNMN, config)
+        out = {}
+        meta = {'config': config, 'T': T, 'seed': SEED, 'questions': []}
+        for qid, form in enumerate(forms):
+            o, d = run_question(model, config, qid, form, T, full_dump=True)
+            out.update(o)
+            meta['questions'].append({'qid': qid, 'form': form})
+        out['meta'] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+        np.savez_compressed(os.path.join(HERE, fname + '.npz'), **out)
+        print(fname, len(out), 'arrays')
+
+    # ---- (ii) full-size config: outputs only ----
+    config = CONFIGS['full']
+    model = build_model(VideoNMN, config)
+    out = {}
+    meta = {'config': config, 'T': 64, 'seed': SEED, 'questions': []}
+    forms = synth.ALL_FORMS + [None] * 20
+    for qid, form in enumerate(forms):
+        o, d = run_question(model, config, qid, form, 64, full_dump=False)
+        out.update(o)
+        meta['questions'].append({'qid': qid, 'form': d['form']})
+    out['meta'] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, 'full.npz'), **out)
+    print('full', len(out), 'arrays')
+
+
+if __name__ == '__main__':
+    main()
