@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Benchmark of the NMN hot path (BASELINE.json metric: questions/sec on AGQA2-shaped inputs).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+
+One step = one pass of the whole path (encode_video, encode_question, every program level, decoder,
+argmax -- program encoding and plan building included) over one batch of B synthetic questions per
+GPU: T=64 frames x V=2048 features (BASELINE.json configs[1] shape), H=512, A=172, programs drawn
+from the 8-form corpus of SURVEY.md Appendix B, inputs resident in HBM before the timed region.
+For N>1 the driver launches this file under torch.distributed.run; questions shard across ranks with
+no data-path collective (inference is embarrassingly parallel), timing is barrier-bracketed and the
+max over ranks is reported.  Rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+  roofline      the dominant kernel (fp32 MFMA GEMM of the LSTM input projection), timed live with
+                events on the launch stream: achieved TFLOP/s vs the 157.3 TFLOP/s fp32 matrix peak.
+  roofline_hbm  whole-path algorithmic bytes (1.93 MB/question incl. weights/128) x q/s
+                vs 8 TB/s -- reported separately, never blended.
+  cpu_baseline  the oracle (CPU restatement, kind "port") timed on this box's host cores on a bounded
+                sample of the same questions; also the checker for top-1 agreement.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from stair_amd import spec, synth  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md, "HBM3E peak BW" (spec)
+ALGO_BYTES_PER_QUESTION = 1.93e6   # SURVEY.md section 8(d), mean over the 8 forms, fp32, weights/128
+ALGO_FLOP_PER_QUESTION = 0.86e9
+
+
+def make_batch(config, B, T, seed, device):
+    """B synthetic questions; programs/spans from the deterministic generator, tensors drawn on the GPU."""
+    qs = [synth.make_question(config, seed, i, T=T, with_video=False) for i in range(B)]
+    g = torch.Generator(device=device).manual_seed(1234 + seed)
+    video = torch.randn(B, T, config['video_size'], device=device, generator=g)
+    q_lens = [q['question'].shape[0] for q in qs]
+    question = torch.randn(sum(q_lens), config['text_size'], device=device, generator=g)
+    return qs, video, question, q_lens
+
+
+def time_dominant_kernel(model, B, T, device, iters=10):
+    """HIP-event timing of the input-projection GEMM launch (M=B*T, N=4*Hh, K=V), same stream."""
+    from stair_amd import ops
+    H, V = model.config['hidden_size'], model.config['video_size']
+    M, N, K = B * T, 2 * H, V
+    x = torch.randn(M, K, device=device)
+    w = model.submodules['video_encoder'].weight_ih_l0
+    b = model.submodules['video_encoder'].bias_ih_l0
+    out = torch.empty(M, 4 * H, device=device)
+    run = lambda: ops.gemm_grouped(x, K, None, w, b, out, 4 * H, None, M, 1, N, K, lda=K, ldc=4 * H)
+    for _ in range(3):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    return ms, 2.0 * M * N * K
+
+
+def cpu_baseline(config, weights, qs, video, question, q_lens, budget_s=15.0, max_q=512):
+    from oracle import nmn_oracle as O
+    w = O.to_torch(weights)
+    off = np.concatenate([[0], np.cumsum(q_lens)])
+    n = min(max_q, len(qs))
+    vid = video[:n].cpu()
+    qst = question[:off[n]].cpu()
+    preds, logits = [], []
+    t0 = time.perf_counter()
+    done = 0
+    with torch.no_grad():
+        for i in range(n):
+            d = dict(qs[i], video_features=vid[i], question=qst[off[i]:off[i + 1]])
+            r = O.forward(w, config, d, return_res_by_step=False)
+            preds.append(int(torch.argmax(r['logits'])))
+            logits.append(r['logits'])
+            done += 1
+            if time.perf_counter() - t0 > budget_s:
+                break
+    dt = time.perf_counter() - t0
+    return done / dt, done, preds, torch.stack(logits)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=1024, help='questions per GPU per step')
+    ap.add_argument('--frames', type=int, default=64)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+
+    from stair_amd.module_net import VideoNMN      # raises if libstair_hip.so is missing
+    config = dict(spec.DEFAULT_CONFIG)
+    weights = synth.make_weights(config, 0)
+    model = VideoNMN(config)
+    model.load_state_dict({k: torch.from_numpy(weights[k].copy()) for k in spec.state_dict_keys(config)})
+    model = model.to(device)
+
+    B, T = args.batch, args.frames
+    qs, video, question, q_lens = make_batch(config, B, T, seed=rank, device=device)
+    programs = [q['nmn_program_list'] for q in qs]
+    spans = [q['prog_str_to_question_tokens'] for q in qs]
+
+    def step():
+        return model.run_programs(programs, spans, video, question, q_lens)
+
+    res = None
+    for _ in range(args.warmup):
+        res = step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_q = B * args.steps * world
+    qps = total_q / elapsed
+
+    if rank == 0:
+        gemm_ms, gemm_flop = time_dominant_kernel(model, B, T, device)
+        achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12
+        line = {
+            'metric': 'questions/sec on AGQA2-shaped synthetic features (NMN forward: encode -> program -> decoder -> argmax)',
+            'value': round(qps, 1), 'unit': 'questions/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'AGQA2-shaped inference, I3D-like [T=%d,V=%d] features, H=512, A=172, 8 program forms '
+                                   '(BASELINE.json configs[1] shape; forward only, fp32)' % (T, config['video_size']),
+                       'questions_per_gpu_per_step': B, 'parallelism': 'dp%d (questions sharded, no collective)' % world},
+            'roofline': {'bound': 'mfma', 'kernel': 'gemm_f32_kernel (LSTM input projection, M=%d N=%d K=%d)' % (B * T, 2 * config['hidden_size'], config['video_size']),
+                         'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                         'launch_ms': round(gemm_ms, 4)},
+            'roofline_hbm': {'bound': 'hbm', 'scope': 'whole path, algorithmic bytes x q/s (per GPU)',
+                             'achieved': round(ALGO_BYTES_PER_QUESTION * qps / world / 1e9, 2), 'peak': HBM_PEAK_GBS,
+                             'unit': 'GB/s', 'frac': round(ALGO_BYTES_PER_QUESTION * qps / world / 1e9 / HBM_PEAK_GBS, 5)},
+            'path_tflops': round(ALGO_FLOP_PER_QUESTION * qps / world / 1e12, 2),
+        }
+        if not args.no_cpu_baseline:
+            ncores = os.cpu_count() or 1
+            torch.set_num_threads(ncores)
+            cpu_qps, n_done, preds, cpu_logits = cpu_baseline(config, weights, qs, video, question, q_lens)
+            gpu_pred = res.pred[:n_done].cpu().tolist()
+            agree = sum(int(a == b) for a, b in zip(gpu_pred, preds)) / max(1, n_done)
+            maxdiff = float((res.logits[:n_done].cpu() - cpu_logits).abs().max())
+            line['cpu_baseline'] = {'value': round(cpu_qps, 1), 'unit': 'questions/s', 'cores': torch.get_num_threads(),
+                                    'kind': 'port',
+                                    'sample': 'first %d questions of the rank-0 batch through oracle/nmn_oracle.py (batch-1, ATen CPU)' % n_done}
+            line['top1_agreement_vs_oracle'] = round(agree, 4)
+            line['max_abs_logit_diff_vs_oracle'] = maxdiff
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

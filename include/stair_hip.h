@@ -1,0 +1,180 @@
+/*
+ * stair_hip.h -- C ABI of libstair_hip.so, the MI355X (gfx950) executor for STAIR's
+ * neural-module-network hot path.
+ *
+ * The reference (yellow-binary-tree/STAIR) is pure Python and has no FFI of its own; the boundary
+ * this library replaces is the Python-level one of
+ *     /root/reference/video_nmn/module_net.py:65-145   VideoNMN.forward (stack interpreter)
+ *     /root/reference/video_nmn/module_net.py:151-163  encode_question / encode_video (bi-LSTM)
+ *     /root/reference/video_nmn/modules.py:7-465       the 18 registered module operators
+ * Each entry point below names the reference lines it stands in for.  INTEGRATION.md shows the
+ * ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer named *_dev / documented "device" is a HIP device pointer owned by the CALLER
+ *     (allocated by torch in the Python host); the library never allocates, frees or retains
+ *     caller memory beyond the duration documented per call.  Weights are BORROWED until the ctx
+ *     is destroyed or the weight is re-set.
+ *   - `stream` is a hipStream_t passed as void* (the caller's current torch-ROCm stream).  All
+ *     work is enqueued on it; nothing synchronises the device.
+ *   - return value 0 = success; non-zero = error, message via stair_last_error() (thread local).
+ *   - not thread-safe per ctx; one ctx per GPU / process.
+ *   - all floating-point data is IEEE fp32, row-major.
+ */
+#ifndef STAIR_HIP_H
+#define STAIR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STAIR_ABI_VERSION 1
+
+typedef struct stair_ctx stair_ctx;
+typedef struct stair_plan stair_plan;
+typedef void *stair_stream; /* hipStream_t */
+
+/* Model configuration: the keys of the reference's config dict that change shapes
+ * (/root/reference/train_module.py:304-310). */
+typedef struct stair_config {
+    int32_t hidden_size;         /* H, multiple of 32; H/2 (LSTM hidden) multiple of 16, <= 256 or 2^k*16 */
+    int32_t video_size;          /* V, multiple of 4 */
+    int32_t text_size;           /* E (300), multiple of 4 */
+    int32_t answer_vocab_length; /* A */
+    int32_t max_video_length;    /* selects Conv1d (>32) or Linear(T,T) Temporal nets, modules.py:255 */
+    int32_t object_types;        /* O, FilterFrame pretrain head width */
+    int32_t have_pretrain_head;  /* 0/1 */
+} stair_config;
+
+/* program token codes (stair_amd/spec.py mirrors these): module tokens 0..17 in the order of
+ * NAME_TO_MODULE (modules.py:446-465), keyword tokens 100.., everything else = span mean. */
+enum stair_token {
+    STAIR_OP_AND = 0, STAIR_OP_ATTNVIDEO, STAIR_OP_CHOOSE, STAIR_OP_COMPARE, STAIR_OP_EQUALS,
+    STAIR_OP_EXISTS, STAIR_OP_EXISTSFRAME, STAIR_OP_FILTER, STAIR_OP_FILTERFRAME, STAIR_OP_HASITEM,
+    STAIR_OP_LOCALIZE, STAIR_OP_RELATE, STAIR_OP_SUPERLATIVE, STAIR_OP_TEMPORAL, STAIR_OP_TOACTION,
+    STAIR_OP_XOR, STAIR_OP_XORFRAME, STAIR_OP_ARRAY2,
+    STAIR_OP_COUNT = 18,
+    STAIR_KW_FORWARD = 100, STAIR_KW_BACKWARD, STAIR_KW_WHILE, STAIR_KW_BETWEEN, STAIR_KW_BEFORE,
+    STAIR_KW_AFTER, STAIR_KW_MAX, STAIR_KW_MIN, STAIR_KW_START, STAIR_KW_END, STAIR_KW_VIDEO,
+    STAIR_KW_ACTIONS, STAIR_KW_OBJECTS, STAIR_KW_RELATIONS,
+    STAIR_TOK_SPAN = 200
+};
+
+/* value kinds a program node can produce (returned by stair_plan_node) */
+enum stair_value_kind {
+    STAIR_VAL_STR = 0,   /* keyword string, no storage */
+    STAIR_VAL_VEC = 1,   /* [H]      in the vec arena,  slot = row                        */
+    STAIR_VAL_MAP = 2,   /* [T,H]    in the map arena,  slot = tile                       */
+    STAIR_VAL_ATT = 3,   /* [K,T]    in the att arena,  slot = first row, aux = K         */
+    STAIR_VAL_FRAME = 4, /* [T]      in the att arena,  slot = row                        */
+    STAIR_VAL_PAIR = 5   /* [2,H]    two vec rows (Array2), slot = first row, aux = second row */
+};
+
+int stair_abi_version(void);
+const char *stair_last_error(void);
+
+/* ---- context: configuration + borrowed weight pointers ------------------------------------ */
+int stair_ctx_create(const stair_config *cfg, stair_ctx **out);
+void stair_ctx_destroy(stair_ctx *ctx);
+
+/* Weight table: ids 0..count-1 enumerate the reference's state_dict keys in state_dict order,
+ * aliases excluded (module_net.py:27-53; Superlative.localize_module.* IS Localize.*). */
+int stair_weight_count(const stair_ctx *ctx);
+const char *stair_weight_name(const stair_ctx *ctx, int id);
+int64_t stair_weight_numel(const stair_ctx *ctx, int id);
+int stair_ctx_set_weight(stair_ctx *ctx, int id, const float *dev_ptr, int64_t numel);
+
+/* ---- building blocks (exported for unit tests and reuse; the plan runner calls the same code) */
+
+/* C[g][r][n] = act( sum_k rs[g][r] * A[g][r][k] * W[n][k] + bias[n] ),  g < groups, r < rows_per_group.
+ * Replaces every nn.Linear on the path (modules.py: Filter :347-360, Localize :187-195, ...).
+ * Group g of A lives at A + (a_gidx ? a_gidx[g] : g) * a_gstride (same for C and row_scale), which
+ * is how ragged program nodes are packed into one launch.  K % 4 == 0, lda/ldw % 4 == 0, pointers
+ * 16-byte aligned.  act: 0 none, 1 ReLU, 2 sigmoid. */
+typedef struct stair_gemm_args {
+    const float *A; int64_t lda; int64_t a_gstride; const int32_t *a_gidx;
+    const float *W; int64_t ldw; const float *bias;
+    float *C; int64_t ldc; int64_t c_gstride; const int32_t *c_gidx;
+    const float *row_scale; int64_t rs_gstride; const int32_t *rs_gidx;
+    int32_t groups, rows_per_group, N, K, act;
+} stair_gemm_args;
+int stair_gemm_f32(const stair_gemm_args *args, stair_stream stream);
+
+/* Bidirectional single-layer LSTM over n ragged sequences (nn.LSTM as used at
+ * module_net.py:39-47,151-163).  x [rows, I] with sequence s at rows seq_off[s]..seq_off[s+1]-1
+ * (seq_off on device, int32 [n+1]; max_len = longest sequence).  w_* are the eight tensors of the
+ * reference layer, forward then reverse.  xproj_ws: device scratch [rows, 8*Hh] floats; bias_ws
+ * [8*Hh].  out [rows, 2*Hh]; h_n [n, 2*Hh] = [h_fwd(last) ; h_bwd(first)]. */
+typedef struct stair_lstm_args {
+    const float *x; int64_t ldx; int32_t rows, n, max_len, I, Hh;
+    const int32_t *seq_off;
+    const float *w_ih[2], *w_hh[2], *b_ih[2], *b_hh[2];
+    float *xproj_ws, *bias_ws;
+    float *out; int64_t ldo; float *h_n;
+} stair_lstm_args;
+int stair_lstm_bidir_fwd(const stair_lstm_args *args, stair_stream stream);
+
+/* att[p][t] = (cos(F[f_idx[p]][t][:], Kmat[k_idx[p]][:]) + 1) * 0.49 -- nn.CosineSimilarity(dim=-1,
+ * eps=1e-8) of LocalizeModule / ExistsFrameModule (modules.py:162-217) without materialising the
+ * [K,T,H] expands.  F tile p at F + f_idx[p]*f_gstride, [T,H]; output row att + out_idx[p]*T. */
+int stair_cosine_attn_fwd(const float *F, int64_t f_gstride, const int32_t *f_idx, const float *Kmat,
+                          const int32_t *k_idx, float *att, const int32_t *out_idx, int32_t npairs,
+                          int32_t T, int32_t H, stair_stream stream);
+
+/* r = relate_mode(mean_k att[att_idx[i] .. +K[i]-1]) for TemporalModule (modules.py:255-277,317-323).
+ * mode 0 while (identity), 1 before, 2 after, 3 between.  conv != 0: three Conv1d(1,1,k,'same')
+ * (k, k, 2k+1) with ReLU, ReLU, Sigmoid; else three Linear(T,T).  w[6] = weight/bias of layers 0,2,4. */
+int stair_temporal_relate_fwd(const float *att, const int32_t *att_idx, const int32_t *att_k,
+                              float *out, const int32_t *out_idx, int32_t n, int32_t T, int32_t mode,
+                              int32_t conv, int32_t ksize, const float *const w[6], stair_stream stream);
+
+/* out[i] = x[i] / max(||x[i]||_2, 1e-12): L2Normalize, the contrastive / pretrain head of Filter,
+ * Superlative and ToAction (module_net.py:21, 211-216).  x, out [n,H]. */
+int stair_l2normalize_fwd(const float *x, float *out, int32_t n, int32_t H, stair_stream stream);
+
+/* ---- program plans: the batched stack interpreter (module_net.py:94-138) -------------------- */
+
+/* Compile n questions' prefix programs into a launch plan: nodes are levelled as
+ * utils/program_parser.py:307-321 (stat_module_levels) and all nodes of one (level, module,
+ * keyword-variant) go into one packed launch.  Host arrays:
+ *   prog_off [n+1]      token range of question q in `tokens`
+ *   tokens   [ntok]     enum stair_token codes
+ *   span_lo/hi [ntok]   question-token span of token i (prog_str_to_question_tokens), used for STAIR_TOK_SPAN
+ *   q_off    [n+1]      row range of question q in the packed question embedding matrix
+ *   T                   frames per video in this batch (<= max_video_length; == for Linear Temporal)
+ * Errors (non-zero) mirror the reference's failures: invalid program (assert len(stack)==1,
+ * module_net.py:135), operand of the wrong kind, span outside the question. */
+int stair_plan_build(stair_ctx *ctx, int32_t n, const int32_t *prog_off, const int32_t *tokens,
+                     const int32_t *span_lo, const int32_t *span_hi, const int32_t *q_off, int32_t T,
+                     stair_plan **out);
+void stair_plan_destroy(stair_plan *plan);
+
+/* Workspace the caller must provide to stair_plan_run (bytes, device) and its arena layout
+ * (offsets in floats from the workspace base) so a host can read any intermediate result. */
+typedef struct stair_plan_info {
+    int64_t workspace_bytes;
+    int64_t vec_off, map_off, att_off, tok_off, qfeat_off; /* float offsets */
+    int32_t n_vec, n_map, n_att, n_tok_rows;
+    int32_t n_nodes, n_launches, n_levels, n_questions, T;
+} stair_plan_info;
+int stair_plan_get_info(const stair_plan *plan, stair_plan_info *info);
+
+/* kind/slot/aux of program token `tok` (global index into `tokens`); level as stat_module_levels;
+ * rel_slot = att-arena row of Temporal's related_attn (-1 otherwise). */
+int stair_plan_node(const stair_plan *plan, int32_t tok, int32_t *kind, int32_t *slot, int32_t *aux,
+                    int32_t *level, int32_t *rel_slot);
+
+/* Run the whole path for the batch: encode_video, encode_question, every program level, decoder,
+ * argmax.  video [n,T,V], question [q_off[n],E] device fp32; logits [n,A]; argmax [n] int32
+ * (either may be NULL).  Everything is enqueued on `stream`. */
+int stair_plan_run(stair_ctx *ctx, stair_plan *plan, const float *video, const float *question,
+                   void *workspace, int64_t workspace_bytes, float *logits, int32_t *argmax,
+                   stair_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STAIR_HIP_H */

@@ -1,0 +1,100 @@
+"""ctypes binding of libstair_hip.so (include/stair_hip.h).
+
+There is NO fallback: if the shared library is missing or a symbol is absent, importing this module
+raises, and so does every product entry point that depends on it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libstair_hip.so')
+
+c_float_p = C.POINTER(C.c_float)
+c_int32_p = C.POINTER(C.c_int32)
+
+
+class StairConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('hidden_size', 'video_size', 'text_size', 'answer_vocab_length',
+                                         'max_video_length', 'object_types', 'have_pretrain_head')]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [('A', C.c_void_p), ('lda', C.c_int64), ('a_gstride', C.c_int64), ('a_gidx', C.c_void_p),
+                ('W', C.c_void_p), ('ldw', C.c_int64), ('bias', C.c_void_p),
+                ('C', C.c_void_p), ('ldc', C.c_int64), ('c_gstride', C.c_int64), ('c_gidx', C.c_void_p),
+                ('row_scale', C.c_void_p), ('rs_gstride', C.c_int64), ('rs_gidx', C.c_void_p),
+                ('groups', C.c_int32), ('rows_per_group', C.c_int32), ('N', C.c_int32), ('K', C.c_int32),
+                ('act', C.c_int32)]
+
+
+class LstmArgs(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('ldx', C.c_int64), ('rows', C.c_int32), ('n', C.c_int32),
+                ('max_len', C.c_int32), ('I', C.c_int32), ('Hh', C.c_int32), ('seq_off', C.c_void_p),
+                ('w_ih', C.c_void_p * 2), ('w_hh', C.c_void_p * 2), ('b_ih', C.c_void_p * 2), ('b_hh', C.c_void_p * 2),
+                ('xproj_ws', C.c_void_p), ('bias_ws', C.c_void_p),
+                ('out', C.c_void_p), ('ldo', C.c_int64), ('h_n', C.c_void_p)]
+
+
+class PlanInfo(C.Structure):
+    _fields_ = [('workspace_bytes', C.c_int64), ('vec_off', C.c_int64), ('map_off', C.c_int64), ('att_off', C.c_int64),
+                ('tok_off', C.c_int64), ('qfeat_off', C.c_int64),
+                ('n_vec', C.c_int32), ('n_map', C.c_int32), ('n_att', C.c_int32), ('n_tok_rows', C.c_int32),
+                ('n_nodes', C.c_int32), ('n_launches', C.c_int32), ('n_levels', C.c_int32), ('n_questions', C.c_int32),
+                ('T', C.c_int32)]
+
+
+# every symbol include/stair_hip.h declares: (name, restype, argtypes)
+SIGNATURES = [
+    ('stair_abi_version', C.c_int, []),
+    ('stair_last_error', C.c_char_p, []),
+    ('stair_ctx_create', C.c_int, [C.POINTER(StairConfig), C.POINTER(C.c_void_p)]),
+    ('stair_ctx_destroy', None, [C.c_void_p]),
+    ('stair_weight_count', C.c_int, [C.c_void_p]),
+    ('stair_weight_name', C.c_char_p, [C.c_void_p, C.c_int]),
+    ('stair_weight_numel', C.c_int64, [C.c_void_p, C.c_int]),
+    ('stair_ctx_set_weight', C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
+    ('stair_gemm_f32', C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
+    ('stair_lstm_bidir_fwd', C.c_int, [C.POINTER(LstmArgs), C.c_void_p]),
+    ('stair_cosine_attn_fwd', C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    ('stair_temporal_relate_fwd', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                            C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p),
+                                            C.c_void_p]),
+    ('stair_l2normalize_fwd', C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    ('stair_plan_build', C.c_int, [C.c_void_p, C.c_int32, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p,
+                                   C.c_int32, C.POINTER(C.c_void_p)]),
+    ('stair_plan_destroy', None, [C.c_void_p]),
+    ('stair_plan_get_info', C.c_int, [C.c_void_p, C.POINTER(PlanInfo)]),
+    ('stair_plan_node', C.c_int, [C.c_void_p, C.c_int32, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p]),
+    ('stair_plan_run', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                 C.c_void_p, C.c_void_p]),
+]
+
+
+class StairError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            'libstair_hip.so not found at %s -- build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            'or `make -C stair_amd/csrc`. There is no CPU fallback for the product path.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, restype, argtypes in SIGNATURES:
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.stair_abi_version() != 1:
+        raise ImportError('libstair_hip.so ABI version %d, expected 1' % lib.stair_abi_version())
+    return lib
+
+
+lib = _load()
+
+
+def check(rc):
+    if rc != 0:
+        raise StairError(lib.stair_last_error().decode('utf-8', 'replace'))

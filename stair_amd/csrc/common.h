@@ -1,0 +1,55 @@
+// Shared host/device helpers for libstair_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/stair_hip.h"
+
+namespace stair {
+
+void set_error(const std::string &msg);
+#define STAIR_FAIL(msg)                                                                     \
+    do {                                                                                    \
+        ::stair::set_error(std::string(__func__) + ": " + (msg));                           \
+        return 1;                                                                           \
+    } while (0)
+#define STAIR_CHECK(cond, msg)                                                              \
+    do {                                                                                    \
+        if (!(cond)) STAIR_FAIL(msg);                                                       \
+    } while (0)
+#define STAIR_HIP(call)                                                                     \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) STAIR_FAIL(std::string(#call) + " -> " + hipGetErrorString(e_)); \
+    } while (0)
+#define STAIR_LAUNCH_CHECK()                                                                \
+    do {                                                                                    \
+        hipError_t e_ = hipGetLastError();                                                  \
+        if (e_ != hipSuccess) STAIR_FAIL(std::string("kernel launch -> ") + hipGetErrorString(e_)); \
+    } while (0)
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
+// fast forms for the LSTM cell (absolute error ~1e-7, far inside the 1e-4 logit budget)
+__device__ __forceinline__ float sigmoid_fast(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
+
+static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+// ---- internal launchers shared between the C ABI and the plan runner ----------------------
+int launch_gemm(const stair_gemm_args &a, hipStream_t s);
+int launch_lstm(const stair_lstm_args &a, hipStream_t s);
+
+}  // namespace stair

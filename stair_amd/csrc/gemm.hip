@@ -1,0 +1,205 @@
+// fp32 MFMA GEMM with group gather/scatter, row scaling and fused bias/activation epilogue.
+//
+// Stands in for every nn.Linear on STAIR's NMN path (/root/reference/video_nmn/modules.py) once
+// program nodes of one kind are packed into a launch: C = act((rs * A) W^T + b) with
+// A [M,K] gathered in groups of `rows_per_group` rows (a [T,H] tile of one program node, or one
+// [H] vector), W [N,K] exactly as nn.Linear stores it.
+//
+// gfx950 mapping: 128x128x32 block tile, 4 waves as 2x2, each wave 2x2 v_mfma_f32_32x32x2_f32
+// tiles (exact fp32: one rounding per product, k-ordered -- MI355X_MICROARCH "FP32-input MFMA").
+// Both operands are K-contiguous, so each lane stages float4s along K and the k index inside an
+// 8-wide k group is permuted identically for A and B (half-wave h owns k = 8q+4h..8q+4h+3):
+// fragments are then single ds_read_b128.  LDS image [kq][row ^ kq][4] is conflict-free for the
+// ds_write_b128 of the staging pass and the ds_read_b128 of the fragment pass.  LDS is double
+// buffered with global->register prefetch one chunk ahead (one barrier per chunk).  Blocks are
+// renumbered so that the column tiles sharing one A row-panel run on the same XCD (private L2).
+#include "common.h"
+
+namespace stair {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int KQ = BK / 4;                    // float4 columns per chunk
+constexpr int LDS_FLOATS = 2 * 2 * KQ * 128 * 4;  // [buf][A|B][kq][row][4]
+
+struct GemmParams {
+    stair_gemm_args a;
+    int M, tilesM, tilesN;
+};
+
+__device__ __forceinline__ int lds_off(int buf, int which, int kq, int row) {
+    return ((((buf * 2 + which) * KQ + kq) * 128) + (row ^ kq)) * 4;
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const stair_gemm_args &a = p.a;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+
+    // XCD-aware bijective renumbering: blocks with equal blockIdx%8 share an XCD (speed only)
+    const int nb = p.tilesM * p.tilesN;
+    const int bid = blockIdx.x;
+    const int qd = nb >> 3, rm = nb & 7, xcd = bid & 7, loc = bid >> 3;
+    const int logical = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
+    const int tm = logical / p.tilesN, tn = logical - tm * p.tilesN;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int R = a.rows_per_group;
+
+    // staging assignment: thread -> float4 column kq, rows r0 + 32 i
+    const int kq = tid & 7, r0 = tid >> 3;
+    const float *aptr[4];
+    const float *wptr[4];
+    float rscale[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        aptr[i] = nullptr;
+        rscale[i] = 1.0f;
+        if (m < p.M) {
+            const int g = m / R, rr = m - g * R;
+            const int64_t gi = a.a_gidx ? a.a_gidx[g] : g;
+            aptr[i] = a.A + gi * a.a_gstride + (int64_t)rr * a.lda;
+            if (a.row_scale) {
+                const int64_t si = a.rs_gidx ? a.rs_gidx[g] : g;
+                rscale[i] = a.row_scale[si * a.rs_gstride + rr];
+            }
+        }
+        const int n = n0 + r0 + 32 * i;
+        wptr[i] = n < a.N ? a.W + (int64_t)n * a.ldw : nullptr;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    float4 ra[4], rb[4];
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto gload = [&](int k0) {
+        const int k = k0 + 4 * kq;
+        const bool kin = k < a.K;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = (aptr[i] && kin) ? *reinterpret_cast<const float4 *>(aptr[i] + k) : zero4;
+            rb[i] = (wptr[i] && kin) ? *reinterpret_cast<const float4 *>(wptr[i] + k) : zero4;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 v = ra[i];
+            const float s = rscale[i];
+            v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+            *reinterpret_cast<float4 *>(&lds[lds_off(buf, 0, kq, r0 + 32 * i)]) = v;
+            *reinterpret_cast<float4 *>(&lds[lds_off(buf, 1, kq, r0 + 32 * i)]) = rb[i];
+        }
+    };
+
+    const int nchunks = (a.K + BK - 1) / BK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) gload((c + 1) * BK);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int fq = 2 * q + h;
+            float4 af[2], bf[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                af[t] = *reinterpret_cast<const float4 *>(&lds[lds_off(buf, 0, fq, wm * 64 + t * 32 + r)]);
+                bf[t] = *reinterpret_cast<const float4 *>(&lds[lds_off(buf, 1, fq, wn * 64 + t * 32 + r)]);
+            }
+            const float *afp = reinterpret_cast<const float *>(af);
+            const float *bfp = reinterpret_cast<const float *>(bf);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(afp[mt * 4 + j], bfp[nt * 4 + j],
+                                                                           acc[mt][nt], 0, 0, 0);
+        }
+        if (c + 1 < nchunks) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: per-row output offsets through LDS (the group gather needs a division per row)
+    long long *rowoff = reinterpret_cast<long long *>(lds);
+    if (tid < BM) {
+        const int m = m0 + tid;
+        long long off = -1;
+        if (m < p.M) {
+            const int g = m / R, rr = m - g * R;
+            const int64_t gi = a.c_gidx ? a.c_gidx[g] : g;
+            off = gi * a.c_gstride + (int64_t)rr * a.ldc;
+        }
+        rowoff[tid] = off;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int n = n0 + wn * 64 + nt * 32 + r;
+        if (n >= a.N) continue;
+        const float b = a.bias ? a.bias[n] : 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rowl = wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const long long off = rowoff[rowl];
+                if (off < 0) continue;
+                float v = acc[mt][nt][e] + b;
+                if (ACT == 1) v = fmaxf(v, 0.0f);
+                if (ACT == 2) v = sigmoid_acc(v);
+                a.C[off + n] = v;
+            }
+        }
+    }
+}
+
+int launch_gemm(const stair_gemm_args &a, hipStream_t s) {
+    STAIR_CHECK(a.groups >= 0 && a.rows_per_group > 0 && a.N > 0 && a.K > 0, "bad shape");
+    STAIR_CHECK(a.K % 4 == 0 && a.lda % 4 == 0 && a.ldw % 4 == 0 && a.a_gstride % 4 == 0,
+                "K, lda, ldw and a_gstride must be multiples of 4 floats");
+    STAIR_CHECK((reinterpret_cast<uintptr_t>(a.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.W) & 15) == 0,
+                "A and W must be 16-byte aligned");
+    STAIR_CHECK(a.act >= 0 && a.act <= 2, "act must be 0, 1 or 2");
+    GemmParams p;
+    p.a = a;
+    const int64_t M = (int64_t)a.groups * a.rows_per_group;
+    if (M == 0) return 0;
+    STAIR_CHECK(M < (1ll << 31), "M too large");
+    p.M = (int)M;
+    p.tilesM = (p.M + BM - 1) / BM;
+    p.tilesN = (a.N + BN - 1) / BN;
+    const dim3 grid(p.tilesM * p.tilesN), block(256);
+    const size_t shmem = LDS_FLOATS * sizeof(float);
+    switch (a.act) {
+        case 0: hipLaunchKernelGGL(gemm_f32_kernel<0>, grid, block, shmem, s, p); break;
+        case 1: hipLaunchKernelGGL(gemm_f32_kernel<1>, grid, block, shmem, s, p); break;
+        default: hipLaunchKernelGGL(gemm_f32_kernel<2>, grid, block, shmem, s, p); break;
+    }
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace stair
+
+extern "C" int stair_gemm_f32(const stair_gemm_args *args, stair_stream stream) {
+    if (!args) {
+        stair::set_error("stair_gemm_f32: null args");
+        return 1;
+    }
+    return stair::launch_gemm(*args, static_cast<hipStream_t>(stream));
+}

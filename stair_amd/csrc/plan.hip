@@ -1,0 +1,829 @@
+// Context, program-plan builder and plan runner: the batched form of the stack interpreter in
+// /root/reference/video_nmn/module_net.py:94-138.
+//
+// The reference walks ONE question's prefix program token by token and launches 50-240 tiny ATen
+// kernels per question.  Here n questions are compiled together: every token becomes a node with a
+// value kind and an arena slot, nodes are levelled exactly as utils/program_parser.py:307-321
+// (leaf 0, module 1 + max(children)), and all nodes sharing (level, module, keyword variant) are
+// packed into ONE launch sequence whose operands are gathered through int32 slot arrays.  Launch
+// count per batch is O(levels x module kinds), independent of n.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <tuple>
+#include <unordered_map>
+#include <vector>
+
+#include "ops.h"
+
+namespace stair {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+
+}  // namespace stair
+
+using namespace stair;
+
+// =============================================================================================
+// context
+// =============================================================================================
+struct stair_ctx {
+    stair_config cfg;
+    bool conv;
+    int ksize;
+    std::vector<std::string> names;
+    std::vector<int64_t> numel;
+    std::vector<const float *> ptr;
+    std::unordered_map<std::string, int> by_name;
+
+    void add(const std::string &name, int64_t n) {
+        by_name[name] = (int)names.size();
+        names.push_back(name);
+        numel.push_back(n);
+        ptr.push_back(nullptr);
+    }
+    void lin(const std::string &prefix, int64_t out, int64_t in) {
+        add(prefix + ".weight", out * in);
+        add(prefix + ".bias", out);
+    }
+    const float *find(const std::string &name) const {
+        auto it = by_name.find(name);
+        return it == by_name.end() ? nullptr : ptr[it->second];
+    }
+};
+
+// python's round(): round half to even
+static int py_round(double x) {
+    double f = std::floor(x);
+    double d = x - f;
+    if (d > 0.5) return (int)f + 1;
+    if (d < 0.5) return (int)f;
+    return ((long long)f % 2 == 0) ? (int)f : (int)f + 1;
+}
+
+// mirrors stair_amd/spec.py::weight_table (reference state_dict order, aliases excluded)
+static void build_weight_table(stair_ctx *c) {
+    const stair_config &g = c->cfg;
+    const int64_t H = g.hidden_size, V = g.video_size, E = g.text_size, A = g.answer_vocab_length;
+    const int64_t L = g.max_video_length, O = g.object_types, Hh = H / 2;
+    const bool heads = g.have_pretrain_head != 0;
+    const std::string p = "submodules.";
+    c->lin(p + "Compare.param.0", H, 2 * H);
+    c->lin(p + "Equals.param.0", H, 2 * H);
+    if (heads) c->lin(p + "Equals.pretrain_head", 1, H);
+    c->lin(p + "Exists.param.0", H, 3 * H);
+    c->lin(p + "Exists.param.3", H, H);
+    if (heads) c->lin(p + "Exists.pretrain_head", 2, H);
+    for (const char *kw : {"representation", "actions", "objects", "relations"}) {
+        c->lin(p + "Filter.param." + kw + ".0", H, H);
+        c->lin(p + "Filter.param." + kw + ".3", H, H);
+    }
+    c->lin(p + "Filter.attention.0", 1, 2 * H);
+    c->lin(p + "Filter.dense.0", H, H);
+    for (const char *kw : {"representation", "relations", "actions"}) {
+        c->lin(p + "FilterFrame.param." + kw + ".0", H, H);
+        c->lin(p + "FilterFrame.param." + kw + ".3", H, H);
+    }
+    c->lin(p + "FilterFrame.attention.0", 1, 2 * H);
+    c->lin(p + "FilterFrame.dense.0", H, H);
+    if (heads) c->lin(p + "FilterFrame.pretrain_head", O, H);
+    c->lin(p + "HasItem.param.0", H, H);
+    c->lin(p + "HasItem.param.3", 1, H);
+    c->lin(p + "Localize.video_linear.0", H, H);
+    c->lin(p + "Localize.video_linear.3", H, H);
+    c->lin(p + "Localize.keyword_linear.0", H, H);
+    c->add(p + "Relate.beta", L);
+    c->lin(p + "Superlative.dense.0", H, H);
+    for (const char *mode : {"before", "after", "between"}) {
+        for (int layer : {0, 2, 4}) {
+            const std::string pre = p + "Temporal.relate." + mode + "." + std::to_string(layer);
+            if (c->conv) {
+                const int64_t ks = layer == 4 ? 2 * c->ksize + 1 : c->ksize;
+                c->add(pre + ".weight", ks);
+                c->add(pre + ".bias", 1);
+            } else {
+                c->lin(pre, L, L);
+            }
+        }
+    }
+    c->lin(p + "Temporal.dense.0", H, H);
+    c->add(p + "Temporal.layer_norm.weight", H);
+    c->add(p + "Temporal.layer_norm.bias", H);
+    c->lin(p + "ToAction.param.0", H, 2 * H);
+    c->lin(p + "ToAction.param.3", H, H);
+    c->lin(p + "Xor.param.0", H, 3 * H);
+    if (heads) c->lin(p + "Xor.pretrain_head", 2, H);
+    for (int enc = 0; enc < 2; ++enc) {
+        const std::string e = p + (enc == 0 ? "video_encoder" : "text_encoder");
+        const int64_t in = enc == 0 ? V : E;
+        for (const char *sfx : {"", "_reverse"}) {
+            c->add(e + ".weight_ih_l0" + sfx, 4 * Hh * in);
+            c->add(e + ".weight_hh_l0" + sfx, 4 * Hh * Hh);
+            c->add(e + ".bias_ih_l0" + sfx, 4 * Hh);
+            c->add(e + ".bias_hh_l0" + sfx, 4 * Hh);
+        }
+    }
+    c->lin(p + "decoder.0", 2 * H, 2 * H);
+    c->lin(p + "decoder.3", A, 2 * H);
+}
+
+extern "C" int stair_abi_version(void) { return STAIR_ABI_VERSION; }
+extern "C" const char *stair_last_error(void) { return g_err.c_str(); }
+
+extern "C" int stair_ctx_create(const stair_config *cfg, stair_ctx **out) {
+    STAIR_CHECK(cfg && out, "null argument");
+    STAIR_CHECK(cfg->hidden_size >= 32 && cfg->hidden_size % 32 == 0, "hidden_size must be a multiple of 32");
+    const int Hh = cfg->hidden_size / 2;
+    STAIR_CHECK(Hh <= 128 || Hh == 256, "hidden_size/2 must be <= 128 or exactly 256");
+    STAIR_CHECK(cfg->video_size > 0 && cfg->video_size % 4 == 0, "video_size must be a multiple of 4");
+    STAIR_CHECK(cfg->text_size > 0 && cfg->text_size % 4 == 0, "text_size must be a multiple of 4");
+    STAIR_CHECK(cfg->answer_vocab_length > 0 && cfg->max_video_length > 0 && cfg->object_types > 0, "bad config");
+    auto c = std::make_unique<stair_ctx>();
+    c->cfg = *cfg;
+    c->conv = cfg->max_video_length > 32;                       // modules.py:255
+    c->ksize = py_round(cfg->max_video_length / 4.0);           // modules.py:258
+    build_weight_table(c.get());
+    *out = c.release();
+    return 0;
+}
+extern "C" void stair_ctx_destroy(stair_ctx *ctx) { delete ctx; }
+extern "C" int stair_weight_count(const stair_ctx *ctx) { return ctx ? (int)ctx->names.size() : 0; }
+extern "C" const char *stair_weight_name(const stair_ctx *ctx, int id) {
+    return (ctx && id >= 0 && id < (int)ctx->names.size()) ? ctx->names[id].c_str() : nullptr;
+}
+extern "C" int64_t stair_weight_numel(const stair_ctx *ctx, int id) {
+    return (ctx && id >= 0 && id < (int)ctx->names.size()) ? ctx->numel[id] : -1;
+}
+extern "C" int stair_ctx_set_weight(stair_ctx *ctx, int id, const float *dev_ptr, int64_t numel) {
+    STAIR_CHECK(ctx, "null ctx");
+    STAIR_CHECK(id >= 0 && id < (int)ctx->names.size(), "weight id out of range");
+    STAIR_CHECK(numel == ctx->numel[id], "numel mismatch for " + ctx->names[id]);
+    STAIR_CHECK(dev_ptr && (reinterpret_cast<uintptr_t>(dev_ptr) & 15) == 0, "weight pointer must be 16-byte aligned: " + ctx->names[id]);
+    ctx->ptr[id] = dev_ptr;
+    return 0;
+}
+
+// =============================================================================================
+// plan
+// =============================================================================================
+namespace {
+
+constexpr int OP_SPAN = 50;      // pseudo op: span mean (level 0)
+const int kArity[STAIR_OP_COUNT] = {2, 2, 3, 2, 2, 2, 2, 2, 2, 1, 2, 2, 3, 3, 2, 2, 2, 2};
+const char *kOpName[STAIR_OP_COUNT] = {"And", "AttnVideo", "Choose", "Compare", "Equals", "Exists", "ExistsFrame",
+                                       "Filter", "FilterFrame", "HasItem", "Localize", "Relate", "Superlative",
+                                       "Temporal", "ToAction", "Xor", "XorFrame", "Array2"};
+
+struct Node {
+    int kind = -1, slot = -1, aux = -1, level = 0, rel = -1;
+};
+
+struct Bucket {
+    int level, op, variant, sub;
+    int cnt = 0;        // instances
+    int nrows = 0;      // secondary count (Localize pairs / Superlative action rows)
+    std::vector<int32_t> col[8];
+    int64_t off[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // offsets into the device idx buffer
+};
+
+}  // namespace
+
+struct stair_plan {
+    stair_config cfg;
+    int n = 0, T = 0, rows_q = 0, max_q = 0;
+    std::vector<Node> nodes;
+    std::vector<Bucket> buckets;
+    std::vector<int32_t> roots;
+    std::vector<int32_t> idx;       // host image of the device index buffer
+    int64_t off_seqv = 0, off_seqt = 0, off_roots = 0;
+    int n_vec = 0, n_map = 0, n_att = 0;
+    int maxI = 0, maxV = 0, maxK = 0, maxSupRows = 0, n_levels = 0;
+    // workspace layout (float offsets)
+    int64_t o_idx = 0, o_vec = 0, o_map = 0, o_att = 0, o_tok = 0, o_qfeat = 0, o_vhn = 0, o_xpv = 0, o_xpt = 0,
+            o_bias = 0, o_tmpA = 0, o_tmpB = 0, o_kbuf = 0, o_cat = 0, o_hid = 0, o_rs = 0, o_sup = 0, o_extra = 0,
+            o_logits = 0, total = 0;
+};
+
+namespace {
+
+struct Builder {
+    stair_plan *pl;
+    std::map<std::tuple<int, int, int, int>, int> index;
+    Bucket &bucket(int level, int op, int variant, int sub) {
+        auto key = std::make_tuple(level, op, variant, sub);
+        auto it = index.find(key);
+        if (it == index.end()) {
+            Bucket b;
+            b.level = level; b.op = op; b.variant = variant; b.sub = sub;
+            pl->buckets.push_back(b);
+            it = index.emplace(key, (int)pl->buckets.size() - 1).first;
+        }
+        return pl->buckets[it->second];
+    }
+};
+
+std::string where(int q, int i, int tok) {
+    std::string s = "question " + std::to_string(q) + ", token " + std::to_string(i);
+    if (tok >= 0 && tok < STAIR_OP_COUNT) s += std::string(" (") + kOpName[tok] + ")";
+    return s;
+}
+
+}  // namespace
+
+extern "C" int stair_plan_build(stair_ctx *ctx, int32_t n, const int32_t *prog_off, const int32_t *tokens,
+                                const int32_t *span_lo, const int32_t *span_hi, const int32_t *q_off, int32_t T,
+                                stair_plan **out) {
+    STAIR_CHECK(ctx && prog_off && tokens && span_lo && span_hi && q_off && out, "null argument");
+    STAIR_CHECK(n > 0 && T > 0, "n and T must be positive");
+    STAIR_CHECK(ctx->conv || T == ctx->cfg.max_video_length,
+                "Linear(T,T) Temporal nets need T == max_video_length (modules.py:266-277)");
+    auto plp = std::make_unique<stair_plan>();
+    stair_plan *pl = plp.get();
+    pl->cfg = ctx->cfg;
+    pl->n = n;
+    pl->T = T;
+    const int ntok = prog_off[n];
+    pl->nodes.assign(ntok, Node());
+    pl->roots.assign(n, -1);
+    pl->n_map = n;   // map slot q = encoded video of question q
+    Builder B{pl};
+    std::vector<int> stack;
+
+    for (int q = 0; q < n; ++q) {
+        const int Q = q_off[q + 1] - q_off[q];
+        STAIR_CHECK(Q > 0, "empty question " + std::to_string(q));
+        pl->max_q = std::max(pl->max_q, Q);
+        stack.clear();
+        STAIR_CHECK(prog_off[q + 1] > prog_off[q], "empty program, question " + std::to_string(q));
+        for (int i = prog_off[q + 1] - 1; i >= prog_off[q]; --i) {
+            const int tok = tokens[i];
+            Node &nd = pl->nodes[i];
+            if (tok >= 0 && tok < STAIR_OP_COUNT) {
+                const int ar = kArity[tok];
+                STAIR_CHECK((int)stack.size() >= ar, "invalid program (stack underflow) at " + where(q, i, tok));
+                int ch[3] = {-1, -1, -1};
+                int lvl = 0;
+                for (int k = 0; k < ar; ++k) {
+                    ch[k] = stack.back();
+                    stack.pop_back();
+                    lvl = std::max(lvl, pl->nodes[ch[k]].level);
+                }
+                nd.level = lvl + 1;
+                const Node &c0 = pl->nodes[ch[0]];
+                const Node &c1 = ar > 1 ? pl->nodes[ch[1]] : c0;
+                const Node &c2 = ar > 2 ? pl->nodes[ch[2]] : c0;
+                auto bad = [&](const char *what) {
+                    set_error(std::string("stair_plan_build: operand kind mismatch (") + what + ") at " + where(q, i, tok));
+                    return 1;
+                };
+                switch (tok) {
+                    case STAIR_OP_AND:
+                    case STAIR_OP_XORFRAME: {
+                        if (!(c0.kind == c1.kind && (c0.kind == STAIR_VAL_VEC || c0.kind == STAIR_VAL_FRAME)))
+                            return bad("needs two [H] vectors or two [T] frame attentions");
+                        nd.kind = c0.kind;
+                        nd.slot = c0.kind == STAIR_VAL_VEC ? pl->n_vec++ : pl->n_att++;
+                        Bucket &b = B.bucket(nd.level, tok, 0, c0.kind);
+                        b.col[0].push_back(c0.slot); b.col[1].push_back(c1.slot); b.col[2].push_back(nd.slot);
+                        b.cnt++;
+                        break;
+                    }
+                    case STAIR_OP_ATTNVIDEO: {
+                        if (c0.kind != STAIR_VAL_MAP || c1.kind != STAIR_VAL_FRAME) return bad("AttnVideo(feat [T,H], attn [T])");
+                        nd.kind = STAIR_VAL_MAP; nd.slot = pl->n_map++;
+                        Bucket &b = B.bucket(nd.level, tok, 0, 0);
+                        b.col[0].push_back(c0.slot); b.col[1].push_back(c1.slot); b.col[2].push_back(nd.slot);
+                        b.cnt++;
+                        break;
+                    }
+                    case STAIR_OP_CHOOSE: {
+                        if (c0.kind != STAIR_VAL_VEC || c1.kind != STAIR_VAL_VEC || c2.kind != STAIR_VAL_VEC)
+                            return bad("Choose(kw1 [H], kw2 [H], query [H])");
+                        nd.kind = STAIR_VAL_VEC; nd.slot = pl->n_vec++;
+                        Bucket &b = B.bucket(nd.level, tok, 0, 0);
+                        b.col[0].push_back(c0.slot); b.col[1].push_back(c1.slot); b.col[2].push_back(c2.slot);
+                        b.col[3].push_back(nd.slot);
+                        b.cnt++;
+                        break;
+                    }
+                    case STAIR_OP_COMPARE:
+                    case STAIR_OP_EQUALS:
+                    case STAIR_OP_XOR:
+                    case STAIR_OP_TOACTION:
+                    case STAIR_OP_EXISTS: {
+                        if (c0.kind != STAIR_VAL_VEC || c1.kind != STAIR_VAL_VEC) return bad("needs two [H] vectors");
+                        nd.kind = STAIR_VAL_VEC; nd.slot = pl->n_vec++;
+                        Bucket &b = B.bucket(nd.level, tok, 0, 0);
+                        b.col[0].push_back(c0.slot); b.col[1].push_back(c1.slot); b.col[2].push_back(nd.slot);
+                        b.cnt++;
+                        break;
+                    }
+                    case STAIR_OP_EXISTSFRAME: {
+                        if (c0.kind != STAIR_VAL_VEC || c1.kind != STAIR_VAL_MAP) return bad("ExistsFrame(keyword [H], feat [T,H])");
+                        nd.kind = STAIR_VAL_FRAME; nd.slot = pl->n_att++;
+                        Bucket &b = B.bucket(nd.level, tok, 0, 0);
+                        b.col[0].push_back(c0.slot); b.col[1].push_back(c1.slot); b.col[2].push_back(nd.slot);
+                        b.cnt++;
+                        break;
+                    }
+                    case STAIR_OP_FILTER: {
+                        if (c0.kind != STAIR_VAL_MAP) return bad("Filter(feat [T,H], keyword)");
+                        int variant;
+                        if (c1.kind == STAIR_VAL_VEC) variant = 0;
+                        else if (c1.kind == STAIR_VAL_STR && c1.aux == STAIR_KW_ACTIONS) variant = 1;
+                        else if (c1.kind == STAIR_VAL_STR && c1.aux == STAIR_KW_OBJECTS) variant = 2;
+                        else if (c1.kind == STAIR_VAL_STR && c1.aux == STAIR_KW_RELATIONS) variant = 3;
+                        else return bad("Filter keyword must be a [H] vector or actions/objects/relations (modules.py:346-351)");
+                        nd.kind = STAIR_VAL_VEC; nd.slot = pl->n_vec++;
+                        Bucket &b = B.bucket(nd.level, tok, variant, 0);
+                        b.col[0].push_back(c0.slot); b.col[1].push_back(nd.slot);
+                        b.cnt++;
+                        break;
+                    }
+                    case STAIR_OP_FILTERFRAME: {
+                        if (c0.kind != STAIR_VAL_MAP) return bad("FilterFrame(feat [T,H], keyword)");
+                        int variant;
+                        if (c1.kind == STAIR_VAL_VEC) variant = 0;
+                        else if (c1.kind == STAIR_VAL_STR && c1.aux == STAIR_KW_RELATIONS) variant = 1;
+                        else if (c1.kind == STAIR_VAL_STR && c1.aux == STAIR_KW_ACTIONS) variant = 2;
+                        else return bad("FilterFrame keyword must be a [H] vector or relations/actions (modules.py:384-388)");
+                        nd.kind = STAIR_VAL_MAP; nd.slot = pl->n_map++;
+                        Bucket &b = B.bucket(nd.level, tok, variant, 0);
+                        b.col[0].push_back(c0.slot); b.col[1].push_back(variant == 0 ? c1.slot : 0); b.col[2].push_back(nd.slot);
+                        b.cnt++;
+                        break;
+                    }
+                    case STAIR_OP_HASITEM: {
+                        if (c0.kind != STAIR_VAL_MAP) return bad("HasItem(feat [T,H])");
+                        nd.kind = STAIR_VAL_FRAME; nd.slot = pl->n_att++;
+                        Bucket &b = B.bucket(nd.level, tok, 0, 0);
+                        b.col[0].push_back(c0.slot); b.col[1].push_back(nd.slot);
+                        b.cnt++;
+                        break;
+                    }
+                    case STAIR_OP_LOCALIZE: {
+                        if (c0.kind != STAIR_VAL_MAP || !(c1.kind == STAIR_VAL_VEC || c1.kind == STAIR_VAL_PAIR))
+                            return bad("Localize(feat [T,H], keyword [H] or [2,H])");
+                        const int K = c1.kind == STAIR_VAL_PAIR ? 2 : 1;
+                        nd.kind = STAIR_VAL_ATT; nd.slot = pl->n_att; nd.aux = K;
+                        pl->n_att += K;
+                        Bucket &b = B.bucket(nd.level, tok, 0, 0);
+                        b.col[0].push_back(c0.slot);
+                        for (int k = 0; k < K; ++k) {
+                            b.col[1].push_back(b.cnt);                       // pair -> instance
+                            b.col[2].push_back(k == 0 ? c1.slot : c1.aux);   // pair -> keyword vec row
+                            b.col[3].push_back(nd.slot + k);                 // pair -> att row
+                            b.nrows++;
+                        }
+                        b.cnt++;
+                        break;
+                    }
+                    case STAIR_OP_RELATE: {
+                        if (c0.kind != STAIR_VAL_STR || c1.kind != STAIR_VAL_FRAME) return bad("Relate(mode, attn [T])");
+                        nd.kind = STAIR_VAL_FRAME; nd.slot = pl->n_att++;
+                        Bucket &b = B.bucket(nd.level, tok, c0.aux == STAIR_KW_FORWARD ? 0 : 1, 0);   // modules.py:429
+                        b.col[0].push_back(c1.slot); b.col[1].push_back(nd.slot);
+                        b.cnt++;
+                        break;
+                    }
+                    case STAIR_OP_SUPERLATIVE: {
+                        if (c0.kind != STAIR_VAL_STR || c2.kind != STAIR_VAL_MAP ||
+                            !(c1.kind == STAIR_VAL_MAP || c1.kind == STAIR_VAL_PAIR || c1.kind == STAIR_VAL_VEC))
+                            return bad("Superlative(mode, actions [Ka,H], feat [T,H])");
+                        nd.kind = STAIR_VAL_VEC; nd.slot = pl->n_vec++;
+                        Bucket &b = B.bucket(nd.level, tok, c0.aux == STAIR_KW_MIN ? 1 : 0, 0);       // modules.py:245
+                        b.col[0].push_back(c2.slot);          // feat map
+                        b.col[1].push_back(b.nrows);          // first action row of this instance
+                        const int Ka = c1.kind == STAIR_VAL_MAP ? T : (c1.kind == STAIR_VAL_PAIR ? 2 : 1);
+                        b.col[2].push_back(Ka);
+                        b.col[3].push_back(nd.slot);
+                        for (int a = 0; a < Ka; ++a) {
+                            // action row id: >= 0 -> vec arena row; < 0 -> -(map row + 1) (resolved at finalise)
+                            int rid;
+                            if (c1.kind == STAIR_VAL_MAP) rid = -(c1.slot * T + a) - 1;
+                            else rid = a == 0 ? c1.slot : c1.aux;
+                            b.col[4].push_back(rid);
+                            b.col[5].push_back(b.cnt);        // row -> instance
+                            b.nrows++;
+                        }
+                        b.cnt++;
+                        break;
+                    }
+                    case STAIR_OP_TEMPORAL: {
+                        if (c0.kind != STAIR_VAL_STR || c1.kind != STAIR_VAL_MAP || c2.kind != STAIR_VAL_ATT)
+                            return bad("Temporal(mode, feat [T,H], attention [K,T])");
+                        int mode;
+                        if (c0.aux == STAIR_KW_WHILE) mode = 0;
+                        else if (c0.aux == STAIR_KW_BEFORE) mode = 1;
+                        else if (c0.aux == STAIR_KW_AFTER) mode = 2;
+                        else if (c0.aux == STAIR_KW_BETWEEN) mode = 3;
+                        else return bad("Temporal mode must be while/before/after/between (modules.py:263,279)");
+                        nd.kind = STAIR_VAL_MAP; nd.slot = pl->n_map++; nd.rel = pl->n_att++;
+                        Bucket &b = B.bucket(nd.level, tok, mode, 0);
+                        b.col[0].push_back(c1.slot); b.col[1].push_back(c2.slot); b.col[2].push_back(c2.aux);
+                        b.col[3].push_back(nd.rel); b.col[4].push_back(nd.slot);
+                        b.cnt++;
+                        break;
+                    }
+                    case STAIR_OP_ARRAY2: {
+                        if (c0.kind != STAIR_VAL_VEC || c1.kind != STAIR_VAL_VEC) return bad("Array2(a [H], b [H])");
+                        nd.kind = STAIR_VAL_PAIR; nd.slot = c0.slot; nd.aux = c1.slot;   // alias, no launch
+                        break;
+                    }
+                    default:
+                        STAIR_FAIL("unknown module token at " + where(q, i, tok));
+                }
+            } else if (tok >= STAIR_KW_FORWARD && tok <= STAIR_KW_RELATIONS) {
+                if (tok == STAIR_KW_VIDEO) {        // module_net.py:103-104
+                    nd.kind = STAIR_VAL_MAP; nd.slot = q;
+                } else {
+                    nd.kind = STAIR_VAL_STR; nd.aux = tok;
+                }
+            } else if (tok == STAIR_TOK_SPAN) {     // module_net.py:126-129
+                const int lo = span_lo[i], hi = std::min(span_hi[i], Q);
+                STAIR_CHECK(lo >= 0 && lo < hi, "empty or out-of-range question span at " + where(q, i, tok));
+                nd.kind = STAIR_VAL_VEC; nd.slot = pl->n_vec++;
+                Bucket &b = B.bucket(0, OP_SPAN, 0, 0);
+                b.col[0].push_back(q_off[q] + lo); b.col[1].push_back(hi - lo); b.col[2].push_back(nd.slot);
+                b.cnt++;
+            } else {
+                STAIR_FAIL("unknown token code " + std::to_string(tok) + " at " + where(q, i, tok));
+            }
+            stack.push_back(i);
+        }
+        STAIR_CHECK(stack.size() == 1, "invalid program: stack holds " + std::to_string(stack.size()) +
+                                           " values at the end (module_net.py:135), question " + std::to_string(q));
+        const Node &root = pl->nodes[stack[0]];
+        STAIR_CHECK(root.kind == STAIR_VAL_VEC, "program root must produce a [H] vector for the decoder (module_net.py:136), question " + std::to_string(q));
+        pl->roots[q] = root.slot;
+    }
+    pl->rows_q = q_off[n];
+
+    std::sort(pl->buckets.begin(), pl->buckets.end(), [](const Bucket &a, const Bucket &b) {
+        return std::tie(a.level, a.op, a.variant, a.sub) < std::tie(b.level, b.op, b.variant, b.sub);
+    });
+
+    // ---- sizes & the device index buffer image --------------------------------------------
+    const int64_t H = ctx->cfg.hidden_size, A = ctx->cfg.answer_vocab_length;
+    pl->maxV = n;
+    for (Bucket &b : pl->buckets) {
+        pl->n_levels = std::max(pl->n_levels, b.level + 1);
+        switch (b.op) {
+            case STAIR_OP_FILTER: case STAIR_OP_FILTERFRAME: case STAIR_OP_HASITEM: case STAIR_OP_LOCALIZE:
+            case STAIR_OP_SUPERLATIVE:
+                pl->maxI = std::max(pl->maxI, b.cnt);
+                break;
+            default: break;
+        }
+        pl->maxV = std::max(pl->maxV, b.cnt);
+        if (b.op == STAIR_OP_LOCALIZE) pl->maxK = std::max(pl->maxK, b.nrows);
+        if (b.op == STAIR_OP_SUPERLATIVE) {
+            pl->maxK = std::max(pl->maxK, b.nrows);
+            pl->maxSupRows = std::max(pl->maxSupRows, b.nrows);
+        }
+    }
+    auto push = [&](const std::vector<int32_t> &v) {
+        const int64_t off = (int64_t)pl->idx.size();
+        pl->idx.insert(pl->idx.end(), v.begin(), v.end());
+        while (pl->idx.size() % 4) pl->idx.push_back(0);
+        return off;
+    };
+    {
+        std::vector<int32_t> sv(n + 1), st(q_off, q_off + n + 1);
+        for (int q = 0; q <= n; ++q) sv[q] = q * T;
+        pl->off_seqv = push(sv);
+        pl->off_seqt = push(st);
+        pl->off_roots = push(pl->roots);
+    }
+    // layout (float offsets; vec and map arenas start on multiples of H so that any [H] row of
+    // either arena has a global row id relative to the workspace base)
+    int64_t o = 0;
+    auto take = [&](int64_t nfloats, int64_t align) {
+        o = align_up(o, align);
+        const int64_t r = o;
+        o += nfloats;
+        return r;
+    };
+    // idx buffer placed first: its size is known only after bucket columns are pushed -> reserve now
+    int64_t idx_ints = (int64_t)pl->idx.size();
+    for (Bucket &b : pl->buckets)
+        for (int c = 0; c < 8; ++c) idx_ints += align_up((int64_t)b.col[c].size(), 4);
+    pl->o_idx = take(idx_ints, 64);
+    pl->o_vec = take((int64_t)pl->n_vec * H, H);
+    pl->o_map = take((int64_t)pl->n_map * T * H, H);
+    // resolve Superlative action row ids into global row ids (units of H floats from workspace base)
+    for (Bucket &b : pl->buckets)
+        if (b.op == STAIR_OP_SUPERLATIVE)
+            for (int32_t &rid : b.col[4]) rid = rid >= 0 ? (int32_t)(pl->o_vec / H + rid) : (int32_t)(pl->o_map / H + (-rid - 1));
+    STAIR_CHECK((pl->o_map + (int64_t)pl->n_map * T * H) / H < (1ll << 31), "batch too large for 32-bit row ids");
+    for (Bucket &b : pl->buckets)
+        for (int c = 0; c < 8; ++c) b.off[c] = push(b.col[c]);
+    STAIR_CHECK((int64_t)pl->idx.size() == idx_ints, "internal: idx size");
+    pl->o_att = take((int64_t)std::max(pl->n_att, 1) * T, 64);
+    pl->o_tok = take((int64_t)pl->rows_q * H, 64);
+    pl->o_qfeat = take((int64_t)n * H, 64);
+    pl->o_vhn = take((int64_t)n * H, 64);
+    pl->o_xpv = take((int64_t)n * T * 4 * H, 64);
+    pl->o_xpt = take((int64_t)pl->rows_q * 4 * H, 64);
+    pl->o_bias = take(2 * 4 * H, 64);
+    pl->o_tmpA = take((int64_t)std::max(pl->maxI, 1) * T * H, 64);
+    pl->o_tmpB = take((int64_t)std::max(pl->maxI, 1) * T * H, 64);
+    pl->o_kbuf = take((int64_t)std::max(pl->maxK, 1) * H, 64);
+    pl->o_cat = take((int64_t)pl->maxV * 3 * H, 64);
+    pl->o_hid = take((int64_t)pl->maxV * 2 * H, 64);
+    pl->o_rs = take((int64_t)std::max(pl->maxI, 1) * T, 64);
+    pl->o_sup = take((int64_t)std::max(pl->maxSupRows, 1) * T, 64);
+    pl->o_extra = take(std::max(pl->maxI, 1), 64);
+    pl->o_logits = take((int64_t)n * A, 64);
+    pl->total = align_up(o, 64);
+    *out = plp.release();
+    return 0;
+}
+
+extern "C" void stair_plan_destroy(stair_plan *plan) { delete plan; }
+
+extern "C" int stair_plan_get_info(const stair_plan *pl, stair_plan_info *info) {
+    STAIR_CHECK(pl && info, "null argument");
+    info->workspace_bytes = pl->total * (int64_t)sizeof(float);
+    info->vec_off = pl->o_vec; info->map_off = pl->o_map; info->att_off = pl->o_att;
+    info->tok_off = pl->o_tok; info->qfeat_off = pl->o_qfeat;
+    info->n_vec = pl->n_vec; info->n_map = pl->n_map; info->n_att = pl->n_att; info->n_tok_rows = pl->rows_q;
+    info->n_nodes = (int)pl->nodes.size();
+    int launches = 0;
+    for (const Bucket &b : pl->buckets) launches += b.cnt > 0;
+    info->n_launches = launches; info->n_levels = pl->n_levels; info->n_questions = pl->n; info->T = pl->T;
+    return 0;
+}
+
+extern "C" int stair_plan_node(const stair_plan *pl, int32_t tok, int32_t *kind, int32_t *slot, int32_t *aux,
+                               int32_t *level, int32_t *rel_slot) {
+    STAIR_CHECK(pl, "null plan");
+    STAIR_CHECK(tok >= 0 && tok < (int)pl->nodes.size(), "token index out of range");
+    const Node &nd = pl->nodes[tok];
+    if (kind) *kind = nd.kind;
+    if (slot) *slot = nd.slot;
+    if (aux) *aux = nd.aux;
+    if (level) *level = nd.level;
+    if (rel_slot) *rel_slot = nd.rel;
+    return 0;
+}
+
+// =============================================================================================
+// runner
+// =============================================================================================
+namespace {
+
+struct Lin { const float *w = nullptr, *b = nullptr; };
+struct Weights {
+    Lin compare, equals, exists0, exists3, f0[4], f3[4], fdense, ff0[3], ff3[3], ffatt, ffdense, hi0, hi3, lv0, lv3,
+        lk, supdense, tdense, ta0, ta3, xorl, dec0, dec3;
+    const float *beta = nullptr, *ln_w = nullptr, *ln_b = nullptr;
+    const float *relate[3][6] = {};
+    const float *enc[2][8] = {};   // [video|text][w_ih, w_hh, b_ih, b_hh, then reverse]
+};
+
+int resolve(const stair_ctx *ctx, Weights &W) {
+    const std::string p = "submodules.";
+    auto get = [&](const std::string &name, const float *&dst) {
+        dst = ctx->find(name);
+        if (!dst) {
+            set_error("stair_plan_run: weight not set: " + name);
+            return 1;
+        }
+        return 0;
+    };
+    auto lin = [&](const std::string &prefix, Lin &l) { return get(prefix + ".weight", l.w) || get(prefix + ".bias", l.b); };
+#define R(x) if (x) return 1
+    R(lin(p + "Compare.param.0", W.compare));
+    R(lin(p + "Equals.param.0", W.equals));
+    R(lin(p + "Exists.param.0", W.exists0));
+    R(lin(p + "Exists.param.3", W.exists3));
+    const char *fk[4] = {"representation", "actions", "objects", "relations"};
+    for (int i = 0; i < 4; ++i) {
+        R(lin(p + "Filter.param." + fk[i] + ".0", W.f0[i]));
+        R(lin(p + "Filter.param." + fk[i] + ".3", W.f3[i]));
+    }
+    R(lin(p + "Filter.dense.0", W.fdense));
+    const char *ffk[3] = {"representation", "relations", "actions"};
+    for (int i = 0; i < 3; ++i) {
+        R(lin(p + "FilterFrame.param." + ffk[i] + ".0", W.ff0[i]));
+        R(lin(p + "FilterFrame.param." + ffk[i] + ".3", W.ff3[i]));
+    }
+    R(lin(p + "FilterFrame.attention.0", W.ffatt));
+    R(lin(p + "FilterFrame.dense.0", W.ffdense));
+    R(lin(p + "HasItem.param.0", W.hi0));
+    R(lin(p + "HasItem.param.3", W.hi3));
+    R(lin(p + "Localize.video_linear.0", W.lv0));
+    R(lin(p + "Localize.video_linear.3", W.lv3));
+    R(lin(p + "Localize.keyword_linear.0", W.lk));
+    R(get(p + "Relate.beta", W.beta));
+    R(lin(p + "Superlative.dense.0", W.supdense));
+    const char *modes[3] = {"before", "after", "between"};
+    for (int m = 0; m < 3; ++m)
+        for (int l = 0; l < 3; ++l) {
+            const std::string pre = p + "Temporal.relate." + modes[m] + "." + std::to_string(2 * l);
+            R(get(pre + ".weight", W.relate[m][2 * l]));
+            R(get(pre + ".bias", W.relate[m][2 * l + 1]));
+        }
+    R(lin(p + "Temporal.dense.0", W.tdense));
+    R(get(p + "Temporal.layer_norm.weight", W.ln_w));
+    R(get(p + "Temporal.layer_norm.bias", W.ln_b));
+    R(lin(p + "ToAction.param.0", W.ta0));
+    R(lin(p + "ToAction.param.3", W.ta3));
+    R(lin(p + "Xor.param.0", W.xorl));
+    for (int e = 0; e < 2; ++e) {
+        const std::string enc = p + (e == 0 ? "video_encoder" : "text_encoder");
+        const char *sfx[2] = {"", "_reverse"};
+        for (int d = 0; d < 2; ++d) {
+            R(get(enc + ".weight_ih_l0" + sfx[d], W.enc[e][4 * d + 0]));
+            R(get(enc + ".weight_hh_l0" + sfx[d], W.enc[e][4 * d + 1]));
+            R(get(enc + ".bias_ih_l0" + sfx[d], W.enc[e][4 * d + 2]));
+            R(get(enc + ".bias_hh_l0" + sfx[d], W.enc[e][4 * d + 3]));
+        }
+    }
+    R(lin(p + "decoder.0", W.dec0));
+    R(lin(p + "decoder.3", W.dec3));
+#undef R
+    return 0;
+}
+
+// dense helper: C[g][r] = act(rs * A[g][r] W^T + b)
+int dense(hipStream_t s, const float *A, int64_t lda, int64_t a_gs, const int32_t *a_gidx, const Lin &l, int64_t ldw,
+          float *C, int64_t ldc, int64_t c_gs, const int32_t *c_gidx, int groups, int R, int N, int K, int act,
+          const float *rs = nullptr, int64_t rs_gs = 0, const int32_t *rs_gidx = nullptr) {
+    stair_gemm_args g = {};
+    g.A = A; g.lda = lda; g.a_gstride = a_gs; g.a_gidx = a_gidx;
+    g.W = l.w; g.ldw = ldw; g.bias = l.b;
+    g.C = C; g.ldc = ldc; g.c_gstride = c_gs; g.c_gidx = c_gidx;
+    g.row_scale = rs; g.rs_gstride = rs_gs; g.rs_gidx = rs_gidx;
+    g.groups = groups; g.rows_per_group = R; g.N = N; g.K = K; g.act = act;
+    return launch_gemm(g, s);
+}
+
+}  // namespace
+
+extern "C" int stair_plan_run(stair_ctx *ctx, stair_plan *pl, const float *video, const float *question,
+                              void *workspace, int64_t workspace_bytes, float *logits, int32_t *argmax,
+                              stair_stream stream) {
+    STAIR_CHECK(ctx && pl && video && question && workspace, "null argument");
+    STAIR_CHECK(workspace_bytes >= pl->total * (int64_t)sizeof(float), "workspace too small");
+    STAIR_CHECK((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "workspace must be 256-byte aligned");
+    STAIR_CHECK(memcmp(&ctx->cfg, &pl->cfg, sizeof(stair_config)) == 0, "plan was built for another configuration");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Weights W;
+    if (resolve(ctx, W)) return 1;
+
+    const stair_config &g = ctx->cfg;
+    const int H = g.hidden_size, Hh = H / 2, V = g.video_size, E = g.text_size, A = g.answer_vocab_length;
+    const int n = pl->n, T = pl->T;
+    const int64_t TH = (int64_t)T * H;
+    float *ws = static_cast<float *>(workspace);
+    int32_t *didx = reinterpret_cast<int32_t *>(ws + pl->o_idx);
+    float *vec = ws + pl->o_vec, *map = ws + pl->o_map, *att = ws + pl->o_att, *tok = ws + pl->o_tok;
+    float *qfeat = ws + pl->o_qfeat, *tmpA = ws + pl->o_tmpA, *tmpB = ws + pl->o_tmpB, *kbuf = ws + pl->o_kbuf;
+    float *cat = ws + pl->o_cat, *hid = ws + pl->o_hid, *rsb = ws + pl->o_rs, *sup = ws + pl->o_sup;
+    float *extra = ws + pl->o_extra;
+    if (!logits) logits = ws + pl->o_logits;
+
+    STAIR_HIP(hipMemcpyAsync(didx, pl->idx.data(), pl->idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+
+#define RUN(x) do { if (int rc_ = (x)) return rc_; } while (0)
+    // ---- encoders (module_net.py:74-75) ------------------------------------------------------
+    {
+        stair_lstm_args a = {};
+        a.x = video; a.ldx = V; a.rows = n * T; a.n = n; a.max_len = T; a.I = V; a.Hh = Hh;
+        a.seq_off = didx + pl->off_seqv;
+        for (int d = 0; d < 2; ++d) {
+            a.w_ih[d] = W.enc[0][4 * d]; a.w_hh[d] = W.enc[0][4 * d + 1];
+            a.b_ih[d] = W.enc[0][4 * d + 2]; a.b_hh[d] = W.enc[0][4 * d + 3];
+        }
+        a.xproj_ws = ws + pl->o_xpv; a.bias_ws = ws + pl->o_bias;
+        a.out = map; a.ldo = H; a.h_n = ws + pl->o_vhn;
+        RUN(launch_lstm(a, s));
+    }
+    {
+        stair_lstm_args a = {};
+        a.x = question; a.ldx = E; a.rows = pl->rows_q; a.n = n; a.max_len = pl->max_q; a.I = E; a.Hh = Hh;
+        a.seq_off = didx + pl->off_seqt;
+        for (int d = 0; d < 2; ++d) {
+            a.w_ih[d] = W.enc[1][4 * d]; a.w_hh[d] = W.enc[1][4 * d + 1];
+            a.b_ih[d] = W.enc[1][4 * d + 2]; a.b_hh[d] = W.enc[1][4 * d + 3];
+        }
+        a.xproj_ws = ws + pl->o_xpt; a.bias_ws = ws + pl->o_bias + 4 * H;
+        a.out = tok; a.ldo = H; a.h_n = qfeat;
+        RUN(launch_lstm(a, s));
+    }
+
+    // ---- program levels ----------------------------------------------------------------------
+    for (const Bucket &b : pl->buckets) {
+        if (b.cnt == 0) continue;
+        const int c = b.cnt;
+        const int32_t *I0 = didx + b.off[0], *I1 = didx + b.off[1], *I2 = didx + b.off[2], *I3 = didx + b.off[3],
+                      *I4 = didx + b.off[4], *I5 = didx + b.off[5];
+        switch (b.op) {
+            case OP_SPAN:
+                RUN(launch_span_mean(tok, H, I0, I1, vec, I2, c, H, s));
+                break;
+            case STAIR_OP_AND:
+            case STAIR_OP_XORFRAME: {
+                const bool isvec = b.sub == STAIR_VAL_VEC;
+                RUN(launch_eltwise(b.op == STAIR_OP_AND ? 0 : 1, isvec ? vec : att, I0, I1, I2, c, isvec ? H : T, s));
+                break;
+            }
+            case STAIR_OP_ATTNVIDEO:
+                RUN(launch_attnvideo(map, I0, att, I1, I2, c, T, H, s));
+                break;
+            case STAIR_OP_CHOOSE:
+                RUN(launch_choose(vec, I0, I1, I2, I3, c, H, s));
+                break;
+            case STAIR_OP_COMPARE:      // modules.py:15-21
+            case STAIR_OP_EQUALS: {     // modules.py:24-37
+                RUN(launch_pack(PACK_CAT2, vec, I0, vec, I1, cat, c, H, s));
+                RUN(dense(s, cat, 2 * H, 2 * H, nullptr, b.op == STAIR_OP_COMPARE ? W.compare : W.equals, 2 * H, vec, H, H,
+                          I2, c, 1, H, 2 * H, 1));
+                break;
+            }
+            case STAIR_OP_XOR:          // modules.py:59-72: cat[|a-b|, a, b]
+                RUN(launch_pack(PACK_XOR, vec, I0, vec, I1, cat, c, H, s));
+                RUN(dense(s, cat, 3 * H, 3 * H, nullptr, W.xorl, 3 * H, vec, H, H, I2, c, 1, H, 3 * H, 1));
+                break;
+            case STAIR_OP_TOACTION:     // modules.py:102-120: cat[action, keyword]
+                RUN(launch_pack(PACK_CAT2, vec, I0, vec, I1, cat, c, H, s));
+                RUN(dense(s, cat, 2 * H, 2 * H, nullptr, W.ta0, 2 * H, hid, H, H, nullptr, c, 1, H, 2 * H, 1));
+                RUN(dense(s, hid, H, H, nullptr, W.ta3, H, vec, H, H, I2, c, 1, H, H, 1));
+                break;
+            case STAIR_OP_EXISTS:       // modules.py:141-159: Exists(keyword, feat) -> cat[feat, keyword, feat*keyword]
+                RUN(launch_pack(PACK_EXISTS, vec, I1, vec, I0, cat, c, H, s));
+                RUN(dense(s, cat, 3 * H, 3 * H, nullptr, W.exists0, 3 * H, hid, H, H, nullptr, c, 1, H, 3 * H, 1));
+                RUN(dense(s, hid, H, H, nullptr, W.exists3, H, vec, H, H, I2, c, 1, H, H, 1));
+                break;
+            case STAIR_OP_EXISTSFRAME:  // modules.py:162-178
+                RUN(launch_cosine_attn(map, TH, I1, vec, I0, att, I2, c, T, H, s));
+                break;
+            case STAIR_OP_FILTER: {     // modules.py:343-378 (attention == 1 exactly, see oracle op_filter)
+                const int v = b.variant;
+                RUN(dense(s, map, H, TH, I0, W.f0[v], H, tmpA, H, TH, nullptr, c, T, H, H, 1));
+                RUN(dense(s, tmpA, H, TH, nullptr, W.f3[v], H, tmpB, H, TH, nullptr, c, T, H, H, 1));
+                RUN(launch_sum_rows(tmpB, cat, c, T, H, s));
+                RUN(dense(s, cat, H, H, nullptr, W.fdense, H, vec, H, H, I1, c, 1, H, H, 1));
+                break;
+            }
+            case STAIR_OP_FILTERFRAME: {   // modules.py:381-414
+                const int v = b.variant;
+                RUN(dense(s, map, H, TH, I0, W.ff0[v], H, tmpA, H, TH, nullptr, c, T, H, H, 1));
+                RUN(dense(s, tmpA, H, TH, nullptr, W.ff3[v], H, tmpB, H, TH, nullptr, c, T, H, H, 1));
+                if (v == 0) {
+                    // sigmoid(Lin(2H->1)(cat[f_t, kw])) = sigmoid(w[:H].f_t + w[H:].kw + b)
+                    RUN(launch_vecdot(vec, I1, W.ffatt.w + H, extra, c, H, s));
+                    RUN(launch_rowdot_sigmoid(tmpB, c, T, H, W.ffatt.w, W.ffatt.b, extra, rsb, nullptr, T, s));
+                    RUN(dense(s, tmpB, H, TH, nullptr, W.ffdense, H, map, H, TH, I2, c, T, H, H, 1, rsb, T, nullptr));
+                } else {
+                    RUN(dense(s, tmpB, H, TH, nullptr, W.ffdense, H, map, H, TH, I2, c, T, H, H, 1));
+                }
+                break;
+            }
+            case STAIR_OP_HASITEM:      // modules.py:123-138
+                RUN(dense(s, map, H, TH, I0, W.hi0, H, tmpA, H, TH, nullptr, c, T, H, H, 1));
+                RUN(launch_rowdot_sigmoid(tmpA, c, T, H, W.hi3.w, W.hi3.b, nullptr, att, I1, T, s));
+                break;
+            case STAIR_OP_LOCALIZE:     // modules.py:181-217
+                RUN(dense(s, map, H, TH, I0, W.lv0, H, tmpA, H, TH, nullptr, c, T, H, H, 1));
+                RUN(dense(s, tmpA, H, TH, nullptr, W.lv3, H, tmpB, H, TH, nullptr, c, T, H, H, 0));
+                RUN(dense(s, vec, H, H, I2, W.lk, H, kbuf, H, H, nullptr, b.nrows, 1, H, H, 0));
+                RUN(launch_cosine_attn(tmpB, TH, I1, kbuf, nullptr, att, I3, b.nrows, T, H, s));
+                break;
+            case STAIR_OP_RELATE:       // modules.py:417-435
+                RUN(launch_relate_softmax(att, I0, I1, W.beta, b.variant == 0 ? 1.0f : -1.0f, c, T, s));
+                break;
+            case STAIR_OP_SUPERLATIVE:  // modules.py:220-248 (shares Localize's weights, module_net.py:31-32)
+                RUN(dense(s, map, H, TH, I0, W.lv0, H, tmpA, H, TH, nullptr, c, T, H, H, 1));
+                RUN(dense(s, tmpA, H, TH, nullptr, W.lv3, H, tmpB, H, TH, nullptr, c, T, H, H, 0));
+                RUN(dense(s, ws, H, H, I4, W.lk, H, kbuf, H, H, nullptr, b.nrows, 1, H, H, 0));
+                RUN(launch_cosine_attn(tmpB, TH, I5, kbuf, nullptr, sup, nullptr, b.nrows, T, H, s));
+                RUN(launch_superlative_pool(sup, ws, I4, I1, I2, b.variant, cat, c, T, H, s));
+                RUN(dense(s, cat, H, H, nullptr, W.supdense, H, vec, H, H, I3, c, 1, H, H, 1));
+                break;
+            case STAIR_OP_TEMPORAL: {   // modules.py:310-327
+                const int mode = b.variant;
+                RUN(launch_temporal_relate(att, I1, I2, att, I3, c, T, mode, ctx->conv ? 1 : 0, ctx->ksize,
+                                           mode ? W.relate[mode - 1] : nullptr, s));
+                RUN(dense(s, map, H, TH, I0, W.tdense, H, map, H, TH, I4, c, T, H, H, 1, att, T, I3));
+                RUN(launch_layernorm(map, TH, I4, c, T, H, W.ln_w, W.ln_b, 1e-5f, s));
+                break;
+            }
+            default:
+                STAIR_FAIL("internal: unhandled bucket op " + std::to_string(b.op));
+        }
+    }
+
+    // ---- decoder (module_net.py:136-138) -----------------------------------------------------
+    RUN(launch_pack(PACK_CAT2, vec, didx + pl->off_roots, qfeat, nullptr, cat, n, H, s));
+    RUN(dense(s, cat, 2 * H, 2 * H, nullptr, W.dec0, 2 * H, hid, 2 * H, 2 * H, nullptr, n, 1, 2 * H, 2 * H, 1));
+    RUN(dense(s, hid, 2 * H, 2 * H, nullptr, W.dec3, 2 * H, logits, A, A, nullptr, n, 1, A, 2 * H, 0));
+    if (argmax) RUN(launch_argmax(logits, argmax, n, A, s));
+#undef RUN
+    return 0;
+}

@@ -1,0 +1,348 @@
+"""Host-side mirror of the reference's ``video_nmn/module_net.py``: a ``VideoNMN`` with the same
+constructor, ``forward(data, ...)`` contract, ``state_dict`` keys and helper entry points
+(/root/reference/video_nmn/module_net.py:11-216), executing on libstair_hip.so.
+
+Differences that matter to a caller:
+
+* ``forward_batch`` runs MANY questions in one pass (the reference is batch-1 by construction,
+  train_module.py:282); ``forward(data)`` is the drop-in single-question form built on it.
+* inference only in this round: outputs carry no autograd graph (backward kernels are next).
+* programs whose operand kinds do not fit a module raise ``StairError`` at plan-build time instead
+  of a torch shape error in the middle of execution.
+
+torch is plumbing here (device memory, streams, Parameter containers); the arithmetic is HIP.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import ops, spec
+from ._lib import PlanInfo, StairConfig, StairError, check, lib
+
+VAL_STR, VAL_VEC, VAL_MAP, VAL_ATT, VAL_FRAME, VAL_PAIR = range(6)
+
+
+class L2Normalize(nn.Module):
+    """module_net.py:211-216."""
+
+    def forward(self, feat):
+        return ops.l2normalize(feat)
+
+
+class _Node(nn.Module):
+    """Parameter container reproducing the reference's attribute paths (``param.representation.0`` ...).
+    Calling a node that holds ``weight``/``bias`` applies it as a Linear (used for pretrain heads)."""
+
+    def __getitem__(self, key):
+        return self._modules[str(key)]
+
+    def forward(self, x):
+        return ops.linear(x, self.weight, self.bias)
+
+
+class _TemporalNode(_Node):
+    """TemporalModule.pretrain_head returns the relate output of the LAST call (modules.py:285-288)."""
+    related_attn = None
+
+    def pretrain_head(self, *args):
+        return self.related_attn
+
+
+def _init_param(name, p, config):
+    H = config['hidden_size']
+    with torch.no_grad():
+        if name.endswith('layer_norm.weight'):
+            p.fill_(1.0)
+        elif name.endswith('layer_norm.bias'):
+            p.zero_()
+        elif name.endswith('Relate.beta'):
+            p.uniform_(0.0, 1.0)                                   # torch.rand, modules.py:420
+        elif '_encoder.' in name:
+            b = 1.0 / math.sqrt(H // 2)
+            p.uniform_(-b, b)                                      # nn.LSTM default
+        else:
+            table = dict(spec.weight_table(config))
+            wshape = table[name[:-5] + '.weight'] if name.endswith('.bias') else tuple(p.shape)
+            b = 1.0 / math.sqrt(int(np.prod(wshape[1:])))
+            p.uniform_(-b, b)                                      # nn.Linear / nn.Conv1d default
+
+
+class BatchResult:
+    """Outputs of one batched pass plus read access to every intermediate program value."""
+
+    def __init__(self, model, plan, info, ws, logits, pred, prog_off, programs):
+        self._model, self._plan, self.info, self._ws = model, plan, info, ws
+        self.logits, self.pred = logits, pred
+        self._prog_off, self._programs = prog_off, programs
+
+    def __del__(self):
+        if getattr(self, '_plan', None):
+            lib.stair_plan_destroy(self._plan)
+            self._plan = None
+
+    def _arena(self, off, rows, cols):
+        return self._ws[off: off + rows * cols].view(rows, cols)
+
+    def node_info(self, q, i):
+        k, s, a, l, r = (C.c_int32() for _ in range(5))
+        check(lib.stair_plan_node(self._plan, int(self._prog_off[q] + i), C.byref(k), C.byref(s), C.byref(a),
+                                  C.byref(l), C.byref(r)))
+        return k.value, s.value, a.value, l.value, r.value
+
+    def node(self, q, i):
+        """Value of token i of question q: a str for keywords, else a tensor VIEW into the workspace."""
+        H, T, inf = self._model.config['hidden_size'], self.info.T, self.info
+        kind, slot, aux, _, _ = self.node_info(q, i)
+        if kind == VAL_STR:
+            return self._programs[q][i]
+        if kind == VAL_VEC:
+            return self._arena(inf.vec_off, inf.n_vec, H)[slot]
+        if kind == VAL_MAP:
+            return self._ws[inf.map_off: inf.map_off + inf.n_map * T * H].view(inf.n_map, T, H)[slot]
+        if kind == VAL_ATT:
+            return self._arena(inf.att_off, inf.n_att, T)[slot: slot + aux]
+        if kind == VAL_FRAME:
+            return self._arena(inf.att_off, inf.n_att, T)[slot]
+        if kind == VAL_PAIR:
+            v = self._arena(inf.vec_off, inf.n_vec, H)
+            return torch.stack([v[slot], v[aux]])
+        raise StairError('node has no value')
+
+    def related_attn(self, q, i):
+        _, _, _, _, rel = self.node_info(q, i)
+        return self._arena(self.info.att_off, self.info.n_att, self.info.T)[rel] if rel >= 0 else None
+
+    def levels(self, q):
+        return [self.node_info(q, i)[3] for i in range(len(self._programs[q]))]
+
+    @property
+    def token_feature(self):
+        return self._arena(self.info.tok_off, self.info.n_tok_rows, self._model.config['hidden_size'])
+
+    @property
+    def question_feature(self):
+        return self._arena(self.info.qfeat_off, self.info.n_questions, self._model.config['hidden_size'])
+
+
+class VideoNMN(nn.Module):
+    def __init__(self, config, debug=False, pretrain_modules=set()):
+        super().__init__()
+        self.debug = debug
+        self.config = dict(config)
+        self.pretrain_modules = pretrain_modules
+        self.contrastive_head = L2Normalize()
+        self.words_to_keep = set(spec.KEYWORDS)
+
+        self.submodules = nn.ModuleDict()
+        for name in spec.MODULE_NAMES:
+            self.submodules[name] = _TemporalNode() if name == 'Temporal' else _Node()
+        for name in ('video_encoder', 'text_encoder', 'decoder'):
+            self.submodules[name] = _Node()
+        for key in spec.state_dict_keys(self.config):
+            parts = key.split('.')[1:]                  # drop 'submodules'
+            node = self.submodules[parts[0]]
+            for part in parts[1:-1]:
+                if part not in node._modules:
+                    if parts[0] == 'Superlative' and part == 'localize_module':
+                        node.add_module(part, self.submodules['Localize'])      # module_net.py:31-32
+                    else:
+                        node.add_module(part, _Node())
+                node = node._modules[part]
+            if parts[-1] not in node._parameters:
+                shape = dict(spec.weight_table(self.config))[key]
+                p = nn.Parameter(torch.empty(*shape), requires_grad=False)
+                _init_param(key, p, self.config)
+                node.register_parameter(parts[-1], p)
+        if self.config['have_pretrain_head']:
+            for name in ('Filter', 'Superlative', 'ToAction'):
+                self.submodules[name].pretrain_head = self.contrastive_head     # modules.py:110,234,363
+            for name in ('Localize', 'HasItem', 'ExistsFrame'):
+                self.submodules[name].pretrain_head = nn.Identity()
+
+        cfg = StairConfig(self.config['hidden_size'], self.config['video_size'], self.config['text_size'],
+                          self.config['answer_vocab_length'], self.config['max_video_length'],
+                          self.config['object_types'], 1 if self.config['have_pretrain_head'] else 0)
+        handle = C.c_void_p()
+        check(lib.stair_ctx_create(C.byref(cfg), C.byref(handle)))
+        self._ctx = handle
+        self._weight_names = [lib.stair_weight_name(self._ctx, i).decode() for i in range(lib.stair_weight_count(self._ctx))]
+        self._bound = {}
+        self._ws = None
+        self._prog_cache = {}
+
+    def __del__(self):
+        if getattr(self, '_ctx', None):
+            lib.stair_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    # ---------------------------------------------------------------------------------------
+    def _bind_weights(self):
+        """(Re)hand the current parameter storage to the ctx; pointers are borrowed by the library."""
+        sd = dict(self.named_parameters())
+        for i, name in enumerate(self._weight_names):
+            p = sd[name]
+            if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                raise RuntimeError('parameter %s must be a contiguous float32 tensor on the GPU; call model.cuda()' % name)
+            if self._bound.get(name) != p.data_ptr():
+                check(lib.stair_ctx_set_weight(self._ctx, i, C.c_void_p(p.data_ptr()), p.numel()))
+                self._bound[name] = p.data_ptr()
+
+    def _workspace(self, nbytes, device):
+        n = (nbytes + 3) // 4
+        if self._ws is None or self._ws.numel() < n or self._ws.device != device:
+            self._ws = torch.empty(int(n * 1.25), dtype=torch.float32, device=device)
+        return self._ws
+
+    def _encode_program(self, program):
+        key = tuple(program)
+        hit = self._prog_cache.get(key)
+        if hit is None:
+            codes = np.asarray(spec.encode_program(program), dtype=np.int32)
+            hit = (codes, np.nonzero(codes == spec.TOK_SPAN)[0])
+            self._prog_cache[key] = hit
+        return hit
+
+    # ---------------------------------------------------------------------------------------
+    def run_programs(self, programs, spans, video, question, q_lens):
+        """Batched pass.  programs: list of token lists; spans: list of {pos: (lo, hi)}; video
+        [n,T,V] and question [sum(q_lens), E] float32 on the GPU.  Returns a BatchResult."""
+        n = len(programs)
+        if video.dim() != 3 or video.shape[0] != n:
+            raise ValueError('video must be [n, T, V]')
+        ops._req(video, 'video'); ops._req(question, 'question')
+        T = video.shape[1]
+        self._bind_weights()
+        enc = [self._encode_program(p) for p in programs]
+        prog_off = np.zeros(n + 1, dtype=np.int32)
+        np.cumsum([len(e[0]) for e in enc], out=prog_off[1:])
+        tokens = np.concatenate([e[0] for e in enc])
+        lo = np.zeros(tokens.shape[0], dtype=np.int32)
+        hi = np.zeros(tokens.shape[0], dtype=np.int32)
+        for q, (codes, pos) in enumerate(enc):
+            sp, base = spans[q], prog_off[q]
+            for i in pos:
+                try:
+                    s, e = sp[int(i)]
+                except KeyError:
+                    raise KeyError(int(i))          # the reference fails the same way, module_net.py:127
+                lo[base + i], hi[base + i] = s, e
+        q_off = np.zeros(n + 1, dtype=np.int32)
+        np.cumsum(np.asarray(q_lens, dtype=np.int64), out=q_off[1:])
+        if question.shape[0] != int(q_off[-1]):
+            raise ValueError('question rows (%d) != sum(q_lens) (%d)' % (question.shape[0], int(q_off[-1])))
+
+        def ip(a):
+            return a.ctypes.data_as(C.POINTER(C.c_int32))
+        plan = C.c_void_p()
+        check(lib.stair_plan_build(self._ctx, n, ip(prog_off), ip(tokens), ip(lo), ip(hi), ip(q_off), T, C.byref(plan)))
+        try:
+            info = PlanInfo()
+            check(lib.stair_plan_get_info(plan, C.byref(info)))
+            ws = self._workspace(info.workspace_bytes, video.device)
+            A = self.config['answer_vocab_length']
+            logits = torch.empty(n, A, dtype=torch.float32, device=video.device)
+            pred = torch.empty(n, dtype=torch.int32, device=video.device)
+            check(lib.stair_plan_run(self._ctx, plan, C.c_void_p(video.data_ptr()), C.c_void_p(question.data_ptr()),
+                                     C.c_void_p(ws.data_ptr()), ws.numel() * 4, C.c_void_p(logits.data_ptr()),
+                                     C.c_void_p(pred.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        except Exception:
+            lib.stair_plan_destroy(plan)
+            raise
+        return BatchResult(self, plan, info, ws, logits, pred, prog_off, programs)
+
+    def forward_batch(self, batch):
+        """batch: list of question dicts in the reference layout (dataset.py:191-233), all with the
+        same number of frames.  Tensors may live on the host; they are moved once, packed."""
+        dev = next(self.parameters()).device
+        video = torch.stack([torch.as_tensor(d['video_features']) for d in batch]).to(dev, torch.float32).contiguous()
+        qs = [torch.as_tensor(d['question']) for d in batch]
+        question = torch.cat(qs).to(dev, torch.float32).contiguous()
+        return self.run_programs([d['nmn_program_list'] for d in batch],
+                                 [d['prog_str_to_question_tokens'] for d in batch], video, question,
+                                 [q.shape[0] for q in qs])
+
+    # ---------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, data, return_res_by_step=True, return_result_of_each_step=False, test_mode=False):
+        """Single-question form with the reference's return dict (module_net.py:65-145)."""
+        program_list, program_idx = data['nmn_program_list'], data['nmn_program_idx']
+        res = self.forward_batch([data])
+        heads = self.config['have_pretrain_head']
+
+        new_sg_res_by_step = dict()
+        if not test_mode:
+            for key, value in data.get('sg_res_by_step', {}).items():      # module_net.py:78-89
+                if isinstance(value, list) and len(value) and isinstance(value[0][1], torch.Tensor):
+                    ans = []
+                    for v_class_name, v_emb in value:
+                        _, v_emb = self.encode_question_no_grad(v_emb)
+                        ans.append((v_class_name, self.contrastive_head(v_emb)))
+                    new_sg_res_by_step[key] = ans
+                else:
+                    new_sg_res_by_step[key] = value
+
+        res_by_step, each = dict(), []
+        arity = spec.ARITY
+        if return_res_by_step or return_result_of_each_step:
+            values = [res.node(0, i) for i in range(len(program_list))]
+            values = [v.clone() if isinstance(v, torch.Tensor) else v for v in values]
+            # children of each module token, in pop order (module_net.py:100-106)
+            stack, children = [], [None] * len(program_list)
+            for i in range(len(program_list) - 1, -1, -1):
+                if program_list[i] in arity:
+                    children[i] = [stack.pop() for _ in range(arity[program_list[i]])]
+                stack.append(i)
+            for i in range(len(program_list) - 1, -1, -1):
+                prog = program_list[i]
+                if prog in arity:
+                    result = values[i]
+                    if prog == 'Temporal':
+                        self.submodules['Temporal'].related_attn = res.related_attn(0, i).clone()
+                    if return_res_by_step and program_idx[i] is not None and prog in self.pretrain_modules and i != 0:
+                        out = self.submodules[prog].pretrain_head(result) if heads else result
+                        res_by_step[program_idx[i]] = (prog, out)
+                    if return_result_of_each_step:
+                        params = [values[c] for c in children[i]]
+                        if heads and prog in self.pretrain_modules:
+                            each.append((params, self.submodules[prog].pretrain_head(result)))
+                        else:
+                            each.append((params, result))
+                elif return_result_of_each_step:
+                    each.append(([], values[i]))
+
+        ret = {'logits': res.logits[0], 'res_by_step': res_by_step}
+        if return_result_of_each_step:
+            ret['result_of_each_step'] = list(reversed(each))
+        if not test_mode:
+            ret['sg_res_by_step'] = new_sg_res_by_step
+        return ret
+
+    @torch.no_grad()
+    def encode_question_no_grad(self, question):
+        return self.encode_question(question)
+
+    def _lstm_weights(self, enc):
+        m = self.submodules[enc]
+        return [getattr(m, n + sfx) for sfx in ('', '_reverse')
+                for n in ('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0')]
+
+    def encode_question(self, question):
+        """module_net.py:151-158 -> (token_feature [Q,H], sentence feature [H])."""
+        dev = next(self.parameters()).device
+        x = torch.as_tensor(question).to(dev, torch.float32).contiguous()
+        off = torch.tensor([0, x.shape[0]], dtype=torch.int32, device=dev)
+        out, h_n = ops.lstm_bidir(x, off, x.shape[0], self._lstm_weights('text_encoder'))
+        return out, h_n[0]
+
+    def encode_video(self, video_feat):
+        """module_net.py:160-163 -> [T,H]."""
+        dev = next(self.parameters()).device
+        x = torch.as_tensor(video_feat).to(dev, torch.float32).contiguous()
+        off = torch.tensor([0, x.shape[0]], dtype=torch.int32, device=dev)
+        out, _ = ops.lstm_bidir(x, off, x.shape[0], self._lstm_weights('video_encoder'))
+        return out

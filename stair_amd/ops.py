@@ -1,0 +1,119 @@
+"""Thin tensor-level wrappers over the C ABI (include/stair_hip.h).
+
+torch is used only for device memory and the current stream; all arithmetic happens in
+libstair_hip.so.  Every function requires CUDA(ROCm) float32 contiguous tensors and raises otherwise
+-- there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from ._lib import GemmArgs, LstmArgs, check, lib
+
+ACT = {None: 0, 'none': 0, 'relu': 1, 'sigmoid': 2}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(t, name, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError('%s must be a tensor on the GPU (the HIP path has no CPU fallback)' % name)
+    if t.dtype != dtype or not t.is_contiguous():
+        raise RuntimeError('%s must be contiguous %s' % (name, dtype))
+    return t
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def linear(x, weight, bias=None, act=None):
+    """act(x @ weight.T + bias) through stair_gemm_f32.  x [..., K] -> [..., N]."""
+    _req(x, 'x'); _req(weight, 'weight')
+    K = x.shape[-1]
+    N = weight.shape[0]
+    assert weight.shape[1] == K
+    x2 = x.reshape(-1, K)
+    out = torch.empty(x2.shape[0], N, device=x.device, dtype=torch.float32)
+    a = GemmArgs()
+    a.A, a.lda, a.a_gstride, a.a_gidx = x2.data_ptr(), K, K, None
+    a.W, a.ldw, a.bias = weight.data_ptr(), K, (bias.data_ptr() if bias is not None else None)
+    a.C, a.ldc, a.c_gstride, a.c_gidx = out.data_ptr(), N, N, None
+    a.row_scale, a.rs_gstride, a.rs_gidx = None, 0, None
+    a.groups, a.rows_per_group, a.N, a.K, a.act = x2.shape[0], 1, N, K, ACT[act]
+    check(lib.stair_gemm_f32(C.byref(a), _stream()))
+    return out.reshape(*x.shape[:-1], N)
+
+
+def gemm_grouped(A, a_gstride, a_gidx, W, bias, Cmat, c_gstride, c_gidx, groups, rows_per_group, N, K, act=None,
+                 lda=None, ldc=None, row_scale=None, rs_gstride=0, rs_gidx=None):
+    """Raw grouped form (see stair_gemm_args)."""
+    a = GemmArgs()
+    a.A, a.lda, a.a_gstride, a.a_gidx = A.data_ptr(), lda or K, a_gstride, (a_gidx.data_ptr() if a_gidx is not None else None)
+    a.W, a.ldw, a.bias = W.data_ptr(), K, (bias.data_ptr() if bias is not None else None)
+    a.C, a.ldc, a.c_gstride, a.c_gidx = Cmat.data_ptr(), ldc or N, c_gstride, (c_gidx.data_ptr() if c_gidx is not None else None)
+    a.row_scale = row_scale.data_ptr() if row_scale is not None else None
+    a.rs_gstride, a.rs_gidx = rs_gstride, (rs_gidx.data_ptr() if rs_gidx is not None else None)
+    a.groups, a.rows_per_group, a.N, a.K, a.act = groups, rows_per_group, N, K, ACT[act]
+    check(lib.stair_gemm_f32(C.byref(a), _stream()))
+
+
+def lstm_bidir(x, seq_off, max_len, weights):
+    """Bidirectional LSTM over packed ragged sequences.
+
+    x [rows, I]; seq_off int32 [n+1] (device); weights = (w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r).
+    Returns (out [rows, 2*Hh], h_n [n, 2*Hh]).
+    """
+    _req(x, 'x'); _req(seq_off, 'seq_off', torch.int32)
+    for w in weights:
+        _req(w, 'lstm weight')
+    rows, I = x.shape
+    n = seq_off.numel() - 1
+    Hh = weights[1].shape[1]
+    out = torch.empty(rows, 2 * Hh, device=x.device, dtype=torch.float32)
+    h_n = torch.empty(n, 2 * Hh, device=x.device, dtype=torch.float32)
+    xproj = torch.empty(rows, 8 * Hh, device=x.device, dtype=torch.float32)
+    bias_ws = torch.empty(8 * Hh, device=x.device, dtype=torch.float32)
+    a = LstmArgs()
+    a.x, a.ldx, a.rows, a.n, a.max_len, a.I, a.Hh = x.data_ptr(), I, rows, n, max_len, I, Hh
+    a.seq_off = seq_off.data_ptr()
+    for d in range(2):
+        a.w_ih[d], a.w_hh[d] = weights[4 * d].data_ptr(), weights[4 * d + 1].data_ptr()
+        a.b_ih[d], a.b_hh[d] = weights[4 * d + 2].data_ptr(), weights[4 * d + 3].data_ptr()
+    a.xproj_ws, a.bias_ws = xproj.data_ptr(), bias_ws.data_ptr()
+    a.out, a.ldo, a.h_n = out.data_ptr(), 2 * Hh, h_n.data_ptr()
+    check(lib.stair_lstm_bidir_fwd(C.byref(a), _stream()))
+    return out, h_n
+
+
+def l2normalize(x):
+    """x / max(||x||, 1e-12) over the last dim (module_net.py:211-216 applied row-wise)."""
+    _req(x, 'x')
+    H = x.shape[-1]
+    out = torch.empty_like(x)
+    check(lib.stair_l2normalize_fwd(_ptr(x), _ptr(out), x.numel() // H, H, _stream()))
+    return out
+
+
+def cosine_attn(F, f_idx, Kmat, k_idx, npairs, T, H, out=None, out_idx=None):
+    """(cos + 1) * 0.49 rows; F [G,T,H], Kmat [*,H]; returns att [npairs, T] unless `out` is given."""
+    _req(F, 'F'); _req(Kmat, 'Kmat')
+    if out is None:
+        out = torch.empty(npairs, T, device=F.device, dtype=torch.float32)
+    check(lib.stair_cosine_attn_fwd(_ptr(F), T * H, _ptr(f_idx), _ptr(Kmat), _ptr(k_idx), _ptr(out), _ptr(out_idx),
+                                    npairs, T, H, _stream()))
+    return out
+
+
+def temporal_relate(att, att_idx, att_k, n, T, mode, conv, ksize, w6):
+    """Temporal relate nets; att [rows,T]; returns r [n,T]."""
+    _req(att, 'att')
+    out = torch.empty(n, T, device=att.device, dtype=torch.float32)
+    arr = (C.c_void_p * 6)(*[(w.data_ptr() if w is not None else None) for w in w6])
+    check(lib.stair_temporal_relate_fwd(_ptr(att), _ptr(att_idx), _ptr(att_k), _ptr(out), None, n, T, mode,
+                                        1 if conv else 0, ksize, arr, _stream()))
+    return out

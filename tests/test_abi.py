@@ -1,0 +1,156 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads and exports every symbol the header
+declares, its weight table equals the reference's state_dict keys, the VideoNMN mirror has the
+reference's state_dict layout, and the plan builder (host-only code) levels programs exactly like
+utils/program_parser.py::stat_module_levels.  No kernel is launched here."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from stair_amd import spec, synth
+from stair_amd import _lib
+from stair_amd._lib import lib, check, StairConfig, PlanInfo, StairError
+from helpers import GOLDEN
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    header = open(os.path.join(ROOT, 'include', 'stair_hip.h')).read()
+    header = re.sub(r'/\*.*?\*/', '', header, flags=re.S)
+    declared = set(re.findall(r'\b(stair_[a-z0-9_]+)\s*\(', header))
+    bound = {name for name, _, _ in _lib.SIGNATURES}
+    assert declared == bound, (declared ^ bound)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.stair_abi_version() == 1
+
+
+def _ctx(config):
+    cfg = StairConfig(config['hidden_size'], config['video_size'], config['text_size'], config['answer_vocab_length'],
+                      config['max_video_length'], config['object_types'], 1 if config['have_pretrain_head'] else 0)
+    h = C.c_void_p()
+    check(lib.stair_ctx_create(C.byref(cfg), C.byref(h)))
+    return h
+
+
+CONFIGS = [
+    dict(spec.DEFAULT_CONFIG),
+    dict(spec.DEFAULT_CONFIG, have_pretrain_head=False),
+    dict(spec.DEFAULT_CONFIG, max_video_length=8, video_size=4096),
+    dict(spec.DEFAULT_CONFIG, max_video_length=150),          # args.py:29 default -> k = round(37.5) = 38
+    dict(spec.DEFAULT_CONFIG, hidden_size=64, video_size=128, answer_vocab_length=16, max_video_length=40, object_types=10),
+]
+
+
+@pytest.mark.parametrize('config', CONFIGS)
+def test_weight_table_matches_spec(config):
+    h = _ctx(config)
+    try:
+        table = spec.weight_table(config)
+        assert lib.stair_weight_count(h) == len(table)
+        for i, (name, shape) in enumerate(table):
+            assert lib.stair_weight_name(h, i).decode() == name
+            assert lib.stair_weight_numel(h, i) == int(np.prod(shape)), name
+    finally:
+        lib.stair_ctx_destroy(h)
+
+
+def test_bad_config_is_rejected():
+    cfg = StairConfig(100, 2048, 300, 172, 64, 36, 1)
+    h = C.c_void_p()
+    assert lib.stair_ctx_create(C.byref(cfg), C.byref(h)) != 0
+    assert b'hidden_size' in lib.stair_last_error()
+
+
+@pytest.mark.parametrize('heads', [True, False])
+def test_videonmn_state_dict_layout(heads):
+    from stair_amd.module_net import VideoNMN
+    config = dict(spec.DEFAULT_CONFIG, hidden_size=64, video_size=128, answer_vocab_length=16, max_video_length=40,
+                  object_types=10, have_pretrain_head=heads)
+    m = VideoNMN(config)
+    sd = m.state_dict()
+    assert list(sd.keys()) == spec.state_dict_keys(config)
+    shapes = dict(spec.weight_table(config))
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(shapes[spec.WEIGHT_ALIASES.get(k, k)]), k
+    # Superlative.localize_module IS Localize (module_net.py:31-32)
+    assert sd['submodules.Superlative.localize_module.video_linear.0.weight'].data_ptr() == \
+        sd['submodules.Localize.video_linear.0.weight'].data_ptr()
+    # loading a reference-layout checkpoint works
+    w = synth.make_weights(config, 3)
+    import torch
+    m.load_state_dict({k: torch.from_numpy(w[k].copy()) for k in spec.state_dict_keys(config)})
+    assert np.array_equal(m.state_dict()['submodules.decoder.3.bias'].numpy(), w['submodules.decoder.3.bias'])
+
+
+def _build(config, programs, spans, q_lens, T):
+    h = _ctx(config)
+    enc = [np.asarray(spec.encode_program(p), dtype=np.int32) for p in programs]
+    n = len(programs)
+    prog_off = np.zeros(n + 1, np.int32); np.cumsum([len(e) for e in enc], out=prog_off[1:])
+    tokens = np.concatenate(enc)
+    lo = np.zeros(len(tokens), np.int32); hi = np.zeros(len(tokens), np.int32)
+    for q in range(n):
+        for i, c in enumerate(enc[q]):
+            if c == spec.TOK_SPAN:
+                lo[prog_off[q] + i], hi[prog_off[q] + i] = spans[q][i]
+    q_off = np.zeros(n + 1, np.int32); np.cumsum(q_lens, out=q_off[1:])
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    plan = C.c_void_p()
+    rc = lib.stair_plan_build(h, n, ip(prog_off), ip(tokens), ip(lo), ip(hi), ip(q_off), T, C.byref(plan))
+    return h, plan, rc, prog_off
+
+
+def test_plan_levels_match_reference_stat_module_levels():
+    progs = json.load(open(os.path.join(GOLDEN, 'programs.json')))
+    progs.pop('_nary_mappings')
+    config = dict(spec.DEFAULT_CONFIG)
+    names = sorted(progs)
+    qs = [synth.make_question(config, 0, i, form=name, with_video=False) for i, name in enumerate(names)]
+    h, plan, rc, prog_off = _build(config, [q['nmn_program_list'] for q in qs],
+                                   [q['prog_str_to_question_tokens'] for q in qs], [q['question'].shape[0] for q in qs], 64)
+    assert rc == 0, lib.stair_last_error()
+    try:
+        for qi, name in enumerate(names):
+            lv = []
+            for i in range(len(progs[name]['nmn'])):
+                k, s, a, l, r = (C.c_int32() for _ in range(5))
+                check(lib.stair_plan_node(plan, int(prog_off[qi] + i), C.byref(k), C.byref(s), C.byref(a), C.byref(l), C.byref(r)))
+                lv.append(l.value)
+            assert lv == progs[name]['levels'], name
+        info = PlanInfo()
+        check(lib.stair_plan_get_info(plan, C.byref(info)))
+        assert info.n_questions == len(names) and info.n_levels == 1 + max(max(p['levels']) for p in progs.values())
+        assert info.workspace_bytes > 0 and info.vec_off % config['hidden_size'] == 0 and info.map_off % config['hidden_size'] == 0
+    finally:
+        lib.stair_plan_destroy(plan)
+        lib.stair_ctx_destroy(h)
+
+
+@pytest.mark.parametrize('program,msg', [
+    (['Filter', 'video'], 'stack underflow'),                              # invalid: missing operand
+    (['video', 'video'], 'stack holds 2'),                                 # assert len(stack)==1, module_net.py:135
+    (['Temporal', 'while', 'video', 'Localize', 'video', 'x'], 'root must produce'),   # root is a [T,H] map
+    (['Filter', 'dish', 'objects'], 'kind mismatch'),                      # feat is not a map
+    (['Exists', 'dish', 'Filter', 'video', 'max'], 'Filter keyword'),      # KeyError 'max' in the reference
+])
+def test_invalid_programs_are_rejected(program, msg):
+    config = dict(spec.DEFAULT_CONFIG)
+    spans = {i: (1, 2) for i in range(len(program))}
+    h, plan, rc, _ = _build(config, [program], [spans], [8], 64)
+    try:
+        assert rc != 0
+        assert msg in lib.stair_last_error().decode(), lib.stair_last_error()
+    finally:
+        lib.stair_ctx_destroy(h)
+
+
+def test_linear_temporal_requires_full_length():
+    config = dict(spec.DEFAULT_CONFIG, max_video_length=8)
+    h, plan, rc, _ = _build(config, [['Filter', 'video', 'objects']], [{}], [8], 6)
+    assert rc != 0 and b'max_video_length' in lib.stair_last_error()
+    lib.stair_ctx_destroy(h)
