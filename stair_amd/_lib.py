@@ -8,6 +8,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch must be imported BEFORE the library is dlopened: torch ships its own libamdhip64.so (SONAME
+# libamdhip64.so.7) and our NEEDED entry then resolves to that already-loaded runtime.  Loading in the
+# other order puts two HIP runtimes into one process and the second one finds no device.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libstair_hip.so')
 
