@@ -172,7 +172,8 @@ def main():
             'path_tflops': round(ALGO_FLOP_PER_QUESTION * qps / world / 1e12, 2),
         }
         if not args.no_cpu_baseline:
-            ncores = os.cpu_count() or 1
+            # the box gives one GPU a 16-core CPU share; more ATen threads than that only thrash
+            ncores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
             torch.set_num_threads(ncores)
             cpu_qps, n_done, preds, cpu_logits = cpu_baseline(config, weights, qs, video, question, q_lens)
             gpu_pred = res.pred[:n_done].cpu().tolist()

@@ -32,6 +32,12 @@ __device__ __forceinline__ int lds_off(int buf, int which, int kq, int row) {
     return ((((buf * 2 + which) * KQ + kq) * 128) + (row ^ kq)) * 4;
 }
 
+using v4f = __attribute__((ext_vector_type(4))) float;
+// explicit global address space: pointers that arrive inside a by-value struct are otherwise treated
+// as generic and lowered to flat_load, which counts on lgkmcnt as well and so drains the prefetch at
+// every LDS wait of the fragment loop.
+using gv4p = const __attribute__((address_space(1))) v4f *;
+
 template <int ACT>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -49,90 +55,96 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     const int tm = logical / p.tilesN, tn = logical - tm * p.tilesN;
     const int m0 = tm * BM, n0 = tn * BN;
     const int R = a.rows_per_group;
+    const int K = a.K;
 
-    // staging assignment: thread -> float4 column kq, rows r0 + 32 i
+    // staging assignment: thread -> float4 column kq, rows r0 + 32 i.  Rows past M / N are clamped
+    // to the last valid row: their products are computed and never stored (the epilogue masks them),
+    // so the loads need no predicate.  Columns past K are clamped too and zeroed through the scale.
     const int kq = tid & 7, r0 = tid >> 3;
-    const float *aptr[4];
-    const float *wptr[4];
-    float rscale[4];
+    const float *aptr0, *aptr1, *aptr2, *aptr3, *wptr0, *wptr1, *wptr2, *wptr3;
+    float rs0, rs1, rs2, rs3;
+    {
+        const float *ap[4];
+        const float *wp[4];
+        float rs[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + r0 + 32 * i;
-        aptr[i] = nullptr;
-        rscale[i] = 1.0f;
-        if (m < p.M) {
+        for (int i = 0; i < 4; ++i) {
+            const int m = min(m0 + r0 + 32 * i, p.M - 1);
             const int g = m / R, rr = m - g * R;
             const int64_t gi = a.a_gidx ? a.a_gidx[g] : g;
-            aptr[i] = a.A + gi * a.a_gstride + (int64_t)rr * a.lda;
+            ap[i] = a.A + gi * a.a_gstride + (int64_t)rr * a.lda;
+            rs[i] = 1.0f;
             if (a.row_scale) {
                 const int64_t si = a.rs_gidx ? a.rs_gidx[g] : g;
-                rscale[i] = a.row_scale[si * a.rs_gstride + rr];
+                rs[i] = a.row_scale[si * a.rs_gstride + rr];
             }
+            const int n = min(n0 + r0 + 32 * i, a.N - 1);
+            wp[i] = a.W + (int64_t)n * a.ldw;
         }
-        const int n = n0 + r0 + 32 * i;
-        wptr[i] = n < a.N ? a.W + (int64_t)n * a.ldw : nullptr;
+        aptr0 = ap[0]; aptr1 = ap[1]; aptr2 = ap[2]; aptr3 = ap[3];
+        wptr0 = wp[0]; wptr1 = wp[1]; wptr2 = wp[2]; wptr3 = wp[3];
+        rs0 = rs[0]; rs1 = rs[1]; rs2 = rs[2]; rs3 = rs[3];
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc00, acc01, acc10, acc11;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    for (int e = 0; e < 16; ++e) acc00[e] = acc01[e] = acc10[e] = acc11[e] = 0.0f;
 
-    float4 ra[4], rb[4];
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto gload = [&](int k0) {
-        const int k = k0 + 4 * kq;
-        const bool kin = k < a.K;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ra[i] = (aptr[i] && kin) ? *reinterpret_cast<const float4 *>(aptr[i] + k) : zero4;
-            rb[i] = (wptr[i] && kin) ? *reinterpret_cast<const float4 *>(wptr[i] + k) : zero4;
-        }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float4 v = ra[i];
-            const float s = rscale[i];
-            v.x *= s; v.y *= s; v.z *= s; v.w *= s;
-            *reinterpret_cast<float4 *>(&lds[lds_off(buf, 0, kq, r0 + 32 * i)]) = v;
-            *reinterpret_cast<float4 *>(&lds[lds_off(buf, 1, kq, r0 + 32 * i)]) = rb[i];
-        }
-    };
+    v4f ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    float kmask;
+#define STAIR_GLOAD(k0)                                                       \
+    {                                                                         \
+        const int kraw = (k0) + 4 * kq;                                       \
+        const int k = min(kraw, K - 4);                                       \
+        kmask = kraw < K ? 1.0f : 0.0f;                                       \
+        ra0 = *(gv4p)(aptr0 + k); ra1 = *(gv4p)(aptr1 + k);                   \
+        ra2 = *(gv4p)(aptr2 + k); ra3 = *(gv4p)(aptr3 + k);                   \
+        rb0 = *(gv4p)(wptr0 + k); rb1 = *(gv4p)(wptr1 + k);                   \
+        rb2 = *(gv4p)(wptr2 + k); rb3 = *(gv4p)(wptr3 + k);                   \
+    }
+#define STAIR_LSTORE(buf)                                                                     \
+    {                                                                                         \
+        *reinterpret_cast<v4f *>(&lds[lds_off(buf, 0, kq, r0)]) = ra0 * (rs0 * kmask);        \
+        *reinterpret_cast<v4f *>(&lds[lds_off(buf, 0, kq, r0 + 32)]) = ra1 * (rs1 * kmask);   \
+        *reinterpret_cast<v4f *>(&lds[lds_off(buf, 0, kq, r0 + 64)]) = ra2 * (rs2 * kmask);   \
+        *reinterpret_cast<v4f *>(&lds[lds_off(buf, 0, kq, r0 + 96)]) = ra3 * (rs3 * kmask);   \
+        *reinterpret_cast<v4f *>(&lds[lds_off(buf, 1, kq, r0)]) = rb0;                        \
+        *reinterpret_cast<v4f *>(&lds[lds_off(buf, 1, kq, r0 + 32)]) = rb1;                   \
+        *reinterpret_cast<v4f *>(&lds[lds_off(buf, 1, kq, r0 + 64)]) = rb2;                   \
+        *reinterpret_cast<v4f *>(&lds[lds_off(buf, 1, kq, r0 + 96)]) = rb3;                   \
+    }
 
-    const int nchunks = (a.K + BK - 1) / BK;
-    gload(0);
-    lstore(0);
+    const int nchunks = (K + BK - 1) / BK;
+    STAIR_GLOAD(0);
+    STAIR_LSTORE(0);
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
-        if (c + 1 < nchunks) gload((c + 1) * BK);
+        // prefetch the next chunk into registers (the last iteration re-reads its own chunk: the
+        // loads stay unconditional and the data is simply not used)
+        STAIR_GLOAD(min(c + 1, nchunks - 1) * BK);
+        __builtin_amdgcn_sched_barrier(0);   // keep the loads ABOVE the MFMA phase (hipcc sinks them otherwise)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int fq = 2 * q + h;
-            float4 af[2], bf[2];
+            const v4f a0 = *reinterpret_cast<const v4f *>(&lds[lds_off(buf, 0, fq, wm * 64 + r)]);
+            const v4f a1 = *reinterpret_cast<const v4f *>(&lds[lds_off(buf, 0, fq, wm * 64 + 32 + r)]);
+            const v4f b0 = *reinterpret_cast<const v4f *>(&lds[lds_off(buf, 1, fq, wn * 64 + r)]);
+            const v4f b1 = *reinterpret_cast<const v4f *>(&lds[lds_off(buf, 1, fq, wn * 64 + 32 + r)]);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                af[t] = *reinterpret_cast<const float4 *>(&lds[lds_off(buf, 0, fq, wm * 64 + t * 32 + r)]);
-                bf[t] = *reinterpret_cast<const float4 *>(&lds[lds_off(buf, 1, fq, wn * 64 + t * 32 + r)]);
+            for (int j = 0; j < 4; ++j) {
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc00, 0, 0, 0);
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc01, 0, 0, 0);
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc10, 0, 0, 0);
+                acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc11, 0, 0, 0);
             }
-            const float *afp = reinterpret_cast<const float *>(af);
-            const float *bfp = reinterpret_cast<const float *>(bf);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(afp[mt * 4 + j], bfp[nt * 4 + j],
-                                                                           acc[mt][nt], 0, 0, 0);
         }
-        if (c + 1 < nchunks) lstore(buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        STAIR_LSTORE(buf ^ 1);
         __syncthreads();
     }
+#undef STAIR_GLOAD
+#undef STAIR_LSTORE
 
     // epilogue: per-row output offsets through LDS (the group gather needs a division per row)
     long long *rowoff = reinterpret_cast<long long *>(lds);
@@ -147,6 +159,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         rowoff[tid] = off;
     }
     __syncthreads();
+    __attribute__((address_space(1))) float *Cg = (__attribute__((address_space(1))) float *)a.C;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int n = n0 + wn * 64 + nt * 32 + r;
@@ -154,15 +167,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         const float b = a.bias ? a.bias[n] : 0.0f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
+            const f32x16 &acc = mt == 0 ? (nt == 0 ? acc00 : acc01) : (nt == 0 ? acc10 : acc11);
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int rowl = wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 const long long off = rowoff[rowl];
                 if (off < 0) continue;
-                float v = acc[mt][nt][e] + b;
+                float v = acc[e] + b;
                 if (ACT == 1) v = fmaxf(v, 0.0f);
                 if (ACT == 2) v = sigmoid_acc(v);
-                a.C[off + n] = v;
+                Cg[off + n] = v;
             }
         }
     }
