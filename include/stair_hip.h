@@ -40,7 +40,7 @@ typedef void *stair_stream; /* hipStream_t */
 /* Model configuration: the keys of the reference's config dict that change shapes
  * (/root/reference/train_module.py:304-310). */
 typedef struct stair_config {
-    int32_t hidden_size;         /* H, multiple of 32; H/2 (LSTM hidden) multiple of 16, <= 256 or 2^k*16 */
+    int32_t hidden_size;         /* H, multiple of 64, <= 512 (Hh = H/2 tiles in blocks of 32) */
     int32_t video_size;          /* V, multiple of 4 */
     int32_t text_size;           /* E (300), multiple of 4 */
     int32_t answer_vocab_length; /* A */
@@ -106,13 +106,14 @@ int stair_gemm_f32(const stair_gemm_args *args, stair_stream stream);
 /* Bidirectional single-layer LSTM over n ragged sequences (nn.LSTM as used at
  * module_net.py:39-47,151-163).  x [rows, I] with sequence s at rows seq_off[s]..seq_off[s+1]-1
  * (seq_off on device, int32 [n+1]; max_len = longest sequence).  w_* are the eight tensors of the
- * reference layer, forward then reverse.  xproj_ws: device scratch [rows, 8*Hh] floats; bias_ws
- * [8*Hh].  out [rows, 2*Hh]; h_n [n, 2*Hh] = [h_fwd(last) ; h_bwd(first)]. */
+ * reference layer, forward then reverse.  Device scratch: xproj_ws [rows, 8*Hh] floats, bias_ws
+ * [8*Hh], whh_pack_ws [8*Hh*Hh] (W_hh re-laid in MFMA fragment order, rebuilt every call).
+ * out [rows, 2*Hh]; h_n [n, 2*Hh] = [h_fwd(last) ; h_bwd(first)]. */
 typedef struct stair_lstm_args {
     const float *x; int64_t ldx; int32_t rows, n, max_len, I, Hh;
     const int32_t *seq_off;
     const float *w_ih[2], *w_hh[2], *b_ih[2], *b_hh[2];
-    float *xproj_ws, *bias_ws;
+    float *xproj_ws, *bias_ws, *whh_pack_ws;
     float *out; int64_t ldo; float *h_n;
 } stair_lstm_args;
 int stair_lstm_bidir_fwd(const stair_lstm_args *args, stair_stream stream);

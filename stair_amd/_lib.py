@@ -38,7 +38,7 @@ class LstmArgs(C.Structure):
     _fields_ = [('x', C.c_void_p), ('ldx', C.c_int64), ('rows', C.c_int32), ('n', C.c_int32),
                 ('max_len', C.c_int32), ('I', C.c_int32), ('Hh', C.c_int32), ('seq_off', C.c_void_p),
                 ('w_ih', C.c_void_p * 2), ('w_hh', C.c_void_p * 2), ('b_ih', C.c_void_p * 2), ('b_hh', C.c_void_p * 2),
-                ('xproj_ws', C.c_void_p), ('bias_ws', C.c_void_p),
+                ('xproj_ws', C.c_void_p), ('bias_ws', C.c_void_p), ('whh_pack_ws', C.c_void_p),
                 ('out', C.c_void_p), ('ldo', C.c_int64), ('h_n', C.c_void_p)]
 
 

@@ -18,11 +18,10 @@
 
 namespace stair {
 
-using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 struct LstmRecParams {
     const float *xproj;      // [rows, 8Hh]
-    const float *w_hh[2];    // [4Hh, Hh]
+    const float *w_pack;     // [2][Hh/32][4*Hh/16][2][64][4] W_hh in MFMA-fragment order (see whh_pack_kernel)
     const int32_t *seq_off;  // [n+1]
     float *out;              // [rows, ldo]
     int64_t ldo;
@@ -36,16 +35,54 @@ __global__ void bias_sum_kernel(const float *a0, const float *b0, const float *a
     else if (i < 2 * n4) out[i] = a1[i - n4] + b1[i - n4];
 }
 
+// Re-lay W_hh [4Hh, Hh] (both directions) into the order the recurrent kernel's B fragments are read:
+//   pack[dir][kb][tile][half][lane][j] = W_hh[dir][tile*16 + (lane&15)][32*kb + 8*(lane>>4) + 4*half + j]
+// so that one wave-wide 16-byte load is 1 KiB contiguous.  In W_hh's own layout the 16 lanes that form
+// an MFMA column group sit in 16 different rows (1 KiB apart): every load instruction then touches 64
+// scattered 16-B pieces and the texture path, not L2, bounds the recurrence (measured: MFMA pipe 40 % busy).
+__global__ void whh_pack_kernel(const float *w0, const float *w1, float *pack, int Hh) {
+    const int64_t per_dir = 4 * (int64_t)Hh * Hh;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one float4 per thread
+    if (i >= 2 * per_dir / 4) return;
+    const int64_t e = i * 4;
+    const int dir = (int)(e / per_dir);
+    int64_t r = e - dir * per_dir;
+    const int lane = (int)((r >> 2) & 63);
+    r >>= 8;
+    const int half = (int)(r & 1);
+    r >>= 1;
+    const int ntile = 4 * Hh / 16;
+    const int tile = (int)(r % ntile), kb = (int)(r / ntile);
+    const float *w = dir == 0 ? w0 : w1;
+    const float4 v = *reinterpret_cast<const float4 *>(w + (int64_t)(tile * 16 + (lane & 15)) * Hh + 32 * kb + 8 * (lane >> 4) + 4 * half);
+    *reinterpret_cast<float4 *>(pack + e) = v;
+}
+
+using v4f = __attribute__((ext_vector_type(4))) float;
+using gv4p = const __attribute__((address_space(1))) v4f *;
+using gfp = const __attribute__((address_space(1))) float *;
+
+// One step of the recurrence per loop trip.  The W_hh fragments of a 32-wide k block are split in
+// two groups (gates i,f | g,o per owned tile column); while the MFMAs of one group run, the loads
+// of the other group (or of the next k block) are in flight, so the L2 latency of the weight
+// stream is hidden behind matrix work instead of being paid 2*Hh/32 times per step.  Every lane
+// reads two adjacent float4 of a W_hh row per k block, so the four lane groups of a row cover one
+// full 128-B line (k permutation inside the block: lane group g owns k = 32b+8g..32b+8g+7).
 template <int NCT, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64) void lstm_rec_kernel(LstmRecParams p) {
     extern __shared__ __attribute__((aligned(16))) float hbuf[];  // [2][16][Hh+4]
+    constexpr int NT = NCT * 4;      // MFMA tiles per wave: tile ti -> column block ti/4, gate ti%4
+    constexpr int GS = NT / 2;       // tiles per pipeline group
     const int Hh = p.Hh, ldh = Hh + 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cl = lane & 15, g4 = lane >> 4;
     const int dir = blockIdx.y;
     const int s0 = blockIdx.x * 16;
-    const int ntiles = Hh >> 4;
-    const float *__restrict__ whh = p.w_hh[dir];
+    const int ntiles = Hh >> 4, nkb = Hh >> 5;
+    const int ntile4 = 4 * ntiles;                               // fragment tiles per k block (4 gates)
+    gfp whh = (gfp)p.w_pack + (int64_t)dir * 4 * Hh * Hh + lane * 4;
+    gfp xproj = (gfp)p.xproj;
+    __attribute__((address_space(1))) float *outp = (__attribute__((address_space(1))) float *)p.out;
 
     // my four sequences (accumulator rows 4*g4 + e)
     int off4[4], len4[4];
@@ -68,9 +105,8 @@ __global__ __launch_bounds__(NWAVES * 64) void lstm_rec_kernel(LstmRecParams p) 
     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
         for (int e = 0; e < 4; ++e) creg[ct][e] = hreg[ct][e] = 0.0f;
-    __syncthreads();
 
-    // tiles owned by this wave; waves beyond the tile count idle but keep the barriers
+    // tile columns owned by this wave; waves beyond the tile count idle but keep the barriers
     bool own[NCT];
     int unit[NCT];
 #pragma unroll
@@ -79,79 +115,103 @@ __global__ __launch_bounds__(NWAVES * 64) void lstm_rec_kernel(LstmRecParams p) 
         own[ct] = tile < ntiles;
         unit[ct] = (own[ct] ? tile : 0) * 16 + cl;
     }
+    // offsets (floats) of my B fragments inside a k block of the packed image: tile = gate*ntiles + column block
+    int woff[NT];
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) {
+        const int colblk = own[ti >> 2] ? wave * NCT + (ti >> 2) : 0;
+        woff[ti] = ((ti & 3) * ntiles + colblk) * 512;
+    }
 
     const int64_t ldx = 8 * (int64_t)Hh;
-    for (int tau = 0; tau < lmax; ++tau) {
-        const int cur = tau & 1;
-        const float *hc = hbuf + cur * 16 * ldh;
-        float *hn = hbuf + (cur ^ 1) * 16 * ldh;
-        bool active[4];
-        int64_t row[4];
+    const int xcol = dir * 4 * Hh;
+
+    v4f bq[2][GS][2];
+#define STAIR_LOADB(grp, kb)                                                      \
+    _Pragma("unroll") for (int t_ = 0; t_ < GS; ++t_) {                            \
+        gfp src_ = whh + (int64_t)(kb) * ntile4 * 512 + woff[(grp) * GS + t_];     \
+        bq[grp][t_][0] = *(gv4p)(src_);                                            \
+        bq[grp][t_][1] = *(gv4p)(src_ + 256);                                      \
+    }
+#define STAIR_MFMA(grp)                                                                            \
+    _Pragma("unroll") for (int jj_ = 0; jj_ < 8; ++jj_)                                             \
+        _Pragma("unroll") for (int t_ = 0; t_ < GS; ++t_)                                           \
+            acc[(grp) * GS + t_] = __builtin_amdgcn_mfma_f32_16x16x4f32(                            \
+                acur[jj_ >> 2][jj_ & 3], bq[grp][t_][jj_ >> 2][jj_ & 3], acc[(grp) * GS + t_], 0, 0, 0);
+
+    // xproj values of the CURRENT step live in xp; they are re-loaded for the next step inside the
+    // cell update, right after their last use, so their HBM latency overlaps the update + barrier.
+    float xp[NCT][4][4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            active[e] = tau < len4[e];
-            const int t = dir == 0 ? tau : len4[e] - 1 - tau;
-            row[e] = off4[e] + (active[e] ? t : 0);
-        }
-        // issue this step's xproj reads now; they are consumed after the MFMA chain
-        float xp[NCT][4][4];
+    for (int e = 0; e < 4; ++e) {
+        const bool act = 0 < len4[e];
+        const int64_t row = off4[e] + (act ? (dir == 0 ? 0 : len4[e] - 1) : 0);
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
             for (int gate = 0; gate < 4; ++gate)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    xp[ct][gate][e] = (active[e] && own[ct])
-                                          ? p.xproj[row[e] * ldx + dir * 4 * Hh + gate * Hh + unit[ct]]
-                                          : 0.0f;
+                xp[ct][gate][e] = (act && own[ct]) ? xproj[row * ldx + xcol + gate * Hh + unit[ct]] : 0.0f;
+    }
+    STAIR_LOADB(0, 0);
+    __syncthreads();
 
-        f32x4 acc[NCT][4];
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-            for (int gate = 0; gate < 4; ++gate) acc[ct][gate] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int tau = 0; tau < lmax; ++tau) {
+        const int cur = tau & 1;
+        const float *hc = hbuf + cur * 16 * ldh;
+        float *hn = hbuf + (cur ^ 1) * 16 * ldh;
 
-        for (int kb = 0; kb < ntiles; ++kb) {
-            const float4 a4 = *reinterpret_cast<const float4 *>(hc + cl * ldh + kb * 16 + 4 * g4);
-            const float *ap = reinterpret_cast<const float *>(&a4);
-            float4 b4[NCT][4];
+        v4f acc[NT];
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-                for (int gate = 0; gate < 4; ++gate)
-                    b4[ct][gate] = *reinterpret_cast<const float4 *>(
-                        whh + (int64_t)(gate * Hh + unit[ct]) * Hh + kb * 16 + 4 * g4);
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-                for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-                    for (int gate = 0; gate < 4; ++gate)
-                        acc[ct][gate] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                            ap[jj], reinterpret_cast<const float *>(&b4[ct][gate])[jj], acc[ct][gate], 0, 0, 0);
+        for (int ti = 0; ti < NT; ++ti) acc[ti] = v4f{0.f, 0.f, 0.f, 0.f};
+
+        v4f acur[2], anxt[2];
+        acur[0] = *reinterpret_cast<const v4f *>(hc + cl * ldh + 8 * g4);
+        acur[1] = *reinterpret_cast<const v4f *>(hc + cl * ldh + 8 * g4 + 4);
+        for (int kb = 0; kb < nkb; ++kb) {
+            STAIR_LOADB(1, kb);
+            __builtin_amdgcn_sched_barrier(0);
+            STAIR_MFMA(0);
+            const int kn = kb + 1 < nkb ? kb + 1 : 0;       // wraps to the next step's first block
+            STAIR_LOADB(0, kn);
+            anxt[0] = *reinterpret_cast<const v4f *>(hc + cl * ldh + kn * 32 + 8 * g4);
+            anxt[1] = *reinterpret_cast<const v4f *>(hc + cl * ldh + kn * 32 + 8 * g4 + 4);
+            __builtin_amdgcn_sched_barrier(0);
+            STAIR_MFMA(1);
+            acur[0] = anxt[0];
+            acur[1] = anxt[1];
         }
 
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-            if (!own[ct]) continue;
+        for (int e = 0; e < 4; ++e) {
+            const bool active = tau < len4[e];
+            const int t = dir == 0 ? tau : len4[e] - 1 - tau;
+            const int64_t row = off4[e] + (active ? t : 0);
+            const bool act_n = tau + 1 < len4[e];
+            const int64_t row_n = off4[e] + (act_n ? (dir == 0 ? tau + 1 : len4[e] - 2 - tau) : 0);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float gi = acc[ct][0][e] + xp[ct][0][e];
-                const float gf = acc[ct][1][e] + xp[ct][1][e];
-                const float gg = acc[ct][2][e] + xp[ct][2][e];
-                const float go = acc[ct][3][e] + xp[ct][3][e];
+            for (int ct = 0; ct < NCT; ++ct) {
+                if (!own[ct]) continue;
+                const float gi = acc[ct * 4 + 0][e] + xp[ct][0][e];
+                const float gf = acc[ct * 4 + 1][e] + xp[ct][1][e];
+                const float gg = acc[ct * 4 + 2][e] + xp[ct][2][e];
+                const float go = acc[ct * 4 + 3][e] + xp[ct][3][e];
                 const float cn = sigmoid_fast(gf) * creg[ct][e] + sigmoid_fast(gi) * tanh_fast(gg);
                 const float hv = sigmoid_fast(go) * tanh_fast(cn);
-                if (active[e]) {
+                if (active) {
                     creg[ct][e] = cn;
                     hreg[ct][e] = hv;
-                    p.out[row[e] * p.ldo + dir * Hh + unit[ct]] = hv;
+                    outp[row * p.ldo + dir * Hh + unit[ct]] = hv;
                 }
                 hn[(g4 * 4 + e) * ldh + unit[ct]] = hreg[ct][e];
+#pragma unroll
+                for (int gate = 0; gate < 4; ++gate)
+                    xp[ct][gate][e] = act_n ? xproj[row_n * ldx + xcol + gate * Hh + unit[ct]] : 0.0f;
             }
         }
         __syncthreads();
     }
+#undef STAIR_LOADB
+#undef STAIR_MFMA
 
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
@@ -166,7 +226,7 @@ __global__ __launch_bounds__(NWAVES * 64) void lstm_rec_kernel(LstmRecParams p) 
 
 int launch_lstm(const stair_lstm_args &a, hipStream_t s) {
     STAIR_CHECK(a.n >= 0 && a.rows >= 0 && a.I > 0 && a.Hh > 0, "bad shape");
-    STAIR_CHECK(a.Hh % 16 == 0 && (a.Hh <= 128 || a.Hh == 256), "LSTM hidden size must be 16..128 (multiple of 16) or 256");
+    STAIR_CHECK(a.Hh % 32 == 0 && a.Hh <= 256, "LSTM hidden size must be a multiple of 32, at most 256");
     STAIR_CHECK(a.I % 4 == 0 && a.ldx % 4 == 0, "LSTM input size / ldx must be multiples of 4");
     if (a.n == 0 || a.rows == 0) return 0;
     const int Hh = a.Hh;
@@ -181,13 +241,20 @@ int launch_lstm(const stair_lstm_args &a, hipStream_t s) {
         g.groups = a.rows; g.rows_per_group = 1; g.N = 4 * Hh; g.K = a.I; g.act = 0;
         if (int rc = launch_gemm(g, s)) return rc;
     }
+    STAIR_CHECK(a.whh_pack_ws != nullptr, "whh_pack_ws missing");
+    {
+        const int64_t n4 = 2 * 4 * (int64_t)Hh * Hh / 4;
+        hipLaunchKernelGGL(whh_pack_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a.w_hh[0], a.w_hh[1],
+                           a.whh_pack_ws, Hh);
+        STAIR_LAUNCH_CHECK();
+    }
     LstmRecParams p;
-    p.xproj = a.xproj_ws; p.w_hh[0] = a.w_hh[0]; p.w_hh[1] = a.w_hh[1];
+    p.xproj = a.xproj_ws; p.w_pack = a.whh_pack_ws;
     p.seq_off = a.seq_off; p.out = a.out; p.ldo = a.ldo; p.h_n = a.h_n; p.n = a.n; p.Hh = Hh;
     const dim3 grid((a.n + 15) / 16, 2);
     const size_t shmem = 2 * 16 * (Hh + 4) * sizeof(float);
     const int tiles = Hh / 16;
-    if (tiles == 16) hipLaunchKernelGGL((lstm_rec_kernel<2, 8>), grid, dim3(512), shmem, s, p);
+    if (tiles > 8) hipLaunchKernelGGL((lstm_rec_kernel<2, 8>), grid, dim3(512), shmem, s, p);
     else if (tiles > 4) hipLaunchKernelGGL((lstm_rec_kernel<1, 8>), grid, dim3(512), shmem, s, p);
     else if (tiles > 2) hipLaunchKernelGGL((lstm_rec_kernel<1, 4>), grid, dim3(256), shmem, s, p);
     else hipLaunchKernelGGL((lstm_rec_kernel<1, 2>), grid, dim3(128), shmem, s, p);

@@ -135,9 +135,8 @@ extern "C" const char *stair_last_error(void) { return g_err.c_str(); }
 
 extern "C" int stair_ctx_create(const stair_config *cfg, stair_ctx **out) {
     STAIR_CHECK(cfg && out, "null argument");
-    STAIR_CHECK(cfg->hidden_size >= 32 && cfg->hidden_size % 32 == 0, "hidden_size must be a multiple of 32");
-    const int Hh = cfg->hidden_size / 2;
-    STAIR_CHECK(Hh <= 128 || Hh == 256, "hidden_size/2 must be <= 128 or exactly 256");
+    STAIR_CHECK(cfg->hidden_size >= 64 && cfg->hidden_size % 64 == 0 && cfg->hidden_size <= 512,
+                "hidden_size must be a multiple of 64, at most 512 (LSTM recurrence tiles Hh = H/2 in blocks of 32)");
     STAIR_CHECK(cfg->video_size > 0 && cfg->video_size % 4 == 0, "video_size must be a multiple of 4");
     STAIR_CHECK(cfg->text_size > 0 && cfg->text_size % 4 == 0, "text_size must be a multiple of 4");
     STAIR_CHECK(cfg->answer_vocab_length > 0 && cfg->max_video_length > 0 && cfg->object_types > 0, "bad config");
@@ -203,7 +202,7 @@ struct stair_plan {
     int maxI = 0, maxV = 0, maxK = 0, maxSupRows = 0, n_levels = 0;
     // workspace layout (float offsets)
     int64_t o_idx = 0, o_vec = 0, o_map = 0, o_att = 0, o_tok = 0, o_qfeat = 0, o_vhn = 0, o_xpv = 0, o_xpt = 0,
-            o_bias = 0, o_tmpA = 0, o_tmpB = 0, o_kbuf = 0, o_cat = 0, o_hid = 0, o_rs = 0, o_sup = 0, o_extra = 0,
+            o_bias = 0, o_wpack = 0, o_tmpA = 0, o_tmpB = 0, o_kbuf = 0, o_cat = 0, o_hid = 0, o_rs = 0, o_sup = 0, o_extra = 0,
             o_logits = 0, total = 0;
 };
 
@@ -529,6 +528,7 @@ extern "C" int stair_plan_build(stair_ctx *ctx, int32_t n, const int32_t *prog_o
     pl->o_xpv = take((int64_t)n * T * 4 * H, 64);
     pl->o_xpt = take((int64_t)pl->rows_q * 4 * H, 64);
     pl->o_bias = take(2 * 4 * H, 64);
+    pl->o_wpack = take(2 * 2 * H * H, 64);       // 8*Hh*Hh floats per encoder
     pl->o_tmpA = take((int64_t)std::max(pl->maxI, 1) * T * H, 64);
     pl->o_tmpB = take((int64_t)std::max(pl->maxI, 1) * T * H, 64);
     pl->o_kbuf = take((int64_t)std::max(pl->maxK, 1) * H, 64);
@@ -700,7 +700,7 @@ extern "C" int stair_plan_run(stair_ctx *ctx, stair_plan *pl, const float *video
             a.w_ih[d] = W.enc[0][4 * d]; a.w_hh[d] = W.enc[0][4 * d + 1];
             a.b_ih[d] = W.enc[0][4 * d + 2]; a.b_hh[d] = W.enc[0][4 * d + 3];
         }
-        a.xproj_ws = ws + pl->o_xpv; a.bias_ws = ws + pl->o_bias;
+        a.xproj_ws = ws + pl->o_xpv; a.bias_ws = ws + pl->o_bias; a.whh_pack_ws = ws + pl->o_wpack;
         a.out = map; a.ldo = H; a.h_n = ws + pl->o_vhn;
         RUN(launch_lstm(a, s));
     }
@@ -712,7 +712,7 @@ extern "C" int stair_plan_run(stair_ctx *ctx, stair_plan *pl, const float *video
             a.w_ih[d] = W.enc[1][4 * d]; a.w_hh[d] = W.enc[1][4 * d + 1];
             a.b_ih[d] = W.enc[1][4 * d + 2]; a.b_hh[d] = W.enc[1][4 * d + 3];
         }
-        a.xproj_ws = ws + pl->o_xpt; a.bias_ws = ws + pl->o_bias + 4 * H;
+        a.xproj_ws = ws + pl->o_xpt; a.bias_ws = ws + pl->o_bias + 4 * H; a.whh_pack_ws = ws + pl->o_wpack + 2 * (int64_t)H * H;
         a.out = tok; a.ldo = H; a.h_n = qfeat;
         RUN(launch_lstm(a, s));
     }

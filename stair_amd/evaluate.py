@@ -1,0 +1,74 @@
+"""Accuracy evaluation driver: the batched, multi-GPU counterpart of the reference's
+``evaluate_by_module`` accuracy loop (/root/reference/train_module.py:219-270, the working one) and
+of ``evaluate.py:28-62`` (whose argmax over dim=1 of a 1-D tensor crashes as shipped; the intended
+rule is the one implemented here).
+
+Questions are independent, so rank r of a world of W processes takes questions r, r+W, r+2W, ...
+and runs them in batches on its own GPU with NO data-path collective; predictions are gathered on the
+host once at the end (torch.distributed.all_gather_object -- RCCL is not needed for it, and the CPU
+test uses gloo).
+"""
+from __future__ import annotations
+
+import json
+
+import torch
+
+
+def shard_indices(n, rank, world):
+    """Indices of the questions rank `rank` processes (round-robin)."""
+    return list(range(rank, n, world))
+
+
+def group_by_frames(batch):
+    """The executor wants one frame count per launch batch; bucket a list of question dicts by T."""
+    groups = {}
+    for i, d in enumerate(batch):
+        groups.setdefault(int(d['video_features'].shape[0]), []).append(i)
+    return groups
+
+
+def predict(model, questions, batch_size=1024):
+    """Top-1 answer ids (python ints) for a list of question dicts, in order."""
+    preds = [None] * len(questions)
+    for T, idxs in sorted(group_by_frames(questions).items()):
+        for s in range(0, len(idxs), batch_size):
+            chunk = idxs[s:s + batch_size]
+            res = model.forward_batch([questions[i] for i in chunk])
+            for i, p in zip(chunk, res.pred.cpu().tolist()):
+                preds[i] = int(p)
+    return preds
+
+
+def accuracy(preds, golds, unk_token_id):
+    """train_module.py:252-253: a prediction counts only if it equals the gold answer AND the gold
+    answer is not <UNK>."""
+    acc = [int(p == g and g != unk_token_id) for p, g in zip(preds, golds)]
+    return sum(acc) / max(1, len(acc))
+
+
+def evaluate(model, questions, unk_token_id, rank=0, world=1, batch_size=1024, predict_fn=None, preds_file=None,
+             id2word=None):
+    """Sharded accuracy evaluation.  Every rank passes the SAME full question list; returns
+    (accuracy, preds) on every rank.  `predict_fn(questions) -> list[int]` defaults to the HIP path
+    (tests substitute a CPU function to exercise the sharding logic without a GPU)."""
+    mine = shard_indices(len(questions), rank, world)
+    fn = predict_fn or (lambda qs: predict(model, qs, batch_size))
+    local = fn([questions[i] for i in mine])
+    if world > 1:
+        import torch.distributed as dist
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (mine, local))
+    else:
+        gathered = [(mine, local)]
+    preds = [None] * len(questions)
+    for idxs, vals in gathered:
+        for i, p in zip(idxs, vals):
+            preds[i] = int(p)
+    golds = [int(q['answer']) for q in questions]
+    acc = accuracy(preds, golds, unk_token_id)
+    if preds_file is not None and rank == 0:       # train_module.py:267-268 layout
+        w = (lambda i: id2word[str(i)] if id2word and str(i) in id2word else i)
+        json.dump({'preds': [w(p) for p in preds], 'golds': [w(g) for g in golds],
+                   'qa_ids': [q.get('qa_id') for q in questions]}, open(preds_file, 'w'))
+    return acc, preds

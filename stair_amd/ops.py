@@ -78,13 +78,14 @@ def lstm_bidir(x, seq_off, max_len, weights):
     h_n = torch.empty(n, 2 * Hh, device=x.device, dtype=torch.float32)
     xproj = torch.empty(rows, 8 * Hh, device=x.device, dtype=torch.float32)
     bias_ws = torch.empty(8 * Hh, device=x.device, dtype=torch.float32)
+    pack_ws = torch.empty(8 * Hh * Hh, device=x.device, dtype=torch.float32)
     a = LstmArgs()
     a.x, a.ldx, a.rows, a.n, a.max_len, a.I, a.Hh = x.data_ptr(), I, rows, n, max_len, I, Hh
     a.seq_off = seq_off.data_ptr()
     for d in range(2):
         a.w_ih[d], a.w_hh[d] = weights[4 * d].data_ptr(), weights[4 * d + 1].data_ptr()
         a.b_ih[d], a.b_hh[d] = weights[4 * d + 2].data_ptr(), weights[4 * d + 3].data_ptr()
-    a.xproj_ws, a.bias_ws = xproj.data_ptr(), bias_ws.data_ptr()
+    a.xproj_ws, a.bias_ws, a.whh_pack_ws = xproj.data_ptr(), bias_ws.data_ptr(), pack_ws.data_ptr()
     a.out, a.ldo, a.h_n = out.data_ptr(), 2 * Hh, h_n.data_ptr()
     check(lib.stair_lstm_bidir_fwd(C.byref(a), _stream()))
     return out, h_n

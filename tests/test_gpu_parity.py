@@ -207,3 +207,25 @@ def test_missing_gpu_tensor_fails_loudly():
     from stair_amd import ops
     with pytest.raises(RuntimeError):
         ops.linear(torch.randn(4, 8), torch.randn(4, 8))
+
+
+def test_evaluation_driver_buckets_by_frame_count():
+    """stair_amd.evaluate.predict on a mixed-T question list (T=40 and T=24) reproduces the reference's
+    top-1 answers; accuracy follows train_module.py:252-253."""
+    from stair_amd import evaluate as E
+    z40, m40 = load_golden('tiny_conv')
+    z24, m24 = load_golden('tiny_conv_t24')
+    model = _model(m40['config'], m40['seed'])
+    qs, gold_pred = [], []
+    for z, meta in ((z40, m40), (z24, m24)):
+        for q in meta['questions']:
+            qs.append(question_for(meta, q))
+            gold_pred.append(int(np.argmax(z['q%d/logits' % q['qid']])))
+    order = np.random.RandomState(1).permutation(len(qs))
+    qs = [qs[i] for i in order]
+    gold_pred = [gold_pred[i] for i in order]
+    preds = E.predict(model, qs, batch_size=5)
+    assert preds == gold_pred
+    acc, preds2 = E.evaluate(model, qs, unk_token_id=15, batch_size=7)
+    assert preds2 == gold_pred
+    assert acc == E.accuracy(gold_pred, [q['answer'] for q in qs], 15)

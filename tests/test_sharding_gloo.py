@@ -1,0 +1,68 @@
+"""world_size-2 gloo test of the multi-GPU (here: multi-process CPU) inference path: questions shard
+round-robin across ranks with no data-path collective, predictions are gathered once, and every rank
+ends with the same full prediction list and accuracy.  The per-rank predictor is the oracle (CPU) so
+the test exercises the sharding / gather logic of stair_amd/evaluate.py without a GPU."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from oracle import nmn_oracle as O
+    from stair_amd import evaluate as E, spec, synth
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    config = dict(spec.DEFAULT_CONFIG, hidden_size=64, video_size=128, answer_vocab_length=16, max_video_length=40, object_types=10)
+    w = O.to_torch(synth.make_weights(config, 0))
+    qs = synth.make_questions(config, 3, 13, forms=synth.ALL_FORMS)       # odd count: ragged shards
+
+    def predict_fn(sub):
+        return [int(torch.argmax(O.forward(w, config, q, return_res_by_step=False)['logits'])) for q in sub]
+
+    acc, preds = E.evaluate(None, qs, unk_token_id=15, rank=rank, world=world, predict_fn=predict_fn)
+    torch.save({'acc': acc, 'preds': preds, 'mine': E.shard_indices(len(qs), rank, world)}, os.path.join(out_dir, 'r%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_evaluation(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(os.path.join(tmp_path, 'r0.pt'))
+    r1 = torch.load(os.path.join(tmp_path, 'r1.pt'))
+    assert r0['preds'] == r1['preds'] and r0['acc'] == r1['acc']
+    assert sorted(r0['mine'] + r1['mine']) == list(range(13)) and not set(r0['mine']) & set(r1['mine'])
+    # single-process reference
+    sys.path.insert(0, ROOT)
+    from oracle import nmn_oracle as O
+    from stair_amd import evaluate as E, spec, synth
+    config = dict(spec.DEFAULT_CONFIG, hidden_size=64, video_size=128, answer_vocab_length=16, max_video_length=40, object_types=10)
+    w = O.to_torch(synth.make_weights(config, 0))
+    qs = synth.make_questions(config, 3, 13, forms=synth.ALL_FORMS)
+    solo = [int(torch.argmax(O.forward(w, config, q, return_res_by_step=False)['logits'])) for q in qs]
+    assert r0['preds'] == solo
+    assert r0['acc'] == E.accuracy(solo, [q['answer'] for q in qs], 15)
+
+
+def test_accuracy_rule_ignores_unk_gold():
+    from stair_amd import evaluate as E
+    assert E.accuracy([1, 2, 5], [1, 3, 5], unk_token_id=5) == pytest.approx(1 / 3)    # train_module.py:252-253
+    assert E.shard_indices(7, 1, 3) == [1, 4]
