@@ -100,8 +100,23 @@ typedef struct stair_gemm_args {
     float *C; int64_t ldc; int64_t c_gstride; const int32_t *c_gidx;
     const float *row_scale; int64_t rs_gstride; const int32_t *rs_gidx;
     int32_t groups, rows_per_group, N, K, act;
+    int32_t accumulate; /* 0: C = ...; 1: C += ... with fp32 atomics (act must be 0) -- the dX products of the
+                           backward pass, where several program nodes may read the same slot */
 } stair_gemm_args;
 int stair_gemm_f32(const stair_gemm_args *args, stair_stream stream);
+
+/* C[n][k] += sum_m A[m][n] * (rs[m] * B[m][k]): the weight gradient dW = dZ^T X of every nn.Linear on the
+ * path (autograd of modules.py's Linear layers; train_module.py:408 backward()).  A [M,N] plain rows;
+ * B [M,K] gathered in groups of rows_per_group rows like stair_gemm_args.A.  C [N,K] is ACCUMULATED
+ * with fp32 atomics (M is split over workgroups), so zero it first.  N, K multiples of 4. */
+typedef struct stair_gemm_tn_args {
+    const float *A; int64_t lda;
+    const float *B; int64_t ldb; int64_t b_gstride; const int32_t *b_gidx;
+    const float *row_scale; int64_t rs_gstride; const int32_t *rs_gidx;
+    float *C; int64_t ldc;
+    int32_t M, rows_per_group, N, K;
+} stair_gemm_tn_args;
+int stair_gemm_tn_f32(const stair_gemm_tn_args *args, stair_stream stream);
 
 /* Bidirectional single-layer LSTM over n ragged sequences (nn.LSTM as used at
  * module_net.py:39-47,151-163).  x [rows, I] with sequence s at rows seq_off[s]..seq_off[s+1]-1
@@ -115,8 +130,27 @@ typedef struct stair_lstm_args {
     const float *w_ih[2], *w_hh[2], *b_ih[2], *b_hh[2];
     float *xproj_ws, *bias_ws, *whh_pack_ws;
     float *out; int64_t ldo; float *h_n;
+    float *cbuf; /* NULL for inference.  Training: [rows, 2*Hh] cell states are saved here and xproj_ws is left
+                    holding the ACTIVATED gates (i, f, g, o) of every step, both consumed by stair_lstm_bidir_bwd */
 } stair_lstm_args;
 int stair_lstm_bidir_fwd(const stair_lstm_args *args, stair_stream stream);
+
+/* Backward through time of the same layer (autograd of nn.LSTM in train_module.py:408).  gates = the
+ * xproj_ws of a training-mode forward (overwritten in place with the gate pre-activation gradients),
+ * cbuf/out from that forward, d_out [rows, ldd] and d_hn [n, 2*Hh] (may be NULL) the incoming gradients.
+ * dw_ih/dw_hh/db_ih/db_hh are ACCUMULATED (fp32 atomics).  No input gradient is produced: the inputs
+ * of both encoders are data (video features, GloVe vectors).  Scratch: whh_pack_ws [8*Hh*Hh],
+ * hprev_ws [rows, 2*Hh]. */
+typedef struct stair_lstm_bwd_args {
+    const float *x; int64_t ldx; int32_t rows, n, max_len, I, Hh;
+    const int32_t *seq_off;
+    const float *w_hh[2];
+    float *gates; const float *cbuf; const float *out; int64_t ldo;
+    const float *d_out; int64_t ldd; const float *d_hn;
+    float *whh_pack_ws, *hprev_ws;
+    float *dw_ih[2], *dw_hh[2], *db_ih[2], *db_hh[2];
+} stair_lstm_bwd_args;
+int stair_lstm_bidir_bwd(const stair_lstm_bwd_args *args, stair_stream stream);
 
 /* att[p][t] = (cos(F[f_idx[p]][t][:], Kmat[k_idx[p]][:]) + 1) * 0.49 -- nn.CosineSimilarity(dim=-1,
  * eps=1e-8) of LocalizeModule / ExistsFrameModule (modules.py:162-217) without materialising the

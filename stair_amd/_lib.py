@@ -31,7 +31,15 @@ class GemmArgs(C.Structure):
                 ('C', C.c_void_p), ('ldc', C.c_int64), ('c_gstride', C.c_int64), ('c_gidx', C.c_void_p),
                 ('row_scale', C.c_void_p), ('rs_gstride', C.c_int64), ('rs_gidx', C.c_void_p),
                 ('groups', C.c_int32), ('rows_per_group', C.c_int32), ('N', C.c_int32), ('K', C.c_int32),
-                ('act', C.c_int32)]
+                ('act', C.c_int32), ('accumulate', C.c_int32)]
+
+
+class GemmTnArgs(C.Structure):
+    _fields_ = [('A', C.c_void_p), ('lda', C.c_int64),
+                ('B', C.c_void_p), ('ldb', C.c_int64), ('b_gstride', C.c_int64), ('b_gidx', C.c_void_p),
+                ('row_scale', C.c_void_p), ('rs_gstride', C.c_int64), ('rs_gidx', C.c_void_p),
+                ('C', C.c_void_p), ('ldc', C.c_int64),
+                ('M', C.c_int32), ('rows_per_group', C.c_int32), ('N', C.c_int32), ('K', C.c_int32)]
 
 
 class LstmArgs(C.Structure):
@@ -39,7 +47,17 @@ class LstmArgs(C.Structure):
                 ('max_len', C.c_int32), ('I', C.c_int32), ('Hh', C.c_int32), ('seq_off', C.c_void_p),
                 ('w_ih', C.c_void_p * 2), ('w_hh', C.c_void_p * 2), ('b_ih', C.c_void_p * 2), ('b_hh', C.c_void_p * 2),
                 ('xproj_ws', C.c_void_p), ('bias_ws', C.c_void_p), ('whh_pack_ws', C.c_void_p),
-                ('out', C.c_void_p), ('ldo', C.c_int64), ('h_n', C.c_void_p)]
+                ('out', C.c_void_p), ('ldo', C.c_int64), ('h_n', C.c_void_p), ('cbuf', C.c_void_p)]
+
+
+class LstmBwdArgs(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('ldx', C.c_int64), ('rows', C.c_int32), ('n', C.c_int32),
+                ('max_len', C.c_int32), ('I', C.c_int32), ('Hh', C.c_int32), ('seq_off', C.c_void_p),
+                ('w_hh', C.c_void_p * 2),
+                ('gates', C.c_void_p), ('cbuf', C.c_void_p), ('out', C.c_void_p), ('ldo', C.c_int64),
+                ('d_out', C.c_void_p), ('ldd', C.c_int64), ('d_hn', C.c_void_p),
+                ('whh_pack_ws', C.c_void_p), ('hprev_ws', C.c_void_p),
+                ('dw_ih', C.c_void_p * 2), ('dw_hh', C.c_void_p * 2), ('db_ih', C.c_void_p * 2), ('db_hh', C.c_void_p * 2)]
 
 
 class PlanInfo(C.Structure):
@@ -61,7 +79,9 @@ SIGNATURES = [
     ('stair_weight_numel', C.c_int64, [C.c_void_p, C.c_int]),
     ('stair_ctx_set_weight', C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
     ('stair_gemm_f32', C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
+    ('stair_gemm_tn_f32', C.c_int, [C.POINTER(GemmTnArgs), C.c_void_p]),
     ('stair_lstm_bidir_fwd', C.c_int, [C.POINTER(LstmArgs), C.c_void_p]),
+    ('stair_lstm_bidir_bwd', C.c_int, [C.POINTER(LstmBwdArgs), C.c_void_p]),
     ('stair_cosine_attn_fwd', C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     ('stair_temporal_relate_fwd', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,

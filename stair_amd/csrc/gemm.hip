@@ -13,6 +13,8 @@
 // ds_write_b128 of the staging pass and the ds_read_b128 of the fragment pass.  LDS is double
 // buffered with global->register prefetch one chunk ahead (one barrier per chunk).  Blocks are
 // renumbered so that the column tiles sharing one A row-panel run on the same XCD (private L2).
+#include <algorithm>
+
 #include "common.h"
 
 namespace stair {
@@ -176,7 +178,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                 float v = acc[e] + b;
                 if (ACT == 1) v = fmaxf(v, 0.0f);
                 if (ACT == 2) v = sigmoid_acc(v);
-                Cg[off + n] = v;
+                if (a.accumulate) unsafeAtomicAdd(a.C + off + n, v);   // several groups may share an output slot
+                else Cg[off + n] = v;
             }
         }
     }
@@ -189,6 +192,7 @@ int launch_gemm(const stair_gemm_args &a, hipStream_t s) {
     STAIR_CHECK((reinterpret_cast<uintptr_t>(a.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.W) & 15) == 0,
                 "A and W must be 16-byte aligned");
     STAIR_CHECK(a.act >= 0 && a.act <= 2, "act must be 0, 1 or 2");
+    STAIR_CHECK(!(a.accumulate && a.act), "accumulate is only defined for act == 0");
     GemmParams p;
     p.a = a;
     const int64_t M = (int64_t)a.groups * a.rows_per_group;
@@ -208,6 +212,144 @@ int launch_gemm(const stair_gemm_args &a, hipStream_t s) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Weight-gradient GEMM:  C[n][k] += sum_m A[m][n] * B[m][k]   (dW = dZ^T X of every nn.Linear).
+// The contraction runs over ROWS of both operands, so a 32-row slab of A and of B is staged as is
+// (float4 along n / k, LDS images [m][128+4]) and the MFMA fragments are single ds_read_b32 with the
+// lane on the n / k axis (consecutive banks).  M is split over blockIdx.z; partial tiles are summed
+// with fp32 atomics (one 128x128 tile per block: 64 KB of adds per ~2048-row slab, far below the
+// chip-wide atomic rate).  B rows can be gathered in groups exactly like the forward kernel's A.
+struct GemmTnParams {
+    const float *A; int64_t lda;                    // [M, N]
+    const float *B; int64_t ldb, b_gstride; const int32_t *b_gidx; int R;   // [M, K] in groups of R rows
+    const float *row_scale; int64_t rs_gstride; const int32_t *rs_gidx;     // optional scale on B rows
+    float *C; int64_t ldc;                          // [N, K]
+    int M, N, K, mslab;
+};
+
+constexpr int TN_LD = 128 + 4;
+
+__global__ __launch_bounds__(256) void gemm_tn_f32_kernel(GemmTnParams p) {
+    __shared__ __attribute__((aligned(16))) float As[32 * TN_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[32 * TN_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
+    const int mbeg = blockIdx.z * p.mslab, mend = min(p.M, mbeg + p.mslab);
+
+    f32x16 acc00, acc01, acc10, acc11;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc00[e] = acc01[e] = acc10[e] = acc11[e] = 0.0f;
+
+    // staging: thread -> column quad c4 (0..31) and rows mr + 8 i of the 32-row slab
+    const int c4 = tid & 31, mr = tid >> 5;
+    const int an = min(n0 + 4 * c4, p.N - 4), bk = min(k0 + 4 * c4, p.K - 4);   // clamped (N, K multiples of 4)
+    const float amask = n0 + 4 * c4 < p.N ? 1.0f : 0.0f, bmask = k0 + 4 * c4 < p.K ? 1.0f : 0.0f;
+    for (int m0 = mbeg; m0 < mend; m0 += 32) {
+        v4f ra[4], rb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int mraw = m0 + mr + 8 * i;
+            const int m = min(mraw, p.M - 1);
+            const float live = mraw < mend ? 1.0f : 0.0f;
+            ra[i] = *(gv4p)(p.A + (int64_t)m * p.lda + an) * (live * amask);
+            const int g = m / p.R, rr = m - g * p.R;
+            const int64_t gi = p.b_gidx ? p.b_gidx[g] : g;
+            float sc = bmask;
+            if (p.row_scale) sc *= p.row_scale[(p.rs_gidx ? p.rs_gidx[g] : g) * p.rs_gstride + rr];
+            rb[i] = *(gv4p)(p.B + gi * p.b_gstride + (int64_t)rr * p.ldb + bk) * sc;
+        }
+        __syncthreads();      // previous slab fully consumed
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<v4f *>(&As[(mr + 8 * i) * TN_LD + 4 * c4]) = ra[i];
+            *reinterpret_cast<v4f *>(&Bs[(mr + 8 * i) * TN_LD + 4 * c4]) = rb[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int mm = 2 * s + h;
+            const float a0 = As[mm * TN_LD + wm * 64 + r], a1 = As[mm * TN_LD + wm * 64 + 32 + r];
+            const float b0 = Bs[mm * TN_LD + wn * 64 + r], b1 = Bs[mm * TN_LD + wn * 64 + 32 + r];
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int k = k0 + wn * 64 + nt * 32 + r;
+        if (k >= p.K) continue;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const f32x16 &acc = mt == 0 ? (nt == 0 ? acc00 : acc01) : (nt == 0 ? acc10 : acc11);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = n0 + wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (n < p.N) unsafeAtomicAdd(p.C + (int64_t)n * p.ldc + k, acc[e]);
+            }
+        }
+    }
+}
+
+int launch_gemm_tn(const stair_gemm_tn_args &a, hipStream_t s) {
+    STAIR_CHECK(a.M >= 0 && a.N > 0 && a.K > 0 && a.rows_per_group > 0, "bad shape");
+    STAIR_CHECK(a.N % 4 == 0 && a.K % 4 == 0 && a.lda % 4 == 0 && a.ldb % 4 == 0 && a.b_gstride % 4 == 0,
+                "N, K, lda, ldb, b_gstride must be multiples of 4 floats");
+    if (a.M == 0) return 0;
+    GemmTnParams p;
+    p.A = a.A; p.lda = a.lda; p.B = a.B; p.ldb = a.ldb; p.b_gstride = a.b_gstride; p.b_gidx = a.b_gidx;
+    p.R = a.rows_per_group; p.row_scale = a.row_scale; p.rs_gstride = a.rs_gstride; p.rs_gidx = a.rs_gidx;
+    p.C = a.C; p.ldc = a.ldc; p.M = a.M; p.N = a.N; p.K = a.K;
+    const int tiles = ((a.N + 127) / 128) * ((a.K + 127) / 128);
+    // enough slabs to fill the chip (>= ~1024 blocks) but at least 256 rows each
+    int slabs = std::max(1, std::min((a.M + 255) / 256, (1024 + tiles - 1) / tiles));
+    p.mslab = ((a.M + slabs - 1) / slabs + 31) / 32 * 32;
+    slabs = (a.M + p.mslab - 1) / p.mslab;
+    hipLaunchKernelGGL(gemm_tn_f32_kernel, dim3((a.N + 127) / 128, (a.K + 127) / 128, slabs), dim3(256), 0, s, p);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
+// out[n] += sum_m A[m][n]  (bias gradients)
+__global__ void colsum_kernel(const float *A, int64_t lda, float *out, int M, int N, int mslab) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int mbeg = blockIdx.y * mslab, mend = min(M, mbeg + mslab);
+    float acc = 0.f;
+    for (int m = mbeg; m < mend; ++m) acc += A[(int64_t)m * lda + n];
+    unsafeAtomicAdd(out + n, acc);
+}
+int launch_colsum(const float *A, int64_t lda, float *out, int M, int N, hipStream_t s) {
+    if (M == 0) return 0;
+    const int mslab = std::max(64, (M + 255) / 256);
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, (M + mslab - 1) / mslab), dim3(256), 0, s, A, lda, out, M, N, mslab);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
+// out[c][r] = in[r][c]   (W^T images for the dX products; 32x32 LDS tile)
+__global__ void transpose_kernel(const float *in, float *out, int rows, int cols) {
+    __shared__ float t[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+        const int rr = r0 + i, cc = c0 + threadIdx.x;
+        if (rr < rows && cc < cols) t[i][threadIdx.x] = in[(int64_t)rr * cols + cc];
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+        const int cc = c0 + i, rr = r0 + threadIdx.x;
+        if (rr < rows && cc < cols) out[(int64_t)cc * rows + rr] = t[threadIdx.x][i];
+    }
+}
+int launch_transpose(const float *in, float *out, int rows, int cols, hipStream_t s) {
+    hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, s, in, out, rows, cols);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace stair
 
 extern "C" int stair_gemm_f32(const stair_gemm_args *args, stair_stream stream) {
@@ -216,4 +358,12 @@ extern "C" int stair_gemm_f32(const stair_gemm_args *args, stair_stream stream) 
         return 1;
     }
     return stair::launch_gemm(*args, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int stair_gemm_tn_f32(const stair_gemm_tn_args *args, stair_stream stream) {
+    if (!args) {
+        stair::set_error("stair_gemm_tn_f32: null args");
+        return 1;
+    }
+    return stair::launch_gemm_tn(*args, static_cast<hipStream_t>(stream));
 }

@@ -26,6 +26,7 @@ struct LstmRecParams {
     float *out;              // [rows, ldo]
     int64_t ldo;
     float *h_n;              // [n, 2Hh]
+    float *cbuf;             // [rows, 2Hh] cell states, training mode only (else null)
     int n, Hh;
 };
 
@@ -195,12 +196,18 @@ __global__ __launch_bounds__(NWAVES * 64) void lstm_rec_kernel(LstmRecParams p) 
                 const float gf = acc[ct * 4 + 1][e] + xp[ct][1][e];
                 const float gg = acc[ct * 4 + 2][e] + xp[ct][2][e];
                 const float go = acc[ct * 4 + 3][e] + xp[ct][3][e];
-                const float cn = sigmoid_fast(gf) * creg[ct][e] + sigmoid_fast(gi) * tanh_fast(gg);
-                const float hv = sigmoid_fast(go) * tanh_fast(cn);
+                const float si = sigmoid_fast(gi), sf = sigmoid_fast(gf), tg = tanh_fast(gg), so = sigmoid_fast(go);
+                const float cn = sf * creg[ct][e] + si * tg;
+                const float hv = so * tanh_fast(cn);
                 if (active) {
                     creg[ct][e] = cn;
                     hreg[ct][e] = hv;
                     outp[row * p.ldo + dir * Hh + unit[ct]] = hv;
+                    if (p.cbuf) {   // training: activated gates replace this row's xproj (already consumed), c saved
+                        float *gsave = const_cast<float *>(p.xproj) + row * ldx + xcol + unit[ct];
+                        gsave[0] = si; gsave[Hh] = sf; gsave[2 * Hh] = tg; gsave[3 * Hh] = so;
+                        p.cbuf[row * 2 * Hh + dir * Hh + unit[ct]] = cn;
+                    }
                 }
                 hn[(g4 * 4 + e) * ldh + unit[ct]] = hreg[ct][e];
 #pragma unroll
@@ -222,6 +229,208 @@ __global__ __launch_bounds__(NWAVES * 64) void lstm_rec_kernel(LstmRecParams p) 
             if (s < p.n) p.h_n[(int64_t)s * 2 * Hh + dir * Hh + unit[ct]] = hreg[ct][e];
         }
     }
+}
+
+
+// =============================================================================================
+// backward through time
+// =============================================================================================
+// pack^T image for the recurrent product of the backward pass, dh_prev = dgates . W_hh:
+//   packT[dir][kb][colblk][half][lane][j] = W_hh[dir][32*kb + 8*(lane>>4) + 4*half + j][colblk*16 + (lane&15)]
+// (contraction over the 4Hh gate rows, output column = hidden unit).
+__global__ void whh_packT_kernel(const float *w0, const float *w1, float *pack, int Hh) {
+    const int64_t per_dir = 4 * (int64_t)Hh * Hh;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one float per thread (strided source)
+    if (e >= 2 * per_dir) return;
+    const int dir = (int)(e / per_dir);
+    int64_t r = e - dir * per_dir;
+    const int j = (int)(r & 3), lane = (int)((r >> 2) & 63);
+    r >>= 8;
+    const int half = (int)(r & 1);
+    r >>= 1;
+    const int ncol = Hh / 16;
+    const int colblk = (int)(r % ncol), kb = (int)(r / ncol);
+    const float *w = dir == 0 ? w0 : w1;
+    pack[e] = w[(int64_t)(32 * kb + 8 * (lane >> 4) + 4 * half + j) * Hh + colblk * 16 + (lane & 15)];
+}
+
+// hprev[row][dir*Hh + u] = h of the previous step of that direction (0 at the sequence start)
+__global__ void lstm_hprev_kernel(const float *out, int64_t ldo, const int32_t *seq_off, int n, int Hh, float *hprev) {
+    const int s = blockIdx.x;
+    const int beg = seq_off[s], len = seq_off[s + 1] - beg;
+    for (int i = threadIdx.x; i < len * 2 * Hh; i += blockDim.x) {
+        const int t = i / (2 * Hh), c = i - t * 2 * Hh;
+        const int dir = c >= Hh;
+        const int tp = dir == 0 ? t - 1 : t + 1;
+        hprev[(int64_t)(beg + t) * 2 * Hh + c] = (tp >= 0 && tp < len) ? out[(int64_t)(beg + tp) * ldo + c] : 0.0f;
+    }
+}
+
+struct LstmBwdParams {
+    float *G;                // [rows, 8Hh]: activated gates in, gate pre-activation gradients out (in place)
+    const float *cbuf;       // [rows, 2Hh]
+    const float *d_out;      // [rows, ldd] gradient w.r.t. the layer output
+    int64_t ldd;
+    const float *d_hn;       // [n, 2Hh] or null
+    const float *w_packT;
+    const int32_t *seq_off;
+    int n, Hh;
+};
+
+// Reverse-time recurrence.  Same ownership as the forward kernel (workgroup = 16 sequences x one
+// direction, lane = (sequence 4*g4+e, hidden unit) in the MFMA C/D layout), so dh and dc stay in
+// registers; only the gate gradients cross waves, through an LDS image [16][4Hh] that is the A
+// operand of dh_prev = dgates . W_hh (v_mfma_f32_16x16x4_f32, contraction over the 4Hh gate rows).
+template <int NCT, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void lstm_bwd_kernel(LstmBwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) float dgs[];   // [16][4Hh+4]
+    const int Hh = p.Hh, ldg = 4 * Hh + 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cl = lane & 15, g4 = lane >> 4;
+    const int dir = blockIdx.y;
+    const int s0 = blockIdx.x * 16;
+    const int ntiles = Hh >> 4, nkb = (4 * Hh) >> 5;
+    const int64_t ldx = 8 * (int64_t)Hh;
+    const int xcol = dir * 4 * Hh;
+
+    int off4[4], len4[4];
+    int lmax = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int s = s0 + g4 * 4 + e;
+        off4[e] = 0; len4[e] = 0;
+        if (s < p.n) { off4[e] = p.seq_off[s]; len4[e] = p.seq_off[s + 1] - off4[e]; }
+    }
+    for (int s = s0; s < min(s0 + 16, p.n); ++s) lmax = max(lmax, p.seq_off[s + 1] - p.seq_off[s]);
+
+    bool own[NCT];
+    int unit[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        const int tile = wave * NCT + ct;
+        own[ct] = tile < ntiles;
+        unit[ct] = (own[ct] ? tile : 0) * 16 + cl;
+    }
+    gfp wp = (gfp)p.w_packT + (int64_t)dir * 4 * Hh * Hh + lane * 4;
+
+    float dh[NCT][4], dc[NCT][4];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int s = s0 + g4 * 4 + e;
+            dc[ct][e] = 0.0f;
+            dh[ct][e] = (p.d_hn && s < p.n && own[ct]) ? p.d_hn[(int64_t)s * 2 * Hh + dir * Hh + unit[ct]] : 0.0f;
+        }
+    for (int i = tid; i < 16 * ldg; i += NWAVES * 64) dgs[i] = 0.0f;
+    __syncthreads();
+
+    for (int tau = lmax - 1; tau >= 0; --tau) {
+        // ---- cell backward (lane-local) ----
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool active = tau < len4[e];
+            const int t = dir == 0 ? tau : len4[e] - 1 - tau;
+            const int64_t row = off4[e] + (active ? t : 0);
+            const int64_t rowp = row + (dir == 0 ? -1 : 1);      // row of step tau-1 (valid iff tau > 0)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                if (!own[ct]) continue;
+                float di = 0.f, df = 0.f, dg = 0.f, dob = 0.f;
+                if (active) {
+                    float *g = p.G + row * ldx + xcol + unit[ct];
+                    const float gi = g[0], gf = g[Hh], gg = g[2 * Hh], go = g[3 * Hh];
+                    const float c = p.cbuf[row * 2 * Hh + dir * Hh + unit[ct]];
+                    const float cp = tau > 0 ? p.cbuf[rowp * 2 * Hh + dir * Hh + unit[ct]] : 0.0f;
+                    const float dht = dh[ct][e] + p.d_out[row * p.ldd + dir * Hh + unit[ct]];
+                    const float tc = tanh_fast(c);
+                    dob = dht * tc * go * (1.0f - go);
+                    const float dct = dc[ct][e] + dht * go * (1.0f - tc * tc);
+                    di = dct * gg * gi * (1.0f - gi);
+                    df = dct * cp * gf * (1.0f - gf);
+                    dg = dct * gi * (1.0f - gg * gg);
+                    dc[ct][e] = dct * gf;
+                    g[0] = di; g[Hh] = df; g[2 * Hh] = dg; g[3 * Hh] = dob;
+                }
+                float *l = dgs + (g4 * 4 + e) * ldg + unit[ct];
+                l[0] = di; l[Hh] = df; l[2 * Hh] = dg; l[3 * Hh] = dob;
+            }
+        }
+        __syncthreads();
+        // ---- dh_prev = dgates . W_hh ----
+        v4f acc[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) acc[ct] = v4f{0.f, 0.f, 0.f, 0.f};
+        for (int kb = 0; kb < nkb; ++kb) {
+            const v4f a0 = *reinterpret_cast<const v4f *>(dgs + cl * ldg + kb * 32 + 8 * g4);
+            const v4f a1 = *reinterpret_cast<const v4f *>(dgs + cl * ldg + kb * 32 + 8 * g4 + 4);
+            v4f b[NCT][2];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const int colblk = own[ct] ? wave * NCT + ct : 0;
+                gfp src = wp + ((int64_t)kb * ntiles + colblk) * 512;
+                b[ct][0] = *(gv4p)(src);
+                b[ct][1] = *(gv4p)(src + 256);
+            }
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj)
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(jj < 4 ? a0[jj & 3] : a1[jj & 3], b[ct][jj >> 2][jj & 3],
+                                                                   acc[ct], 0, 0, 0);
+        }
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (tau < len4[e]) dh[ct][e] = acc[ct][e];
+        __syncthreads();
+    }
+}
+
+int launch_lstm_bwd(const stair_lstm_bwd_args &a, hipStream_t s) {
+    STAIR_CHECK(a.n >= 0 && a.rows >= 0 && a.I > 0 && a.Hh > 0, "bad shape");
+    STAIR_CHECK(a.Hh % 32 == 0 && a.Hh <= 256, "LSTM hidden size must be a multiple of 32, at most 256");
+    STAIR_CHECK(a.gates && a.cbuf && a.out && a.d_out && a.whh_pack_ws && a.hprev_ws, "null buffer");
+    if (a.n == 0 || a.rows == 0) return 0;
+    const int Hh = a.Hh;
+    {
+        const int64_t ne = 2 * 4 * (int64_t)Hh * Hh;
+        hipLaunchKernelGGL(whh_packT_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, a.w_hh[0], a.w_hh[1],
+                           a.whh_pack_ws, Hh);
+        STAIR_LAUNCH_CHECK();
+    }
+    LstmBwdParams p;
+    p.G = a.gates; p.cbuf = a.cbuf; p.d_out = a.d_out; p.ldd = a.ldd; p.d_hn = a.d_hn; p.w_packT = a.whh_pack_ws;
+    p.seq_off = a.seq_off; p.n = a.n; p.Hh = Hh;
+    const dim3 grid((a.n + 15) / 16, 2);
+    const size_t shmem = 16 * (4 * Hh + 4) * sizeof(float);
+    const int tiles = Hh / 16;
+    if (shmem > 48 * 1024) {   // 16 x (4*256+4) floats = 65.8 KB: above the default dynamic-LDS limit
+        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_bwd_kernel<2, 8>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    }
+    if (tiles > 8) hipLaunchKernelGGL((lstm_bwd_kernel<2, 8>), grid, dim3(512), shmem, s, p);
+    else if (tiles > 4) hipLaunchKernelGGL((lstm_bwd_kernel<1, 8>), grid, dim3(512), shmem, s, p);
+    else if (tiles > 2) hipLaunchKernelGGL((lstm_bwd_kernel<1, 4>), grid, dim3(256), shmem, s, p);
+    else hipLaunchKernelGGL((lstm_bwd_kernel<1, 2>), grid, dim3(128), shmem, s, p);
+    STAIR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(lstm_hprev_kernel, dim3(a.n), dim3(256), 0, s, a.out, a.ldo, a.seq_off, a.n, Hh, a.hprev_ws);
+    STAIR_LAUNCH_CHECK();
+    // weight gradients: dW_ih = dG^T X, dW_hh = dG^T Hprev, db_ih = db_hh = colsum(dG)
+    for (int dir = 0; dir < 2; ++dir) {
+        stair_gemm_tn_args g = {};
+        g.A = a.gates + dir * 4 * Hh; g.lda = 8 * (int64_t)Hh;
+        g.B = a.x; g.ldb = a.ldx; g.b_gstride = a.ldx; g.rows_per_group = 1;
+        g.C = a.dw_ih[dir]; g.ldc = a.I; g.M = a.rows; g.N = 4 * Hh; g.K = a.I;
+        if (int rc = launch_gemm_tn(g, s)) return rc;
+        g.B = a.hprev_ws + dir * Hh; g.ldb = 2 * (int64_t)Hh; g.b_gstride = 2 * (int64_t)Hh;
+        g.C = a.dw_hh[dir]; g.ldc = Hh; g.K = Hh;
+        if (int rc = launch_gemm_tn(g, s)) return rc;
+        if (int rc = launch_colsum(a.gates + dir * 4 * Hh, 8 * (int64_t)Hh, a.db_ih[dir], a.rows, 4 * Hh, s)) return rc;
+        if (int rc = launch_colsum(a.gates + dir * 4 * Hh, 8 * (int64_t)Hh, a.db_hh[dir], a.rows, 4 * Hh, s)) return rc;
+    }
+    return 0;
 }
 
 int launch_lstm(const stair_lstm_args &a, hipStream_t s) {
@@ -250,7 +459,7 @@ int launch_lstm(const stair_lstm_args &a, hipStream_t s) {
     }
     LstmRecParams p;
     p.xproj = a.xproj_ws; p.w_pack = a.whh_pack_ws;
-    p.seq_off = a.seq_off; p.out = a.out; p.ldo = a.ldo; p.h_n = a.h_n; p.n = a.n; p.Hh = Hh;
+    p.seq_off = a.seq_off; p.out = a.out; p.ldo = a.ldo; p.h_n = a.h_n; p.cbuf = a.cbuf; p.n = a.n; p.Hh = Hh;
     const dim3 grid((a.n + 15) / 16, 2);
     const size_t shmem = 2 * 16 * (Hh + 4) * sizeof(float);
     const int tiles = Hh / 16;
@@ -270,4 +479,12 @@ extern "C" int stair_lstm_bidir_fwd(const stair_lstm_args *args, stair_stream st
         return 1;
     }
     return stair::launch_lstm(*args, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int stair_lstm_bidir_bwd(const stair_lstm_bwd_args *args, stair_stream stream) {
+    if (!args) {
+        stair::set_error("stair_lstm_bidir_bwd: null args");
+        return 1;
+    }
+    return stair::launch_lstm_bwd(*args, static_cast<hipStream_t>(stream));
 }

@@ -10,7 +10,7 @@ import ctypes as C
 
 import torch
 
-from ._lib import GemmArgs, LstmArgs, check, lib
+from ._lib import GemmArgs, GemmTnArgs, LstmArgs, LstmBwdArgs, check, lib
 
 ACT = {None: 0, 'none': 0, 'relu': 1, 'sigmoid': 2}
 
@@ -50,7 +50,7 @@ def linear(x, weight, bias=None, act=None):
 
 
 def gemm_grouped(A, a_gstride, a_gidx, W, bias, Cmat, c_gstride, c_gidx, groups, rows_per_group, N, K, act=None,
-                 lda=None, ldc=None, row_scale=None, rs_gstride=0, rs_gidx=None):
+                 lda=None, ldc=None, row_scale=None, rs_gstride=0, rs_gidx=None, accumulate=False):
     """Raw grouped form (see stair_gemm_args)."""
     a = GemmArgs()
     a.A, a.lda, a.a_gstride, a.a_gidx = A.data_ptr(), lda or K, a_gstride, (a_gidx.data_ptr() if a_gidx is not None else None)
@@ -59,14 +59,29 @@ def gemm_grouped(A, a_gstride, a_gidx, W, bias, Cmat, c_gstride, c_gidx, groups,
     a.row_scale = row_scale.data_ptr() if row_scale is not None else None
     a.rs_gstride, a.rs_gidx = rs_gstride, (rs_gidx.data_ptr() if rs_gidx is not None else None)
     a.groups, a.rows_per_group, a.N, a.K, a.act = groups, rows_per_group, N, K, ACT[act]
+    a.accumulate = 1 if accumulate else 0
     check(lib.stair_gemm_f32(C.byref(a), _stream()))
 
 
-def lstm_bidir(x, seq_off, max_len, weights):
+def gemm_tn(A, B, Cmat, M, N, K, rows_per_group=1, b_gstride=None, b_gidx=None, row_scale=None, rs_gstride=0,
+            rs_gidx=None):
+    """Cmat[N,K] += A[M,N]^T @ (rs * B[M,K]) -- weight gradients (see stair_gemm_tn_args)."""
+    a = GemmTnArgs()
+    a.A, a.lda = A.data_ptr(), N
+    a.B, a.ldb, a.b_gstride = B.data_ptr(), K, (b_gstride if b_gstride is not None else K * rows_per_group)
+    a.b_gidx = b_gidx.data_ptr() if b_gidx is not None else None
+    a.row_scale = row_scale.data_ptr() if row_scale is not None else None
+    a.rs_gstride, a.rs_gidx = rs_gstride, (rs_gidx.data_ptr() if rs_gidx is not None else None)
+    a.C, a.ldc = Cmat.data_ptr(), K
+    a.M, a.rows_per_group, a.N, a.K = M, rows_per_group, N, K
+    check(lib.stair_gemm_tn_f32(C.byref(a), _stream()))
+
+
+def lstm_bidir(x, seq_off, max_len, weights, save=False):
     """Bidirectional LSTM over packed ragged sequences.
 
     x [rows, I]; seq_off int32 [n+1] (device); weights = (w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r).
-    Returns (out [rows, 2*Hh], h_n [n, 2*Hh]).
+    Returns (out [rows, 2*Hh], h_n [n, 2*Hh]); with save=True also (gates, cbuf) for lstm_bidir_bwd.
     """
     _req(x, 'x'); _req(seq_off, 'seq_off', torch.int32)
     for w in weights:
@@ -87,8 +102,34 @@ def lstm_bidir(x, seq_off, max_len, weights):
         a.b_ih[d], a.b_hh[d] = weights[4 * d + 2].data_ptr(), weights[4 * d + 3].data_ptr()
     a.xproj_ws, a.bias_ws, a.whh_pack_ws = xproj.data_ptr(), bias_ws.data_ptr(), pack_ws.data_ptr()
     a.out, a.ldo, a.h_n = out.data_ptr(), 2 * Hh, h_n.data_ptr()
+    cbuf = torch.empty(rows, 2 * Hh, device=x.device, dtype=torch.float32) if save else None
+    a.cbuf = cbuf.data_ptr() if save else None
     check(lib.stair_lstm_bidir_fwd(C.byref(a), _stream()))
-    return out, h_n
+    return (out, h_n, xproj, cbuf) if save else (out, h_n)
+
+
+def lstm_bidir_bwd(x, seq_off, max_len, weights, out, gates, cbuf, d_out, d_hn=None):
+    """Gradients of (w_ih, w_hh, b_ih, b_hh) x 2 directions given d_out [rows, 2Hh] and d_hn [n, 2Hh].
+    `gates` (from lstm_bidir(save=True)) is overwritten."""
+    rows, I = x.shape
+    n = seq_off.numel() - 1
+    Hh = weights[1].shape[1]
+    grads = [torch.zeros_like(w) for w in weights]
+    a = LstmBwdArgs()
+    a.x, a.ldx, a.rows, a.n, a.max_len, a.I, a.Hh = x.data_ptr(), I, rows, n, max_len, I, Hh
+    a.seq_off = seq_off.data_ptr()
+    pack_ws = torch.empty(8 * Hh * Hh, device=x.device, dtype=torch.float32)
+    hprev = torch.empty(rows, 2 * Hh, device=x.device, dtype=torch.float32)
+    for d in range(2):
+        a.w_hh[d] = weights[4 * d + 1].data_ptr()
+        a.dw_ih[d], a.dw_hh[d] = grads[4 * d].data_ptr(), grads[4 * d + 1].data_ptr()
+        a.db_ih[d], a.db_hh[d] = grads[4 * d + 2].data_ptr(), grads[4 * d + 3].data_ptr()
+    a.gates, a.cbuf, a.out, a.ldo = gates.data_ptr(), cbuf.data_ptr(), out.data_ptr(), 2 * Hh
+    a.d_out, a.ldd = d_out.data_ptr(), 2 * Hh
+    a.d_hn = d_hn.data_ptr() if d_hn is not None else None
+    a.whh_pack_ws, a.hprev_ws = pack_ws.data_ptr(), hprev.data_ptr()
+    check(lib.stair_lstm_bidir_bwd(C.byref(a), _stream()))
+    return grads
 
 
 def l2normalize(x):

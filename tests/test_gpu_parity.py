@@ -229,3 +229,74 @@ def test_evaluation_driver_buckets_by_frame_count():
     acc, preds2 = E.evaluate(model, qs, unk_token_id=15, batch_size=7)
     assert preds2 == gold_pred
     assert acc == E.accuracy(gold_pred, [q['answer'] for q in qs], 15)
+
+
+# ---------------------------------------------------------------------------------------------
+# backward building blocks (training path)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('M,N,K,R', [(64, 16, 64, 1), (5000, 512, 512, 1), (24 * 7, 64, 128, 24), (1000, 1024, 300, 1),
+                                     (333, 36, 512, 1)])
+def test_gemm_tn_weight_gradient(M, N, K, R):
+    """dW = dZ^T (rs * X) with X gathered in groups, accumulated on top of existing contents."""
+    from stair_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    G = M // R
+    slots = G + 3
+    X = torch.randn(slots, R, K, generator=g)
+    idx = torch.randperm(slots, generator=g)[:G].to(torch.int32)
+    dZ = torch.randn(M, N, generator=g)
+    rs = torch.rand(slots, R, generator=g)
+    C0 = torch.randn(N, K, generator=g)
+    d = lambda t: t.to(DEV)
+    Cm = d(C0.clone())
+    ops.gemm_tn(d(dZ), d(X), Cm, M, N, K, rows_per_group=R, b_gstride=R * K, b_gidx=d(idx), row_scale=d(rs),
+                rs_gstride=R, rs_gidx=d(idx))
+    Xg = (X[idx.long()] * rs[idx.long()].unsqueeze(-1)).reshape(M, K).double()
+    ref = C0.double() + dZ.double().t() @ Xg
+    assert _maxerr(Cm, ref) < 1e-4 * max(1.0, (M / 1000) ** 0.5 * 3)
+
+
+def test_gemm_accumulate_scatter_add():
+    """dX products: two groups writing the same output slot must add up (atomic epilogue)."""
+    from stair_amd import ops
+    g = torch.Generator().manual_seed(9)
+    T, H = 8, 64
+    dY = torch.randn(3, T, H, generator=g)
+    Wt = torch.randn(H, H, generator=g) / 8
+    out0 = torch.randn(4, T, H, generator=g)
+    c_idx = torch.tensor([2, 2, 0], dtype=torch.int32)
+    d = lambda t: t.to(DEV)
+    Cm = d(out0.clone())
+    ops.gemm_grouped(d(dY), T * H, None, d(Wt), None, Cm, T * H, d(c_idx), 3, T, H, H, lda=H, ldc=H, accumulate=True)
+    ref = out0.clone().double()
+    for gi in range(3):
+        ref[c_idx[gi]] += dY[gi].double() @ Wt.double().t()
+    assert _maxerr(Cm, ref) < 1e-5
+
+
+@pytest.mark.parametrize('Hh,I,lens', [(32, 128, [5, 1, 9, 9, 3]), (256, 300, [8, 25, 12, 19, 25, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 20]),
+                                       (256, 512, [64] * 5), (64, 64, [4, 6]), (128, 64, [10, 3, 7])])
+def test_lstm_backward_matches_autograd_of_oracle(Hh, I, lens):
+    from stair_amd import ops
+    cfg = dict(spec.DEFAULT_CONFIG, hidden_size=2 * Hh, video_size=I, max_video_length=64)
+    names = ['submodules.video_encoder.' + n + sfx for sfx in ('', '_reverse')
+             for n in ('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0')]
+    w = {k: v.clone().requires_grad_(k in names) for k, v in oracle_weights(cfg, seed=4).items()}
+    g = torch.Generator().manual_seed(Hh + I)
+    xs = [torch.randn(L, I, generator=g) for L in lens]
+    d_outs = [torch.randn(L, 2 * Hh, generator=g) for L in lens]
+    d_hn = torch.randn(len(lens), 2 * Hh, generator=g)
+    loss = 0
+    for s, x in enumerate(xs):
+        ro, rh = O.lstm_bidir_explicit(w, 'video_encoder', x)
+        loss = loss + (ro * d_outs[s]).sum() + (rh.reshape(-1) * d_hn[s]).sum()
+    loss.backward()
+    off = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32).to(DEV)
+    X = torch.cat(xs).to(DEV)
+    ws = [w[n].detach().to(DEV) for n in names]
+    out, h_n, gates, cbuf = ops.lstm_bidir(X, off, max(lens), ws, save=True)
+    grads = ops.lstm_bidir_bwd(X, off, max(lens), ws, out, gates, cbuf, torch.cat(d_outs).to(DEV), d_hn.to(DEV))
+    for n, gr in zip(names, grads):
+        ref = w[n].grad
+        scale = max(1.0, float(ref.abs().max()))
+        assert _maxerr(gr, ref) < 2e-4 * scale, (n, _maxerr(gr, ref), scale)
