@@ -3,13 +3,16 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
 
-One step = one pass of the whole path (encode_video, encode_question, every program level, decoder,
-argmax -- program encoding and plan building included) over one batch of B synthetic questions per
-GPU: T=64 frames x V=2048 features (BASELINE.json configs[1] shape), H=512, A=172, programs drawn
-from the 8-form corpus of SURVEY.md Appendix B, inputs resident in HBM before the timed region.
-For N>1 the driver launches this file under torch.distributed.run; questions shard across ranks with
-no data-path collective (inference is embarrassingly parallel), timing is barrier-bracketed and the
-max over ranks is reported.  Rank 0 prints ONE JSON line.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--mode train|infer]
+
+Default mode `train` = BASELINE.json configs[1] ("AGQA2 full train ... 1 MI355X"): one step = one optimizer
+step over a window of B synthetic questions per GPU -- program encoding, plan build, encode_video,
+encode_question, every program level, decoder, cross-entropy loss, the full backward pass (BPTT through both
+bi-LSTMs included), one flat-bucket RCCL gradient all-reduce when N>1, Adam + LambdaLR.  `--mode infer` times
+the forward path + argmax only (configs[3] without hipGraph).  Shapes: T=64 frames x V=2048 features, H=512,
+A=172, programs drawn from the 8-form corpus of SURVEY.md Appendix B, inputs resident in HBM before the timed
+region.  For N>1 the driver launches this file under torch.distributed.run; questions shard across ranks,
+timing is barrier-bracketed and the max over ranks is reported.  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
   roofline      the dominant kernel (fp32 MFMA GEMM of the LSTM input projection), timed live with
@@ -71,6 +74,31 @@ def time_dominant_kernel(model, B, T, device, iters=10):
     return ms, 2.0 * M * N * K
 
 
+def cpu_baseline_train(config, weights, qs, video, question, q_lens, budget_s=15.0, max_q=256):
+    """The reference's training loop shape on the CPU: batch-1 forward + CE + backward per question through the
+    oracle (torch autograd), one Adam step per 32 questions (train_module.py:341-412)."""
+    from oracle import nmn_oracle as O
+    names = [n for n, _ in spec.weight_table(config)]
+    w = {k: torch.from_numpy(weights[k].copy()).requires_grad_(True) for k in names}
+    opt = torch.optim.Adam([w[n] for n in names], lr=2e-4)
+    off = np.concatenate([[0], np.cumsum(q_lens)])
+    n = min(max_q, len(qs))
+    vid, qst = video[:n].cpu(), question[:off[n]].cpu()
+    t0 = time.perf_counter()
+    done = 0
+    for i in range(n):
+        d = dict(qs[i], video_features=vid[i], question=qst[off[i]:off[i + 1]])
+        logits = O.forward(w, config, d, return_res_by_step=False)['logits']
+        loss = torch.nn.functional.cross_entropy(logits.unsqueeze(0), torch.tensor([qs[i]['answer']])) / 32
+        loss.backward()
+        done += 1
+        if done % 32 == 0:
+            opt.step(); opt.zero_grad(set_to_none=False)
+        if time.perf_counter() - t0 > budget_s:
+            break
+    return done / (time.perf_counter() - t0), done
+
+
 def cpu_baseline(config, weights, qs, video, question, q_lens, budget_s=15.0, max_q=512):
     from oracle import nmn_oracle as O
     w = O.to_torch(weights)
@@ -102,6 +130,7 @@ def main():
     ap.add_argument('--batch', type=int, default=1024, help='questions per GPU per step')
     ap.add_argument('--frames', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--mode', choices=['train', 'infer'], default='train')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -125,7 +154,15 @@ def main():
     programs = [q['nmn_program_list'] for q in qs]
     spans = [q['prog_str_to_question_tokens'] for q in qs]
 
+    answers = torch.tensor([q['answer'] for q in qs], dtype=torch.int32, device=device)
+    trainer = None
+    if args.mode == 'train':
+        from stair_amd.train import Trainer
+        trainer = Trainer(model, world=world)
+
     def step():
+        if trainer is not None:
+            return trainer.step(programs, spans, video, question, q_lens, answers)[1]
         return model.run_programs(programs, spans, video, question, q_lens)
 
     res = None
@@ -151,17 +188,33 @@ def main():
     total_q = B * args.steps * world
     qps = total_q / elapsed
 
+    infer_qps = None
+    if args.mode == 'train':          # the forward-only rate in the same process, for reference
+        torch.cuda.synchronize()
+        ti = time.perf_counter()
+        for _ in range(3):
+            r_inf = model.run_programs(programs, spans, video, question, q_lens)
+        torch.cuda.synchronize()
+        infer_qps = 3 * B / (time.perf_counter() - ti)
+        res = r_inf
+
     if rank == 0:
         gemm_ms, gemm_flop = time_dominant_kernel(model, B, T, device)
         achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12
         line = {
-            'metric': 'questions/sec on AGQA2-shaped synthetic features (NMN forward: encode -> program -> decoder -> argmax)',
+            'metric': ('questions/sec on AGQA2-shaped synthetic features, training step (forward + CE + backward + Adam)'
+                       if args.mode == 'train' else
+                       'questions/sec on AGQA2-shaped synthetic features (NMN forward: encode -> program -> decoder -> argmax)'),
             'value': round(qps, 1), 'unit': 'questions/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'AGQA2-shaped inference, I3D-like [T=%d,V=%d] features, H=512, A=172, 8 program forms '
-                                   '(BASELINE.json configs[1] shape; forward only, fp32)' % (T, config['video_size']),
-                       'questions_per_gpu_per_step': B, 'parallelism': 'dp%d (questions sharded, no collective)' % world},
+            'config': {'workload': ('AGQA2 full train (BASELINE.json configs[1]): I3D-like [T=%d,V=%d] features, H=512, A=172, 8 program '
+                                    'forms, decoder CE loss, fp32, one Adam step per window' if args.mode == 'train' else
+                                    'AGQA2-shaped inference, I3D-like [T=%d,V=%d] features, H=512, A=172, 8 program forms, fp32')
+                                   % (T, config['video_size']),
+                       'questions_per_gpu_per_step': B, 'mode': args.mode,
+                       'parallelism': ('dp%d (questions sharded, one flat fp32 gradient all-reduce per step)' if args.mode == 'train'
+                                       else 'dp%d (questions sharded, no collective)') % world},
             'roofline': {'bound': 'mfma', 'kernel': 'gemm_f32_kernel (LSTM input projection, M=%d N=%d K=%d)' % (B * T, 2 * config['hidden_size'], config['video_size']),
                          'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
@@ -169,19 +222,32 @@ def main():
             'roofline_hbm': {'bound': 'hbm', 'scope': 'whole path, algorithmic bytes x q/s (per GPU)',
                              'achieved': round(ALGO_BYTES_PER_QUESTION * qps / world / 1e9, 2), 'peak': HBM_PEAK_GBS,
                              'unit': 'GB/s', 'frac': round(ALGO_BYTES_PER_QUESTION * qps / world / 1e9 / HBM_PEAK_GBS, 5)},
-            'path_tflops': round(ALGO_FLOP_PER_QUESTION * qps / world / 1e12, 2),
+            'path_tflops': round(ALGO_FLOP_PER_QUESTION * (3.0 if args.mode == 'train' else 1.0) * qps / world / 1e12, 2),
         }
+        if infer_qps is not None:
+            line['inference_questions_per_s_per_gpu'] = round(infer_qps, 1)
         if not args.no_cpu_baseline:
             # the box gives one GPU a 16-core CPU share; more ATen threads than that only thrash
             ncores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
             torch.set_num_threads(ncores)
-            cpu_qps, n_done, preds, cpu_logits = cpu_baseline(config, weights, qs, video, question, q_lens)
+            if args.mode == 'train':
+                tq, tn = cpu_baseline_train(config, weights, qs, video, question, q_lens)
+                line['cpu_baseline'] = {'value': round(tq, 1), 'unit': 'questions/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+                                        'sample': 'first %d questions: batch-1 oracle forward + CE + autograd backward, Adam every 32 '
+                                                  '(the reference loop shape, train_module.py:341-412), ATen CPU' % tn}
+                model.load_state_dict({k: torch.from_numpy(weights[k].copy()) for k in spec.state_dict_keys(config)})
+                res = model.run_programs(programs, spans, video, question, q_lens)     # parity check below on the initial weights
+            cpu_qps, n_done, preds, cpu_logits = cpu_baseline(config, weights, qs, video, question, q_lens,
+                                                              budget_s=8.0 if args.mode == 'train' else 15.0)
             gpu_pred = res.pred[:n_done].cpu().tolist()
             agree = sum(int(a == b) for a, b in zip(gpu_pred, preds)) / max(1, n_done)
             maxdiff = float((res.logits[:n_done].cpu() - cpu_logits).abs().max())
-            line['cpu_baseline'] = {'value': round(cpu_qps, 1), 'unit': 'questions/s', 'cores': torch.get_num_threads(),
-                                    'kind': 'port',
-                                    'sample': 'first %d questions of the rank-0 batch through oracle/nmn_oracle.py (batch-1, ATen CPU)' % n_done}
+            inf = {'value': round(cpu_qps, 1), 'unit': 'questions/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+                   'sample': 'first %d questions of the rank-0 batch through oracle/nmn_oracle.py (batch-1 forward, ATen CPU)' % n_done}
+            if args.mode == 'train':
+                line['cpu_baseline_inference'] = inf
+            else:
+                line['cpu_baseline'] = inf
             line['top1_agreement_vs_oracle'] = round(agree, 4)
             line['max_abs_logit_diff_vs_oracle'] = maxdiff
         print(json.dumps(line), flush=True)

@@ -86,6 +86,9 @@ int stair_weight_count(const stair_ctx *ctx);
 const char *stair_weight_name(const stair_ctx *ctx, int id);
 int64_t stair_weight_numel(const stair_ctx *ctx, int id);
 int stair_ctx_set_weight(stair_ctx *ctx, int id, const float *dev_ptr, int64_t numel);
+/* Gradient buffer of weight `id` (same shape), needed only for stair_plan_backward; gradients are ACCUMULATED
+ * into it, the caller zeroes it (optimizer.zero_grad(), train_module.py:411). */
+int stair_ctx_set_grad(stair_ctx *ctx, int id, float *dev_ptr, int64_t numel);
 
 /* ---- building blocks (exported for unit tests and reuse; the plan runner calls the same code) */
 
@@ -182,16 +185,17 @@ int stair_l2normalize_fwd(const float *x, float *out, int32_t n, int32_t H, stai
  *   T                   frames per video in this batch (<= max_video_length; == for Linear Temporal)
  * Errors (non-zero) mirror the reference's failures: invalid program (assert len(stack)==1,
  * module_net.py:135), operand of the wrong kind, span outside the question. */
+#define STAIR_PLAN_TRAIN 1 /* flags: keep every intermediate and lay out gradient arenas for stair_plan_backward */
 int stair_plan_build(stair_ctx *ctx, int32_t n, const int32_t *prog_off, const int32_t *tokens,
                      const int32_t *span_lo, const int32_t *span_hi, const int32_t *q_off, int32_t T,
-                     stair_plan **out);
+                     int32_t flags, stair_plan **out);
 void stair_plan_destroy(stair_plan *plan);
 
 /* Workspace the caller must provide to stair_plan_run (bytes, device) and its arena layout
  * (offsets in floats from the workspace base) so a host can read any intermediate result. */
 typedef struct stair_plan_info {
     int64_t workspace_bytes;
-    int64_t vec_off, map_off, att_off, tok_off, qfeat_off; /* float offsets */
+    int64_t vec_off, map_off, att_off, tok_off, qfeat_off, logits_off; /* float offsets */
     int32_t n_vec, n_map, n_att, n_tok_rows;
     int32_t n_nodes, n_launches, n_levels, n_questions, T;
 } stair_plan_info;
@@ -208,6 +212,27 @@ int stair_plan_node(const stair_plan *plan, int32_t tok, int32_t *kind, int32_t 
 int stair_plan_run(stair_ctx *ctx, stair_plan *plan, const float *video, const float *question,
                    void *workspace, int64_t workspace_bytes, float *logits, int32_t *argmax,
                    stair_stream stream);
+
+/* Reverse pass of a STAIR_PLAN_TRAIN plan after stair_plan_run on the same workspace: decoder cross
+ * entropy against answers[n] (train_module.py:193-194,376-380), d(loss_scale * sum_i CE_i) propagated
+ * through decoder, every program level in reverse, and both encoders (BPTT); parameter gradients are
+ * accumulated into the buffers given to stair_ctx_set_grad.  loss_out [n] (device, may be NULL)
+ * receives the unscaled per-question CE.  What torch autograd does for train_module.py:408. */
+int stair_plan_backward(stair_ctx *ctx, stair_plan *plan, const float *video, const float *question,
+                        void *workspace, int64_t workspace_bytes, const int32_t *answers, float loss_scale,
+                        float *loss_out, stair_stream stream);
+
+/* touched[id] = 1 iff weight `id` receives a gradient from this plan (host array, count = stair_weight_count).
+ * Parameters of modules that no program used keep grad == None in the reference and are skipped by Adam. */
+int stair_plan_touched(const stair_ctx *ctx, const stair_plan *plan, int32_t *touched, int32_t count);
+
+/* torch.optim.Adam (train_module.py:326) over a flat fp32 parameter buffer of n floats.  Parameter tensors
+ * ("segments") start on multiples of 256 floats; seg_of_block[b] = segment of elements 256b..256b+255;
+ * segments with touched[seg] == 0 are skipped (no moment decay, no step), step_of_seg[seg] is the 1-based
+ * Adam step of the segment (already incremented by the caller).  All arrays on the device. */
+int stair_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq,
+                    const int32_t *seg_of_block, const int32_t *touched, const float *step_of_seg, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, int64_t n, stair_stream stream);
 
 #ifdef __cplusplus
 }

@@ -62,7 +62,7 @@ class LstmBwdArgs(C.Structure):
 
 class PlanInfo(C.Structure):
     _fields_ = [('workspace_bytes', C.c_int64), ('vec_off', C.c_int64), ('map_off', C.c_int64), ('att_off', C.c_int64),
-                ('tok_off', C.c_int64), ('qfeat_off', C.c_int64),
+                ('tok_off', C.c_int64), ('qfeat_off', C.c_int64), ('logits_off', C.c_int64),
                 ('n_vec', C.c_int32), ('n_map', C.c_int32), ('n_att', C.c_int32), ('n_tok_rows', C.c_int32),
                 ('n_nodes', C.c_int32), ('n_launches', C.c_int32), ('n_levels', C.c_int32), ('n_questions', C.c_int32),
                 ('T', C.c_int32)]
@@ -78,6 +78,7 @@ SIGNATURES = [
     ('stair_weight_name', C.c_char_p, [C.c_void_p, C.c_int]),
     ('stair_weight_numel', C.c_int64, [C.c_void_p, C.c_int]),
     ('stair_ctx_set_weight', C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
+    ('stair_ctx_set_grad', C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
     ('stair_gemm_f32', C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     ('stair_gemm_tn_f32', C.c_int, [C.POINTER(GemmTnArgs), C.c_void_p]),
     ('stair_lstm_bidir_fwd', C.c_int, [C.POINTER(LstmArgs), C.c_void_p]),
@@ -89,7 +90,12 @@ SIGNATURES = [
                                             C.c_void_p]),
     ('stair_l2normalize_fwd', C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     ('stair_plan_build', C.c_int, [C.c_void_p, C.c_int32, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p,
-                                   C.c_int32, C.POINTER(C.c_void_p)]),
+                                   C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    ('stair_plan_backward', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                      C.c_float, C.c_void_p, C.c_void_p]),
+    ('stair_plan_touched', C.c_int, [C.c_void_p, C.c_void_p, c_int32_p, C.c_int32]),
+    ('stair_adam_step', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64, C.c_void_p]),
     ('stair_plan_destroy', None, [C.c_void_p]),
     ('stair_plan_get_info', C.c_int, [C.c_void_p, C.POINTER(PlanInfo)]),
     ('stair_plan_node', C.c_int, [C.c_void_p, C.c_int32, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p]),

@@ -37,6 +37,7 @@ struct stair_ctx {
     std::vector<std::string> names;
     std::vector<int64_t> numel;
     std::vector<const float *> ptr;
+    std::vector<float *> gptr;           // gradient buffers (training), same ids
     std::unordered_map<std::string, int> by_name;
 
     void add(const std::string &name, int64_t n) {
@@ -44,6 +45,7 @@ struct stair_ctx {
         names.push_back(name);
         numel.push_back(n);
         ptr.push_back(nullptr);
+        gptr.push_back(nullptr);
     }
     void lin(const std::string &prefix, int64_t out, int64_t in) {
         add(prefix + ".weight", out * in);
@@ -52,6 +54,10 @@ struct stair_ctx {
     const float *find(const std::string &name) const {
         auto it = by_name.find(name);
         return it == by_name.end() ? nullptr : ptr[it->second];
+    }
+    float *findg(const std::string &name) const {
+        auto it = by_name.find(name);
+        return it == by_name.end() ? nullptr : gptr[it->second];
     }
 };
 
@@ -165,6 +171,15 @@ extern "C" int stair_ctx_set_weight(stair_ctx *ctx, int id, const float *dev_ptr
     return 0;
 }
 
+extern "C" int stair_ctx_set_grad(stair_ctx *ctx, int id, float *dev_ptr, int64_t numel) {
+    STAIR_CHECK(ctx, "null ctx");
+    STAIR_CHECK(id >= 0 && id < (int)ctx->names.size(), "weight id out of range");
+    STAIR_CHECK(numel == ctx->numel[id], "numel mismatch for " + ctx->names[id]);
+    STAIR_CHECK(dev_ptr && (reinterpret_cast<uintptr_t>(dev_ptr) & 15) == 0, "gradient pointer must be 16-byte aligned: " + ctx->names[id]);
+    ctx->gptr[id] = dev_ptr;
+    return 0;
+}
+
 // =============================================================================================
 // plan
 // =============================================================================================
@@ -186,6 +201,9 @@ struct Bucket {
     int nrows = 0;      // secondary count (Localize pairs / Superlative action rows)
     std::vector<int32_t> col[8];
     int64_t off[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // offsets into the device idx buffer
+    // float offsets of this bucket's intermediates.  Inference: all buckets share one scratch set;
+    // training: private regions, kept until stair_plan_backward has consumed them.
+    int64_t svA = 0, svB = 0, svK = 0, svCat = 0, svHid = 0, svRs = 0, svSup = 0, svExtra = 0;
 };
 
 }  // namespace
@@ -204,9 +222,21 @@ struct stair_plan {
     int64_t o_idx = 0, o_vec = 0, o_map = 0, o_att = 0, o_tok = 0, o_qfeat = 0, o_vhn = 0, o_xpv = 0, o_xpt = 0,
             o_bias = 0, o_wpack = 0, o_tmpA = 0, o_tmpB = 0, o_kbuf = 0, o_cat = 0, o_hid = 0, o_rs = 0, o_sup = 0, o_extra = 0,
             o_logits = 0, total = 0;
+    // training only
+    bool train = false;
+    int64_t o_cv = 0, o_ct = 0, o_hprev = 0, o_gblock = 0, o_gatt = 0, o_gtok = 0, o_gqfeat = 0, o_gA = 0, o_gB = 0,
+            o_gK = 0, o_gV0 = 0, o_gV1 = 0, o_gCat = 0, o_gS = 0, o_gRs = 0, o_gRs2 = 0, o_gExtra = 0, o_gStats = 0,
+            o_wt = 0, o_dlogits = 0, o_loss = 0, o_zero_beg = 0, o_zero_end = 0;
 };
 
 namespace {
+
+// floats needed for the transposed weight images used by the dX products (all 2-D weights)
+int64_t ctx_weight_floats(const stair_ctx *ctx) {
+    int64_t t = 0;
+    for (int64_t v : ctx->numel) t += align_up(v, 64);
+    return t;
+}
 
 struct Builder {
     stair_plan *pl;
@@ -234,7 +264,7 @@ std::string where(int q, int i, int tok) {
 
 extern "C" int stair_plan_build(stair_ctx *ctx, int32_t n, const int32_t *prog_off, const int32_t *tokens,
                                 const int32_t *span_lo, const int32_t *span_hi, const int32_t *q_off, int32_t T,
-                                stair_plan **out) {
+                                int32_t flags, stair_plan **out) {
     STAIR_CHECK(ctx && prog_off && tokens && span_lo && span_hi && q_off && out, "null argument");
     STAIR_CHECK(n > 0 && T > 0, "n and T must be positive");
     STAIR_CHECK(ctx->conv || T == ctx->cfg.max_video_length,
@@ -244,6 +274,7 @@ extern "C" int stair_plan_build(stair_ctx *ctx, int32_t n, const int32_t *prog_o
     pl->cfg = ctx->cfg;
     pl->n = n;
     pl->T = T;
+    pl->train = (flags & STAIR_PLAN_TRAIN) != 0;
     const int ntok = prog_off[n];
     pl->nodes.assign(ntok, Node());
     pl->roots.assign(n, -1);
@@ -538,6 +569,61 @@ extern "C" int stair_plan_build(stair_ctx *ctx, int32_t n, const int32_t *prog_o
     pl->o_sup = take((int64_t)std::max(pl->maxSupRows, 1) * T, 64);
     pl->o_extra = take(std::max(pl->maxI, 1), 64);
     pl->o_logits = take((int64_t)n * A, 64);
+    for (Bucket &b : pl->buckets) {
+        b.svA = pl->o_tmpA; b.svB = pl->o_tmpB; b.svK = pl->o_kbuf; b.svCat = pl->o_cat; b.svHid = pl->o_hid;
+        b.svRs = pl->o_rs; b.svSup = pl->o_sup; b.svExtra = pl->o_extra;
+        if (!pl->train) continue;
+        const int64_t c = b.cnt;
+        switch (b.op) {
+            case STAIR_OP_FILTER:
+                b.svA = take(c * T * H, 64); b.svB = take(c * T * H, 64); b.svCat = take(c * H, 64); break;
+            case STAIR_OP_FILTERFRAME:
+                b.svA = take(c * T * H, 64); b.svB = take(c * T * H, 64); b.svRs = take(c * T, 64); b.svExtra = take(c, 64); break;
+            case STAIR_OP_HASITEM:
+            case STAIR_OP_TEMPORAL:
+                b.svA = take(c * T * H, 64); break;
+            case STAIR_OP_LOCALIZE:
+                b.svA = take(c * T * H, 64); b.svB = take(c * T * H, 64); b.svK = take((int64_t)b.nrows * H, 64); break;
+            case STAIR_OP_SUPERLATIVE:
+                b.svA = take(c * T * H, 64); b.svB = take(c * T * H, 64); b.svK = take((int64_t)b.nrows * H, 64);
+                b.svSup = take((int64_t)b.nrows * T, 64); b.svCat = take(c * H, 64); break;
+            case STAIR_OP_COMPARE: case STAIR_OP_EQUALS: case STAIR_OP_XOR:
+                b.svCat = take(c * 3 * H, 64); break;
+            case STAIR_OP_TOACTION: case STAIR_OP_EXISTS:
+                b.svCat = take(c * 3 * H, 64); b.svHid = take(c * H, 64); break;
+            default: break;
+        }
+    }
+    if (pl->train) {
+        const int64_t I = std::max(pl->maxI, 1), Vv = pl->maxV;
+        pl->o_cv = take((int64_t)n * T * H, 64);
+        pl->o_ct = take((int64_t)pl->rows_q * H, 64);
+        pl->o_hprev = take((int64_t)std::max(n * T, pl->rows_q) * H, 64);
+        pl->o_wt = take(ctx_weight_floats(ctx), 64);
+        pl->o_gA = take(I * T * H, 64);
+        pl->o_gB = take(I * T * H, 64);
+        pl->o_gV0 = take(Vv * 2 * H, 64);
+        pl->o_gV1 = take(Vv * 2 * H, 64);
+        pl->o_gCat = take(Vv * 3 * H, 64);
+        pl->o_gStats = take(I * T * 2, 64);
+        pl->o_gRs2 = take(I * T, 64);
+        pl->o_dlogits = take((int64_t)n * A, 64);
+        pl->o_loss = take(n, 64);
+        // everything from here to o_zero_end is cleared at the start of every backward pass
+        pl->o_zero_beg = align_up(o, 64);
+        o = pl->o_zero_beg;
+        pl->o_gblock = take(pl->o_map + (int64_t)pl->n_map * T * H - pl->o_vec, H);   // mirrors [vec arena .. map arena]
+        pl->o_gatt = take((int64_t)std::max(pl->n_att, 1) * T, 64);
+        pl->o_gtok = take((int64_t)pl->rows_q * H, 64);
+        pl->o_gqfeat = take((int64_t)n * H, 64);
+        pl->o_zero_end = align_up(o, 64);
+        o = pl->o_zero_end;
+        // scratch that individual buckets clear themselves before accumulating into it
+        pl->o_gK = take((int64_t)std::max(pl->maxK, 1) * H, 64);
+        pl->o_gS = take((int64_t)std::max(pl->maxSupRows, 1) * T, 64);
+        pl->o_gRs = take(I * T, 64);
+        pl->o_gExtra = take(I, 64);
+    }
     pl->total = align_up(o, 64);
     *out = plp.release();
     return 0;
@@ -549,7 +635,7 @@ extern "C" int stair_plan_get_info(const stair_plan *pl, stair_plan_info *info) 
     STAIR_CHECK(pl && info, "null argument");
     info->workspace_bytes = pl->total * (int64_t)sizeof(float);
     info->vec_off = pl->o_vec; info->map_off = pl->o_map; info->att_off = pl->o_att;
-    info->tok_off = pl->o_tok; info->qfeat_off = pl->o_qfeat;
+    info->tok_off = pl->o_tok; info->qfeat_off = pl->o_qfeat; info->logits_off = pl->o_logits;
     info->n_vec = pl->n_vec; info->n_map = pl->n_map; info->n_att = pl->n_att; info->n_tok_rows = pl->rows_q;
     info->n_nodes = (int)pl->nodes.size();
     int launches = 0;
@@ -576,26 +662,39 @@ extern "C" int stair_plan_node(const stair_plan *pl, int32_t tok, int32_t *kind,
 // =============================================================================================
 namespace {
 
-struct Lin { const float *w = nullptr, *b = nullptr; };
+struct Lin { const float *w = nullptr, *b = nullptr; float *dw = nullptr, *db = nullptr; int id = -1; };
 struct Weights {
     Lin compare, equals, exists0, exists3, f0[4], f3[4], fdense, ff0[3], ff3[3], ffatt, ffdense, hi0, hi3, lv0, lv3,
         lk, supdense, tdense, ta0, ta3, xorl, dec0, dec3;
     const float *beta = nullptr, *ln_w = nullptr, *ln_b = nullptr;
+    float *dbeta = nullptr, *dln_w = nullptr, *dln_b = nullptr;
     const float *relate[3][6] = {};
+    float *drelate[3][6] = {};
     const float *enc[2][8] = {};   // [video|text][w_ih, w_hh, b_ih, b_hh, then reverse]
+    float *denc[2][8] = {};
 };
 
-int resolve(const stair_ctx *ctx, Weights &W) {
+int resolve(const stair_ctx *ctx, Weights &W, bool grads) {
     const std::string p = "submodules.";
-    auto get = [&](const std::string &name, const float *&dst) {
+    auto get = [&](const std::string &name, const float *&dst, float **gdst) {
         dst = ctx->find(name);
         if (!dst) {
-            set_error("stair_plan_run: weight not set: " + name);
+            set_error("weight not set: " + name);
             return 1;
+        }
+        if (grads) {
+            *gdst = ctx->findg(name);
+            if (!*gdst) {
+                set_error("gradient buffer not set: " + name);
+                return 1;
+            }
         }
         return 0;
     };
-    auto lin = [&](const std::string &prefix, Lin &l) { return get(prefix + ".weight", l.w) || get(prefix + ".bias", l.b); };
+    auto lin = [&](const std::string &prefix, Lin &l) {
+        l.id = ctx->by_name.at(prefix + ".weight");
+        return get(prefix + ".weight", l.w, &l.dw) || get(prefix + ".bias", l.b, &l.db);
+    };
 #define R(x) if (x) return 1
     R(lin(p + "Compare.param.0", W.compare));
     R(lin(p + "Equals.param.0", W.equals));
@@ -619,18 +718,18 @@ int resolve(const stair_ctx *ctx, Weights &W) {
     R(lin(p + "Localize.video_linear.0", W.lv0));
     R(lin(p + "Localize.video_linear.3", W.lv3));
     R(lin(p + "Localize.keyword_linear.0", W.lk));
-    R(get(p + "Relate.beta", W.beta));
+    R(get(p + "Relate.beta", W.beta, &W.dbeta));
     R(lin(p + "Superlative.dense.0", W.supdense));
     const char *modes[3] = {"before", "after", "between"};
     for (int m = 0; m < 3; ++m)
         for (int l = 0; l < 3; ++l) {
             const std::string pre = p + "Temporal.relate." + modes[m] + "." + std::to_string(2 * l);
-            R(get(pre + ".weight", W.relate[m][2 * l]));
-            R(get(pre + ".bias", W.relate[m][2 * l + 1]));
+            R(get(pre + ".weight", W.relate[m][2 * l], &W.drelate[m][2 * l]));
+            R(get(pre + ".bias", W.relate[m][2 * l + 1], &W.drelate[m][2 * l + 1]));
         }
     R(lin(p + "Temporal.dense.0", W.tdense));
-    R(get(p + "Temporal.layer_norm.weight", W.ln_w));
-    R(get(p + "Temporal.layer_norm.bias", W.ln_b));
+    R(get(p + "Temporal.layer_norm.weight", W.ln_w, &W.dln_w));
+    R(get(p + "Temporal.layer_norm.bias", W.ln_b, &W.dln_b));
     R(lin(p + "ToAction.param.0", W.ta0));
     R(lin(p + "ToAction.param.3", W.ta3));
     R(lin(p + "Xor.param.0", W.xorl));
@@ -638,10 +737,10 @@ int resolve(const stair_ctx *ctx, Weights &W) {
         const std::string enc = p + (e == 0 ? "video_encoder" : "text_encoder");
         const char *sfx[2] = {"", "_reverse"};
         for (int d = 0; d < 2; ++d) {
-            R(get(enc + ".weight_ih_l0" + sfx[d], W.enc[e][4 * d + 0]));
-            R(get(enc + ".weight_hh_l0" + sfx[d], W.enc[e][4 * d + 1]));
-            R(get(enc + ".bias_ih_l0" + sfx[d], W.enc[e][4 * d + 2]));
-            R(get(enc + ".bias_hh_l0" + sfx[d], W.enc[e][4 * d + 3]));
+            R(get(enc + ".weight_ih_l0" + sfx[d], W.enc[e][4 * d + 0], &W.denc[e][4 * d + 0]));
+            R(get(enc + ".weight_hh_l0" + sfx[d], W.enc[e][4 * d + 1], &W.denc[e][4 * d + 1]));
+            R(get(enc + ".bias_ih_l0" + sfx[d], W.enc[e][4 * d + 2], &W.denc[e][4 * d + 2]));
+            R(get(enc + ".bias_hh_l0" + sfx[d], W.enc[e][4 * d + 3], &W.denc[e][4 * d + 3]));
         }
     }
     R(lin(p + "decoder.0", W.dec0));
@@ -663,6 +762,11 @@ int dense(hipStream_t s, const float *A, int64_t lda, int64_t a_gs, const int32_
     return launch_gemm(g, s);
 }
 
+struct Ptrs {     // workspace views shared by forward and backward
+    float *ws, *vec, *map, *att, *tok, *qfeat;
+    int32_t *didx;
+};
+
 }  // namespace
 
 extern "C" int stair_plan_run(stair_ctx *ctx, stair_plan *pl, const float *video, const float *question,
@@ -674,7 +778,7 @@ extern "C" int stair_plan_run(stair_ctx *ctx, stair_plan *pl, const float *video
     STAIR_CHECK(memcmp(&ctx->cfg, &pl->cfg, sizeof(stair_config)) == 0, "plan was built for another configuration");
     hipStream_t s = static_cast<hipStream_t>(stream);
     Weights W;
-    if (resolve(ctx, W)) return 1;
+    if (resolve(ctx, W, false)) return 1;
 
     const stair_config &g = ctx->cfg;
     const int H = g.hidden_size, Hh = H / 2, V = g.video_size, E = g.text_size, A = g.answer_vocab_length;
@@ -683,10 +787,9 @@ extern "C" int stair_plan_run(stair_ctx *ctx, stair_plan *pl, const float *video
     float *ws = static_cast<float *>(workspace);
     int32_t *didx = reinterpret_cast<int32_t *>(ws + pl->o_idx);
     float *vec = ws + pl->o_vec, *map = ws + pl->o_map, *att = ws + pl->o_att, *tok = ws + pl->o_tok;
-    float *qfeat = ws + pl->o_qfeat, *tmpA = ws + pl->o_tmpA, *tmpB = ws + pl->o_tmpB, *kbuf = ws + pl->o_kbuf;
-    float *cat = ws + pl->o_cat, *hid = ws + pl->o_hid, *rsb = ws + pl->o_rs, *sup = ws + pl->o_sup;
-    float *extra = ws + pl->o_extra;
-    if (!logits) logits = ws + pl->o_logits;
+    float *qfeat = ws + pl->o_qfeat;
+    if (pl->train) logits = ws + pl->o_logits;       // backward reads them from the workspace
+    else if (!logits) logits = ws + pl->o_logits;
 
     STAIR_HIP(hipMemcpyAsync(didx, pl->idx.data(), pl->idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
 
@@ -702,6 +805,7 @@ extern "C" int stair_plan_run(stair_ctx *ctx, stair_plan *pl, const float *video
         }
         a.xproj_ws = ws + pl->o_xpv; a.bias_ws = ws + pl->o_bias; a.whh_pack_ws = ws + pl->o_wpack;
         a.out = map; a.ldo = H; a.h_n = ws + pl->o_vhn;
+        a.cbuf = pl->train ? ws + pl->o_cv : nullptr;
         RUN(launch_lstm(a, s));
     }
     {
@@ -714,6 +818,7 @@ extern "C" int stair_plan_run(stair_ctx *ctx, stair_plan *pl, const float *video
         }
         a.xproj_ws = ws + pl->o_xpt; a.bias_ws = ws + pl->o_bias + 4 * H; a.whh_pack_ws = ws + pl->o_wpack + 2 * (int64_t)H * H;
         a.out = tok; a.ldo = H; a.h_n = qfeat;
+        a.cbuf = pl->train ? ws + pl->o_ct : nullptr;
         RUN(launch_lstm(a, s));
     }
 
@@ -723,6 +828,8 @@ extern "C" int stair_plan_run(stair_ctx *ctx, stair_plan *pl, const float *video
         const int c = b.cnt;
         const int32_t *I0 = didx + b.off[0], *I1 = didx + b.off[1], *I2 = didx + b.off[2], *I3 = didx + b.off[3],
                       *I4 = didx + b.off[4], *I5 = didx + b.off[5];
+        float *tmpA = ws + b.svA, *tmpB = ws + b.svB, *kbuf = ws + b.svK, *cat = ws + b.svCat, *hid = ws + b.svHid;
+        float *rsb = ws + b.svRs, *sup = ws + b.svSup, *extra = ws + b.svExtra;
         switch (b.op) {
             case OP_SPAN:
                 RUN(launch_span_mean(tok, H, I0, I1, vec, I2, c, H, s));
@@ -810,8 +917,8 @@ extern "C" int stair_plan_run(stair_ctx *ctx, stair_plan *pl, const float *video
                 const int mode = b.variant;
                 RUN(launch_temporal_relate(att, I1, I2, att, I3, c, T, mode, ctx->conv ? 1 : 0, ctx->ksize,
                                            mode ? W.relate[mode - 1] : nullptr, s));
-                RUN(dense(s, map, H, TH, I0, W.tdense, H, map, H, TH, I4, c, T, H, H, 1, att, T, I3));
-                RUN(launch_layernorm(map, TH, I4, c, T, H, W.ln_w, W.ln_b, 1e-5f, s));
+                RUN(dense(s, map, H, TH, I0, W.tdense, H, tmpA, H, TH, nullptr, c, T, H, H, 1, att, T, I3));
+                RUN(launch_layernorm(tmpA, map, TH, I4, c, T, H, W.ln_w, W.ln_b, 1e-5f, s));
                 break;
             }
             default:
@@ -820,10 +927,321 @@ extern "C" int stair_plan_run(stair_ctx *ctx, stair_plan *pl, const float *video
     }
 
     // ---- decoder (module_net.py:136-138) -----------------------------------------------------
+    float *cat = ws + pl->o_cat, *hid = ws + pl->o_hid;
     RUN(launch_pack(PACK_CAT2, vec, didx + pl->off_roots, qfeat, nullptr, cat, n, H, s));
     RUN(dense(s, cat, 2 * H, 2 * H, nullptr, W.dec0, 2 * H, hid, 2 * H, 2 * H, nullptr, n, 1, 2 * H, 2 * H, 1));
     RUN(dense(s, hid, 2 * H, 2 * H, nullptr, W.dec3, 2 * H, logits, A, A, nullptr, n, 1, A, 2 * H, 0));
     if (argmax) RUN(launch_argmax(logits, argmax, n, A, s));
+    return 0;
+}
+
+// =============================================================================================
+// backward
+// =============================================================================================
+namespace {
+
+struct BwdCtx {
+    hipStream_t s;
+    float *wt;                       // transposed weight images
+    std::vector<int64_t> wt_off;     // per weight id
+};
+
+// Backward of Y = act(rs * X W^T + b) given dZ (already multiplied by act'):
+//   dW += dZ^T (rs * X);  db += colsum(dZ);  dX (+)= dZ W      (dX is w.r.t. the scaled input rs*X)
+int dense_bwd(const BwdCtx &B, const float *dZ, int groups, int R, int N, int K, const float *X, int64_t ldx, int64_t x_gs,
+              const int32_t *x_gidx, const Lin &l, float *dX, int64_t ldd, int64_t d_gs, const int32_t *d_gidx, int accumulate,
+              const float *rs = nullptr, int64_t rs_gs = 0, const int32_t *rs_gidx = nullptr) {
+    const int M = groups * R;
+    if (M == 0) return 0;
+    stair_gemm_tn_args t = {};
+    t.A = dZ; t.lda = N; t.B = X; t.ldb = ldx; t.b_gstride = x_gs; t.b_gidx = x_gidx;
+    t.row_scale = rs; t.rs_gstride = rs_gs; t.rs_gidx = rs_gidx;
+    t.C = l.dw; t.ldc = K; t.M = M; t.rows_per_group = R; t.N = N; t.K = K;
+    if (int rc = launch_gemm_tn(t, B.s)) return rc;
+    if (int rc = launch_colsum(dZ, N, l.db, M, N, B.s)) return rc;
+    if (dX) {
+        stair_gemm_args g = {};
+        g.A = dZ; g.lda = N; g.a_gstride = (int64_t)R * N;
+        g.W = B.wt + B.wt_off[l.id]; g.ldw = N;                 // W^T [K][N]
+        g.C = dX; g.ldc = ldd; g.c_gstride = d_gs; g.c_gidx = d_gidx;
+        g.groups = groups; g.rows_per_group = R; g.N = K; g.K = N; g.act = 0; g.accumulate = accumulate;
+        if (int rc = launch_gemm(g, B.s)) return rc;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *video, const float *question,
+                                   void *workspace, int64_t workspace_bytes, const int32_t *answers, float loss_scale,
+                                   float *loss_out, stair_stream stream) {
+    STAIR_CHECK(ctx && pl && video && question && workspace && answers, "null argument");
+    STAIR_CHECK(pl->train, "plan was not built with STAIR_PLAN_TRAIN");
+    STAIR_CHECK(workspace_bytes >= pl->total * (int64_t)sizeof(float), "workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Weights W;
+    if (resolve(ctx, W, true)) return 1;
+
+    const stair_config &g = ctx->cfg;
+    const int H = g.hidden_size, Hh = H / 2, V = g.video_size, E = g.text_size, A = g.answer_vocab_length;
+    const int n = pl->n, T = pl->T;
+    const int64_t TH = (int64_t)T * H;
+    float *ws = static_cast<float *>(workspace);
+    int32_t *didx = reinterpret_cast<int32_t *>(ws + pl->o_idx);
+    float *vec = ws + pl->o_vec, *map = ws + pl->o_map, *att = ws + pl->o_att;
+    float *qfeat = ws + pl->o_qfeat, *logits = ws + pl->o_logits;
+    float *gws = ws + pl->o_gblock - pl->o_vec;          // gradient of workspace row r lives at gws + r*H
+    float *g_vec = ws + pl->o_gblock, *g_map = ws + pl->o_gblock + (pl->o_map - pl->o_vec), *g_att = ws + pl->o_gatt;
+    float *g_tok = ws + pl->o_gtok, *g_qfeat = ws + pl->o_gqfeat;
+    float *gA = ws + pl->o_gA, *gB = ws + pl->o_gB, *gK = ws + pl->o_gK, *gV0 = ws + pl->o_gV0, *gV1 = ws + pl->o_gV1;
+    float *gCat = ws + pl->o_gCat, *gS = ws + pl->o_gS, *gRs = ws + pl->o_gRs, *gRs2 = ws + pl->o_gRs2;
+    float *gExtra = ws + pl->o_gExtra, *gStats = ws + pl->o_gStats, *dlogits = ws + pl->o_dlogits;
+    float *loss = loss_out ? loss_out : ws + pl->o_loss;
+
+#define RUN(x) do { if (int rc_ = (x)) return rc_; } while (0)
+    STAIR_HIP(hipMemsetAsync(ws + pl->o_zero_beg, 0, (pl->o_zero_end - pl->o_zero_beg) * sizeof(float), s));
+
+    // transposed images of every 2-D weight that needs a dX product
+    BwdCtx B;
+    B.s = s; B.wt = ws + pl->o_wt;
+    B.wt_off.assign(ctx->names.size(), 0);
+    {
+        int64_t o = 0;
+        for (size_t i = 0; i < ctx->names.size(); ++i) { B.wt_off[i] = o; o += align_up(ctx->numel[i], 64); }
+        const Lin *lins[] = {&W.compare, &W.equals, &W.exists0, &W.exists3, &W.f0[0], &W.f0[1], &W.f0[2], &W.f0[3], &W.f3[0],
+                             &W.f3[1], &W.f3[2], &W.f3[3], &W.fdense, &W.ff0[0], &W.ff0[1], &W.ff0[2], &W.ff3[0], &W.ff3[1],
+                             &W.ff3[2], &W.ffdense, &W.hi0, &W.lv0, &W.lv3, &W.lk, &W.supdense, &W.tdense, &W.ta0, &W.ta3,
+                             &W.xorl, &W.dec0, &W.dec3};
+        for (const Lin *l : lins) {
+            const int64_t rows = ctx->numel[l->id + 1];                 // bias length = out features
+            const int64_t cols = ctx->numel[l->id] / rows;
+            RUN(launch_transpose(l->w, B.wt + B.wt_off[l->id], (int)rows, (int)cols, s));
+        }
+    }
+
+    // ---- loss + decoder ------------------------------------------------------------------------
+    RUN(launch_ce_loss(logits, answers, loss_scale, loss, dlogits, n, A, s));
+    {
+        const float *cat = ws + pl->o_cat, *hid = ws + pl->o_hid;     // decoder buffers are never reused by buckets in training
+        RUN(dense_bwd(B, dlogits, n, 1, A, 2 * H, hid, 2 * H, 2 * H, nullptr, W.dec3, gV0, 2 * H, 2 * H, nullptr, 0));
+        RUN(launch_mask_relu(gV0, gV0, 2 * H, nullptr, hid, 2 * H, nullptr, n, 2 * H, s));
+        RUN(dense_bwd(B, gV0, n, 1, 2 * H, 2 * H, cat, 2 * H, 2 * H, nullptr, W.dec0, gCat, 2 * H, 2 * H, nullptr, 0));
+        RUN(launch_pack_bwd(PACK_CAT2, vec, didx + pl->off_roots, qfeat, nullptr, gCat, g_vec, g_qfeat, n, H, s));
+    }
+
+    // ---- program levels in reverse ---------------------------------------------------------------
+    for (auto it = pl->buckets.rbegin(); it != pl->buckets.rend(); ++it) {
+        const Bucket &b = *it;
+        if (b.cnt == 0) continue;
+        const int c = b.cnt;
+        const int32_t *I0 = didx + b.off[0], *I1 = didx + b.off[1], *I2 = didx + b.off[2], *I3 = didx + b.off[3],
+                      *I4 = didx + b.off[4], *I5 = didx + b.off[5];
+        const float *svA = ws + b.svA, *svB = ws + b.svB, *svK = ws + b.svK, *svCat = ws + b.svCat, *svHid = ws + b.svHid;
+        const float *svRs = ws + b.svRs, *svSup = ws + b.svSup;
+        // tail shared by Filter / FilterFrame / Localize / Superlative: gB = d(second linear output)
+        auto mlp_tail = [&](const Lin &l3, const Lin &l0, bool relu_second) -> int {
+            if (relu_second) RUN(launch_mask_relu(gB, gB, TH, nullptr, svB, TH, nullptr, c, (int)TH, s));
+            RUN(dense_bwd(B, gB, c, T, H, H, svA, H, TH, nullptr, l3, gA, H, TH, nullptr, 0));
+            RUN(launch_mask_relu(gA, gA, TH, nullptr, svA, TH, nullptr, c, (int)TH, s));
+            RUN(dense_bwd(B, gA, c, T, H, H, map, H, TH, I0, l0, g_map, H, TH, I0, 1));
+            return 0;
+        };
+        switch (b.op) {
+            case OP_SPAN:
+                RUN(launch_span_mean_bwd(g_tok, H, I0, I1, g_vec, I2, c, H, s));
+                break;
+            case STAIR_OP_AND:
+            case STAIR_OP_XORFRAME: {
+                const bool isvec = b.sub == STAIR_VAL_VEC;
+                RUN(launch_eltwise_bwd(b.op == STAIR_OP_AND ? 0 : 1, isvec ? vec : att, isvec ? g_vec : g_att, I0, I1, I2, c,
+                                       isvec ? H : T, s));
+                break;
+            }
+            case STAIR_OP_ATTNVIDEO:
+                RUN(launch_attnvideo_bwd(map, g_map, att, g_att, I0, I1, I2, c, T, H, s));
+                break;
+            case STAIR_OP_CHOOSE:
+                RUN(launch_choose_bwd(vec, g_vec, I0, I1, I2, I3, c, H, s));
+                break;
+            case STAIR_OP_COMPARE:
+            case STAIR_OP_EQUALS:
+            case STAIR_OP_XOR: {
+                const bool isx = b.op == STAIR_OP_XOR;
+                const int K = isx ? 3 * H : 2 * H;
+                const Lin &l = isx ? W.xorl : (b.op == STAIR_OP_COMPARE ? W.compare : W.equals);
+                RUN(launch_mask_relu(gV0, g_vec, H, I2, vec, H, I2, c, H, s));
+                RUN(dense_bwd(B, gV0, c, 1, H, K, svCat, K, K, nullptr, l, gCat, K, K, nullptr, 0));
+                RUN(launch_pack_bwd(isx ? PACK_XOR : PACK_CAT2, vec, I0, vec, I1, gCat, g_vec, g_vec, c, H, s));
+                break;
+            }
+            case STAIR_OP_TOACTION:
+            case STAIR_OP_EXISTS: {
+                const bool ex = b.op == STAIR_OP_EXISTS;
+                const int K = ex ? 3 * H : 2 * H;
+                RUN(launch_mask_relu(gV0, g_vec, H, I2, vec, H, I2, c, H, s));
+                RUN(dense_bwd(B, gV0, c, 1, H, H, svHid, H, H, nullptr, ex ? W.exists3 : W.ta3, gV1, H, H, nullptr, 0));
+                RUN(launch_mask_relu(gV1, gV1, H, nullptr, svHid, H, nullptr, c, H, s));
+                RUN(dense_bwd(B, gV1, c, 1, H, K, svCat, K, K, nullptr, ex ? W.exists0 : W.ta0, gCat, K, K, nullptr, 0));
+                if (ex) RUN(launch_pack_bwd(PACK_EXISTS, vec, I1, vec, I0, gCat, g_vec, g_vec, c, H, s));
+                else RUN(launch_pack_bwd(PACK_CAT2, vec, I0, vec, I1, gCat, g_vec, g_vec, c, H, s));
+                break;
+            }
+            case STAIR_OP_EXISTSFRAME:
+                RUN(launch_cosine_attn_bwd(map, TH, I1, vec, I0, g_att, I2, g_map, g_vec, c, T, H, s));
+                break;
+            case STAIR_OP_FILTER: {
+                const int v = b.variant;
+                RUN(launch_mask_relu(gV0, g_vec, H, I1, vec, H, I1, c, H, s));
+                RUN(dense_bwd(B, gV0, c, 1, H, H, svCat, H, H, nullptr, W.fdense, gV1, H, H, nullptr, 0));
+                RUN(launch_bcast_mask_relu(gB, gV1, svB, c, T, H, s));
+                RUN(mlp_tail(W.f3[v], W.f0[v], false));
+                break;
+            }
+            case STAIR_OP_FILTERFRAME: {
+                const int v = b.variant;
+                RUN(launch_mask_relu(gA, g_map, TH, I2, map, TH, I2, c, (int)TH, s));        // dZ of the dense layer
+                if (v == 0) {
+                    // dense input is a_t * f_t: weight grads see the scaled input, G = dZ.W is d(a*f)
+                    RUN(dense_bwd(B, gA, c, T, H, H, svB, H, TH, nullptr, W.ffdense, gB, H, TH, nullptr, 0, svRs, T, nullptr));
+                    STAIR_HIP(hipMemsetAsync(gRs, 0, (size_t)c * T * sizeof(float), s));
+                    STAIR_HIP(hipMemsetAsync(gExtra, 0, (size_t)c * sizeof(float), s));
+                    RUN(launch_rowscale_bwd(gB, svB, TH, nullptr, svRs, T, nullptr, nullptr, gRs, c, T, H, s));   // da_t = G_t . f_t
+                    RUN(launch_scale_rows(gB, svRs, (int64_t)c * T, H, s));                                        // df  = a_t * G_t
+                    RUN(launch_rowdot_sigmoid_bwd(gRs, T, nullptr, svRs, T, nullptr, W.ffatt.w, gB, 1, gRs2, gExtra, c, T, H, s));
+                    RUN(launch_weighted_colsum(svB, H, nullptr, gRs2, W.ffatt.dw, c * T, H, s));                  // d w[:H]
+                    RUN(launch_weighted_colsum(vec, H, I1, gExtra, W.ffatt.dw + H, c, H, s));                     // d w[H:]
+                    RUN(launch_sum_all(gRs2, W.ffatt.db, c * T, s));
+                    RUN(launch_axpy_rows(g_vec, I1, gExtra, W.ffatt.w + H, c, H, s));                             // d keyword
+                } else {
+                    RUN(dense_bwd(B, gA, c, T, H, H, svB, H, TH, nullptr, W.ffdense, gB, H, TH, nullptr, 0));
+                }
+                RUN(mlp_tail(W.ff3[v], W.ff0[v], true));
+                break;
+            }
+            case STAIR_OP_HASITEM:
+                RUN(launch_rowdot_sigmoid_bwd(g_att, T, I1, att, T, I1, W.hi3.w, gA, 0, gRs2, nullptr, c, T, H, s));
+                RUN(launch_weighted_colsum(svA, H, nullptr, gRs2, W.hi3.dw, c * T, H, s));
+                RUN(launch_sum_all(gRs2, W.hi3.db, c * T, s));
+                RUN(launch_mask_relu(gA, gA, TH, nullptr, svA, TH, nullptr, c, (int)TH, s));
+                RUN(dense_bwd(B, gA, c, T, H, H, map, H, TH, I0, W.hi0, g_map, H, TH, I0, 1));
+                break;
+            case STAIR_OP_LOCALIZE:
+                STAIR_HIP(hipMemsetAsync(gB, 0, (size_t)c * TH * sizeof(float), s));
+                STAIR_HIP(hipMemsetAsync(gK, 0, (size_t)b.nrows * H * sizeof(float), s));
+                RUN(launch_cosine_attn_bwd(svB, TH, I1, svK, nullptr, g_att, I3, gB, gK, b.nrows, T, H, s));
+                RUN(dense_bwd(B, gK, b.nrows, 1, H, H, vec, H, H, I2, W.lk, g_vec, H, H, I2, 1));
+                RUN(mlp_tail(W.lv3, W.lv0, false));
+                break;
+            case STAIR_OP_RELATE:
+                RUN(launch_relate_softmax_bwd(att, g_att, I0, I1, W.dbeta, b.variant == 0 ? 1.0f : -1.0f, c, T, s));
+                break;
+            case STAIR_OP_SUPERLATIVE:
+                RUN(launch_mask_relu(gV0, g_vec, H, I3, vec, H, I3, c, H, s));
+                RUN(dense_bwd(B, gV0, c, 1, H, H, svCat, H, H, nullptr, W.supdense, gV1, H, H, nullptr, 0));
+                RUN(launch_superlative_pool_bwd(svSup, ws, gws, I4, I1, I2, b.variant, gV1, gS, c, T, H, s));
+                STAIR_HIP(hipMemsetAsync(gB, 0, (size_t)c * TH * sizeof(float), s));
+                STAIR_HIP(hipMemsetAsync(gK, 0, (size_t)b.nrows * H * sizeof(float), s));
+                RUN(launch_cosine_attn_bwd(svB, TH, I5, svK, nullptr, gS, nullptr, gB, gK, b.nrows, T, H, s));
+                RUN(dense_bwd(B, gK, b.nrows, 1, H, H, ws, H, H, I4, W.lk, gws, H, H, I4, 1));
+                RUN(mlp_tail(W.lv3, W.lv0, false));
+                break;
+            case STAIR_OP_TEMPORAL: {
+                const int mode = b.variant;
+                RUN(launch_layernorm_bwd(g_map, TH, I4, svA, c, T, H, W.ln_w, 1e-5f, gA, gStats, W.dln_w, W.dln_b, s));
+                RUN(dense_bwd(B, gA, c, T, H, H, map, H, TH, I0, W.tdense, gB, H, TH, nullptr, 0, att, T, I3));
+                RUN(launch_rowscale_bwd(gB, map, TH, I0, att, T, I3, g_map, g_att, c, T, H, s));
+                RUN(launch_temporal_relate_bwd(att, I1, I2, g_att, I3, g_att, c, T, mode, ctx->conv ? 1 : 0, ctx->ksize,
+                                               mode ? W.relate[mode - 1] : nullptr, mode ? W.drelate[mode - 1] : nullptr, s));
+                break;
+            }
+            default:
+                STAIR_FAIL("internal: unhandled bucket op " + std::to_string(b.op));
+        }
+    }
+
+    // ---- encoders ------------------------------------------------------------------------------------
+    for (int e = 1; e >= 0; --e) {
+        stair_lstm_bwd_args a = {};
+        if (e == 0) {
+            a.x = video; a.ldx = V; a.rows = n * T; a.max_len = T; a.I = V; a.seq_off = didx + pl->off_seqv;
+            a.gates = ws + pl->o_xpv; a.cbuf = ws + pl->o_cv; a.out = map; a.d_out = g_map; a.d_hn = nullptr;
+            a.whh_pack_ws = ws + pl->o_wpack;
+        } else {
+            a.x = question; a.ldx = E; a.rows = pl->rows_q; a.max_len = pl->max_q; a.I = E; a.seq_off = didx + pl->off_seqt;
+            a.gates = ws + pl->o_xpt; a.cbuf = ws + pl->o_ct; a.out = ws + pl->o_tok; a.d_out = g_tok; a.d_hn = g_qfeat;
+            a.whh_pack_ws = ws + pl->o_wpack + 2 * (int64_t)H * H;
+        }
+        a.n = n; a.Hh = Hh; a.ldo = H; a.ldd = H; a.hprev_ws = ws + pl->o_hprev;
+        for (int d = 0; d < 2; ++d) {
+            a.w_hh[d] = W.enc[e][4 * d + 1];
+            a.dw_ih[d] = W.denc[e][4 * d]; a.dw_hh[d] = W.denc[e][4 * d + 1];
+            a.db_ih[d] = W.denc[e][4 * d + 2]; a.db_hh[d] = W.denc[e][4 * d + 3];
+        }
+        RUN(launch_lstm_bwd(a, s));
+    }
 #undef RUN
     return 0;
+}
+
+// Which weights receive a gradient from this plan (1) and which do not (0).  torch leaves .grad = None
+// for parameters of modules no program in the window used, and Adam then skips them entirely
+// (train_module.py:408-410); the optimizer kernel reproduces that with this mask.
+extern "C" int stair_plan_touched(const stair_ctx *ctx, const stair_plan *pl, int32_t *touched, int32_t count) {
+    STAIR_CHECK(ctx && pl && touched, "null argument");
+    STAIR_CHECK(count == (int)ctx->names.size(), "count must equal stair_weight_count");
+    for (int i = 0; i < count; ++i) touched[i] = 0;
+    auto mark = [&](const std::string &name) {
+        auto it = ctx->by_name.find("submodules." + name);
+        if (it != ctx->by_name.end()) touched[it->second] = 1;
+    };
+    auto lin = [&](const std::string &prefix) { mark(prefix + ".weight"); mark(prefix + ".bias"); };
+    for (const char *enc : {"video_encoder", "text_encoder"})
+        for (const char *sfx : {"", "_reverse"})
+            for (const char *w : {"weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"}) mark(std::string(enc) + "." + w + sfx);
+    lin("decoder.0"); lin("decoder.3");
+    const char *fk[4] = {"representation", "actions", "objects", "relations"};
+    const char *ffk[3] = {"representation", "relations", "actions"};
+    const char *modes[4] = {"", "before", "after", "between"};
+    for (const Bucket &b : pl->buckets) {
+        if (b.cnt == 0) continue;
+        switch (b.op) {
+            case STAIR_OP_COMPARE: lin("Compare.param.0"); break;
+            case STAIR_OP_EQUALS: lin("Equals.param.0"); break;
+            case STAIR_OP_XOR: lin("Xor.param.0"); break;
+            case STAIR_OP_TOACTION: lin("ToAction.param.0"); lin("ToAction.param.3"); break;
+            case STAIR_OP_EXISTS: lin("Exists.param.0"); lin("Exists.param.3"); break;
+            case STAIR_OP_FILTER:
+                lin(std::string("Filter.param.") + fk[b.variant] + ".0"); lin(std::string("Filter.param.") + fk[b.variant] + ".3");
+                lin("Filter.dense.0");
+                if (b.variant == 0) lin("Filter.attention.0");     // receives an all-zero gradient (softmax over one element)
+                break;
+            case STAIR_OP_FILTERFRAME:
+                lin(std::string("FilterFrame.param.") + ffk[b.variant] + ".0"); lin(std::string("FilterFrame.param.") + ffk[b.variant] + ".3");
+                lin("FilterFrame.dense.0");
+                if (b.variant == 0) lin("FilterFrame.attention.0");
+                break;
+            case STAIR_OP_HASITEM: lin("HasItem.param.0"); lin("HasItem.param.3"); break;
+            case STAIR_OP_LOCALIZE: lin("Localize.video_linear.0"); lin("Localize.video_linear.3"); lin("Localize.keyword_linear.0"); break;
+            case STAIR_OP_SUPERLATIVE:
+                lin("Localize.video_linear.0"); lin("Localize.video_linear.3"); lin("Localize.keyword_linear.0");
+                lin("Superlative.dense.0");
+                break;
+            case STAIR_OP_RELATE: mark("Relate.beta"); break;
+            case STAIR_OP_TEMPORAL:
+                lin("Temporal.dense.0"); mark("Temporal.layer_norm.weight"); mark("Temporal.layer_norm.bias");
+                if (b.variant)
+                    for (int l : {0, 2, 4}) lin(std::string("Temporal.relate.") + modes[b.variant] + "." + std::to_string(l));
+                break;
+            default: break;
+        }
+    }
+    return 0;
+}
+
+extern "C" int stair_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq,
+                               const int32_t *seg_of_block, const int32_t *touched, const float *step_of_seg, float lr,
+                               float beta1, float beta2, float eps, float weight_decay, int64_t n, stair_stream stream) {
+    STAIR_CHECK(params && grads && exp_avg && exp_avg_sq && seg_of_block && touched && step_of_seg, "null argument");
+    return launch_adam(params, grads, exp_avg, exp_avg_sq, seg_of_block, touched, step_of_seg, lr, beta1, beta2, eps, weight_decay, n,
+                       static_cast<hipStream_t>(stream));
 }

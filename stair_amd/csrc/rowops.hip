@@ -160,39 +160,40 @@ int launch_temporal_relate(const float *att, const int32_t *att_idx, const int32
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ void layernorm_kernel(float *X, int64_t gstride, const int32_t *gidx, int n, int T, int H,
+__global__ void layernorm_kernel(const float *Y, float *X, int64_t gstride, const int32_t *gidx, int n, int T, int H,
                                  const float *gamma, const float *beta, float eps) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (row >= (int64_t)n * T) return;
     const int g = (int)(row / T), t = (int)(row - (int64_t)g * T);
+    const float4 *y = reinterpret_cast<const float4 *>(Y + row * H);
     float4 *x = reinterpret_cast<float4 *>(X + (int64_t)idx_or_id(gidx, g) * gstride + (int64_t)t * H);
     const int n4 = H / 4;
     float sum = 0.f;
-    for (int c = lane; c < n4; c += 64) { const float4 v = x[c]; sum += v.x + v.y + v.z + v.w; }
+    for (int c = lane; c < n4; c += 64) { const float4 v = y[c]; sum += v.x + v.y + v.z + v.w; }
     const float mean = wave_sum(sum) / (float)H;
     float sq = 0.f;
     for (int c = lane; c < n4; c += 64) {
-        const float4 v = x[c];
+        const float4 v = y[c];
         const float a = v.x - mean, b = v.y - mean, cc = v.z - mean, d = v.w - mean;
         sq += a * a + b * b + cc * cc + d * d;
     }
     const float rstd = rsqrtf(wave_sum(sq) / (float)H + eps);
     const float4 *g4 = reinterpret_cast<const float4 *>(gamma), *b4 = reinterpret_cast<const float4 *>(beta);
     for (int c = lane; c < n4; c += 64) {
-        float4 v = x[c];
+        float4 v = y[c];
         const float4 gg = g4[c], bb = b4[c];
         v.x = (v.x - mean) * rstd * gg.x + bb.x; v.y = (v.y - mean) * rstd * gg.y + bb.y;
         v.z = (v.z - mean) * rstd * gg.z + bb.z; v.w = (v.w - mean) * rstd * gg.w + bb.w;
         x[c] = v;
     }
 }
-int launch_layernorm(float *X, int64_t gstride, const int32_t *gidx, int n, int T, int H, const float *gamma,
+int launch_layernorm(const float *Y, float *X, int64_t gstride, const int32_t *gidx, int n, int T, int H, const float *gamma,
                      const float *beta, float eps, hipStream_t s) {
     if (n == 0) return 0;
     const int64_t rows = (int64_t)n * T;
     hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0,
-                       s, X, gstride, gidx, n, T, H, gamma, beta, eps);
+                       s, Y, X, gstride, gidx, n, T, H, gamma, beta, eps);
     STAIR_LAUNCH_CHECK();
     return 0;
 }

@@ -1,0 +1,688 @@
+// Backward (reverse-mode) counterparts of csrc/rowops.hip: what autograd does for the reference's
+// small operators when train_module.py:408 calls batch_loss.backward().  Same mapping rules as the
+// forward kernels (one wave per row for row reductions, one block per instance where an instance
+// needs LDS).  Gradient arenas mirror the value arenas slot for slot; a slot can have several
+// consumers (the encoded video feeds every module of a question), so contributions into arenas are
+// fp32 atomic adds (order-dependent in the last bits, as any parallel reduction is).
+#include "ops.h"
+
+namespace stair {
+
+namespace {
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = kBlock / 64;
+__device__ __forceinline__ int idx_or_id(const int32_t *idx, int i) { return idx ? idx[i] : i; }
+__device__ __forceinline__ float sgn(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
+}  // namespace
+
+// dst[g][:] = G[gi][:] * (Y[yi][:] > 0)      (ReLU backward with optional gathers; rowlen floats per group)
+__global__ void mask_relu_kernel(float *dst, const float *G, int64_t g_gs, const int32_t *g_idx, const float *Y,
+                                 int64_t y_gs, const int32_t *y_idx, int groups, int rowlen) {
+    const int64_t total = (int64_t)groups * rowlen;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(e / rowlen);
+        const int64_t r = e - (int64_t)g * rowlen;
+        const float gv = G[(int64_t)idx_or_id(g_idx, g) * g_gs + r];
+        const float yv = Y[(int64_t)idx_or_id(y_idx, g) * y_gs + r];
+        dst[e] = yv > 0.f ? gv : 0.f;
+    }
+}
+int launch_mask_relu(float *dst, const float *G, int64_t g_gs, const int32_t *g_idx, const float *Y, int64_t y_gs,
+                     const int32_t *y_idx, int groups, int rowlen, hipStream_t s) {
+    if (groups == 0) return 0;
+    const int64_t total = (int64_t)groups * rowlen;
+    hipLaunchKernelGGL(mask_relu_kernel, dim3((unsigned)std::min<int64_t>((total + kBlock - 1) / kBlock, 4096)), dim3(kBlock), 0,
+                       s, dst, G, g_gs, g_idx, Y, y_gs, y_idx, groups, rowlen);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
+// Filter's sum over frames, backward + ReLU mask: dst[g][t][:] = dsum[g][:] * (Y[g][t][:] > 0)
+__global__ void bcast_mask_relu_kernel(float *dst, const float *dsum, const float *Y, int groups, int T, int H) {
+    const int64_t total = (int64_t)groups * T * H;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(e / ((int64_t)T * H));
+        const int c = (int)(e % H);
+        dst[e] = Y[e] > 0.f ? dsum[(int64_t)g * H + c] : 0.f;
+    }
+}
+int launch_bcast_mask_relu(float *dst, const float *dsum, const float *Y, int groups, int T, int H, hipStream_t s) {
+    if (groups == 0) return 0;
+    const int64_t total = (int64_t)groups * T * H;
+    hipLaunchKernelGGL(bcast_mask_relu_kernel, dim3((unsigned)std::min<int64_t>((total + kBlock - 1) / kBlock, 4096)), dim3(kBlock),
+                       0, s, dst, dsum, Y, groups, T, H);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
+// dst[dst_idx[i]][:] += src[i][:] * scale   (rows of `len` floats, atomic)
+__global__ void scatter_add_rows_kernel(float *dst, const int32_t *dst_idx, const float *src, int n, int len, float scale) {
+    const int i = blockIdx.x;
+    float *d = dst + (int64_t)idx_or_id(dst_idx, i) * len;
+    const float *sr = src + (int64_t)i * len;
+    for (int c = threadIdx.x; c < len; c += blockDim.x) unsafeAtomicAdd(d + c, sr[c] * scale);
+}
+int launch_scatter_add_rows(float *dst, const int32_t *dst_idx, const float *src, int n, int len, float scale, hipStream_t s) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(n), dim3(128), 0, s, dst, dst_idx, src, n, len, scale);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// cat backward (modules.py cat inputs of Exists/Xor/Equals/Compare/ToAction, decoder module_net.py:137)
+//   CAT2: dA[ia] += g0, dB[ib] += g1;  EXISTS [a,b,a*b]: dA += g0 + g2*b, dB += g1 + g2*a
+//   XOR [|a-b|,a,b]: dA += g0*sign(a-b) + g1, dB += -g0*sign(a-b) + g2
+__global__ void pack_bwd_kernel(int mode, const float *A, const int32_t *ia, const float *B, const int32_t *ib,
+                                const float *g, float *dA, float *dB, int n, int H) {
+    const int i = blockIdx.x;
+    const int64_t ra = (int64_t)idx_or_id(ia, i) * H, rb = (int64_t)idx_or_id(ib, i) * H;
+    const int segs = mode == PACK_CAT2 ? 2 : 3;
+    const float *gi = g + (int64_t)i * segs * H;
+    for (int c = threadIdx.x; c < H; c += blockDim.x) {
+        float da, db;
+        if (mode == PACK_CAT2) {
+            da = gi[c]; db = gi[H + c];
+        } else if (mode == PACK_EXISTS) {
+            const float a = A[ra + c], b = B[rb + c];
+            da = gi[c] + gi[2 * H + c] * b; db = gi[H + c] + gi[2 * H + c] * a;
+        } else {
+            const float sg = sgn(A[ra + c] - B[rb + c]);
+            da = gi[c] * sg + gi[H + c]; db = -gi[c] * sg + gi[2 * H + c];
+        }
+        unsafeAtomicAdd(dA + ra + c, da);
+        unsafeAtomicAdd(dB + rb + c, db);
+    }
+}
+int launch_pack_bwd(int mode, const float *A, const int32_t *ia, const float *B, const int32_t *ib, const float *g,
+                    float *dA, float *dB, int n, int H, hipStream_t s) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(pack_bwd_kernel, dim3(n), dim3(128), 0, s, mode, A, ia, B, ib, g, dA, dB, n, H);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
+// span mean backward: dtok[start+r][:] += dvec[out][:] / count
+__global__ void span_mean_bwd_kernel(float *dtok, int64_t ld, const int32_t *start, const int32_t *count, const float *dvec,
+                                     const int32_t *out_idx, int n, int H) {
+    const int i = blockIdx.x;
+    const int s = start[i], c = count[i];
+    const float *g = dvec + (int64_t)out_idx[i] * H;
+    const float inv = 1.0f / (float)c;
+    for (int col = threadIdx.x; col < H; col += blockDim.x) {
+        const float v = g[col] * inv;
+        for (int r = 0; r < c; ++r) unsafeAtomicAdd(dtok + (int64_t)(s + r) * ld + col, v);
+    }
+}
+int launch_span_mean_bwd(float *dtok, int64_t ld, const int32_t *start, const int32_t *count, const float *dvec,
+                         const int32_t *out_idx, int n, int H, hipStream_t s) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(span_mean_bwd_kernel, dim3(n), dim3(128), 0, s, dtok, ld, start, count, dvec, out_idx, n, H);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// cosine attention backward.  out = (cos+1)*0.49, cos = f.k / (nf * nk), nf = max(|f|,eps), nk likewise.
+//   dF[fi][t][:] += dcos * (k/(nf nk) - cos f/nf^2)        (atomic: pairs of one Localize share the tile)
+//   dK[p][:]     += sum_t dcos_t * (f_t/(nf_t nk) - cos_t k/nk^2)
+// One block per pair: phase 1 computes per-frame scalars into LDS, phase 2 is column-parallel.
+__global__ void cosine_attn_bwd_kernel(const float *F, int64_t f_gs, const int32_t *f_idx, const float *Kmat,
+                                       const int32_t *k_idx, const float *datt, const int32_t *out_idx, float *dF,
+                                       float *dK, int npairs, int T, int H) {
+    extern __shared__ float sm[];       // [3][T]: a_t = dcos/(nf nk), b_t = dcos*cos/nf^2, c_t = dcos*cos
+    float *sa = sm, *sb = sm + T, *sc = sm + 2 * T;
+    __shared__ float s_nk2;
+    const int p = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fi = idx_or_id(f_idx, p), ki = idx_or_id(k_idx, p);
+    const float *f = F + (int64_t)fi * f_gs;
+    const float *k = Kmat + (int64_t)ki * H;
+    const float *g = datt + (int64_t)idx_or_id(out_idx, p) * T;
+    float nk2 = 0.f;
+    for (int c = lane; c < H; c += 64) nk2 += k[c] * k[c];
+    nk2 = wave_sum(nk2);
+    const float nk = fmaxf(sqrtf(nk2), 1e-8f);
+    if (threadIdx.x == 0) s_nk2 = nk * nk;
+    for (int t = wave; t < T; t += kWavesPerBlock) {
+        const float *ft = f + (int64_t)t * H;
+        float d = 0.f, nf2 = 0.f;
+        for (int c = lane; c < H; c += 64) { d += ft[c] * k[c]; nf2 += ft[c] * ft[c]; }
+        d = wave_sum(d); nf2 = wave_sum(nf2);
+        const float nf = fmaxf(sqrtf(nf2), 1e-8f);
+        const float cosv = d / (nf * nk);
+        const float dcos = 0.49f * g[t];
+        if (lane == 0) { sa[t] = dcos / (nf * nk); sb[t] = dcos * cosv / (nf * nf); sc[t] = dcos * cosv; }
+    }
+    __syncthreads();
+    const float inv_nk2 = 1.0f / s_nk2;
+    for (int c = threadIdx.x; c < H; c += blockDim.x) {
+        const float kc = k[c];
+        float dk = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const float fc = f[(int64_t)t * H + c];
+            unsafeAtomicAdd(dF + (int64_t)fi * f_gs + (int64_t)t * H + c, sa[t] * kc - sb[t] * fc);
+            dk += sa[t] * fc - sc[t] * kc * inv_nk2;
+        }
+        unsafeAtomicAdd(dK + (int64_t)ki * H + c, dk);
+    }
+}
+int launch_cosine_attn_bwd(const float *F, int64_t f_gs, const int32_t *f_idx, const float *Kmat, const int32_t *k_idx,
+                           const float *datt, const int32_t *out_idx, float *dF, float *dK, int npairs, int T, int H,
+                           hipStream_t s) {
+    if (npairs == 0) return 0;
+    hipLaunchKernelGGL(cosine_attn_bwd_kernel, dim3(npairs), dim3(kBlock), 3 * T * sizeof(float), s, F, f_gs, f_idx, Kmat,
+                       k_idx, datt, out_idx, dF, dK, npairs, T, H);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Temporal relate nets backward (recomputes the three layers in LDS).  dw[6] accumulate with atomics.
+struct RelateWB { const float *w[6]; float *dw[6]; };
+__global__ void temporal_relate_bwd_kernel(const float *att, const int32_t *att_idx, const int32_t *att_k,
+                                           const float *drel, const int32_t *rel_idx, float *datt, int n, int T, int mode,
+                                           int conv, int ksize, RelateWB W) {
+    extern __shared__ float sm[];   // x0, y1, y2, y3 (post-activation), g (ping), g2 (pong): 6 rows of T
+    float *x0 = sm, *y1 = sm + T, *y2 = sm + 2 * T, *y3 = sm + 3 * T, *ga = sm + 4 * T, *gb = sm + 5 * T;
+    const int i = blockIdx.x;
+    const int K = att_k[i];
+    const float *a = att + (int64_t)att_idx[i] * T;
+    const float *dr = drel + (int64_t)rel_idx[i] * T;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+        float acc = 0.f;
+        for (int k = 0; k < K; ++k) acc += a[(int64_t)k * T + t];
+        x0[t] = acc / (float)K;
+        ga[t] = dr[t];
+    }
+    __syncthreads();
+    if (mode != 0) {
+        const float *xin[3] = {x0, y1, y2};
+        float *yout[3] = {y1, y2, y3};
+        for (int layer = 0; layer < 3; ++layer) {           // forward recompute
+            const float *w = W.w[2 * layer], *b = W.w[2 * layer + 1];
+            const float *x = xin[layer];
+            float *y = yout[layer];
+            const int k = layer < 2 ? ksize : 2 * ksize + 1, left = (k - 1) / 2;
+            for (int t = threadIdx.x; t < T; t += blockDim.x) {
+                float acc;
+                if (conv) {
+                    acc = b[0];
+                    for (int j = 0; j < k; ++j) { const int u = t + j - left; if (u >= 0 && u < T) acc += w[j] * x[u]; }
+                } else {
+                    acc = b[t];
+                    for (int u = 0; u < T; ++u) acc += w[(int64_t)t * T + u] * x[u];
+                }
+                y[t] = layer < 2 ? fmaxf(acc, 0.f) : sigmoid_acc(acc);
+            }
+            __syncthreads();
+        }
+        float *gin = ga, *gout = gb;
+        for (int layer = 2; layer >= 0; --layer) {          // backward
+            const float *w = W.w[2 * layer];
+            const float *x = xin[layer], *y = yout[layer];
+            const int k = layer < 2 ? ksize : 2 * ksize + 1, left = (k - 1) / 2;
+            for (int t = threadIdx.x; t < T; t += blockDim.x)      // through the activation
+                gin[t] = layer < 2 ? (y[t] > 0.f ? gin[t] : 0.f) : gin[t] * y[t] * (1.f - y[t]);
+            __syncthreads();
+            if (conv) {
+                for (int j = threadIdx.x; j < k; j += blockDim.x) {        // dw[j] = sum_t dz[t] x[t+j-left]
+                    float acc = 0.f;
+                    for (int t = 0; t < T; ++t) { const int u = t + j - left; if (u >= 0 && u < T) acc += gin[t] * x[u]; }
+                    unsafeAtomicAdd(W.dw[2 * layer] + j, acc);
+                }
+                if (threadIdx.x == 0) {
+                    float acc = 0.f;
+                    for (int t = 0; t < T; ++t) acc += gin[t];
+                    unsafeAtomicAdd(W.dw[2 * layer + 1], acc);
+                }
+                for (int u = threadIdx.x; u < T; u += blockDim.x) {       // dx[u] = sum_j w[j] dz[u-j+left]
+                    float acc = 0.f;
+                    for (int j = 0; j < k; ++j) { const int t = u - j + left; if (t >= 0 && t < T) acc += w[j] * gin[t]; }
+                    gout[u] = acc;
+                }
+            } else {
+                for (int e = threadIdx.x; e < T * T; e += blockDim.x) {
+                    const int t = e / T, u = e - t * T;
+                    unsafeAtomicAdd(W.dw[2 * layer] + e, gin[t] * x[u]);
+                }
+                for (int t = threadIdx.x; t < T; t += blockDim.x) unsafeAtomicAdd(W.dw[2 * layer + 1] + t, gin[t]);
+                for (int u = threadIdx.x; u < T; u += blockDim.x) {
+                    float acc = 0.f;
+                    for (int t = 0; t < T; ++t) acc += w[(int64_t)t * T + u] * gin[t];
+                    gout[u] = acc;
+                }
+            }
+            __syncthreads();
+            float *tmp = gin; gin = gout; gout = tmp;
+        }
+        ga = gin;
+    }
+    // mean over K rows backward
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+        const float v = ga[t] / (float)K;
+        for (int k = 0; k < K; ++k) unsafeAtomicAdd(datt + ((int64_t)att_idx[i] + k) * T + t, v);
+    }
+}
+int launch_temporal_relate_bwd(const float *att, const int32_t *att_idx, const int32_t *att_k, const float *drel,
+                               const int32_t *rel_idx, float *datt, int n, int T, int mode, int conv, int ksize,
+                               const float *const w[6], float *const dw[6], hipStream_t s) {
+    if (n == 0) return 0;
+    RelateWB W;
+    for (int i = 0; i < 6; ++i) { W.w[i] = (mode && w) ? w[i] : nullptr; W.dw[i] = (mode && dw) ? dw[i] : nullptr; }
+    hipLaunchKernelGGL(temporal_relate_bwd_kernel, dim3(n), dim3(64), 6 * T * sizeof(float), s, att, att_idx, att_k, drel,
+                       rel_idx, datt, n, T, mode, conv, ksize, W);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm backward fused with the ReLU that precedes it in TemporalModule (modules.py:326-327):
+//   y = relu(z) saved; out = LN(y).  dz = relu'(y) * rstd * (dxh - mean(dxh) - xh * mean(dxh*xh)), dxh = dout*gamma
+// stats[row] = (mean, rstd) for the parameter-gradient pass.
+__global__ void layernorm_bwd_kernel(const float *dOut, int64_t g_gs, const int32_t *g_idx, const float *Y, int n, int T,
+                                     int H, const float *gamma, float eps, float *dZ, float *stats) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (row >= (int64_t)n * T) return;
+    const int g = (int)(row / T), t = (int)(row - (int64_t)g * T);
+    const float *y = Y + row * H;
+    const float *go = dOut + (int64_t)idx_or_id(g_idx, g) * g_gs + (int64_t)t * H;
+    float sum = 0.f;
+    for (int c = lane; c < H; c += 64) sum += y[c];
+    const float mean = wave_sum(sum) / (float)H;
+    float sq = 0.f;
+    for (int c = lane; c < H; c += 64) { const float d = y[c] - mean; sq += d * d; }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)H + eps);
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane; c < H; c += 64) {
+        const float dxh = go[c] * gamma[c], xh = (y[c] - mean) * rstd;
+        s1 += dxh; s2 += dxh * xh;
+    }
+    s1 = wave_sum(s1) / (float)H; s2 = wave_sum(s2) / (float)H;
+    for (int c = lane; c < H; c += 64) {
+        const float dxh = go[c] * gamma[c], xh = (y[c] - mean) * rstd;
+        const float dy = rstd * (dxh - s1 - xh * s2);
+        dZ[row * H + c] = y[c] > 0.f ? dy : 0.f;
+    }
+    if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+}
+__global__ void layernorm_param_grad_kernel(const float *dOut, int64_t g_gs, const int32_t *g_idx, const float *Y,
+                                            const float *stats, int n, int T, int H, float *dgamma, float *dbeta, int slab) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= H) return;
+    const int64_t rbeg = (int64_t)blockIdx.y * slab, rend = min((int64_t)n * T, rbeg + slab);
+    float ag = 0.f, ab = 0.f;
+    for (int64_t row = rbeg; row < rend; ++row) {
+        const int g = (int)(row / T), t = (int)(row - (int64_t)g * T);
+        const float go = dOut[(int64_t)idx_or_id(g_idx, g) * g_gs + (int64_t)t * H + c];
+        ag += go * (Y[row * H + c] - stats[2 * row]) * stats[2 * row + 1];
+        ab += go;
+    }
+    unsafeAtomicAdd(dgamma + c, ag);
+    unsafeAtomicAdd(dbeta + c, ab);
+}
+int launch_layernorm_bwd(const float *dOut, int64_t g_gs, const int32_t *g_idx, const float *Y, int n, int T, int H,
+                         const float *gamma, float eps, float *dZ, float *stats, float *dgamma, float *dbeta, hipStream_t s) {
+    if (n == 0) return 0;
+    const int64_t rows = (int64_t)n * T;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)((rows + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0,
+                       s, dOut, g_gs, g_idx, Y, n, T, H, gamma, eps, dZ, stats);
+    STAIR_LAUNCH_CHECK();
+    const int slab = (int)std::max<int64_t>(64, (rows + 255) / 256);
+    hipLaunchKernelGGL(layernorm_param_grad_kernel, dim3((H + 255) / 256, (unsigned)((rows + slab - 1) / slab)), dim3(256), 0, s,
+                       dOut, g_gs, g_idx, Y, stats, n, T, H, dgamma, dbeta, slab);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// row-scaled dense backward helper: G = dZ.W already computed for the SCALED input (rs_t * x_t):
+//   dX[xi][t][:] += rs_t * G[g][t][:]   (atomic),   drs[ri][t] += sum_c G[g][t][c] * X[xi][t][c]
+__global__ void rowscale_bwd_kernel(const float *G, const float *X, int64_t x_gs, const int32_t *x_idx, const float *rs,
+                                    int64_t rs_gs, const int32_t *rs_idx, float *dX, float *drs, int n, int T, int H) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (row >= (int64_t)n * T) return;
+    const int g = (int)(row / T), t = (int)(row - (int64_t)g * T);
+    const int64_t xo = (int64_t)idx_or_id(x_idx, g) * x_gs + (int64_t)t * H;
+    const int64_t ro = (int64_t)idx_or_id(rs_idx, g) * rs_gs + t;
+    const float r = rs[ro];
+    const float *gr = G + row * H;
+    float d = 0.f;
+    for (int c = lane; c < H; c += 64) {
+        const float gv = gr[c];
+        d += gv * X[xo + c];
+        if (dX) unsafeAtomicAdd(dX + xo + c, r * gv);
+    }
+    d = wave_sum(d);
+    if (lane == 0 && drs) unsafeAtomicAdd(drs + ro, d);
+}
+int launch_rowscale_bwd(const float *G, const float *X, int64_t x_gs, const int32_t *x_idx, const float *rs, int64_t rs_gs,
+                        const int32_t *rs_idx, float *dX, float *drs, int n, int T, int H, hipStream_t s) {
+    if (n == 0) return 0;
+    const int64_t rows = (int64_t)n * T;
+    hipLaunchKernelGGL(rowscale_bwd_kernel, dim3((unsigned)((rows + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, s,
+                       G, X, x_gs, x_idx, rs, rs_gs, rs_idx, dX, drs, n, T, H);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// out[g][t] = sigmoid(X[g][t].w + b + extra[g]) backward:
+//   dpre = dout * a (1-a);  dXdst[g][t][:] (+)= dpre * w;  dextra[g] += sum_t dpre;  dpre_out[g][t] = dpre
+// add_mode: 0 store into dXdst, 1 add (non-atomic read-modify-write: rows are private to this launch)
+__global__ void rowdot_sigmoid_bwd_kernel(const float *dOut, int64_t o_gs, const int32_t *o_idx, const float *A, int64_t a_gs,
+                                          const int32_t *a_idx, const float *w, float *dXdst, int add_mode, float *dpre_out,
+                                          float *dextra, int n, int T, int H) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (row >= (int64_t)n * T) return;
+    const int g = (int)(row / T), t = (int)(row - (int64_t)g * T);
+    const float a = A[(int64_t)idx_or_id(a_idx, g) * a_gs + t];
+    const float dpre = dOut[(int64_t)idx_or_id(o_idx, g) * o_gs + t] * a * (1.f - a);
+    float *dx = dXdst + row * H;
+    for (int c = lane; c < H; c += 64) dx[c] = (add_mode ? dx[c] : 0.f) + dpre * w[c];
+    if (lane == 0) {
+        dpre_out[row] = dpre;
+        if (dextra) unsafeAtomicAdd(dextra + g, dpre);
+    }
+}
+int launch_rowdot_sigmoid_bwd(const float *dOut, int64_t o_gs, const int32_t *o_idx, const float *A, int64_t a_gs,
+                              const int32_t *a_idx, const float *w, float *dXdst, int add_mode, float *dpre_out,
+                              float *dextra, int n, int T, int H, hipStream_t s) {
+    if (n == 0) return 0;
+    const int64_t rows = (int64_t)n * T;
+    hipLaunchKernelGGL(rowdot_sigmoid_bwd_kernel, dim3((unsigned)((rows + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock),
+                       0, s, dOut, o_gs, o_idx, A, a_gs, a_idx, w, dXdst, add_mode, dpre_out, dextra, n, T, H);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
+// out[c] += sum_rows scale[row] * X[row][c]   (gradient of a [H] weight used in a row dot; X rows optionally gathered)
+__global__ void weighted_colsum_kernel(const float *X, int64_t ld, const int32_t *x_idx, const float *scale, float *out,
+                                       int rows, int H, int slab) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= H) return;
+    const int rbeg = blockIdx.y * slab, rend = min(rows, rbeg + slab);
+    float acc = 0.f;
+    for (int r = rbeg; r < rend; ++r) acc += scale[r] * X[(int64_t)idx_or_id(x_idx, r) * ld + c];
+    unsafeAtomicAdd(out + c, acc);
+}
+int launch_weighted_colsum(const float *X, int64_t ld, const int32_t *x_idx, const float *scale, float *out, int rows, int H,
+                           hipStream_t s) {
+    if (rows == 0) return 0;
+    const int slab = std::max(64, (rows + 255) / 256);
+    hipLaunchKernelGGL(weighted_colsum_kernel, dim3((H + 255) / 256, (rows + slab - 1) / slab), dim3(256), 0, s, X, ld, x_idx,
+                       scale, out, rows, H, slab);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
+// dV[idx[i]][:] += scale[i] * w[:]    (vecdot backward w.r.t. the gathered vectors)
+__global__ void axpy_rows_kernel(float *dV, const int32_t *idx, const float *scale, const float *w, int n, int H) {
+    const int i = blockIdx.x;
+    const float sc = scale[i];
+    float *d = dV + (int64_t)idx_or_id(idx, i) * H;
+    for (int c = threadIdx.x; c < H; c += blockDim.x) unsafeAtomicAdd(d + c, sc * w[c]);
+}
+int launch_axpy_rows(float *dV, const int32_t *idx, const float *scale, const float *w, int n, int H, hipStream_t s) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(axpy_rows_kernel, dim3(n), dim3(128), 0, s, dV, idx, scale, w, n, H);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
+// sum of a float array into out[0] (bias of a 1-output Linear)
+__global__ void sum_all_kernel(const float *x, float *out, int n) {
+    float acc = 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) acc += x[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(out, acc);
+}
+int launch_sum_all(const float *x, float *out, int n, hipStream_t s) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(sum_all_kernel, dim3(std::min((n + 255) / 256, 256)), dim3(256), 0, s, x, out, n);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Relate backward: y = softmax(x + sign*beta): dx = y * (dy - sum(dy*y)); datt[in] += dx; dbeta += sign*dx
+__global__ void relate_softmax_bwd_kernel(const float *att, float *datt, const int32_t *in_idx, const int32_t *out_idx,
+                                          float *dbeta, float sign, int n, int T) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const float *y = att + (int64_t)out_idx[i] * T;
+    const float *dy = datt + (int64_t)out_idx[i] * T;
+    float dot = 0.f;
+    for (int t = lane; t < T; t += 64) dot += dy[t] * y[t];
+    dot = wave_sum(dot);
+    for (int t = lane; t < T; t += 64) {
+        const float dx = y[t] * (dy[t] - dot);
+        unsafeAtomicAdd(datt + (int64_t)in_idx[i] * T + t, dx);
+        unsafeAtomicAdd(dbeta + t, sign * dx);
+    }
+}
+int launch_relate_softmax_bwd(const float *att, float *datt, const int32_t *in_idx, const int32_t *out_idx, float *dbeta,
+                              float sign, int n, int T, hipStream_t s) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(relate_softmax_bwd_kernel, dim3((n + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlock), 0, s, att, datt,
+                       in_idx, out_idx, dbeta, sign, n, T);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
+// min / |a-b| backward (torch.minimum splits a tie evenly; sign(0) = 0 for abs)
+__global__ void eltwise_bwd_kernel(int mode, const float *base, float *dbase, const int32_t *ia, const int32_t *ib,
+                                   const int32_t *io, int n, int len) {
+    const int i = blockIdx.x;
+    const int64_t oa = (int64_t)ia[i] * len, ob = (int64_t)ib[i] * len, oo = (int64_t)io[i] * len;
+    for (int c = threadIdx.x; c < len; c += blockDim.x) {
+        const float a = base[oa + c], b = base[ob + c], g = dbase[oo + c];
+        float da, db;
+        if (mode == 0) {
+            da = a < b ? g : (a == b ? 0.5f * g : 0.f);
+            db = b < a ? g : (a == b ? 0.5f * g : 0.f);
+        } else {
+            const float sg = sgn(a - b);
+            da = sg * g; db = -sg * g;
+        }
+        unsafeAtomicAdd(dbase + oa + c, da);
+        unsafeAtomicAdd(dbase + ob + c, db);
+    }
+}
+int launch_eltwise_bwd(int mode, const float *base, float *dbase, const int32_t *ia, const int32_t *ib, const int32_t *io,
+                       int n, int len, hipStream_t s) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(eltwise_bwd_kernel, dim3(n), dim3(128), 0, s, mode, base, dbase, ia, ib, io, n, len);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
+// AttnVideo backward: dmap[in][t][:] += att[a][t]*dmap[out][t][:];  datt[a][t] += dmap[out][t].map[in][t]
+__global__ void attnvideo_bwd_kernel(const float *map, float *dmap, const float *att, float *datt, const int32_t *in_idx,
+                                     const int32_t *att_idx, const int32_t *out_idx, int n, int T, int H) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (row >= (int64_t)n * T) return;
+    const int i = (int)(row / T), t = (int)(row - (int64_t)i * T);
+    const int64_t xi = ((int64_t)in_idx[i] * T + t) * H, xo = ((int64_t)out_idx[i] * T + t) * H;
+    const float a = att[(int64_t)att_idx[i] * T + t];
+    float d = 0.f;
+    for (int c = lane; c < H; c += 64) {
+        const float g = dmap[xo + c];
+        d += g * map[xi + c];
+        unsafeAtomicAdd(dmap + xi + c, a * g);
+    }
+    d = wave_sum(d);
+    if (lane == 0) unsafeAtomicAdd(datt + (int64_t)att_idx[i] * T + t, d);
+}
+int launch_attnvideo_bwd(const float *map, float *dmap, const float *att, float *datt, const int32_t *in_idx,
+                         const int32_t *att_idx, const int32_t *out_idx, int n, int T, int H, hipStream_t s) {
+    if (n == 0) return 0;
+    const int64_t rows = (int64_t)n * T;
+    hipLaunchKernelGGL(attnvideo_bwd_kernel, dim3((unsigned)((rows + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, s,
+                       map, dmap, att, datt, in_idx, att_idx, out_idx, n, T, H);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
+// Choose backward: the output IS one of the two keywords -> route its gradient there (selection recomputed)
+__global__ void choose_bwd_kernel(const float *vec, float *dvec, const int32_t *k1, const int32_t *k2, const int32_t *q,
+                                  const int32_t *out, int n, int H) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const float *a = vec + (int64_t)k1[i] * H, *b = vec + (int64_t)k2[i] * H, *c = vec + (int64_t)q[i] * H;
+    float na = 0.f, nb = 0.f, nc = 0.f;
+    for (int e = lane; e < H; e += 64) { na += a[e] * a[e]; nb += b[e] * b[e]; nc += c[e] * c[e]; }
+    na = fmaxf(sqrtf(wave_sum(na)), 1e-8f); nb = fmaxf(sqrtf(wave_sum(nb)), 1e-8f); nc = fmaxf(sqrtf(wave_sum(nc)), 1e-8f);
+    float da = 0.f, db = 0.f;
+    for (int e = lane; e < H; e += 64) { const float cn = c[e] / nc; da += (a[e] / na) * cn; db += (b[e] / nb) * cn; }
+    da = wave_sum(da); db = wave_sum(db);
+    const int64_t dst = (int64_t)(da > db ? k1[i] : k2[i]) * H, src = (int64_t)out[i] * H;
+    for (int e = lane; e < H; e += 64) unsafeAtomicAdd(dvec + dst + e, dvec[src + e]);
+}
+int launch_choose_bwd(const float *vec, float *dvec, const int32_t *k1, const int32_t *k2, const int32_t *q,
+                      const int32_t *out, int n, int H, hipStream_t s) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(choose_bwd_kernel, dim3((n + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlock), 0, s, vec, dvec, k1, k2,
+                       q, out, n, H);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
+// Superlative pooling backward.  pre[i] = sum_a w'_a rows[a]; w' = w or 1-w, w = softmax_a(sum_t S[a][t]).
+//   drows[row_id[a]] += w'_a dpre;   dS[a][t] = w_a (dw_a - sum_b dw_b w_b),  dw_a = +-(dpre . rows[a])
+__global__ void superlative_pool_bwd_kernel(const float *S, const float *rowbase, float *drowbase, const int32_t *row_id,
+                                            const int32_t *row_start, const int32_t *row_cnt, int is_min, const float *dpre,
+                                            float *dS, int n, int T, int H) {
+    extern __shared__ float sm[];    // w[Ka], dw[Ka]
+    const int i = blockIdx.x;
+    const int r0 = row_start[i], Ka = row_cnt[i];
+    float *w = sm, *dw = sm + Ka;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float *dp = dpre + (int64_t)i * H;
+    for (int a = wave; a < Ka; a += kWavesPerBlock) {
+        const float *sr = S + (int64_t)(r0 + a) * T;
+        float acc = 0.f;
+        for (int t = lane; t < T; t += 64) acc += sr[t];
+        acc = wave_sum(acc);
+        const float *row = rowbase + (int64_t)row_id[r0 + a] * H;
+        float d = 0.f;
+        for (int c = lane; c < H; c += 64) d += dp[c] * row[c];
+        d = wave_sum(d);
+        if (lane == 0) { w[a] = acc; dw[a] = is_min ? -d : d; }
+    }
+    __syncthreads();
+    __shared__ float s_dot;
+    if (wave == 0) {
+        float m = -INFINITY;
+        for (int a = lane; a < Ka; a += 64) m = fmaxf(m, w[a]);
+        m = wave_max(m);
+        float sum = 0.f;
+        for (int a = lane; a < Ka; a += 64) sum += expf(w[a] - m);
+        sum = wave_sum(sum);
+        float dot = 0.f;
+        for (int a = lane; a < Ka; a += 64) { w[a] = expf(w[a] - m) / sum; dot += dw[a] * w[a]; }
+        dot = wave_sum(dot);
+        if (lane == 0) s_dot = dot;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < Ka * T; e += blockDim.x) {
+        const int a = e / T;
+        dS[(int64_t)(r0 + a) * T + (e - a * T)] = w[a] * (dw[a] - s_dot);
+    }
+    for (int c = threadIdx.x; c < H; c += blockDim.x) {
+        const float g = dp[c];
+        for (int a = 0; a < Ka; ++a)
+            unsafeAtomicAdd(drowbase + (int64_t)row_id[r0 + a] * H + c, (is_min ? 1.f - w[a] : w[a]) * g);
+    }
+}
+int launch_superlative_pool_bwd(const float *S, const float *rowbase, float *drowbase, const int32_t *row_id,
+                                const int32_t *row_start, const int32_t *row_cnt, int is_min, const float *dpre, float *dS,
+                                int n, int T, int H, hipStream_t s) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(superlative_pool_bwd_kernel, dim3(n), dim3(kBlock), (size_t)2 * std::max(T, 2) * sizeof(float), s, S, rowbase,
+                       drowbase, row_id, row_start, row_cnt, is_min, dpre, dS, n, T, H);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// decoder cross entropy (train_module.py:193-194, nn.CrossEntropyLoss on one row):
+//   loss[i] = logsumexp(logits[i]) - logits[i][ans[i]];  dlogits[i] = scale * (softmax - onehot)
+__global__ void ce_loss_kernel(const float *logits, const int32_t *answers, float scale, float *loss, float *dlogits, int n,
+                               int A) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const float *x = logits + (int64_t)i * A;
+    float m = -INFINITY;
+    for (int c = lane; c < A; c += 64) m = fmaxf(m, x[c]);
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int c = lane; c < A; c += 64) sum += expf(x[c] - m);
+    sum = wave_sum(sum);
+    const int ans = answers[i];
+    if (lane == 0 && loss) loss[i] = logf(sum) + m - x[ans];
+    if (dlogits)
+        for (int c = lane; c < A; c += 64) dlogits[(int64_t)i * A + c] = scale * (expf(x[c] - m) / sum - (c == ans ? 1.f : 0.f));
+}
+int launch_ce_loss(const float *logits, const int32_t *answers, float scale, float *loss, float *dlogits, int n, int A,
+                   hipStream_t s) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(ce_loss_kernel, dim3((n + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlock), 0, s, logits, answers, scale,
+                       loss, dlogits, n, A);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam defaults, train_module.py:326: betas (0.9, 0.999), eps 1e-8, weight_decay 0 unless given)
+// over a flat parameter buffer.  `touched[seg]` != 0 marks parameter tensors that received a gradient in
+// this window; untouched tensors are skipped entirely, which is what torch does for grad == None
+// (modules that no program of the window used) -- their moments and step count do not advance.
+__global__ void adam_kernel(float *p, const float *g, float *m, float *v, const int32_t *seg_of_block, const int32_t *touched,
+                            const float *step_of_seg, float lr, float b1, float b2, float eps, float wd, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int seg = seg_of_block[blockIdx.x];
+    if (!touched[seg]) return;
+    const float t = step_of_seg[seg];                 // already incremented for this step
+    float grad = g[i];
+    if (wd != 0.f) grad += wd * p[i];
+    const float mi = b1 * m[i] + (1.f - b1) * grad;
+    const float vi = b2 * v[i] + (1.f - b2) * grad * grad;
+    m[i] = mi; v[i] = vi;
+    const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
+    p[i] -= lr / bc1 * mi / (sqrtf(vi) / sqrtf(bc2) + eps);
+}
+int launch_adam(float *p, const float *g, float *m, float *v, const int32_t *seg_of_block, const int32_t *touched,
+                const float *step_of_seg, float lr, float b1, float b2, float eps, float wd, int64_t n, hipStream_t s) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, m, v, seg_of_block, touched,
+                       step_of_seg, lr, b1, b2, eps, wd, n);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace stair
+
+namespace stair {
+// G[g][t][:] *= rs[g][t]   (rows of H floats; rs contiguous [n*T])
+__global__ void scale_rows_kernel(float *G, const float *rs, int64_t rows, int H) {
+    const int64_t total = rows * H;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x)
+        G[e] *= rs[e / H];
+}
+int launch_scale_rows(float *G, const float *rs, int64_t rows, int H, hipStream_t s) {
+    if (rows == 0) return 0;
+    const int64_t total = rows * H;
+    hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, s, G, rs, rows, H);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+}  // namespace stair

@@ -6,7 +6,8 @@ Differences that matter to a caller:
 
 * ``forward_batch`` runs MANY questions in one pass (the reference is batch-1 by construction,
   train_module.py:282); ``forward(data)`` is the drop-in single-question form built on it.
-* inference only in this round: outputs carry no autograd graph (backward kernels are next).
+* no autograd graph: training goes through ``run_programs(train=True)`` + ``BatchResult.backward`` (HIP
+  backward kernels) driven by ``stair_amd.train.Trainer``; only the decoder cross-entropy loss is built.
 * programs whose operand kinds do not fit a module raise ``StairError`` at plan-build time instead
   of a torch shape error in the middle of execution.
 
@@ -75,10 +76,31 @@ def _init_param(name, p, config):
 class BatchResult:
     """Outputs of one batched pass plus read access to every intermediate program value."""
 
-    def __init__(self, model, plan, info, ws, logits, pred, prog_off, programs):
+    def __init__(self, model, plan, info, ws, logits, pred, prog_off, programs, video=None, question=None):
         self._model, self._plan, self.info, self._ws = model, plan, info, ws
         self.logits, self.pred = logits, pred
         self._prog_off, self._programs = prog_off, programs
+        self._video, self._question = video, question
+
+    def backward(self, answers, loss_scale=1.0):
+        """Reverse pass of a train=True run: decoder cross entropy against `answers` (int32 [n] on the GPU),
+        gradients of loss_scale * sum_i CE_i accumulated into the model's gradient buffers.
+        Returns the unscaled per-question losses [n]."""
+        ops._req(answers, 'answers', torch.int32)
+        loss = torch.empty(self.info.n_questions, dtype=torch.float32, device=answers.device)
+        self._model._bind_grads()
+        check(lib.stair_plan_backward(self._model._ctx, self._plan, C.c_void_p(self._video.data_ptr()),
+                                      C.c_void_p(self._question.data_ptr()), C.c_void_p(self._ws.data_ptr()),
+                                      self._ws.numel() * 4, C.c_void_p(answers.data_ptr()), C.c_float(loss_scale),
+                                      C.c_void_p(loss.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return loss
+
+    def touched(self):
+        """bool per canonical weight: does this batch's program mix send a gradient into it?"""
+        n = len(self._model._weight_names)
+        arr = (C.c_int32 * n)()
+        check(lib.stair_plan_touched(self._model._ctx, self._plan, arr, n))
+        return [bool(v) for v in arr]
 
     def __del__(self):
         if getattr(self, '_plan', None):
@@ -155,7 +177,7 @@ class VideoNMN(nn.Module):
                 node = node._modules[part]
             if parts[-1] not in node._parameters:
                 shape = dict(spec.weight_table(self.config))[key]
-                p = nn.Parameter(torch.empty(*shape), requires_grad=False)
+                p = nn.Parameter(torch.empty(*shape))
                 _init_param(key, p, self.config)
                 node.register_parameter(parts[-1], p)
         if self.config['have_pretrain_head']:
@@ -172,6 +194,7 @@ class VideoNMN(nn.Module):
         self._ctx = handle
         self._weight_names = [lib.stair_weight_name(self._ctx, i).decode() for i in range(lib.stair_weight_count(self._ctx))]
         self._bound = {}
+        self._gbound = {}
         self._ws = None
         self._prog_cache = {}
 
@@ -192,6 +215,17 @@ class VideoNMN(nn.Module):
                 check(lib.stair_ctx_set_weight(self._ctx, i, C.c_void_p(p.data_ptr()), p.numel()))
                 self._bound[name] = p.data_ptr()
 
+    def _bind_grads(self):
+        sd = dict(self.named_parameters())
+        for i, name in enumerate(self._weight_names):
+            g = sd[name].grad
+            if g is None or not g.is_cuda or g.dtype != torch.float32 or not g.is_contiguous():
+                raise RuntimeError('parameter %s has no contiguous float32 GPU .grad buffer; use stair_amd.train.Trainer '
+                                   'or allocate p.grad = torch.zeros_like(p)' % name)
+            if self._gbound.get(name) != g.data_ptr():
+                check(lib.stair_ctx_set_grad(self._ctx, i, C.c_void_p(g.data_ptr()), g.numel()))
+                self._gbound[name] = g.data_ptr()
+
     def _workspace(self, nbytes, device):
         n = (nbytes + 3) // 4
         if self._ws is None or self._ws.numel() < n or self._ws.device != device:
@@ -208,7 +242,7 @@ class VideoNMN(nn.Module):
         return hit
 
     # ---------------------------------------------------------------------------------------
-    def run_programs(self, programs, spans, video, question, q_lens):
+    def run_programs(self, programs, spans, video, question, q_lens, train=False):
         """Batched pass.  programs: list of token lists; spans: list of {pos: (lo, hi)}; video
         [n,T,V] and question [sum(q_lens), E] float32 on the GPU.  Returns a BatchResult."""
         n = len(programs)
@@ -239,7 +273,7 @@ class VideoNMN(nn.Module):
         def ip(a):
             return a.ctypes.data_as(C.POINTER(C.c_int32))
         plan = C.c_void_p()
-        check(lib.stair_plan_build(self._ctx, n, ip(prog_off), ip(tokens), ip(lo), ip(hi), ip(q_off), T, C.byref(plan)))
+        check(lib.stair_plan_build(self._ctx, n, ip(prog_off), ip(tokens), ip(lo), ip(hi), ip(q_off), T, 1 if train else 0, C.byref(plan)))
         try:
             info = PlanInfo()
             check(lib.stair_plan_get_info(plan, C.byref(info)))
@@ -250,12 +284,14 @@ class VideoNMN(nn.Module):
             check(lib.stair_plan_run(self._ctx, plan, C.c_void_p(video.data_ptr()), C.c_void_p(question.data_ptr()),
                                      C.c_void_p(ws.data_ptr()), ws.numel() * 4, C.c_void_p(logits.data_ptr()),
                                      C.c_void_p(pred.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            if train:       # a training plan keeps its logits inside the workspace for the backward pass
+                logits = ws[info.logits_off: info.logits_off + n * A].view(n, A)
         except Exception:
             lib.stair_plan_destroy(plan)
             raise
-        return BatchResult(self, plan, info, ws, logits, pred, prog_off, programs)
+        return BatchResult(self, plan, info, ws, logits, pred, prog_off, programs, video, question)
 
-    def forward_batch(self, batch):
+    def forward_batch(self, batch, train=False):
         """batch: list of question dicts in the reference layout (dataset.py:191-233), all with the
         same number of frames.  Tensors may live on the host; they are moved once, packed."""
         dev = next(self.parameters()).device
@@ -264,7 +300,7 @@ class VideoNMN(nn.Module):
         question = torch.cat(qs).to(dev, torch.float32).contiguous()
         return self.run_programs([d['nmn_program_list'] for d in batch],
                                  [d['prog_str_to_question_tokens'] for d in batch], video, question,
-                                 [q.shape[0] for q in qs])
+                                 [q.shape[0] for q in qs], train=train)
 
     # ---------------------------------------------------------------------------------------
     @torch.no_grad()

@@ -1,0 +1,96 @@
+"""Training driver: the batched, data-parallel counterpart of the reference's loop
+(/root/reference/train_module.py:341-412) for the decoder-loss configuration (module_loss_weight = 0):
+
+    for each window of `global_batch` questions:        # the reference: gradient_accumulation = 32, batch 1
+        loss = sum_i CE(logits_i, answer_i) * decoder_loss_weight / global_batch      (:376-380, :372)
+        loss.backward(); Adam.step(); zero_grad(); LambdaLR.step()                     (:408-412)
+
+One window = one batched forward + one HIP backward pass per rank (questions sharded across ranks);
+gradients live in ONE flat fp32 buffer that is sum-all-reduced over RCCL once per step, together with the
+per-parameter "touched" mask (max-reduce), so that parameters of modules no rank used are skipped by Adam
+exactly as torch skips grad == None.  Parameters, gradients and Adam moments are flat buffers whose
+per-tensor segments start on multiples of 256 floats; the model's Parameters are views into them.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from ._lib import check, lib
+
+SEG = 256
+
+
+class Trainer:
+    def __init__(self, model, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decoder_loss_weight=1.0,
+                 scheduler_start_factor=1.0, scheduler_end_factor=0.1, scheduler_total_iters=200000, world=1,
+                 skip_untouched='ever'):
+        """skip_untouched: 'ever'   -- a parameter is skipped by Adam until the first window that sends it a gradient
+                                      (torch 1.13, which the reference pins: zero_grad() keeps zero tensors afterwards);
+                           'window' -- skipped in every window that does not touch it (torch >= 2.0, set_to_none=True)."""
+        assert skip_untouched in ('ever', 'window')
+        self.skip_untouched = skip_untouched
+        self.model, self.world = model, world
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.decoder_loss_weight = decoder_loss_weight
+        self.sched = (scheduler_start_factor, scheduler_end_factor, scheduler_total_iters)
+        self.iters = 0                                      # optimizer steps taken (LambdaLR counter)
+        params = dict(model.named_parameters())
+        names = model._weight_names
+        dev = next(model.parameters()).device
+        assert dev.type == 'cuda', 'Trainer needs the model on the GPU'
+        offs, total = [], 0
+        for nme in names:
+            offs.append(total)
+            total += (params[nme].numel() + SEG - 1) // SEG * SEG
+        self.n = total
+        self.flat_p = torch.zeros(total, device=dev)
+        self.flat_g = torch.zeros(total, device=dev)
+        self.exp_avg = torch.zeros(total, device=dev)
+        self.exp_avg_sq = torch.zeros(total, device=dev)
+        seg_of_block = torch.empty(total // SEG, dtype=torch.int32)
+        for i, nme in enumerate(names):
+            p = params[nme]
+            view = self.flat_p[offs[i]: offs[i] + p.numel()].view_as(p)
+            view.copy_(p.data)
+            p.data = view                                    # Parameters become views of the flat buffer
+            p.grad = self.flat_g[offs[i]: offs[i] + p.numel()].view_as(p)
+            nb = (p.numel() + SEG - 1) // SEG
+            seg_of_block[offs[i] // SEG: offs[i] // SEG + nb] = i
+        self.seg_of_block = seg_of_block.to(dev)
+        self.steps = torch.zeros(len(names), device=dev)     # per-tensor Adam step counts
+        self.touched = torch.zeros(len(names), dtype=torch.int32, device=dev)
+        self.offsets = offs
+
+    def lr_factor(self):
+        """train_module.py:328-331."""
+        start, end, total = self.sched
+        return end if self.iters > total else start + (end - start) / total * self.iters
+
+    def step(self, programs, spans, video, question, q_lens, answers, global_batch=None):
+        """One optimizer step over this rank's shard of a window.  Returns (mean CE of the local shard, BatchResult)."""
+        n = len(programs)
+        G = global_batch or n * self.world
+        self.flat_g.zero_()                                   # optimizer.zero_grad()
+        res = self.model.run_programs(programs, spans, video, question, q_lens, train=True)
+        loss = res.backward(answers, self.decoder_loss_weight / G)
+        t = torch.tensor(res.touched(), dtype=torch.int32).to(self.touched.device, non_blocking=True)
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM)          # ONE flat bucket over RCCL / xGMI
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if self.skip_untouched == 'ever':
+            self.touched = torch.maximum(self.touched, t)
+        else:
+            self.touched.copy_(t)
+        self.steps += self.touched.to(torch.float32)
+        lr = self.lr * self.lr_factor()
+        check(lib.stair_adam_step(C.c_void_p(self.flat_p.data_ptr()), C.c_void_p(self.flat_g.data_ptr()),
+                                  C.c_void_p(self.exp_avg.data_ptr()), C.c_void_p(self.exp_avg_sq.data_ptr()),
+                                  C.c_void_p(self.seg_of_block.data_ptr()), C.c_void_p(self.touched.data_ptr()),
+                                  C.c_void_p(self.steps.data_ptr()), C.c_float(lr), C.c_float(self.betas[0]),
+                                  C.c_float(self.betas[1]), C.c_float(self.eps), C.c_float(self.wd), self.n,
+                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        self.iters += 1                                       # scheduler.step()
+        return loss, res

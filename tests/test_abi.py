@@ -101,7 +101,7 @@ def _build(config, programs, spans, q_lens, T):
     q_off = np.zeros(n + 1, np.int32); np.cumsum(q_lens, out=q_off[1:])
     ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
     plan = C.c_void_p()
-    rc = lib.stair_plan_build(h, n, ip(prog_off), ip(tokens), ip(lo), ip(hi), ip(q_off), T, C.byref(plan))
+    rc = lib.stair_plan_build(h, n, ip(prog_off), ip(tokens), ip(lo), ip(hi), ip(q_off), T, 0, C.byref(plan))
     return h, plan, rc, prog_off
 
 

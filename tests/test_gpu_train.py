@@ -1,0 +1,120 @@
+"""GPU tests of the training path (`-m gpu`): the HIP backward pass against torch autograd of the oracle
+(the oracle is differentiable torch code, itself pinned to the reference's forward by tests/golden), and
+the Adam / LambdaLR step against torch.optim on the oracle's weights."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nmn_oracle as O
+from stair_amd import spec, synth
+from helpers import load_golden, question_for
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _model(config, seed=0):
+    from stair_amd.module_net import VideoNMN
+    m = VideoNMN(config)
+    w = synth.make_weights(config, seed)
+    m.load_state_dict({k: torch.from_numpy(w[k].copy()) for k in spec.state_dict_keys(config)})
+    return m.to(DEV)
+
+
+def _oracle_params(config, seed):
+    names = [n for n, _ in spec.weight_table(config)]
+    w = synth.make_weights(config, seed)
+    return names, {k: torch.from_numpy(w[k].copy()).requires_grad_(True) for k in names}
+
+
+def _oracle_loss(w, config, qs, scale):
+    total, per_q = 0.0, []
+    for q in qs:
+        logits = O.forward(w, config, q, return_res_by_step=False, explicit_lstm=True)['logits']
+        ce = torch.nn.functional.cross_entropy(logits.unsqueeze(0), torch.tensor([q['answer']]))   # train_module.py:193-194
+        per_q.append(float(ce))
+        total = total + ce * scale
+    return total, per_q
+
+
+def _pack(model, qs):
+    video = torch.stack([torch.as_tensor(q['video_features']) for q in qs]).to(DEV)
+    question = torch.cat([torch.as_tensor(q['question']) for q in qs]).to(DEV)
+    return ([q['nmn_program_list'] for q in qs], [q['prog_str_to_question_tokens'] for q in qs], video, question,
+            [q['question'].shape[0] for q in qs], torch.tensor([q['answer'] for q in qs], dtype=torch.int32, device=DEV))
+
+
+@pytest.mark.parametrize('name', ['tiny_conv', 'tiny_linear', 'tiny_conv_t24'])
+def test_backward_matches_autograd_of_oracle(name):
+    """All 12 program forms in one batch: every parameter gradient of the decoder CE loss."""
+    z, meta = load_golden(name)
+    config = meta['config']
+    qs = [question_for(meta, q) for q in meta['questions']]
+    scale = 1.0 / len(qs)
+    names, w = _oracle_params(config, meta['seed'])
+    loss, per_q = _oracle_loss(w, config, qs, scale)
+    loss.backward()
+
+    model = _model(config, meta['seed'])
+    for p in model.parameters():
+        p.grad = torch.zeros_like(p)
+    progs, spans, video, question, q_lens, answers = _pack(model, qs)
+    res = model.run_programs(progs, spans, video, question, q_lens, train=True)
+    # training-mode forward == inference forward == reference
+    for qi, q in enumerate(meta['questions']):
+        assert float((res.logits[qi].cpu() - torch.as_tensor(z['q%d/logits' % q['qid']])).abs().max()) < 2e-5
+    losses = res.backward(answers, scale)
+    assert np.allclose(losses.cpu().numpy(), per_q, rtol=1e-5, atol=1e-5)
+    got = dict(model.named_parameters())
+    touched = dict(zip(model._weight_names, res.touched()))
+    worst = (0.0, None)
+    for n in names:
+        ref = w[n].grad
+        g = got[n].grad.cpu()
+        if ref is None:
+            assert not touched[n] or 'Filter.attention' in n, n
+            assert float(g.abs().max()) == 0.0, n
+            continue
+        assert touched[n], n
+        tol = 2e-4 * max(float(ref.abs().max()), 1e-3)
+        err = float((g - ref).abs().max())
+        worst = max(worst, (err / tol, n))
+        assert err < tol, (n, err, float(ref.abs().max()))
+    print('worst gradient error / tolerance:', worst)
+
+
+def test_trainer_steps_match_torch_adam():
+    """Three optimizer steps (different program mixes per window, so some modules are untouched at first)
+    against torch.optim.Adam + LambdaLR on the oracle's weights, zero_grad(set_to_none=False) = torch 1.13."""
+    from stair_amd.train import Trainer
+    z, meta = load_golden('tiny_conv')
+    config = meta['config']
+    windows = [['P1', 'P4', 'P1', 'P4'], ['P0', 'P2', 'P3', 'P5'], ['P6', 'P7', 'C0', 'C1']]
+    names, w = _oracle_params(config, 0)
+    opt = torch.optim.Adam([w[n] for n in names], lr=2e-4)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda it: 1.0 + (0.1 - 1.0) / 10 * it if it <= 10 else 0.1)
+    model = _model(config, 0)
+    tr = Trainer(model, lr=2e-4, scheduler_total_iters=10, skip_untouched='ever')
+    qid = 100
+    for forms in windows:
+        qs = []
+        for f in forms:
+            qs.append(synth.make_question(config, 5, qid, form=f, T=40))
+            qid += 1
+        loss, _ = _oracle_loss(w, config, qs, 1.0 / len(qs))
+        loss.backward()
+        opt.step(); opt.zero_grad(set_to_none=False); sched.step()
+        progs, spans, video, question, q_lens, answers = _pack(model, qs)
+        tr.step(progs, spans, video, question, q_lens, answers)
+    got = dict(model.named_parameters())
+    for n in names:
+        ref = w[n].detach()
+        err = float((got[n].detach().cpu() - ref).abs().max())
+        # Adam's first steps move every touched weight by ~lr regardless of gradient scale; compare updates
+        assert err < 2e-5, (n, err)
+    # an untouched-so-far tensor must be bit-identical to its initial value
+    init = synth.make_weights(config, 0)
+    # (Filter 'relations' weights are only used by form C2, which is in none of the windows)
+    n = 'submodules.Filter.param.relations.0.weight'
+    assert torch.equal(got[n].detach().cpu(), torch.from_numpy(init[n]))
+    assert not torch.equal(got['submodules.Compare.param.0.weight'].detach().cpu(), torch.from_numpy(init['submodules.Compare.param.0.weight']))
