@@ -22,6 +22,17 @@ from ._lib import check, lib
 SEG = 256
 
 
+def reduce_gradients(flat_g, touched, world):
+    """The one exchange step of data-parallel training: sum the flat fp32 gradient bucket over all ranks and
+    max-reduce the per-parameter touched mask (a parameter is "touched" if ANY rank's shard used its module).
+    Backend-agnostic (RCCL on GPUs, gloo in the CPU test); in place."""
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(flat_g, op=dist.ReduceOp.SUM)
+        dist.all_reduce(touched, op=dist.ReduceOp.MAX)
+    return flat_g, touched
+
+
 class Trainer:
     def __init__(self, model, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decoder_loss_weight=1.0,
                  scheduler_start_factor=1.0, scheduler_end_factor=0.1, scheduler_total_iters=200000, world=1,
@@ -76,10 +87,7 @@ class Trainer:
         res = self.model.run_programs(programs, spans, video, question, q_lens, train=True)
         loss = res.backward(answers, self.decoder_loss_weight / G)
         t = torch.tensor(res.touched(), dtype=torch.int32).to(self.touched.device, non_blocking=True)
-        if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM)          # ONE flat bucket over RCCL / xGMI
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        reduce_gradients(self.flat_g, t, self.world)                    # ONE flat bucket over RCCL / xGMI
         if self.skip_untouched == 'ever':
             self.touched = torch.maximum(self.touched, t)
         else:

@@ -170,6 +170,36 @@ def main():
         np.savez_compressed(os.path.join(HERE, fname + '.npz'), **out)
         print(fname, len(out), 'arrays')
 
+    # ---- (i-b) training fixtures: the reference's own loss.backward() on the decoder CE loss ----
+    # (train_module.py:376-380 with decoder_loss_weight=1, window = the 12 forms, eval-mode dropout).
+    # Large gradient tensors are stored subsampled (every 5th element) to keep the fixture small.
+    for fname, cname, T in (('tiny_conv_grads', 'tiny_conv', 40), ('tiny_linear_grads', 'tiny_linear', 8)):
+        config = CONFIGS[cname]
+        model = build_model(VideoNMN, config)
+        model.pretrain_modules = set()
+        out = {}
+        total = 0.0
+        n = len(synth.ALL_FORMS)
+        for qid, form in enumerate(synth.ALL_FORMS):
+            d = synth.make_question(config, SEED, qid, form=form, T=T)
+            data = {'question': torch.from_numpy(d['question']), 'video_features': torch.from_numpy(d['video_features']),
+                    'prog_str_to_question_tokens': d['prog_str_to_question_tokens'],
+                    'nmn_program_list': d['nmn_program_list'], 'nmn_program_idx': d['nmn_program_idx']}
+            r = model(data, return_res_by_step=False, test_mode=True)
+            ce = torch.nn.CrossEntropyLoss()(r['logits'].unsqueeze(0), torch.tensor(d['answer']).unsqueeze(0))
+            out['ce/q%d' % qid] = to_np(ce)
+            total = total + ce / n
+        total.backward()
+        for k, p_ in model.named_parameters():
+            if p_.grad is None:
+                continue
+            g = p_.grad.detach().reshape(-1)
+            out['grad/' + k] = to_np(g if g.numel() <= 4096 else g[::5])
+        out['meta'] = np.frombuffer(json.dumps({'config': config, 'T': T, 'seed': SEED, 'forms': synth.ALL_FORMS,
+                                                'stride_large': 5, 'large_threshold': 4096}).encode(), dtype=np.uint8)
+        np.savez_compressed(os.path.join(HERE, fname + '.npz'), **out)
+        print(fname, len(out), 'arrays')
+
     # ---- (ii) full-size config: outputs only ----
     config = CONFIGS['full']
     model = build_model(VideoNMN, config)

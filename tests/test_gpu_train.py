@@ -67,7 +67,7 @@ def test_backward_matches_autograd_of_oracle(name):
     assert np.allclose(losses.cpu().numpy(), per_q, rtol=1e-5, atol=1e-5)
     got = dict(model.named_parameters())
     touched = dict(zip(model._weight_names, res.touched()))
-    worst = (0.0, None)
+    worst = (0.0, '')
     for n in names:
         ref = w[n].grad
         g = got[n].grad.cpu()
@@ -118,3 +118,47 @@ def test_trainer_steps_match_torch_adam():
     n = 'submodules.Filter.param.relations.0.weight'
     assert torch.equal(got[n].detach().cpu(), torch.from_numpy(init[n]))
     assert not torch.equal(got['submodules.Compare.param.0.weight'].detach().cpu(), torch.from_numpy(init['submodules.Compare.param.0.weight']))
+
+
+@pytest.mark.parametrize('fixture', ['tiny_conv_grads', 'tiny_linear_grads'])
+def test_backward_matches_reference_backward(fixture):
+    """HIP backward vs the REFERENCE's own loss.backward() (fixtures generated by tests/golden/make_golden.py)."""
+    from helpers import compare_with_reference_grads
+    z, meta = load_golden(fixture)
+    config = meta['config']
+    qs = [synth.make_question(config, meta['seed'], qid, form=form, T=meta['T']) for qid, form in enumerate(meta['forms'])]
+    model = _model(config, meta['seed'])
+    for p in model.parameters():
+        p.grad = torch.zeros_like(p)
+    progs, spans, video, question, q_lens, answers = _pack(model, qs)
+    res = model.run_programs(progs, spans, video, question, q_lens, train=True)
+    losses = res.backward(answers, 1.0 / len(qs))
+    for qid in range(len(qs)):
+        assert abs(float(losses[qid]) - float(z['ce/q%d' % qid])) < 2e-5
+    got = dict(model.named_parameters())
+    worst, _, _ = compare_with_reference_grads(fixture, lambda n: got[n].grad)
+    print('worst gradient error / tolerance vs reference:', worst)
+
+
+def test_full_size_backward_sample():
+    """Full-size shapes (H=512, V=2048, T=64): 6 questions against autograd of the oracle."""
+    config = dict(spec.DEFAULT_CONFIG)
+    qs = [synth.make_question(config, 21, i, form=f) for i, f in enumerate(['P0', 'P2', 'P3', 'P5', 'C0', 'C1'])]
+    names, w = _oracle_params(config, 3)
+    loss, per_q = _oracle_loss(w, config, qs, 1.0 / len(qs))
+    loss.backward()
+    model = _model(config, 3)
+    for p in model.parameters():
+        p.grad = torch.zeros_like(p)
+    progs, spans, video, question, q_lens, answers = _pack(model, qs)
+    res = model.run_programs(progs, spans, video, question, q_lens, train=True)
+    losses = res.backward(answers, 1.0 / len(qs))
+    assert np.allclose(losses.cpu().numpy(), per_q, rtol=1e-5, atol=2e-5)
+    got = dict(model.named_parameters())
+    for n in names:
+        ref = w[n].grad
+        if ref is None:
+            continue
+        tol = 5e-4 * float(ref.abs().max()) + 3e-6      # absolute floor: fp32 cancellation noise of both sides
+        err = float((got[n].grad.cpu() - ref).abs().max())
+        assert err < tol, (n, err, float(ref.abs().max()))

@@ -66,3 +66,61 @@ def test_accuracy_rule_ignores_unk_gold():
     from stair_amd import evaluate as E
     assert E.accuracy([1, 2, 5], [1, 3, 5], unk_token_id=5) == pytest.approx(1 / 3)    # train_module.py:252-253
     assert E.shard_indices(7, 1, 3) == [1, 4]
+
+
+def _grad_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from oracle import nmn_oracle as O
+    from stair_amd import spec, synth
+    from stair_amd.train import reduce_gradients
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    config = dict(spec.DEFAULT_CONFIG, hidden_size=64, video_size=128, answer_vocab_length=16, max_video_length=40, object_types=10)
+    names = [n for n, _ in spec.weight_table(config)]
+    wnp = synth.make_weights(config, 0)
+    w = {k: torch.from_numpy(wnp[k].copy()).requires_grad_(True) for k in names}
+    forms = ['P1', 'P4', 'P3', 'P6']                   # rank 0 gets P1, P3; rank 1 gets P4, P6
+    qs = [synth.make_question(config, 9, i, form=f) for i, f in enumerate(forms)]
+    G = len(qs)
+    loss = 0.0
+    for i in range(rank, G, world):
+        logits = O.forward(w, config, qs[i], return_res_by_step=False)['logits']
+        loss = loss + torch.nn.functional.cross_entropy(logits.unsqueeze(0), torch.tensor([qs[i]['answer']])) / G
+    loss.backward()
+    flat = torch.cat([(w[n].grad if w[n].grad is not None else torch.zeros_like(w[n])).reshape(-1) for n in names])
+    touched = torch.tensor([int(w[n].grad is not None) for n in names], dtype=torch.int32)
+    reduce_gradients(flat, touched, world)
+    torch.save({'flat': flat, 'touched': touched}, os.path.join(out_dir, 'g%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_reduction_equals_single_process(tmp_path):
+    """Sharding a window over 2 ranks + one flat all-reduce == the single-process gradient of the whole
+    window (loss normalised by the GLOBAL window size), and the touched mask is the union over ranks."""
+    world = 2
+    mp.spawn(_grad_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    g0 = torch.load(os.path.join(tmp_path, 'g0.pt'))
+    g1 = torch.load(os.path.join(tmp_path, 'g1.pt'))
+    assert torch.equal(g0['flat'], g1['flat']) and torch.equal(g0['touched'], g1['touched'])
+    sys.path.insert(0, ROOT)
+    from oracle import nmn_oracle as O
+    from stair_amd import spec, synth
+    config = dict(spec.DEFAULT_CONFIG, hidden_size=64, video_size=128, answer_vocab_length=16, max_video_length=40, object_types=10)
+    names = [n for n, _ in spec.weight_table(config)]
+    wnp = synth.make_weights(config, 0)
+    w = {k: torch.from_numpy(wnp[k].copy()).requires_grad_(True) for k in names}
+    qs = [synth.make_question(config, 9, i, form=f) for i, f in enumerate(['P1', 'P4', 'P3', 'P6'])]
+    loss = 0.0
+    for q in qs:
+        logits = O.forward(w, config, q, return_res_by_step=False)['logits']
+        loss = loss + torch.nn.functional.cross_entropy(logits.unsqueeze(0), torch.tensor([q['answer']])) / len(qs)
+    loss.backward()
+    flat = torch.cat([(w[n].grad if w[n].grad is not None else torch.zeros_like(w[n])).reshape(-1) for n in names])
+    touched = torch.tensor([int(w[n].grad is not None) for n in names], dtype=torch.int32)
+    assert torch.allclose(g0['flat'], flat, rtol=1e-5, atol=1e-7)
+    assert torch.equal(g0['touched'], touched)
+    # Equals is only used by P4 (rank 1's shard): rank 0 alone would have left it untouched
+    assert int(touched[names.index('submodules.Equals.param.0.weight')]) == 1
