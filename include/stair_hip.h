@@ -222,6 +222,10 @@ int stair_plan_backward(stair_ctx *ctx, stair_plan *plan, const float *video, co
                         void *workspace, int64_t workspace_bytes, const int32_t *answers, float loss_scale,
                         float *loss_out, stair_stream stream);
 
+/* Test hook: every region of the workspace layout as (name, begin, end) float offsets; returns the region count.
+ * Regions must be pairwise disjoint (tests/test_abi.py checks it for inference and training plans). */
+int stair_plan_regions(stair_plan *plan, const stair_ctx *ctx, const char **names, int64_t *beg, int64_t *end, int32_t cap);
+
 /* touched[id] = 1 iff weight `id` receives a gradient from this plan (host array, count = stair_weight_count).
  * Parameters of modules that no program used keep grad == None in the reference and are skipped by Adam. */
 int stair_plan_touched(const stair_ctx *ctx, const stair_plan *plan, int32_t *touched, int32_t count);

@@ -93,6 +93,7 @@ SIGNATURES = [
                                    C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     ('stair_plan_backward', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                       C.c_float, C.c_void_p, C.c_void_p]),
+    ('stair_plan_regions', C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32]),
     ('stair_plan_touched', C.c_int, [C.c_void_p, C.c_void_p, c_int32_p, C.c_int32]),
     ('stair_adam_step', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64, C.c_void_p]),

@@ -503,7 +503,7 @@ extern "C" int stair_plan_build(stair_ctx *ctx, int32_t n, const int32_t *prog_o
         pl->n_levels = std::max(pl->n_levels, b.level + 1);
         switch (b.op) {
             case STAIR_OP_FILTER: case STAIR_OP_FILTERFRAME: case STAIR_OP_HASITEM: case STAIR_OP_LOCALIZE:
-            case STAIR_OP_SUPERLATIVE:
+            case STAIR_OP_SUPERLATIVE: case STAIR_OP_TEMPORAL:
                 pl->maxI = std::max(pl->maxI, b.cnt);
                 break;
             default: break;
@@ -1244,4 +1244,81 @@ extern "C" int stair_adam_step(float *params, const float *grads, float *exp_avg
     STAIR_CHECK(params && grads && exp_avg && exp_avg_sq && seg_of_block && touched && step_of_seg, "null argument");
     return launch_adam(params, grads, exp_avg, exp_avg_sq, seg_of_block, touched, step_of_seg, lr, beta1, beta2, eps, weight_decay, n,
                        static_cast<hipStream_t>(stream));
+}
+
+// Layout introspection for tests: every workspace region as (name, begin, end) in floats.
+// Returns the number of regions; fills up to `cap` entries.  `names` receives pointers to static strings
+// or to strings owned by the plan (valid until the plan is destroyed).
+extern "C" int stair_plan_regions(stair_plan *pl, const stair_ctx *ctx, const char **names, int64_t *beg, int64_t *end, int32_t cap) {
+    if (!pl || !ctx) return -1;
+    static thread_local std::vector<std::string> store;
+    store.clear();
+    std::vector<std::tuple<std::string, int64_t, int64_t>> r;
+    const int64_t H = ctx->cfg.hidden_size, A = ctx->cfg.answer_vocab_length, T = pl->T, n = pl->n;
+    auto add = [&](const std::string &nm, int64_t b, int64_t len) { if (len > 0) r.emplace_back(nm, b, b + len); };
+    add("idx", pl->o_idx, (int64_t)pl->idx.size());
+    add("vec", pl->o_vec, (int64_t)pl->n_vec * H);
+    add("map", pl->o_map, (int64_t)pl->n_map * T * H);
+    add("att", pl->o_att, (int64_t)std::max(pl->n_att, 1) * T);
+    add("tok", pl->o_tok, (int64_t)pl->rows_q * H);
+    add("qfeat", pl->o_qfeat, n * H);
+    add("vhn", pl->o_vhn, n * H);
+    add("xpv", pl->o_xpv, n * T * 4 * H);
+    add("xpt", pl->o_xpt, (int64_t)pl->rows_q * 4 * H);
+    add("bias", pl->o_bias, 8 * H);
+    add("wpack", pl->o_wpack, 4 * H * H);
+    add("tmpA", pl->o_tmpA, (int64_t)std::max(pl->maxI, 1) * T * H);
+    add("tmpB", pl->o_tmpB, (int64_t)std::max(pl->maxI, 1) * T * H);
+    add("kbuf", pl->o_kbuf, (int64_t)std::max(pl->maxK, 1) * H);
+    add("cat", pl->o_cat, (int64_t)pl->maxV * 3 * H);
+    add("hid", pl->o_hid, (int64_t)pl->maxV * 2 * H);
+    add("rs", pl->o_rs, (int64_t)std::max(pl->maxI, 1) * T);
+    add("sup", pl->o_sup, (int64_t)std::max(pl->maxSupRows, 1) * T);
+    add("extra", pl->o_extra, std::max(pl->maxI, 1));
+    add("logits", pl->o_logits, n * A);
+    if (pl->train) {
+        int bi = 0;
+        for (const Bucket &b : pl->buckets) {
+            const std::string p = "b" + std::to_string(bi++) + "(op" + std::to_string(b.op) + "v" + std::to_string(b.variant) + ").";
+            const int64_t c = b.cnt;
+            if (b.svA != pl->o_tmpA) add(p + "svA", b.svA, c * T * H);
+            if (b.svB != pl->o_tmpB) add(p + "svB", b.svB, c * T * H);
+            if (b.svK != pl->o_kbuf) add(p + "svK", b.svK, (int64_t)b.nrows * H);
+            if (b.svCat != pl->o_cat) add(p + "svCat", b.svCat, (b.op == STAIR_OP_FILTER || b.op == STAIR_OP_SUPERLATIVE) ? c * H : c * 3 * H);
+            if (b.svHid != pl->o_hid) add(p + "svHid", b.svHid, c * H);
+            if (b.svRs != pl->o_rs) add(p + "svRs", b.svRs, c * T);
+            if (b.svSup != pl->o_sup) add(p + "svSup", b.svSup, (int64_t)b.nrows * T);
+            if (b.svExtra != pl->o_extra) add(p + "svExtra", b.svExtra, c);
+        }
+        const int64_t I = std::max(pl->maxI, 1), Vv = pl->maxV;
+        add("cv", pl->o_cv, n * T * H);
+        add("ct", pl->o_ct, (int64_t)pl->rows_q * H);
+        add("hprev", pl->o_hprev, (int64_t)std::max<int64_t>(n * T, pl->rows_q) * H);
+        add("wt", pl->o_wt, ctx_weight_floats(ctx));
+        add("gA", pl->o_gA, I * T * H);
+        add("gB", pl->o_gB, I * T * H);
+        add("gV0", pl->o_gV0, Vv * 2 * H);
+        add("gV1", pl->o_gV1, Vv * 2 * H);
+        add("gCat", pl->o_gCat, Vv * 3 * H);
+        add("gStats", pl->o_gStats, I * T * 2);
+        add("gRs2", pl->o_gRs2, I * T);
+        add("dlogits", pl->o_dlogits, n * A);
+        add("loss", pl->o_loss, n);
+        add("gblock", pl->o_gblock, pl->o_map + (int64_t)pl->n_map * T * H - pl->o_vec);
+        add("gatt", pl->o_gatt, (int64_t)std::max(pl->n_att, 1) * T);
+        add("gtok", pl->o_gtok, (int64_t)pl->rows_q * H);
+        add("gqfeat", pl->o_gqfeat, n * H);
+        add("gK", pl->o_gK, (int64_t)std::max(pl->maxK, 1) * H);
+        add("gS", pl->o_gS, (int64_t)std::max(pl->maxSupRows, 1) * T);
+        add("gRs", pl->o_gRs, I * T);
+        add("gExtra", pl->o_gExtra, I);
+    }
+    add("END", pl->total, 1);
+    for (auto &t : r) store.push_back(std::get<0>(t));
+    for (int i = 0; i < (int)r.size() && i < cap; ++i) {
+        names[i] = store[i].c_str();
+        beg[i] = std::get<1>(r[i]);
+        end[i] = std::get<2>(r[i]);
+    }
+    return (int)r.size();
 }

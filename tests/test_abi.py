@@ -154,3 +154,38 @@ def test_linear_temporal_requires_full_length():
     h, plan, rc, _ = _build(config, [['Filter', 'video', 'objects']], [{}], [8], 6)
     assert rc != 0 and b'max_video_length' in lib.stair_last_error()
     lib.stair_ctx_destroy(h)
+
+
+@pytest.mark.parametrize('train', [False, True])
+def test_workspace_regions_are_disjoint(train):
+    """Every region of the plan's workspace layout (arenas, per-bucket saves, gradient arenas, scratch) must be
+    disjoint from every other one, for all 12 program forms in one batch."""
+    config = dict(spec.DEFAULT_CONFIG)
+    names = sorted(synth.CORPUS)
+    qs = [synth.make_question(config, 0, i, form=name, with_video=False) for i, name in enumerate(names)]
+    h = _ctx(config)
+    enc = [np.asarray(spec.encode_program(q['nmn_program_list']), dtype=np.int32) for q in qs]
+    n = len(qs)
+    prog_off = np.zeros(n + 1, np.int32); np.cumsum([len(e) for e in enc], out=prog_off[1:])
+    tokens = np.concatenate(enc)
+    lo = np.zeros(len(tokens), np.int32); hi = np.zeros(len(tokens), np.int32)
+    for q in range(n):
+        for i, c in enumerate(enc[q]):
+            if c == spec.TOK_SPAN:
+                lo[prog_off[q] + i], hi[prog_off[q] + i] = qs[q]['prog_str_to_question_tokens'][i]
+    q_off = np.zeros(n + 1, np.int32); np.cumsum([q['question'].shape[0] for q in qs], out=q_off[1:])
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    plan = C.c_void_p()
+    check(lib.stair_plan_build(h, n, ip(prog_off), ip(tokens), ip(lo), ip(hi), ip(q_off), 64, 1 if train else 0, C.byref(plan)))
+    cap = 8192
+    nm = (C.c_char_p * cap)(); beg = (C.c_int64 * cap)(); end = (C.c_int64 * cap)()
+    k = lib.stair_plan_regions(plan, h, nm, beg, end, cap)
+    assert 0 < k < cap
+    regs = sorted((beg[i], end[i], nm[i].decode()) for i in range(k))
+    for a, b in zip(regs, regs[1:]):
+        assert a[1] <= b[0], ('overlap', a, b)
+    info = PlanInfo()
+    check(lib.stair_plan_get_info(plan, C.byref(info)))
+    assert regs[-1][2] == 'END' and regs[-1][0] * 4 == info.workspace_bytes
+    lib.stair_plan_destroy(plan)
+    lib.stair_ctx_destroy(h)
