@@ -196,6 +196,7 @@ void stair_plan_destroy(stair_plan *plan);
 typedef struct stair_plan_info {
     int64_t workspace_bytes;
     int64_t vec_off, map_off, att_off, tok_off, qfeat_off, logits_off; /* float offsets */
+    int64_t gvec_off, gmap_off, gatt_off; /* gradient arenas of a STAIR_PLAN_TRAIN plan (same slot numbering), else -1 */
     int32_t n_vec, n_map, n_att, n_tok_rows;
     int32_t n_nodes, n_launches, n_levels, n_questions, T;
 } stair_plan_info;
@@ -220,7 +221,32 @@ int stair_plan_run(stair_ctx *ctx, stair_plan *plan, const float *video, const f
  * receives the unscaled per-question CE.  What torch autograd does for train_module.py:408. */
 int stair_plan_backward(stair_ctx *ctx, stair_plan *plan, const float *video, const float *question,
                         void *workspace, int64_t workspace_bytes, const int32_t *answers, float loss_scale,
-                        float *loss_out, stair_stream stream);
+                        float *loss_out, int32_t flags, stair_stream stream);
+#define STAIR_BWD_KEEP_ARENAS 1 /* flags: the gradient arenas were cleared by stair_plan_zero_grads and already hold
+                                   the gradients injected by the stair_loss_* functions below */
+int stair_plan_zero_grads(stair_plan *plan, void *workspace, stair_stream stream);
+
+/* ---- per-module intermediate-supervision losses (train_module.py:33-194, CriterionByModule) -------------------
+ * Each call evaluates `n` loss items, writes the unscaled loss of item i to loss[i] and ADDS scale * dloss/dresult
+ * into the gradient arena at the result's slot; head parameters' gradients are added to dW/db.  All arrays device. */
+
+/* attention_score_criterion (:83-90) on att rows slot[i] .. slot[i]+K[i]-1 against the soft interval masks of
+ * span_to_attention (:67-81); intervals[2*(iv_off[i]+r)] = (start, end) of row r in frames (double, like the
+ * reference).  Localize (:173-182, K rows, mean over K*T), Temporal / ExistsFrame (:157-164, :184-191, K = 1). */
+int stair_loss_attention(const float *att, float *d_att, const int32_t *slot, const int32_t *K,
+                         const int32_t *iv_off, const double *intervals, int32_t n, int32_t T, float scale,
+                         float *loss, stair_stream stream);
+/* Linear pretrain head W [nout,H] on vec[slot[i]] + loss: nout = 2 CrossEntropy vs bool label (Exists, Xor :92-99),
+ * nout = 1 squared error vs 0/1 (Equals :101-107). */
+int stair_loss_head(int32_t nout, const float *vec, float *d_vec, const int32_t *slot, const int32_t *label,
+                    const float *W, const float *b, float *dW, float *db, int32_t n, int32_t H, float scale,
+                    float *loss, stair_stream stream);
+/* Contrastive CE of Filter / ToAction / Superlative (:113-125) with the per-window class pooling of :388-406:
+ * pred = L2Normalize(vec[slot[i]]); logits over class reps G[win_start[i] .. +win_cnt[i]) ; positive row pos[i]
+ * (absolute row of G).  max_classes = max(win_cnt). */
+int stair_loss_contrastive(const float *vec, float *d_vec, const int32_t *slot, const int32_t *pos,
+                           const int32_t *win_start, const int32_t *win_cnt, const float *G, int32_t n, int32_t H,
+                           int32_t max_classes, float scale, float *loss, stair_stream stream);
 
 /* Test hook: every region of the workspace layout as (name, begin, end) float offsets; returns the region count.
  * Regions must be pairwise disjoint (tests/test_abi.py checks it for inference and training plans). */

@@ -63,6 +63,7 @@ class LstmBwdArgs(C.Structure):
 class PlanInfo(C.Structure):
     _fields_ = [('workspace_bytes', C.c_int64), ('vec_off', C.c_int64), ('map_off', C.c_int64), ('att_off', C.c_int64),
                 ('tok_off', C.c_int64), ('qfeat_off', C.c_int64), ('logits_off', C.c_int64),
+                ('gvec_off', C.c_int64), ('gmap_off', C.c_int64), ('gatt_off', C.c_int64),
                 ('n_vec', C.c_int32), ('n_map', C.c_int32), ('n_att', C.c_int32), ('n_tok_rows', C.c_int32),
                 ('n_nodes', C.c_int32), ('n_launches', C.c_int32), ('n_levels', C.c_int32), ('n_questions', C.c_int32),
                 ('T', C.c_int32)]
@@ -92,7 +93,14 @@ SIGNATURES = [
     ('stair_plan_build', C.c_int, [C.c_void_p, C.c_int32, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p,
                                    C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     ('stair_plan_backward', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
-                                      C.c_float, C.c_void_p, C.c_void_p]),
+                                      C.c_float, C.c_void_p, C.c_int32, C.c_void_p]),
+    ('stair_plan_zero_grads', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    ('stair_loss_attention', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                       C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
+    ('stair_loss_head', C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
+    ('stair_loss_contrastive', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     ('stair_plan_regions', C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32]),
     ('stair_plan_touched', C.c_int, [C.c_void_p, C.c_void_p, c_int32_p, C.c_int32]),
     ('stair_adam_step', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

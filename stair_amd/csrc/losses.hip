@@ -1,0 +1,196 @@
+// Per-module intermediate-supervision losses of /root/reference/train_module.py:33-194 (CriterionByModule),
+// forward value + gradient w.r.t. the module result, injected straight into the plan's gradient arenas
+// (so that stair_plan_backward continues from them).  One wave or one small block per loss item; items are
+// few (a handful per question) and rows short, so these kernels are launch/latency bound by nature.
+#include "ops.h"
+
+namespace stair {
+namespace {
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = kBlock / 64;
+
+// span_to_attention, train_module.py:67-81, evaluated per frame t (double arithmetic like the reference)
+__device__ __forceinline__ float span_gold(double g0, double g1, int L, int t) {
+    const double start = fmin((double)L - 0.002, fmax(0.001, g0));
+    const double end = fmin((double)L - 0.001, g1);
+    const int si = (int)ceil(start), ei = (int)floor(end);
+    double v = 0.0;
+    if (si < ei && t >= si && t < ei) v += 1.0;
+    if (si <= ei) {
+        if (t == si - 1) v += (double)si - start;
+        if (t == ei) v += end - (double)ei;
+    } else if (t == ei) {
+        v += end - start;
+    }
+    return (float)v;
+}
+}  // namespace
+
+// attention_score_criterion (:83-90) for Localize [K,T] (:173-182), Temporal / ExistsFrame [T] (:157-164,184-191)
+__global__ void loss_attention_kernel(const float *att, float *d_att, const int32_t *slot, const int32_t *K,
+                                      const int32_t *iv_off, const double *intervals, int n, int T, float scale, float *loss) {
+    const int i = blockIdx.x;
+    const int k = K[i];
+    const float inv = 1.0f / (float)(k * T);
+    float acc = 0.f;
+    for (int e = threadIdx.x; e < k * T; e += blockDim.x) {
+        const int r = e / T, t = e - r * T;
+        const double *iv = intervals + 2 * (int64_t)(iv_off[i] + r);
+        const float g = span_gold(iv[0], iv[1], T, t);
+        const int64_t o = ((int64_t)slot[i] + r) * T + t;
+        const float p = att[o];
+        acc += -(g * logf(p) + (1.f - g) * logf(1.f - p));
+        unsafeAtomicAdd(d_att + o, scale * inv * (-g / p + (1.f - g) / (1.f - p)));
+    }
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) loss[i] = acc * inv;       // blockDim == 64: one wave
+}
+int launch_loss_attention(const float *att, float *d_att, const int32_t *slot, const int32_t *K, const int32_t *iv_off,
+                          const double *intervals, int n, int T, float scale, float *loss, hipStream_t s) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(loss_attention_kernel, dim3(n), dim3(64), 0, s, att, d_att, slot, K, iv_off, intervals, n, T, scale, loss);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
+// Linear pretrain head [NOUT,H] + loss.  NOUT == 2: CrossEntropy against a bool (Exists / Xor, :92-99);
+// NOUT == 1: mean squared error against 0/1 (Equals, :101-107).
+template <int NOUT>
+__global__ void loss_head_kernel(const float *vec, float *d_vec, const int32_t *slot, const int32_t *label, const float *W,
+                                 const float *b, float *dW, float *db, int n, int H, float scale, float *loss) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const float *x = vec + (int64_t)slot[i] * H;
+    float z[NOUT];
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j) {
+        float d = 0.f;
+        for (int c = lane; c < H; c += 64) d += x[c] * W[(int64_t)j * H + c];
+        z[j] = wave_sum(d) + b[j];
+    }
+    float dz[NOUT];
+    float l;
+    if (NOUT == 2) {
+        const float m = fmaxf(z[0], z[NOUT - 1]);
+        const float e0 = expf(z[0] - m), e1 = expf(z[NOUT - 1] - m), sum = e0 + e1;
+        const int y = label[i] ? 1 : 0;
+        l = logf(sum) + m - z[y];
+        dz[0] = scale * (e0 / sum - (y == 0 ? 1.f : 0.f));
+        dz[NOUT - 1] = scale * (e1 / sum - (y == 1 ? 1.f : 0.f));
+    } else {
+        const float diff = z[0] - (label[i] ? 1.f : 0.f);
+        l = diff * diff;
+        dz[0] = scale * 2.f * diff;
+    }
+    for (int c = lane; c < H; c += 64) {
+        float dx = 0.f;
+#pragma unroll
+        for (int j = 0; j < NOUT; ++j) {
+            dx += dz[j] * W[(int64_t)j * H + c];
+            unsafeAtomicAdd(dW + (int64_t)j * H + c, dz[j] * x[c]);
+        }
+        unsafeAtomicAdd(d_vec + (int64_t)slot[i] * H + c, dx);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < NOUT; ++j) unsafeAtomicAdd(db + j, dz[j]);
+        loss[i] = l;
+    }
+}
+int launch_loss_head(int nout, const float *vec, float *d_vec, const int32_t *slot, const int32_t *label, const float *W,
+                     const float *b, float *dW, float *db, int n, int H, float scale, float *loss, hipStream_t s) {
+    if (n == 0) return 0;
+    STAIR_CHECK(nout == 1 || nout == 2, "head width must be 1 (Equals) or 2 (Exists/Xor)");
+    const dim3 grid((n + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlock);
+    if (nout == 2) hipLaunchKernelGGL(loss_head_kernel<2>, grid, block, 0, s, vec, d_vec, slot, label, W, b, dW, db, n, H, scale, loss);
+    else hipLaunchKernelGGL(loss_head_kernel<1>, grid, block, 0, s, vec, d_vec, slot, label, W, b, dW, db, n, H, scale, loss);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
+// Contrastive CE of Filter / ToAction / Superlative (:113-125 with the window pooling of :388-406):
+//   pred = L2Normalize(x) (module_net.py:211-216); logits_c = G[c] . pred over the classes of the item's window;
+//   loss = -log softmax(logits)[positive].   Gradient goes back through the normalisation into d_vec.
+__global__ void loss_contrastive_kernel(const float *vec, float *d_vec, const int32_t *slot, const int32_t *pos,
+                                        const int32_t *win_start, const int32_t *win_cnt, const float *G, int n, int H,
+                                        float scale, float *loss) {
+    extern __shared__ float sm[];      // [C] logits -> softmax probs, then [H] dpred
+    const int i = blockIdx.x;
+    const int c0 = win_start[i], C = win_cnt[i];
+    float *prob = sm, *dpred = sm + C;
+    __shared__ float s_nrm, s_dot;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float *x = vec + (int64_t)slot[i] * H;
+    if (wave == 0) {
+        float ss = 0.f;
+        for (int h = lane; h < H; h += 64) ss += x[h] * x[h];
+        ss = wave_sum(ss);
+        if (lane == 0) s_nrm = fmaxf(sqrtf(ss), 1e-12f);
+    }
+    __syncthreads();
+    const float inv = 1.0f / s_nrm;
+    for (int c = wave; c < C; c += kWavesPerBlock) {
+        const float *g = G + (int64_t)(c0 + c) * H;
+        float d = 0.f;
+        for (int h = lane; h < H; h += 64) d += g[h] * x[h];
+        d = wave_sum(d);
+        if (lane == 0) prob[c] = d * inv;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float m = -INFINITY;
+        for (int c = lane; c < C; c += 64) m = fmaxf(m, prob[c]);
+        m = wave_max(m);
+        float sum = 0.f;
+        for (int c = lane; c < C; c += 64) sum += expf(prob[c] - m);
+        sum = wave_sum(sum);
+        const int p = pos[i] - c0;
+        if (lane == 0) loss[i] = logf(sum) + m - prob[p];
+        for (int c = lane; c < C; c += 64) prob[c] = scale * (expf(prob[c] - m) / sum - (c == p ? 1.f : 0.f));   // dlogits
+    }
+    __syncthreads();
+    float part = 0.f;
+    for (int h = threadIdx.x; h < H; h += blockDim.x) {
+        float d = 0.f;
+        for (int c = 0; c < C; ++c) d += prob[c] * G[(int64_t)(c0 + c) * H + h];
+        dpred[h] = d;
+        part += d * x[h] * inv;
+    }
+    part = wave_sum(part);
+    if (threadIdx.x == 0) s_dot = 0.f;
+    __syncthreads();
+    if (lane == 0) atomicAdd(&s_dot, part);
+    __syncthreads();
+    const float dot = s_dot;       // pred . dpred
+    for (int h = threadIdx.x; h < H; h += blockDim.x)
+        unsafeAtomicAdd(d_vec + (int64_t)slot[i] * H + h, (dpred[h] - x[h] * inv * dot) * inv);
+}
+int launch_loss_contrastive(const float *vec, float *d_vec, const int32_t *slot, const int32_t *pos, const int32_t *win_start,
+                            const int32_t *win_cnt, const float *G, int n, int H, int max_classes, float scale, float *loss,
+                            hipStream_t s) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(loss_contrastive_kernel, dim3(n), dim3(kBlock), (size_t)(max_classes + H) * sizeof(float), s, vec, d_vec,
+                       slot, pos, win_start, win_cnt, G, n, H, scale, loss);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace stair
+
+extern "C" int stair_loss_attention(const float *att, float *d_att, const int32_t *slot, const int32_t *K,
+                                    const int32_t *iv_off, const double *intervals, int32_t n, int32_t T, float scale,
+                                    float *loss, stair_stream stream) {
+    return stair::launch_loss_attention(att, d_att, slot, K, iv_off, intervals, n, T, scale, loss, static_cast<hipStream_t>(stream));
+}
+extern "C" int stair_loss_head(int32_t nout, const float *vec, float *d_vec, const int32_t *slot, const int32_t *label,
+                               const float *W, const float *b, float *dW, float *db, int32_t n, int32_t H, float scale,
+                               float *loss, stair_stream stream) {
+    return stair::launch_loss_head(nout, vec, d_vec, slot, label, W, b, dW, db, n, H, scale, loss, static_cast<hipStream_t>(stream));
+}
+extern "C" int stair_loss_contrastive(const float *vec, float *d_vec, const int32_t *slot, const int32_t *pos,
+                                      const int32_t *win_start, const int32_t *win_cnt, const float *G, int32_t n, int32_t H,
+                                      int32_t max_classes, float scale, float *loss, stair_stream stream) {
+    return stair::launch_loss_contrastive(vec, d_vec, slot, pos, win_start, win_cnt, G, n, H, max_classes, scale, loss,
+                                          static_cast<hipStream_t>(stream));
+}

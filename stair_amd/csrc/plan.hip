@@ -636,6 +636,9 @@ extern "C" int stair_plan_get_info(const stair_plan *pl, stair_plan_info *info) 
     info->workspace_bytes = pl->total * (int64_t)sizeof(float);
     info->vec_off = pl->o_vec; info->map_off = pl->o_map; info->att_off = pl->o_att;
     info->tok_off = pl->o_tok; info->qfeat_off = pl->o_qfeat; info->logits_off = pl->o_logits;
+    info->gvec_off = pl->train ? pl->o_gblock : -1;
+    info->gmap_off = pl->train ? pl->o_gblock + (pl->o_map - pl->o_vec) : -1;
+    info->gatt_off = pl->train ? pl->o_gatt : -1;
     info->n_vec = pl->n_vec; info->n_map = pl->n_map; info->n_att = pl->n_att; info->n_tok_rows = pl->rows_q;
     info->n_nodes = (int)pl->nodes.size();
     int launches = 0;
@@ -974,7 +977,7 @@ int dense_bwd(const BwdCtx &B, const float *dZ, int groups, int R, int N, int K,
 
 extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *video, const float *question,
                                    void *workspace, int64_t workspace_bytes, const int32_t *answers, float loss_scale,
-                                   float *loss_out, stair_stream stream) {
+                                   float *loss_out, int32_t flags, stair_stream stream) {
     STAIR_CHECK(ctx && pl && video && question && workspace && answers, "null argument");
     STAIR_CHECK(pl->train, "plan was not built with STAIR_PLAN_TRAIN");
     STAIR_CHECK(workspace_bytes >= pl->total * (int64_t)sizeof(float), "workspace too small");
@@ -999,7 +1002,8 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
     float *loss = loss_out ? loss_out : ws + pl->o_loss;
 
 #define RUN(x) do { if (int rc_ = (x)) return rc_; } while (0)
-    STAIR_HIP(hipMemsetAsync(ws + pl->o_zero_beg, 0, (pl->o_zero_end - pl->o_zero_beg) * sizeof(float), s));
+    if (!(flags & STAIR_BWD_KEEP_ARENAS))
+        STAIR_HIP(hipMemsetAsync(ws + pl->o_zero_beg, 0, (pl->o_zero_end - pl->o_zero_beg) * sizeof(float), s));
 
     // transposed images of every 2-D weight that needs a dX product
     BwdCtx B;
@@ -1321,4 +1325,12 @@ extern "C" int stair_plan_regions(stair_plan *pl, const stair_ctx *ctx, const ch
         end[i] = std::get<2>(r[i]);
     }
     return (int)r.size();
+}
+
+extern "C" int stair_plan_zero_grads(stair_plan *pl, void *workspace, stair_stream stream) {
+    STAIR_CHECK(pl && workspace, "null argument");
+    STAIR_CHECK(pl->train, "plan was not built with STAIR_PLAN_TRAIN");
+    float *ws = static_cast<float *>(workspace);
+    STAIR_HIP(hipMemsetAsync(ws + pl->o_zero_beg, 0, (pl->o_zero_end - pl->o_zero_beg) * sizeof(float), static_cast<hipStream_t>(stream)));
+    return 0;
 }

@@ -1,0 +1,131 @@
+"""Host side of the per-module intermediate-supervision losses (BASELINE.json configs[4]): which program
+nodes are supervised, with what gold value, in which contrastive window -- the bookkeeping of
+/root/reference/train_module.py:351-406 -- and the launches of the stair_loss_* kernels that inject the
+gradients into a training plan's gradient arenas.
+
+Gold values per question live in ``q['sg_res_by_step'] = {program_idx: gold}`` exactly as
+``AGQADataset.__getitem__`` produces them (/root/reference/video_nmn/dataset.py:200-221):
+    Localize                -> tuple of (start, end) frame intervals, one per keyword
+    Temporal / ExistsFrame  -> one (start, end)
+    Exists / Xor / Equals   -> bool
+    Filter / ToAction / Superlative -> list of (class_name, GloVe embedding [L,300])
+    FilterFrame             -> dict (excluded by default: args.py:62 modules_no_intermediate_train)
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import ops, spec
+from ._lib import check, lib
+
+CONTRASTIVE = ('Filter', 'Superlative', 'ToAction')
+CRITERION_MODULES = frozenset({'Exists', 'Xor', 'Equals', 'Filter', 'ToAction', 'FilterFrame', 'ExistsFrame',
+                               'Superlative', 'Localize', 'Temporal', 'decoder'})     # train_module.py:36-48
+
+
+def supervised_nodes(question, pretrain_modules):
+    """{program_idx: token position} as VideoNMN.forward records res_by_step (module_net.py:107-113): module
+    tokens with a program_idx, in pretrain_modules, never the root (i == 0); the scan runs from the last token
+    to the first, so for duplicated indices (Compare programs) the EARLIEST position wins."""
+    prog, idx = question['nmn_program_list'], question['nmn_program_idx']
+    out = {}
+    for i in range(len(prog) - 1, 0, -1):
+        if prog[i] in spec.ARITY and idx[i] is not None and prog[i] in pretrain_modules:
+            out[idx[i]] = i
+    return out
+
+
+def apply_module_losses(model, res, questions, scale, pretrain_modules=CRITERION_MODULES,
+                        no_intermediate=('FilterFrame',), window=32):
+    """Evaluate every intermediate loss of the batch and add scale * gradient into res's gradient arenas
+    (call res.zero_grad_arenas() first and res.backward(..., keep_arenas=True) afterwards).
+    Returns ({loss_kind: per-item losses tensor}, set of extra parameter names that received a gradient)."""
+    dev = res.logits.device
+    H, T = model.config['hidden_size'], res.info.T
+    att_items, head_items, cont_items = [], {'Exists': [], 'Xor': [], 'Equals': []}, []
+    windows = {}                      # window id -> {class_name: embedding}
+    for qi, q in enumerate(questions):
+        sg = q.get('sg_res_by_step') or {}
+        if not sg:
+            continue
+        prog = q['nmn_program_list']
+        for step, i in supervised_nodes(q, pretrain_modules).items():
+            module = prog[i]
+            if step not in sg or module in no_intermediate or module == 'decoder' or sg[step] is None:
+                continue
+            gold = sg[step]
+            kind, slot, aux, _, rel = res.node_info(qi, i)
+            if module == 'Localize':
+                att_items.append((slot, aux, [tuple(map(float, gold[r])) for r in range(aux)]))
+            elif module == 'Temporal':
+                att_items.append((rel, 1, [tuple(map(float, gold))]))
+            elif module == 'ExistsFrame':
+                att_items.append((slot, 1, [tuple(map(float, gold))]))
+            elif module in head_items:
+                head_items[module].append((slot, int(bool(gold))))
+            elif module in CONTRASTIVE:
+                w = windows.setdefault(qi // window if window else 0, {})
+                for class_name, emb in gold:
+                    w[class_name] = emb
+                    cont_items.append((slot, qi // window if window else 0, class_name))
+            else:
+                raise NotImplementedError('intermediate loss for %s (the reference excludes it by default, args.py:62)' % module)
+
+    losses, touched = {}, set()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    vec, gvec = res._arena(res.info.vec_off, res.info.n_vec, H), res.grad_arena('vec')
+    att, gatt = res._arena(res.info.att_off, res.info.n_att, T), res.grad_arena('att')
+    i32 = lambda a: torch.tensor(a, dtype=torch.int32, device=dev)
+
+    if att_items:
+        slot = i32([a[0] for a in att_items]); K = i32([a[1] for a in att_items])
+        off = i32(np.concatenate([[0], np.cumsum([a[1] for a in att_items])]).tolist())
+        iv = torch.tensor([p for a in att_items for p in a[2]], dtype=torch.float64, device=dev)
+        out = torch.empty(len(att_items), device=dev)
+        check(lib.stair_loss_attention(C.c_void_p(att.data_ptr()), C.c_void_p(gatt.data_ptr()), C.c_void_p(slot.data_ptr()),
+                                       C.c_void_p(K.data_ptr()), C.c_void_p(off.data_ptr()), C.c_void_p(iv.data_ptr()),
+                                       len(att_items), T, C.c_float(scale), C.c_void_p(out.data_ptr()), stream))
+        losses['attention'] = out
+    for module, items in head_items.items():
+        if not items:
+            continue
+        if not model.config['have_pretrain_head']:
+            raise RuntimeError('%s loss needs have_pretrain_head (modules.py)' % module)
+        head = model.submodules[module].pretrain_head
+        if head.weight.grad is None:
+            raise RuntimeError('pretrain head of %s has no .grad buffer (use stair_amd.train.Trainer)' % module)
+        slot = i32([a[0] for a in items]); lab = i32([a[1] for a in items])
+        out = torch.empty(len(items), device=dev)
+        check(lib.stair_loss_head(head.weight.shape[0], C.c_void_p(vec.data_ptr()), C.c_void_p(gvec.data_ptr()),
+                                  C.c_void_p(slot.data_ptr()), C.c_void_p(lab.data_ptr()), C.c_void_p(head.weight.data_ptr()),
+                                  C.c_void_p(head.bias.data_ptr()), C.c_void_p(head.weight.grad.data_ptr()),
+                                  C.c_void_p(head.bias.grad.data_ptr()), len(items), H, C.c_float(scale),
+                                  C.c_void_p(out.data_ptr()), stream))
+        losses[module] = out
+        touched.update({'submodules.%s.pretrain_head.weight' % module, 'submodules.%s.pretrain_head.bias' % module})
+    if cont_items:
+        # class representations of every window: text encoder without gradient + L2Normalize (module_net.py:78-89)
+        table, embs, win_range = {}, [], {}
+        for wid in sorted(windows):
+            start = len(embs)
+            for name, emb in windows[wid].items():
+                table[(wid, name)] = len(embs)
+                embs.append(torch.as_tensor(emb, dtype=torch.float32))
+            win_range[wid] = (start, len(embs) - start)
+        lens = [e.shape[0] for e in embs]
+        x = torch.cat(embs).to(dev).contiguous()
+        seq_off = i32(np.concatenate([[0], np.cumsum(lens)]).tolist())
+        _, h_n = ops.lstm_bidir(x, seq_off, max(lens), [w.detach() for w in model._lstm_weights('text_encoder')])
+        G = ops.l2normalize(h_n)
+        slot = i32([c[0] for c in cont_items]); pos = i32([table[(c[1], c[2])] for c in cont_items])
+        ws_ = i32([win_range[c[1]][0] for c in cont_items]); wc = i32([win_range[c[1]][1] for c in cont_items])
+        out = torch.empty(len(cont_items), device=dev)
+        check(lib.stair_loss_contrastive(C.c_void_p(vec.data_ptr()), C.c_void_p(gvec.data_ptr()), C.c_void_p(slot.data_ptr()),
+                                         C.c_void_p(pos.data_ptr()), C.c_void_p(ws_.data_ptr()), C.c_void_p(wc.data_ptr()),
+                                         C.c_void_p(G.data_ptr()), len(cont_items), H, max(r[1] for r in win_range.values()),
+                                         C.c_float(scale), C.c_void_p(out.data_ptr()), stream))
+        losses['contrastive'] = out
+    return losses, touched

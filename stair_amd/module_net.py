@@ -82,9 +82,23 @@ class BatchResult:
         self._prog_off, self._programs = prog_off, programs
         self._video, self._question = video, question
 
-    def backward(self, answers, loss_scale=1.0):
+    def zero_grad_arenas(self):
+        check(lib.stair_plan_zero_grads(self._plan, C.c_void_p(self._ws.data_ptr()),
+                                        C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    def grad_arena(self, kind):
+        """View of a gradient arena ('vec' [n_vec,H], 'map' [n_map,T,H], 'att' [n_att,T]) of a training plan."""
+        H, T, inf = self._model.config['hidden_size'], self.info.T, self.info
+        if kind == 'vec':
+            return self._ws[inf.gvec_off: inf.gvec_off + inf.n_vec * H].view(inf.n_vec, H)
+        if kind == 'map':
+            return self._ws[inf.gmap_off: inf.gmap_off + inf.n_map * T * H].view(inf.n_map, T, H)
+        return self._ws[inf.gatt_off: inf.gatt_off + inf.n_att * T].view(inf.n_att, T)
+
+    def backward(self, answers, loss_scale=1.0, keep_arenas=False):
         """Reverse pass of a train=True run: decoder cross entropy against `answers` (int32 [n] on the GPU),
         gradients of loss_scale * sum_i CE_i accumulated into the model's gradient buffers.
+        keep_arenas: the gradient arenas were zeroed by zero_grad_arenas() and hold injected loss gradients.
         Returns the unscaled per-question losses [n]."""
         ops._req(answers, 'answers', torch.int32)
         loss = torch.empty(self.info.n_questions, dtype=torch.float32, device=answers.device)
@@ -92,7 +106,8 @@ class BatchResult:
         check(lib.stair_plan_backward(self._model._ctx, self._plan, C.c_void_p(self._video.data_ptr()),
                                       C.c_void_p(self._question.data_ptr()), C.c_void_p(self._ws.data_ptr()),
                                       self._ws.numel() * 4, C.c_void_p(answers.data_ptr()), C.c_float(loss_scale),
-                                      C.c_void_p(loss.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+                                      C.c_void_p(loss.data_ptr()), 1 if keep_arenas else 0,
+                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         return loss
 
     def touched(self):
@@ -199,9 +214,10 @@ class VideoNMN(nn.Module):
         self._prog_cache = {}
 
     def __del__(self):
-        if getattr(self, '_ctx', None):
-            lib.stair_ctx_destroy(self._ctx)
-            self._ctx = None
+        ctx = self.__dict__.get('_ctx')
+        if ctx:
+            lib.stair_ctx_destroy(ctx)
+            self.__dict__['_ctx'] = None        # plain dict write: nn.Module.__setattr__ may be gone at shutdown
 
     # ---------------------------------------------------------------------------------------
     def _bind_weights(self):

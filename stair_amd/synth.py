@@ -165,3 +165,47 @@ def make_question(config, seed, qid, form=None, T=None, forms=PAPER_FORMS, with_
 
 def make_questions(config, seed, n, T=None, forms=PAPER_FORMS, start=0):
     return [make_question(config, seed, start + i, T=T, forms=forms) for i in range(n)]
+
+
+# --------------------------------------------------------------------------------------------
+# synthetic gold intermediates (the layout of dataset.py:200-221 after rescaling to T frames)
+# --------------------------------------------------------------------------------------------
+N_CLASSES = 214            # size of data/AGQA/filter_answers.json in the reference
+
+
+def class_embedding(config, seed, cid):
+    L = 1 + cid % 3
+    return normal(seed, 'class%d' % cid, (L, config['text_size']))
+
+
+def make_gold(config, seed, q, T=None, keep=0.85):
+    """sg_res_by_step for a question of make_question: one gold per supervised module node, dropped with
+    probability 1-keep (the scene-graph executor does not always produce one, agqa_lite.py:54-57)."""
+    T = T or config['max_video_length']
+    prog, idx = q['nmn_program_list'], q['nmn_program_idx']
+    name = q['qa_id']
+    u = uniform01(seed, name + '/gold', 8 * len(prog))
+    sg = {}
+    for i, tok in enumerate(prog):
+        if i == 0 or idx[i] is None or tok not in ARITY_FOR_GOLD:
+            continue
+        r = u[8 * i: 8 * i + 8]
+        if r[0] > keep:
+            continue
+
+        def interval(a, b):
+            lo, hi = sorted((a * T, b * T))
+            return (float(lo), float(hi))
+        if tok == 'Localize':
+            sg[idx[i]] = (interval(r[1], r[2]), interval(r[3], r[4]))       # two intervals; a K=1 node reads only the first
+        elif tok in ('Temporal', 'ExistsFrame'):
+            sg[idx[i]] = interval(r[1], r[2])
+        elif tok in ('Exists', 'Xor', 'Equals'):
+            sg[idx[i]] = bool(r[1] > 0.5)
+        else:
+            cids = sorted({int(r[1] * N_CLASSES), int(r[2] * N_CLASSES)} if r[3] > 0.5 else {int(r[1] * N_CLASSES)})
+            sg[idx[i]] = [('class_%d' % c, class_embedding(config, seed, c)) for c in cids]
+    return sg
+
+
+ARITY_FOR_GOLD = {'Localize', 'Temporal', 'ExistsFrame', 'Exists', 'Xor', 'Equals', 'Filter', 'ToAction', 'Superlative'}

@@ -35,6 +35,7 @@ def reduce_gradients(flat_g, touched, world):
 
 class Trainer:
     def __init__(self, model, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decoder_loss_weight=1.0,
+                 module_loss_weight=1.0, contrastive_window=32, no_intermediate=('FilterFrame',),
                  scheduler_start_factor=1.0, scheduler_end_factor=0.1, scheduler_total_iters=200000, world=1,
                  skip_untouched='ever'):
         """skip_untouched: 'ever'   -- a parameter is skipped by Adam until the first window that sends it a gradient
@@ -45,6 +46,7 @@ class Trainer:
         self.model, self.world = model, world
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.decoder_loss_weight = decoder_loss_weight
+        self.module_loss_weight, self.contrastive_window, self.no_intermediate = module_loss_weight, contrastive_window, no_intermediate
         self.sched = (scheduler_start_factor, scheduler_end_factor, scheduler_total_iters)
         self.iters = 0                                      # optimizer steps taken (LambdaLR counter)
         params = dict(model.named_parameters())
@@ -79,14 +81,27 @@ class Trainer:
         start, end, total = self.sched
         return end if self.iters > total else start + (end - start) / total * self.iters
 
-    def step(self, programs, spans, video, question, q_lens, answers, global_batch=None):
-        """One optimizer step over this rank's shard of a window.  Returns (mean CE of the local shard, BatchResult)."""
+    def step(self, programs, spans, video, question, q_lens, answers, global_batch=None, questions=None):
+        """One optimizer step over this rank's shard of a window.  `questions` (the dicts, with
+        'sg_res_by_step') switches the per-module intermediate losses on (train_module.py:351-373, 388-406).
+        Returns (per-question decoder CE of the local shard, BatchResult)."""
+        from . import losses as L
         n = len(programs)
         G = global_batch or n * self.world
         self.flat_g.zero_()                                   # optimizer.zero_grad()
         res = self.model.run_programs(programs, spans, video, question, q_lens, train=True)
-        loss = res.backward(answers, self.decoder_loss_weight / G)
-        t = torch.tensor(res.touched(), dtype=torch.int32).to(self.touched.device, non_blocking=True)
+        extra = set()
+        if questions is not None and self.module_loss_weight != 0:
+            res.zero_grad_arenas()
+            self.module_losses, extra = L.apply_module_losses(self.model, res, questions, self.module_loss_weight / G,
+                                                              no_intermediate=self.no_intermediate, window=self.contrastive_window)
+            loss = res.backward(answers, self.decoder_loss_weight / G, keep_arenas=True)
+        else:
+            loss = res.backward(answers, self.decoder_loss_weight / G)
+        tl = res.touched()
+        if extra:
+            tl = [t_ or (nme in extra) for t_, nme in zip(tl, self.model._weight_names)]
+        t = torch.tensor(tl, dtype=torch.int32).to(self.touched.device, non_blocking=True)
         reduce_gradients(self.flat_g, t, self.world)                    # ONE flat bucket over RCCL / xGMI
         if self.skip_untouched == 'ever':
             self.touched = torch.maximum(self.touched, t)

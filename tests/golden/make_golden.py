@@ -200,6 +200,46 @@ def main():
         np.savez_compressed(os.path.join(HERE, fname + '.npz'), **out)
         print(fname, len(out), 'arrays')
 
+    # ---- (v) CriterionByModule of the reference on committed inputs (train_module.py:33-194) ----
+    import importlib.machinery
+    import tempfile
+    tbx = types.ModuleType('tensorboardX'); tbx.SummaryWriter = object
+    tbx.__spec__ = importlib.machinery.ModuleSpec('tensorboardX', None); sys.modules['tensorboardX'] = tbx
+    import train_module
+    with tempfile.NamedTemporaryFile('w', suffix='.json', delete=False) as f:
+        json.dump({'cup': 'o1', 'dish': 'o2'}, f)
+    crit = train_module.CriterionByModule(types.SimpleNamespace(word2id_filename=f.name))
+    train_module.device = 'cpu'
+    g = torch.Generator().manual_seed(7)
+    out = {}
+    cases = []
+    Tc = 40
+    def rec(module, pred, gold, gold_store):
+        pred = pred.clone().requires_grad_(True)
+        loss = crit(module, pred, gold)
+        loss.backward()
+        i = len(cases)
+        out['c%d/pred' % i] = to_np(pred); out['c%d/loss' % i] = to_np(loss); out['c%d/dpred' % i] = to_np(pred.grad)
+        cases.append({'module': module, 'gold': gold_store})
+    for interval in ((3.2, 17.9), (0.0, 40.0), (12.4, 12.9), (39.5, 41.0), (-1.0, 0.4), (5.0, 5.0), (7.0, 9.0)):
+        rec('Temporal', torch.rand(Tc, generator=g) * 0.96 + 0.01, interval, list(interval))
+        rec('ExistsFrame', torch.rand(Tc, generator=g) * 0.96 + 0.01, interval, list(interval))
+    for ivs in (((3.2, 17.9),), ((0.5, 3.5), (20.1, 33.3))):
+        rec('Localize', torch.rand(len(ivs), Tc, generator=g) * 0.96 + 0.01, ivs, [list(i) for i in ivs])
+    for gold in (True, False):
+        rec('Exists', torch.randn(2, generator=g), gold, gold)
+        rec('Xor', torch.randn(2, generator=g), gold, gold)
+        rec('Equals', torch.randn(1, generator=g), gold, gold)
+    for C_ in (1, 5):
+        gold = torch.nn.functional.normalize(torch.randn(C_, 64, generator=g), dim=1)
+        out['gold%d' % C_] = to_np(gold)
+        for m in ('Filter', 'ToAction', 'Superlative'):
+            rec(m, torch.nn.functional.normalize(torch.randn(64, generator=g), dim=0), gold, 'gold%d' % C_)
+    rec('decoder', torch.randn(16, generator=g), torch.tensor(5), 5)
+    out['meta'] = np.frombuffer(json.dumps({'cases': cases, 'T': Tc}).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, 'criteria.npz'), **out)
+    print('criteria', len(cases), 'cases')
+
     # ---- (ii) full-size config: outputs only ----
     config = CONFIGS['full']
     model = build_model(VideoNMN, config)

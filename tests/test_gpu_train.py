@@ -168,3 +168,75 @@ def test_full_size_backward_sample():
         rel_l2 = float((g - ref).norm() / ref.norm().clamp_min(1e-12))
         assert rel_l2 < (3e-3 if ref.numel() >= 64 else 2e-2), (n, rel_l2)     # scalars cannot average a flip out
         assert float((g - ref).abs().max()) < 0.05 * float(ref.abs().max()) + 3e-6, n
+
+
+def _with_gold(config, seed, qs, T):
+    out = []
+    for q in qs:
+        q = dict(q)
+        q['sg_res_by_step'] = synth.make_gold(config, seed, q, T=T)
+        out.append(q)
+    return out
+
+
+def _oracle_view(q):
+    """class-name golds as torch tensors, as the reference's dataset hands them over"""
+    q = dict(q)
+    q['sg_res_by_step'] = {k: ([(n, torch.from_numpy(e)) for n, e in v] if isinstance(v, list) else v)
+                           for k, v in q['sg_res_by_step'].items()}
+    return q
+
+
+@pytest.mark.parametrize('name,window', [('tiny_conv', 32), ('tiny_conv', 5), ('tiny_linear', 32)])
+def test_intermediate_supervision_losses_and_gradients(name, window):
+    """configs[4]: decoder CE + every per-module loss (attention BCE, Exists/Xor CE, Equals MSE, windowed contrastive
+    CE through L2Normalize) -- loss values and all parameter gradients vs autograd of the oracle's restatement of
+    train_module.py:341-406 (whose criteria are pinned to the reference's CriterionByModule)."""
+    from oracle import nmn_losses as OL
+    from stair_amd import losses as L
+    z, meta = load_golden(name)
+    config, T = meta['config'], meta['T']
+    qs = _with_gold(config, 3, [question_for(meta, q) for q in meta['questions']] +
+                    [synth.make_question(config, 8, 50 + i, form=f, T=T) for i, f in enumerate(synth.ALL_FORMS)], T)
+    n_gold = sum(len(q['sg_res_by_step']) for q in qs)
+    assert n_gold > 40
+    Gw = len(qs)
+    names, w = _oracle_params(config, meta['seed'])
+    # the oracle handles ONE contrastive window per call: split the batch the way the trainer windows it
+    total, det_all = 0.0, {'module': [], 'decoder': [], 'contrastive': []}
+    for s in range(0, len(qs), window):
+        t, det = OL.window_loss(w, config, [_oracle_view(q) for q in qs[s:s + window]], L.CRITERION_MODULES,
+                                gradient_accumulation=Gw, explicit_lstm=True)
+        total = total + t
+        for k in det_all:
+            det_all[k] += det[k]
+    total.backward()
+
+    model = _model(config, meta['seed'])
+    model.pretrain_modules = set(L.CRITERION_MODULES)
+    for p in model.parameters():
+        p.grad = torch.zeros_like(p)
+    progs, spans, video, question, q_lens, answers = _pack(model, qs)
+    res = model.run_programs(progs, spans, video, question, q_lens, train=True)
+    res.zero_grad_arenas()
+    losses, extra = L.apply_module_losses(model, res, qs, 1.0 / Gw, window=window)
+    dec = res.backward(answers, 1.0 / Gw, keep_arenas=True)
+    assert np.allclose(dec.cpu().numpy(), det_all['decoder'], rtol=1e-5, atol=2e-5)
+    ref_mod = sorted(x[3] for x in det_all['module'])
+    got_mod = sorted(torch.cat([v for k, v in losses.items() if k != 'contrastive']).cpu().tolist())
+    assert len(ref_mod) == len(got_mod) and np.allclose(got_mod, ref_mod, rtol=2e-5, atol=2e-6)
+    ref_c = sorted(x[3] for x in det_all['contrastive'])
+    got_c = sorted(losses['contrastive'].cpu().tolist())
+    assert len(ref_c) == len(got_c) > 5 and np.allclose(got_c, ref_c, rtol=2e-5, atol=2e-6)
+    got = dict(model.named_parameters())
+    worst = (0.0, '')
+    for n in names:
+        ref = w[n].grad
+        if ref is None:
+            continue
+        tol = 2e-4 * max(float(ref.abs().max()), 1e-3)
+        err = float((got[n].grad.cpu() - ref).abs().max())
+        worst = max(worst, (err / tol, n))
+        assert err < tol, (n, err, float(ref.abs().max()))
+    assert w['submodules.Exists.pretrain_head.weight'].grad is not None and 'submodules.Exists.pretrain_head.weight' in extra
+    print('worst gradient error / tolerance with intermediate supervision:', worst)
