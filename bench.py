@@ -127,7 +127,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=1024, help='questions per GPU per step')
+    ap.add_argument('--batch', type=int, default=2048, help='questions per GPU per step (window size per rank)')
     ap.add_argument('--frames', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--mode', choices=['train', 'infer'], default='train')
