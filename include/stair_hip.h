@@ -90,6 +90,18 @@ int stair_ctx_set_weight(stair_ctx *ctx, int id, const float *dev_ptr, int64_t n
  * into it, the caller zeroes it (optimizer.zero_grad(), train_module.py:411). */
 int stair_ctx_set_grad(stair_ctx *ctx, int id, float *dev_ptr, int64_t numel);
 
+/* Arithmetic of the large contractions (process-wide; default from the environment variable STAIR_MATMUL =
+ * "f32" | "bf16x3", else bf16x3):
+ *   STAIR_MATMUL_F32     v_mfma_f32_32x32x2_f32, exact fp32 products, 157 TFLOP/s peak
+ *   STAIR_MATMUL_BF16X3  each fp32 operand split into bf16 hi + lo on the fly, hi*hi + hi*lo + lo*hi on
+ *                        v_mfma_f32_32x32x16_bf16 with fp32 accumulation: ~4e-6 relative error per dot product,
+ *                        3/16 of the fp32 MFMA's matrix-pipe time.  Inputs and outputs are fp32 in both modes. */
+#define STAIR_MATMUL_F32 0
+#define STAIR_MATMUL_BF16X3 1
+int stair_set_matmul_mode(int32_t mode);
+int stair_get_matmul_mode(void);
+int stair_set_split_min_rows(int32_t rows); /* GEMMs with fewer rows use the exact kernel (default 1 = none) */
+
 /* ---- building blocks (exported for unit tests and reuse; the plan runner calls the same code) */
 
 /* C[g][r][n] = act( sum_k rs[g][r] * A[g][r][k] * W[n][k] + bias[n] ),  g < groups, r < rows_per_group.

@@ -80,6 +80,9 @@ SIGNATURES = [
     ('stair_weight_numel', C.c_int64, [C.c_void_p, C.c_int]),
     ('stair_ctx_set_weight', C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
     ('stair_ctx_set_grad', C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
+    ('stair_set_matmul_mode', C.c_int, [C.c_int32]),
+    ('stair_get_matmul_mode', C.c_int, []),
+    ('stair_set_split_min_rows', C.c_int, [C.c_int32]),
     ('stair_gemm_f32', C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     ('stair_gemm_tn_f32', C.c_int, [C.POINTER(GemmTnArgs), C.c_void_p]),
     ('stair_lstm_bidir_fwd', C.c_int, [C.POINTER(LstmArgs), C.c_void_p]),

@@ -52,6 +52,9 @@ static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * 
 int launch_gemm(const stair_gemm_args &a, hipStream_t s);
 int launch_lstm(const stair_lstm_args &a, hipStream_t s);
 int launch_lstm_bwd(const stair_lstm_bwd_args &a, hipStream_t s);
+int launch_gemm_bf16x3(const stair_gemm_args &a, hipStream_t s);
+int launch_gemm_tn_bf16x3(const stair_gemm_tn_args &a, hipStream_t s);
+int matmul_mode();
 int launch_gemm_tn(const stair_gemm_tn_args &a, hipStream_t s);
 int launch_colsum(const float *A, int64_t lda, float *out, int M, int N, hipStream_t s);
 int launch_transpose(const float *in, float *out, int rows, int cols, hipStream_t s);

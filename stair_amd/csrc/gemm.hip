@@ -14,6 +14,8 @@
 // buffered with global->register prefetch one chunk ahead (one barrier per chunk).  Blocks are
 // renumbered so that the column tiles sharing one A row-panel run on the same XCD (private L2).
 #include <algorithm>
+#include <cstdlib>
+#include <string>
 
 #include "common.h"
 
@@ -185,6 +187,23 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     }
 }
 
+// ---- contraction arithmetic: exact fp32 MFMA or split bf16x3 (csrc/gemm_bf16x3.hip) --------------------
+static int g_matmul_mode = -1;
+int matmul_mode() {
+    if (g_matmul_mode < 0) {
+        const char *e = getenv("STAIR_MATMUL");
+        g_matmul_mode = (e && std::string(e) == "f32") ? STAIR_MATMUL_F32 : STAIR_MATMUL_BF16X3;
+    }
+    return g_matmul_mode;
+}
+void set_matmul_mode(int m) { g_matmul_mode = m; }
+// Row threshold of the split kernels.  Default 1 = every GEMM: a question's result must not depend on how many
+// other questions share its launch (tests/test_gpu_parity.py::test_batch_composition...), and the split kernel's
+// chunk (24 bf16 MFMAs + conversions) is also shorter than the fp32 kernel's (64 fp32 MFMAs) for small, latency
+// bound launches.
+static int kSplitMinRows = 1;
+void set_split_min_rows(int r) { kSplitMinRows = r; }
+
 int launch_gemm(const stair_gemm_args &a, hipStream_t s) {
     STAIR_CHECK(a.groups >= 0 && a.rows_per_group > 0 && a.N > 0 && a.K > 0, "bad shape");
     STAIR_CHECK(a.K % 4 == 0 && a.lda % 4 == 0 && a.ldw % 4 == 0 && a.a_gstride % 4 == 0,
@@ -198,6 +217,7 @@ int launch_gemm(const stair_gemm_args &a, hipStream_t s) {
     const int64_t M = (int64_t)a.groups * a.rows_per_group;
     if (M == 0) return 0;
     STAIR_CHECK(M < (1ll << 31), "M too large");
+    if (matmul_mode() == STAIR_MATMUL_BF16X3 && M >= kSplitMinRows) return launch_gemm_bf16x3(a, s);
     p.M = (int)M;
     p.tilesM = (p.M + BM - 1) / BM;
     p.tilesN = (a.N + BN - 1) / BN;
@@ -299,6 +319,7 @@ int launch_gemm_tn(const stair_gemm_tn_args &a, hipStream_t s) {
     STAIR_CHECK(a.N % 4 == 0 && a.K % 4 == 0 && a.lda % 4 == 0 && a.ldb % 4 == 0 && a.b_gstride % 4 == 0,
                 "N, K, lda, ldb, b_gstride must be multiples of 4 floats");
     if (a.M == 0) return 0;
+    if (matmul_mode() == STAIR_MATMUL_BF16X3 && a.M >= kSplitMinRows) return launch_gemm_tn_bf16x3(a, s);
     GemmTnParams p;
     p.A = a.A; p.lda = a.lda; p.B = a.B; p.ldb = a.ldb; p.b_gstride = a.b_gstride; p.b_gidx = a.b_gidx;
     p.R = a.rows_per_group; p.row_scale = a.row_scale; p.rs_gstride = a.rs_gstride; p.rs_gidx = a.rs_gidx;
@@ -366,4 +387,22 @@ extern "C" int stair_gemm_tn_f32(const stair_gemm_tn_args *args, stair_stream st
         return 1;
     }
     return stair::launch_gemm_tn(*args, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int stair_set_matmul_mode(int32_t mode) {
+    if (mode != STAIR_MATMUL_F32 && mode != STAIR_MATMUL_BF16X3) {
+        stair::set_error("stair_set_matmul_mode: mode must be STAIR_MATMUL_F32 or STAIR_MATMUL_BF16X3");
+        return 1;
+    }
+    stair::set_matmul_mode(mode);
+    return 0;
+}
+extern "C" int stair_get_matmul_mode(void) { return stair::matmul_mode(); }
+extern "C" int stair_set_split_min_rows(int32_t rows) {
+    if (rows < 1) {
+        stair::set_error("stair_set_split_min_rows: rows must be >= 1");
+        return 1;
+    }
+    stair::set_split_min_rows(rows);
+    return 0;
 }

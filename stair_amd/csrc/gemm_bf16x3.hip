@@ -1,0 +1,336 @@
+// Split-precision ("bf16 x 3") MFMA GEMMs with fp32 inputs and outputs.
+//
+// gfx950's fp32-input MFMA runs at the vector rate (157 TFLOP/s, 1/16 of the bf16 MFMA rate), and once
+// questions are batched the NMN path is bound by exactly those contractions.  Here
+// every fp32 operand x is split on the fly into two bf16 numbers, x = hi + lo + O(2^-17 |x|) with
+// hi = bf16(x), lo = bf16(x - hi), and each product is evaluated as hi*hi + hi*lo + lo*hi with three
+// v_mfma_f32_32x32x16_bf16 accumulating in fp32 (the dropped lo*lo term is O(2^-16) relative).  Relative
+// error of a dot product is ~4e-6 (random signs), against ~1e-7 for the exact fp32 kernel -- two orders of
+// magnitude inside the 1e-4 logit budget of BASELINE.json -- at 3/16 of the fp32 MFMA's matrix-pipe time.
+//
+// Structure mirrors csrc/gemm.hip (128x128x32 tile, 4 waves 2x2, LDS double buffer, register prefetch pinned
+// above the MFMA phase, group gather / row scale / bias / activation / accumulate epilogue, XCD renumbering),
+// with bf16 LDS images [kq][row ^ 2kq][8 bf16] (conflict-free ds_write_b128 staging and ds_read_b128
+// fragments).  The TN variant (dW = dZ^T X) transposes 8x4 blocks in registers while staging, so its MFMA
+// phase is the same code.
+#include <algorithm>
+
+#include "common.h"
+
+namespace stair {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using v4f = __attribute__((ext_vector_type(4))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using gv4p = const __attribute__((address_space(1))) v4f *;
+
+namespace {
+
+constexpr int XBK = 32;                 // k (or m, for TN) per chunk
+constexpr int XKQ = XBK / 8;            // 8-element groups per chunk
+constexpr int IMG = XKQ * 128 * 8;      // bf16 elements of one image (8 KB)
+// LDS: [buf 2][operand 2][hi/lo 2][IMG] bf16 = 64 KB
+
+__device__ __forceinline__ int img_off(int buf, int operand, int part, int kq, int row) {
+    return (((buf * 2 + operand) * 2 + part) * IMG) + (kq * 128 + (row ^ (2 * kq))) * 8;
+}
+
+__device__ __forceinline__ void split8(const v4f &x0, const v4f &x1, float scale, bf16x8 &hi, bf16x8 &lo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a = x0[j] * scale, b = x1[j] * scale;
+        hi[j] = (__bf16)a;
+        hi[4 + j] = (__bf16)b;
+        lo[j] = (__bf16)(a - (float)hi[j]);
+        lo[4 + j] = (__bf16)(b - (float)hi[4 + j]);
+    }
+}
+
+// one chunk of MFMAs from LDS buffer `buf`: 2 k-steps x (2x2 tiles) x 3 products
+__device__ __forceinline__ void mfma_chunk(const __bf16 *lds, int buf, int wm, int wn, int r, int h, f32x16 &acc00,
+                                           f32x16 &acc01, f32x16 &acc10, f32x16 &acc11) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int kq = 2 * s + h;
+        const bf16x8 ah0 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 0, 0, kq, wm * 64 + r));
+        const bf16x8 ah1 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 0, 0, kq, wm * 64 + 32 + r));
+        const bf16x8 al0 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 0, 1, kq, wm * 64 + r));
+        const bf16x8 al1 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 0, 1, kq, wm * 64 + 32 + r));
+        const bf16x8 bh0 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 1, 0, kq, wn * 64 + r));
+        const bf16x8 bh1 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 1, 0, kq, wn * 64 + 32 + r));
+        const bf16x8 bl0 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 1, 1, kq, wn * 64 + r));
+        const bf16x8 bl1 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 1, 1, kq, wn * 64 + 32 + r));
+        acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh0, acc00, 0, 0, 0);      // small terms first
+        acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh1, acc01, 0, 0, 0);
+        acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh0, acc10, 0, 0, 0);
+        acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh1, acc11, 0, 0, 0);
+        acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl0, acc00, 0, 0, 0);
+        acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl1, acc01, 0, 0, 0);
+        acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl0, acc10, 0, 0, 0);
+        acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl1, acc11, 0, 0, 0);
+        acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh0, acc00, 0, 0, 0);
+        acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh1, acc01, 0, 0, 0);
+        acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh0, acc10, 0, 0, 0);
+        acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh1, acc11, 0, 0, 0);
+    }
+}
+
+struct XParams {
+    stair_gemm_args a;
+    int M, tilesM, tilesN;
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// NT: C[m][n] = act(sum_k rs[m] A[m][k] W[n][k] + b[n])
+// ---------------------------------------------------------------------------------------------
+template <int ACT>
+__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(XParams p) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 xlds[];
+    const stair_gemm_args &a = p.a;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+
+    const int nb = p.tilesM * p.tilesN;
+    const int bid = blockIdx.x;
+    const int qd = nb >> 3, rm = nb & 7, xcd = bid & 7, loc = bid >> 3;
+    const int logical = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
+    const int tm = logical / p.tilesN, tn = logical - tm * p.tilesN;
+    const int m0 = tm * 128, n0 = tn * 128;
+    const int R = a.rows_per_group, K = a.K;
+
+    // staging units: (row, kq) with row = u >> 2, kq = u & 3, u = tid + 256 i  ->  rows tid/4 and 64 + tid/4
+    const int kq = tid & 3, ra_ = tid >> 2;
+    const float *aptr[2];
+    const float *wptr[2];
+    float rs[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = min(m0 + ra_ + 64 * i, p.M - 1);
+        const int g = m / R, rr = m - g * R;
+        const int64_t gi = a.a_gidx ? a.a_gidx[g] : g;
+        aptr[i] = a.A + gi * a.a_gstride + (int64_t)rr * a.lda;
+        rs[i] = 1.0f;
+        if (a.row_scale) rs[i] = a.row_scale[(a.rs_gidx ? a.rs_gidx[g] : g) * a.rs_gstride + rr];
+        const int n = min(n0 + ra_ + 64 * i, a.N - 1);
+        wptr[i] = a.W + (int64_t)n * a.ldw;
+    }
+
+    f32x16 acc00, acc01, acc10, acc11;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc00[e] = acc01[e] = acc10[e] = acc11[e] = 0.0f;
+
+    v4f va[2][2], vb[2][2];
+    float km0, km1;
+#define X_GLOAD(k0)                                                            \
+    {                                                                          \
+        const int kraw = (k0) + 8 * kq;                                        \
+        const int ka = min(kraw, K - 4), kb = min(kraw + 4, K - 4);            \
+        km0 = kraw < K ? 1.0f : 0.0f;                                          \
+        km1 = kraw + 4 < K ? 1.0f : 0.0f;                                      \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                     \
+            va[i_][0] = *(gv4p)(aptr[i_] + ka); va[i_][1] = *(gv4p)(aptr[i_] + kb);   \
+            vb[i_][0] = *(gv4p)(wptr[i_] + ka); vb[i_][1] = *(gv4p)(wptr[i_] + kb);   \
+        }                                                                      \
+    }
+#define X_LSTORE(buf)                                                                                   \
+    {                                                                                                   \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                              \
+            bf16x8 hi_, lo_;                                                                            \
+            split8(va[i_][0] * km0, va[i_][1] * km1, rs[i_], hi_, lo_);                                 \
+            *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, 0, 0, kq, ra_ + 64 * i_)) = hi_;            \
+            *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, 0, 1, kq, ra_ + 64 * i_)) = lo_;            \
+            split8(vb[i_][0], vb[i_][1], 1.0f, hi_, lo_);                                               \
+            *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, 1, 0, kq, ra_ + 64 * i_)) = hi_;            \
+            *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, 1, 1, kq, ra_ + 64 * i_)) = lo_;            \
+        }                                                                                               \
+    }
+
+    const int nchunks = (K + XBK - 1) / XBK;
+    X_GLOAD(0);
+    X_LSTORE(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        X_GLOAD(min(c + 1, nchunks - 1) * XBK);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_chunk(xlds, buf, wm, wn, r, h, acc00, acc01, acc10, acc11);
+        __builtin_amdgcn_sched_barrier(0);
+        X_LSTORE(buf ^ 1);
+        __syncthreads();
+    }
+#undef X_GLOAD
+#undef X_LSTORE
+
+    long long *rowoff = reinterpret_cast<long long *>(xlds);
+    if (tid < 128) {
+        const int m = m0 + tid;
+        long long off = -1;
+        if (m < p.M) {
+            const int g = m / R, rr = m - g * R;
+            const int64_t gi = a.c_gidx ? a.c_gidx[g] : g;
+            off = gi * a.c_gstride + (int64_t)rr * a.ldc;
+        }
+        rowoff[tid] = off;
+    }
+    __syncthreads();
+    __attribute__((address_space(1))) float *Cg = (__attribute__((address_space(1))) float *)a.C;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int n = n0 + wn * 64 + nt * 32 + r;
+        if (n >= a.N) continue;
+        const float b = a.bias ? a.bias[n] : 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const f32x16 &acc = mt == 0 ? (nt == 0 ? acc00 : acc01) : (nt == 0 ? acc10 : acc11);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rowl = wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const long long off = rowoff[rowl];
+                if (off < 0) continue;
+                float v = acc[e] + b;
+                if (ACT == 1) v = fmaxf(v, 0.0f);
+                if (ACT == 2) v = sigmoid_acc(v);
+                if (a.accumulate) unsafeAtomicAdd(a.C + off + n, v);
+                else Cg[off + n] = v;
+            }
+        }
+    }
+}
+
+int launch_gemm_bf16x3(const stair_gemm_args &a, hipStream_t s) {
+    XParams p;
+    p.a = a;
+    const int64_t M = (int64_t)a.groups * a.rows_per_group;
+    if (M == 0) return 0;
+    p.M = (int)M;
+    p.tilesM = (p.M + 127) / 128;
+    p.tilesN = (a.N + 127) / 128;
+    const dim3 grid(p.tilesM * p.tilesN), block(256);
+    const size_t shmem = 2 * 2 * 2 * IMG * sizeof(__bf16);
+    switch (a.act) {
+        case 0: hipLaunchKernelGGL(gemm_bf16x3_kernel<0>, grid, block, shmem, s, p); break;
+        case 1: hipLaunchKernelGGL(gemm_bf16x3_kernel<1>, grid, block, shmem, s, p); break;
+        default: hipLaunchKernelGGL(gemm_bf16x3_kernel<2>, grid, block, shmem, s, p); break;
+    }
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// TN: C[n][k] += sum_m A[m][n] * (rs[m] B[m][k])      (weight gradients)
+// waves 0,1 stage A, waves 2,3 stage B: a thread owns one 8(m) x 4(column) block, loads it as 8 float4
+// (each wave-load covers 512 contiguous bytes of one row), splits it and writes the four columns as
+// [mq][column][8 m] bf16 vectors -- the same LDS image the NT kernel reads.
+// ---------------------------------------------------------------------------------------------
+struct XTnParams {
+    const float *A; int64_t lda;
+    const float *B; int64_t ldb, b_gstride; const int32_t *b_gidx; int R;
+    const float *row_scale; int64_t rs_gstride; const int32_t *rs_gidx;
+    float *C; int64_t ldc;
+    int M, N, K, mslab;
+};
+
+__global__ __launch_bounds__(256) void gemm_tn_bf16x3_kernel(XTnParams p) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 xlds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
+    const int mbeg = blockIdx.z * p.mslab, mend = min(p.M, mbeg + p.mslab);
+
+    f32x16 acc00, acc01, acc10, acc11;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc00[e] = acc01[e] = acc10[e] = acc11[e] = 0.0f;
+
+    const bool isB = wave >= 2;                    // wave-uniform role
+    const int u = tid & 127;
+    const int cq = u & 31, mq = u >> 5;            // column quad (4 columns), m group (8 rows)
+    const int col0 = isB ? k0 : n0, ncols = isB ? p.K : p.N;
+    const int cc = min(col0 + 4 * cq, ncols - 4);
+    const float cmask = col0 + 4 * cq < ncols ? 1.0f : 0.0f;
+
+    v4f v[8];
+    float sc[8];
+    auto gload = [&](int m0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int mraw = m0 + 8 * mq + j;
+            const int m = min(mraw, p.M - 1);
+            sc[j] = mraw < mend ? cmask : 0.0f;
+            if (!isB) {
+                v[j] = *(gv4p)(p.A + (int64_t)m * p.lda + cc);
+            } else {
+                const int g = m / p.R, rr = m - g * p.R;
+                const int64_t gi = p.b_gidx ? p.b_gidx[g] : g;
+                if (p.row_scale) sc[j] *= p.row_scale[(p.rs_gidx ? p.rs_gidx[g] : g) * p.rs_gstride + rr];
+                v[j] = *(gv4p)(p.B + gi * p.b_gstride + (int64_t)rr * p.ldb + cc);
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+        const int operand = isB ? 1 : 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            bf16x8 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = v[j][c] * sc[j];
+                hi[j] = (__bf16)x;
+                lo[j] = (__bf16)(x - (float)hi[j]);
+            }
+            *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, operand, 0, mq, 4 * cq + c)) = hi;
+            *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, operand, 1, mq, 4 * cq + c)) = lo;
+        }
+    };
+
+    const int nchunks = (mend - mbeg + XBK - 1) / XBK;
+    if (nchunks > 0) {
+        gload(mbeg);
+        lstore(0);
+        __syncthreads();
+        for (int c = 0; c < nchunks; ++c) {
+            const int buf = c & 1;
+            gload(mbeg + min(c + 1, nchunks - 1) * XBK);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_chunk(xlds, buf, wm, wn, r, h, acc00, acc01, acc10, acc11);
+            __builtin_amdgcn_sched_barrier(0);
+            lstore(buf ^ 1);
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int k = k0 + wn * 64 + nt * 32 + r;
+        if (k >= p.K) continue;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const f32x16 &acc = mt == 0 ? (nt == 0 ? acc00 : acc01) : (nt == 0 ? acc10 : acc11);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = n0 + wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (n < p.N) unsafeAtomicAdd(p.C + (int64_t)n * p.ldc + k, acc[e]);
+            }
+        }
+    }
+}
+
+int launch_gemm_tn_bf16x3(const stair_gemm_tn_args &a, hipStream_t s) {
+    if (a.M == 0) return 0;
+    XTnParams p;
+    p.A = a.A; p.lda = a.lda; p.B = a.B; p.ldb = a.ldb; p.b_gstride = a.b_gstride; p.b_gidx = a.b_gidx;
+    p.R = a.rows_per_group; p.row_scale = a.row_scale; p.rs_gstride = a.rs_gstride; p.rs_gidx = a.rs_gidx;
+    p.C = a.C; p.ldc = a.ldc; p.M = a.M; p.N = a.N; p.K = a.K;
+    const int tiles = ((a.N + 127) / 128) * ((a.K + 127) / 128);
+    int slabs = std::max(1, std::min((a.M + 255) / 256, (1024 + tiles - 1) / tiles));
+    p.mslab = ((a.M + slabs - 1) / slabs + 31) / 32 * 32;
+    slabs = (a.M + p.mslab - 1) / p.mslab;
+    const size_t shmem = 2 * 2 * 2 * IMG * sizeof(__bf16);
+    hipLaunchKernelGGL(gemm_tn_bf16x3_kernel, dim3((a.N + 127) / 128, (a.K + 127) / 128, slabs), dim3(256), shmem, s, p);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace stair

@@ -13,6 +13,17 @@ import torch
 from ._lib import GemmArgs, GemmTnArgs, LstmArgs, LstmBwdArgs, check, lib
 
 ACT = {None: 0, 'none': 0, 'relu': 1, 'sigmoid': 2}
+MATMUL_MODES = {'f32': 0, 'bf16x3': 1}
+
+
+def set_matmul_mode(mode, split_min_rows=1):
+    """'f32' (exact fp32 MFMA) or 'bf16x3' (split-precision bf16 MFMA, the default)."""
+    check(lib.stair_set_matmul_mode(MATMUL_MODES[mode]))
+    check(lib.stair_set_split_min_rows(split_min_rows))
+
+
+def get_matmul_mode():
+    return {v: k for k, v in MATMUL_MODES.items()}[lib.stair_get_matmul_mode()]
 
 
 def _stream():

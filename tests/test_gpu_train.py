@@ -13,6 +13,15 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
+@pytest.fixture(params=['f32', 'bf16x3'])
+def matmul(request):
+    """exact fp32 MFMA vs the default split-precision kernels in every GEMM of forward and backward"""
+    from stair_amd import ops
+    ops.set_matmul_mode(request.param)
+    yield request.param
+    ops.set_matmul_mode('bf16x3')
+
+
 def _model(config, seed=0):
     from stair_amd.module_net import VideoNMN
     m = VideoNMN(config)
@@ -45,7 +54,7 @@ def _pack(model, qs):
 
 
 @pytest.mark.parametrize('name', ['tiny_conv', 'tiny_linear', 'tiny_conv_t24'])
-def test_backward_matches_autograd_of_oracle(name):
+def test_backward_matches_autograd_of_oracle(name, matmul):
     """All 12 program forms in one batch: every parameter gradient of the decoder CE loss."""
     z, meta = load_golden(name)
     config = meta['config']
@@ -83,7 +92,7 @@ def test_backward_matches_autograd_of_oracle(name):
     print('worst gradient error / tolerance:', worst)
 
 
-def test_trainer_steps_match_torch_adam():
+def test_trainer_steps_match_torch_adam(matmul):
     """Three optimizer steps (different program mixes per window, so some modules are untouched at first)
     against torch.optim.Adam + LambdaLR on the oracle's weights, zero_grad(set_to_none=False) = torch 1.13."""
     from stair_amd.train import Trainer
@@ -109,9 +118,16 @@ def test_trainer_steps_match_torch_adam():
     got = dict(model.named_parameters())
     for n in names:
         ref = w[n].detach()
-        err = float((got[n].detach().cpu() - ref).abs().max())
-        # Adam's first steps move every touched weight by ~lr regardless of gradient scale; compare updates
-        assert err < 2e-5, (n, err)
+        diff = (got[n].detach().cpu() - ref).abs()
+        # Adam's first steps move every touched weight by ~lr = 2e-4 whatever the gradient's scale (m / sqrt(v) ~ +-1),
+        # so entries whose gradient is ~1e5 times smaller than the tensor's typical entry see the split kernels'
+        # ~1e-5 relative noise as an O(1) change of m / sqrt(v).  Exact mode: every entry within 2e-5.  Split mode:
+        # 99.5 % of the entries within 2e-5 and none further than one step (3 steps x lr = 6e-4 is the hard bound).
+        if matmul == 'f32':
+            assert float(diff.max()) < 2e-5, (n, float(diff.max()))
+        else:
+            assert float((diff < 2e-5).float().mean()) > 0.995, (n, float((diff < 2e-5).float().mean()))
+            assert float(diff.max()) < 2.5e-4, (n, float(diff.max()))
     # an untouched-so-far tensor must be bit-identical to its initial value
     init = synth.make_weights(config, 0)
     # (Filter 'relations' weights are only used by form C2, which is in none of the windows)
@@ -121,7 +137,7 @@ def test_trainer_steps_match_torch_adam():
 
 
 @pytest.mark.parametrize('fixture', ['tiny_conv_grads', 'tiny_linear_grads'])
-def test_backward_matches_reference_backward(fixture):
+def test_backward_matches_reference_backward(fixture, matmul):
     """HIP backward vs the REFERENCE's own loss.backward() (fixtures generated by tests/golden/make_golden.py)."""
     from helpers import compare_with_reference_grads
     z, meta = load_golden(fixture)
@@ -140,7 +156,7 @@ def test_backward_matches_reference_backward(fixture):
     print('worst gradient error / tolerance vs reference:', worst)
 
 
-def test_full_size_backward_sample():
+def test_full_size_backward_sample(matmul):
     """Full-size shapes (H=512, V=2048, T=64): 6 questions against autograd of the oracle."""
     config = dict(spec.DEFAULT_CONFIG)
     qs = [synth.make_question(config, 21, i, form=f) for i, f in enumerate(['P0', 'P2', 'P3', 'P5', 'C0', 'C1'])]
@@ -166,7 +182,8 @@ def test_full_size_backward_sample():
             continue
         g = got[n].grad.cpu()
         rel_l2 = float((g - ref).norm() / ref.norm().clamp_min(1e-12))
-        assert rel_l2 < (3e-3 if ref.numel() >= 64 else 2e-2), (n, rel_l2)     # scalars cannot average a flip out
+        lim = 3e-3 if matmul == 'f32' else 1e-2      # split kernels: ~100x more inputs fall inside the rounding band of a kink
+        assert rel_l2 < (lim if ref.numel() >= 64 else 2e-2), (n, rel_l2)     # scalars cannot average a flip out
         assert float((g - ref).abs().max()) < 0.05 * float(ref.abs().max()) + 3e-6, n
 
 
@@ -188,7 +205,7 @@ def _oracle_view(q):
 
 
 @pytest.mark.parametrize('name,window', [('tiny_conv', 32), ('tiny_conv', 5), ('tiny_linear', 32)])
-def test_intermediate_supervision_losses_and_gradients(name, window):
+def test_intermediate_supervision_losses_and_gradients(name, window, matmul):
     """configs[4]: decoder CE + every per-module loss (attention BCE, Exists/Xor CE, Equals MSE, windowed contrastive
     CE through L2Normalize) -- loss values and all parameter gradients vs autograd of the oracle's restatement of
     train_module.py:341-406 (whose criteria are pinned to the reference's CriterionByModule)."""
