@@ -244,7 +244,7 @@ struct GemmTnParams {
     const float *B; int64_t ldb, b_gstride; const int32_t *b_gidx; int R;   // [M, K] in groups of R rows
     const float *row_scale; int64_t rs_gstride; const int32_t *rs_gidx;     // optional scale on B rows
     float *C; int64_t ldc;                          // [N, K]
-    int M, N, K, mslab;
+    int M, N, K, mslab, tilesN, tilesK;
 };
 
 constexpr int TN_LD = 128 + 4;
@@ -255,8 +255,12 @@ __global__ __launch_bounds__(256) void gemm_tn_f32_kernel(GemmTnParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
-    const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
-    const int mbeg = blockIdx.z * p.mslab, mend = min(p.M, mbeg + p.mslab);
+    // one M-slab per XCD (see gemm_tn_bf16x3_kernel): blocks with equal blockIdx % 8 walk the same rows
+    const int tiles = p.tilesN * p.tilesK;
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int tile = jb % tiles, slab = (jb / tiles) * 8 + xcd;
+    const int n0 = (tile % p.tilesN) * 128, k0 = (tile / p.tilesN) * 128;
+    const int mbeg = min(slab * p.mslab, p.M), mend = min(p.M, mbeg + p.mslab);
 
     f32x16 acc00, acc01, acc10, acc11;
 #pragma unroll
@@ -324,12 +328,13 @@ int launch_gemm_tn(const stair_gemm_tn_args &a, hipStream_t s) {
     p.A = a.A; p.lda = a.lda; p.B = a.B; p.ldb = a.ldb; p.b_gstride = a.b_gstride; p.b_gidx = a.b_gidx;
     p.R = a.rows_per_group; p.row_scale = a.row_scale; p.rs_gstride = a.rs_gstride; p.rs_gidx = a.rs_gidx;
     p.C = a.C; p.ldc = a.ldc; p.M = a.M; p.N = a.N; p.K = a.K;
-    const int tiles = ((a.N + 127) / 128) * ((a.K + 127) / 128);
-    // enough slabs to fill the chip (>= ~1024 blocks) but at least 256 rows each
+    p.tilesN = (a.N + 127) / 128; p.tilesK = (a.K + 127) / 128;
+    const int tiles = p.tilesN * p.tilesK;
+    // enough slabs to fill the chip (>= ~1024 blocks) but at least 256 rows each; a multiple of the XCD count
     int slabs = std::max(1, std::min((a.M + 255) / 256, (1024 + tiles - 1) / tiles));
+    slabs = (slabs + 7) / 8 * 8;
     p.mslab = ((a.M + slabs - 1) / slabs + 31) / 32 * 32;
-    slabs = (a.M + p.mslab - 1) / p.mslab;
-    hipLaunchKernelGGL(gemm_tn_f32_kernel, dim3((a.N + 127) / 128, (a.K + 127) / 128, slabs), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(gemm_tn_f32_kernel, dim3(tiles * slabs), dim3(256), 0, s, p);
     STAIR_LAUNCH_CHECK();
     return 0;
 }

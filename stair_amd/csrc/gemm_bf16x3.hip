@@ -31,8 +31,11 @@ constexpr int XKQ = XBK / 8;            // 8-element groups per chunk
 constexpr int IMG = XKQ * 128 * 8;      // bf16 elements of one image (8 KB)
 // LDS: [buf 2][operand 2][hi/lo 2][IMG] bf16 = 64 KB
 
+// slot = row ^ ((row>>3)&3) ^ 2kq: conflict-free for (a) the NT staging writes (8-lane group = rows {r, r+1} x kq 0..3),
+// (b) the TN staging writes (8-lane group = rows c, 4+c, .., 28+c of one kq) and (c) the fragment reads (32 consecutive
+// rows of one kq; the XORs permute inside aligned groups of 4 and 8).
 __device__ __forceinline__ int img_off(int buf, int operand, int part, int kq, int row) {
-    return (((buf * 2 + operand) * 2 + part) * IMG) + (kq * 128 + (row ^ (2 * kq))) * 8;
+    return (((buf * 2 + operand) * 2 + part) * IMG) + (kq * 128 + ((row ^ ((row >> 3) & 3)) ^ (2 * kq))) * 8;
 }
 
 __device__ __forceinline__ void split8(const v4f &x0, const v4f &x1, float scale, bf16x8 &hi, bf16x8 &lo) {
@@ -122,43 +125,55 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(XParams p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc00[e] = acc01[e] = acc10[e] = acc11[e] = 0.0f;
 
-    v4f va[2][2], vb[2][2];
-    float km0, km1;
-#define X_GLOAD(k0)                                                            \
+    // Two staging register sets: the loads of chunks c+1 and c+2 are in flight while chunk c is multiplied
+    // (one chunk in flight left the kernel latency bound at ~2 us per chunk against ~0.7 us of MFMA work).
+    v4f va[2][2][2], vb[2][2][2];       // [set][row half][k half]
+    float km[2][2];
+#define X_GLOAD(set, k0)                                                       \
     {                                                                          \
         const int kraw = (k0) + 8 * kq;                                        \
-        const int ka = min(kraw, K - 4), kb = min(kraw + 4, K - 4);            \
-        km0 = kraw < K ? 1.0f : 0.0f;                                          \
-        km1 = kraw + 4 < K ? 1.0f : 0.0f;                                      \
+        const int ka = max(0, min(kraw, K - 4)), kb = max(0, min(kraw + 4, K - 4));   \
+        km[set][0] = kraw < K ? 1.0f : 0.0f;                                   \
+        km[set][1] = kraw + 4 < K ? 1.0f : 0.0f;                               \
         _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                     \
-            va[i_][0] = *(gv4p)(aptr[i_] + ka); va[i_][1] = *(gv4p)(aptr[i_] + kb);   \
-            vb[i_][0] = *(gv4p)(wptr[i_] + ka); vb[i_][1] = *(gv4p)(wptr[i_] + kb);   \
+            va[set][i_][0] = *(gv4p)(aptr[i_] + ka); va[set][i_][1] = *(gv4p)(aptr[i_] + kb);   \
+            vb[set][i_][0] = *(gv4p)(wptr[i_] + ka); vb[set][i_][1] = *(gv4p)(wptr[i_] + kb);   \
         }                                                                      \
     }
-#define X_LSTORE(buf)                                                                                   \
+#define X_LSTORE(set, buf)                                                                              \
     {                                                                                                   \
         _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                              \
             bf16x8 hi_, lo_;                                                                            \
-            split8(va[i_][0] * km0, va[i_][1] * km1, rs[i_], hi_, lo_);                                 \
+            split8(va[set][i_][0] * km[set][0], va[set][i_][1] * km[set][1], rs[i_], hi_, lo_);         \
             *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, 0, 0, kq, ra_ + 64 * i_)) = hi_;            \
             *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, 0, 1, kq, ra_ + 64 * i_)) = lo_;            \
-            split8(vb[i_][0], vb[i_][1], 1.0f, hi_, lo_);                                               \
+            split8(vb[set][i_][0], vb[set][i_][1], 1.0f, hi_, lo_);                                     \
             *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, 1, 0, kq, ra_ + 64 * i_)) = hi_;            \
             *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, 1, 1, kq, ra_ + 64 * i_)) = lo_;            \
         }                                                                                               \
     }
 
+    // Chunks past K are not skipped but zeroed (X_GLOAD clamps the address and sets the A mask to 0): every
+    // load stays unconditional, which lets hipcc keep counted vmcnt waits (a load inside a branch forces vmcnt(0)
+    // at the join and drains the second register set).
     const int nchunks = (K + XBK - 1) / XBK;
-    X_GLOAD(0);
-    X_LSTORE(0);
+    X_GLOAD(0, 0);
+    X_GLOAD(1, XBK);
+    X_LSTORE(0, 0);
     __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-        const int buf = c & 1;
-        X_GLOAD(min(c + 1, nchunks - 1) * XBK);
+    for (int c = 0; c < nchunks; c += 2) {
+        // chunk c lives in LDS buffer 0, chunk c+1 in register set 1
+        X_GLOAD(0, (c + 2) * XBK);
         __builtin_amdgcn_sched_barrier(0);
-        mfma_chunk(xlds, buf, wm, wn, r, h, acc00, acc01, acc10, acc11);
+        mfma_chunk(xlds, 0, wm, wn, r, h, acc00, acc01, acc10, acc11);
         __builtin_amdgcn_sched_barrier(0);
-        X_LSTORE(buf ^ 1);
+        X_LSTORE(1, 1);
+        __syncthreads();
+        X_GLOAD(1, (c + 3) * XBK);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_chunk(xlds, 1, wm, wn, r, h, acc00, acc01, acc10, acc11);
+        __builtin_amdgcn_sched_barrier(0);
+        X_LSTORE(0, 0);
         __syncthreads();
     }
 #undef X_GLOAD
@@ -230,16 +245,22 @@ struct XTnParams {
     const float *B; int64_t ldb, b_gstride; const int32_t *b_gidx; int R;
     const float *row_scale; int64_t rs_gstride; const int32_t *rs_gidx;
     float *C; int64_t ldc;
-    int M, N, K, mslab;
+    int M, N, K, mslab, tilesN, tilesK, fast8;
 };
 
-__global__ __launch_bounds__(256) void gemm_tn_bf16x3_kernel(XTnParams p) {
+__global__ __launch_bounds__(256, 2) void gemm_tn_bf16x3_kernel(XTnParams p) {
     extern __shared__ __attribute__((aligned(16))) __bf16 xlds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
-    const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
-    const int mbeg = blockIdx.z * p.mslab, mend = min(p.M, mbeg + p.mslab);
+    // One M-slab per XCD: blocks with equal blockIdx % 8 share an XCD (speed only), so all (n,k) tiles of slab
+    // 8*(j / tiles) + xcd run on one L2 and walk the slab's rows together: A/B rows leave HBM ~once per slab
+    // instead of once per tile (the plain (n,k,slab) grid re-fetched them 8-16x: 16 GB per dW_ih launch).
+    const int tiles = p.tilesN * p.tilesK;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int tile = j % tiles, slab = (j / tiles) * 8 + xcd;
+    const int n0 = (tile % p.tilesN) * 128, k0 = (tile / p.tilesN) * 128;
+    const int mbeg = min(slab * p.mslab, p.M), mend = min(p.M, mbeg + p.mslab);
 
     f32x16 acc00, acc01, acc10, acc11;
 #pragma unroll
@@ -252,55 +273,82 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16x3_kernel(XTnParams p) {
     const int cc = min(col0 + 4 * cq, ncols - 4);
     const float cmask = col0 + 4 * cq < ncols ? 1.0f : 0.0f;
 
-    v4f v[8];
-    float sc[8];
-    auto gload = [&](int m0) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int mraw = m0 + 8 * mq + j;
-            const int m = min(mraw, p.M - 1);
-            sc[j] = mraw < mend ? cmask : 0.0f;
-            if (!isB) {
-                v[j] = *(gv4p)(p.A + (int64_t)m * p.lda + cc);
-            } else {
-                const int g = m / p.R, rr = m - g * p.R;
-                const int64_t gi = p.b_gidx ? p.b_gidx[g] : g;
-                if (p.row_scale) sc[j] *= p.row_scale[(p.rs_gidx ? p.rs_gidx[g] : g) * p.rs_gstride + rr];
-                v[j] = *(gv4p)(p.B + gi * p.b_gstride + (int64_t)rr * p.ldb + cc);
-            }
-        }
-    };
-    auto lstore = [&](int buf) {
-        const int operand = isB ? 1 : 0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            bf16x8 hi, lo;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float x = v[j][c] * sc[j];
-                hi[j] = (__bf16)x;
-                lo[j] = (__bf16)(x - (float)hi[j]);
-            }
-            *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, operand, 0, mq, 4 * cq + c)) = hi;
-            *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, operand, 1, mq, 4 * cq + c)) = lo;
-        }
-    };
+    v4f v[2][8];
+    float sc[2][8];
+    // A thread's 8 rows (mfirst .. mfirst+7) lie inside ONE group whenever groups are multiples of 8 rows (R = T for
+    // [T,H] tiles, or plain matrices passed as one group per 8 rows by the launcher): one group lookup and one 64-bit
+    // base per chunk, then constant strides.  Otherwise (vectors gathered one row per group) every row is looked up.
+#define T_GLOAD(set, m0_)                                                                                   \
+    {                                                                                                       \
+        const int mfirst = (m0_) + 8 * mq;                                                                  \
+        if (!isB) {                                                                                         \
+            const bool full_ = mfirst + 7 < p.M;          /* all 8 rows exist: constant stride from one base */ \
+            const float *base_ = p.A + (int64_t)(full_ ? mfirst : 0) * p.lda + cc;                          \
+            _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) {                                              \
+                sc[set][j_] = mfirst + j_ < mend ? cmask : 0.0f;                                            \
+                const int64_t ro_ = full_ ? (int64_t)j_ * p.lda : (int64_t)max(0, min(mfirst + j_, p.M - 1)) * p.lda;   \
+                v[set][j_] = *(gv4p)(base_ + ro_);                                                          \
+            }                                                                                               \
+        } else if (p.fast8) {                                                                               \
+            const int mc_ = max(0, min(mfirst, p.M - 8));                                                   \
+            const int g_ = mc_ / p.R, rr_ = mc_ - g_ * p.R;                                                 \
+            const float *base_ = p.B + (p.b_gidx ? (int64_t)p.b_gidx[g_] : (int64_t)g_) * p.b_gstride + (int64_t)rr_ * p.ldb + cc;   \
+            const float *rsb_ = p.row_scale ? p.row_scale + (p.rs_gidx ? (int64_t)p.rs_gidx[g_] : (int64_t)g_) * p.rs_gstride + rr_ : nullptr;   \
+            const bool in_ = mfirst <= p.M - 8;                                                             \
+            _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) {                                              \
+                sc[set][j_] = (in_ && mfirst + j_ < mend) ? cmask : 0.0f;                                   \
+                if (rsb_) sc[set][j_] *= rsb_[j_];                                                          \
+                v[set][j_] = *(gv4p)(base_ + (int64_t)j_ * p.ldb);                                          \
+            }                                                                                               \
+        } else {                                                                                            \
+            _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) {                                              \
+                const int mraw_ = mfirst + j_;                                                              \
+                const int m_ = max(0, min(mraw_, p.M - 1));                                                 \
+                const int g_ = m_ / p.R, rr_ = m_ - g_ * p.R;                                               \
+                sc[set][j_] = mraw_ < mend ? cmask : 0.0f;                                                  \
+                if (p.row_scale) sc[set][j_] *= p.row_scale[(p.rs_gidx ? p.rs_gidx[g_] : g_) * p.rs_gstride + rr_];   \
+                v[set][j_] = *(gv4p)(p.B + (p.b_gidx ? (int64_t)p.b_gidx[g_] : (int64_t)g_) * p.b_gstride + (int64_t)rr_ * p.ldb + cc);   \
+            }                                                                                               \
+        }                                                                                                   \
+    }
+#define T_LSTORE(set, buf)                                                                                  \
+    {                                                                                                       \
+        const int operand_ = isB ? 1 : 0;                                                                   \
+        _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) {                                                  \
+            bf16x8 hi_, lo_;                                                                                \
+            _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) {                                              \
+                const float x_ = v[set][j_][c_] * sc[set][j_];                                              \
+                hi_[j_] = (__bf16)x_;                                                                       \
+                lo_[j_] = (__bf16)(x_ - (float)hi_[j_]);                                                    \
+            }                                                                                               \
+            *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, operand_, 0, mq, 4 * cq + c_)) = hi_;           \
+            *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, operand_, 1, mq, 4 * cq + c_)) = lo_;           \
+        }                                                                                                   \
+    }
 
     const int nchunks = (mend - mbeg + XBK - 1) / XBK;
-    if (nchunks > 0) {
-        gload(mbeg);
-        lstore(0);
+    if (nchunks > 0) {      // block-uniform; rows past mend are zeroed by sc, so every load below is unconditional
+        T_GLOAD(0, mbeg);
+        T_GLOAD(1, mbeg + XBK);
+        T_LSTORE(0, 0);
         __syncthreads();
-        for (int c = 0; c < nchunks; ++c) {
-            const int buf = c & 1;
-            gload(mbeg + min(c + 1, nchunks - 1) * XBK);
+        for (int c = 0; c < nchunks; c += 2) {
+            T_GLOAD(0, mbeg + (c + 2) * XBK);
             __builtin_amdgcn_sched_barrier(0);
-            mfma_chunk(xlds, buf, wm, wn, r, h, acc00, acc01, acc10, acc11);
+            mfma_chunk(xlds, 0, wm, wn, r, h, acc00, acc01, acc10, acc11);
             __builtin_amdgcn_sched_barrier(0);
-            lstore(buf ^ 1);
+            T_LSTORE(1, 1);
+            __syncthreads();
+            T_GLOAD(1, mbeg + (c + 3) * XBK);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_chunk(xlds, 1, wm, wn, r, h, acc00, acc01, acc10, acc11);
+            __builtin_amdgcn_sched_barrier(0);
+            T_LSTORE(0, 0);
             __syncthreads();
         }
     }
+#undef T_GLOAD
+#undef T_LSTORE
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int k = k0 + wn * 64 + nt * 32 + r;
@@ -323,12 +371,21 @@ int launch_gemm_tn_bf16x3(const stair_gemm_tn_args &a, hipStream_t s) {
     p.A = a.A; p.lda = a.lda; p.B = a.B; p.ldb = a.ldb; p.b_gstride = a.b_gstride; p.b_gidx = a.b_gidx;
     p.R = a.rows_per_group; p.row_scale = a.row_scale; p.rs_gstride = a.rs_gstride; p.rs_gidx = a.rs_gidx;
     p.C = a.C; p.ldc = a.ldc; p.M = a.M; p.N = a.N; p.K = a.K;
-    const int tiles = ((a.N + 127) / 128) * ((a.K + 127) / 128);
+    p.tilesN = (a.N + 127) / 128; p.tilesK = (a.K + 127) / 128;
+    p.fast8 = 0;
+    if (a.M % 8 == 0 && a.M >= 8) {
+        if (p.R % 8 == 0) p.fast8 = 1;
+        else if (!p.b_gidx && !p.rs_gidx && p.b_gstride == (int64_t)p.R * p.ldb && (!p.row_scale || p.rs_gstride == p.R)) {
+            // a plain contiguous matrix: regroup it as groups of 8 rows
+            p.R = 8; p.b_gstride = 8 * p.ldb; p.rs_gstride = 8; p.fast8 = 1;
+        }
+    }
+    const int tiles = p.tilesN * p.tilesK;
     int slabs = std::max(1, std::min((a.M + 255) / 256, (1024 + tiles - 1) / tiles));
+    slabs = (slabs + 7) / 8 * 8;                                   // a multiple of the XCD count
     p.mslab = ((a.M + slabs - 1) / slabs + 31) / 32 * 32;
-    slabs = (a.M + p.mslab - 1) / p.mslab;
     const size_t shmem = 2 * 2 * 2 * IMG * sizeof(__bf16);
-    hipLaunchKernelGGL(gemm_tn_bf16x3_kernel, dim3((a.N + 127) / 128, (a.K + 127) / 128, slabs), dim3(256), shmem, s, p);
+    hipLaunchKernelGGL(gemm_tn_bf16x3_kernel, dim3(tiles * slabs), dim3(256), shmem, s, p);
     STAIR_LAUNCH_CHECK();
     return 0;
 }
