@@ -56,7 +56,7 @@ int launch_gemm_bf16x3(const stair_gemm_args &a, hipStream_t s);
 int launch_gemm_tn_bf16x3(const stair_gemm_tn_args &a, hipStream_t s);
 int matmul_mode();
 int launch_gemm_tn(const stair_gemm_tn_args &a, hipStream_t s);
-int launch_colsum(const float *A, int64_t lda, float *out, int M, int N, hipStream_t s);
+int launch_colsum(const float *A, int64_t lda, float *out, int M, int N, hipStream_t s, float *out2 = nullptr);
 int launch_transpose(const float *in, float *out, int rows, int cols, hipStream_t s);
 
 }  // namespace stair

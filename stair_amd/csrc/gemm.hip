@@ -339,19 +339,27 @@ int launch_gemm_tn(const stair_gemm_tn_args &a, hipStream_t s) {
     return 0;
 }
 
-// out[n] += sum_m A[m][n]  (bias gradients)
-__global__ void colsum_kernel(const float *A, int64_t lda, float *out, int M, int N, int mslab) {
+// out[n] += sum_m A[m][n]  (bias gradients; out2, if given, receives the same sums: b_ih and b_hh of an LSTM)
+__global__ void colsum_kernel(const float *A, int64_t lda, float *out, float *out2, int M, int N, int mslab) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     const int mbeg = blockIdx.y * mslab, mend = min(M, mbeg + mslab);
-    float acc = 0.f;
-    for (int m = mbeg; m < mend; ++m) acc += A[(int64_t)m * lda + n];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
+    const float *p = A + (int64_t)mbeg * lda + n;
+    int m = mbeg;
+    for (; m + 8 <= mend; m += 8, p += 8 * lda) {      // 8 independent loads in flight per thread
+        a0 += p[0]; a1 += p[lda]; a2 += p[2 * lda]; a3 += p[3 * lda];
+        a4 += p[4 * lda]; a5 += p[5 * lda]; a6 += p[6 * lda]; a7 += p[7 * lda];
+    }
+    for (; m < mend; ++m, p += lda) a0 += *p;
+    const float acc = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
     unsafeAtomicAdd(out + n, acc);
+    if (out2) unsafeAtomicAdd(out2 + n, acc);
 }
-int launch_colsum(const float *A, int64_t lda, float *out, int M, int N, hipStream_t s) {
+int launch_colsum(const float *A, int64_t lda, float *out, int M, int N, hipStream_t s, float *out2) {
     if (M == 0) return 0;
-    const int mslab = std::max(64, (M + 255) / 256);
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, (M + mslab - 1) / mslab), dim3(256), 0, s, A, lda, out, M, N, mslab);
+    const int mslab = std::max(64, (M + 511) / 512);
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, (M + mslab - 1) / mslab), dim3(256), 0, s, A, lda, out, out2, M, N, mslab);
     STAIR_LAUNCH_CHECK();
     return 0;
 }

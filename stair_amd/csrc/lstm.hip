@@ -427,8 +427,7 @@ int launch_lstm_bwd(const stair_lstm_bwd_args &a, hipStream_t s) {
         g.B = a.hprev_ws + dir * Hh; g.ldb = 2 * (int64_t)Hh; g.b_gstride = 2 * (int64_t)Hh;
         g.C = a.dw_hh[dir]; g.ldc = Hh; g.K = Hh;
         if (int rc = launch_gemm_tn(g, s)) return rc;
-        if (int rc = launch_colsum(a.gates + dir * 4 * Hh, 8 * (int64_t)Hh, a.db_ih[dir], a.rows, 4 * Hh, s)) return rc;
-        if (int rc = launch_colsum(a.gates + dir * 4 * Hh, 8 * (int64_t)Hh, a.db_hh[dir], a.rows, 4 * Hh, s)) return rc;
+        if (int rc = launch_colsum(a.gates + dir * 4 * Hh, 8 * (int64_t)Hh, a.db_ih[dir], a.rows, 4 * Hh, s, a.db_hh[dir])) return rc;
     }
     return 0;
 }

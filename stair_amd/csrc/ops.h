@@ -69,6 +69,10 @@ int launch_span_mean_bwd(float *dtok, int64_t ld, const int32_t *start, const in
 int launch_cosine_attn_bwd(const float *F, int64_t f_gs, const int32_t *f_idx, const float *Kmat, const int32_t *k_idx,
                            const float *datt, const int32_t *out_idx, float *dF, float *dK, int npairs, int T, int H,
                            hipStream_t s);
+int launch_cosine_attn_bwd_grouped(const float *F, const float *Kmat, const float *score, const int32_t *score_idx,
+                                   const float *dscore, const int32_t *dscore_idx, const int32_t *pair_start,
+                                   const int32_t *pair_cnt, float *dF, float *dK, float *nf_ws, float *nk_ws, int n, int npairs,
+                                   int T, int H, int ka_max, hipStream_t s);
 int launch_temporal_relate_bwd(const float *att, const int32_t *att_idx, const int32_t *att_k, const float *drel,
                                const int32_t *rel_idx, float *datt, int n, int T, int mode, int conv, int ksize,
                                const float *const w[6], float *const dw[6], hipStream_t s);

@@ -402,6 +402,8 @@ extern "C" int stair_plan_build(stair_ctx *ctx, int32_t n, const int32_t *prog_o
                         pl->n_att += K;
                         Bucket &b = B.bucket(nd.level, tok, 0, 0);
                         b.col[0].push_back(c0.slot);
+                        b.col[4].push_back(b.nrows);      // first pair of this instance
+                        b.col[5].push_back(K);            // number of pairs
                         for (int k = 0; k < K; ++k) {
                             b.col[1].push_back(b.cnt);                       // pair -> instance
                             b.col[2].push_back(k == 0 ? c1.slot : c1.aux);   // pair -> keyword vec row
@@ -1130,9 +1132,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
                 RUN(dense_bwd(B, gA, c, T, H, H, map, H, TH, I0, W.hi0, g_map, H, TH, I0, 1));
                 break;
             case STAIR_OP_LOCALIZE:
-                STAIR_HIP(hipMemsetAsync(gB, 0, (size_t)c * TH * sizeof(float), s));
-                STAIR_HIP(hipMemsetAsync(gK, 0, (size_t)b.nrows * H * sizeof(float), s));
-                RUN(launch_cosine_attn_bwd(svB, TH, I1, svK, nullptr, g_att, I3, gB, gK, b.nrows, T, H, s));
+                RUN(launch_cosine_attn_bwd_grouped(svB, svK, att, I3, g_att, I3, I4, I5, gB, gK, gRs2, gStats, c, b.nrows, T, H, 2, s));
                 RUN(dense_bwd(B, gK, b.nrows, 1, H, H, vec, H, H, I2, W.lk, g_vec, H, H, I2, 1));
                 RUN(mlp_tail(W.lv3, W.lv0, false));
                 break;
@@ -1143,9 +1143,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
                 RUN(launch_mask_relu(gV0, g_vec, H, I3, vec, H, I3, c, H, s));
                 RUN(dense_bwd(B, gV0, c, 1, H, H, svCat, H, H, nullptr, W.supdense, gV1, H, H, nullptr, 0));
                 RUN(launch_superlative_pool_bwd(svSup, ws, gws, I4, I1, I2, b.variant, gV1, gS, c, T, H, s));
-                STAIR_HIP(hipMemsetAsync(gB, 0, (size_t)c * TH * sizeof(float), s));
-                STAIR_HIP(hipMemsetAsync(gK, 0, (size_t)b.nrows * H * sizeof(float), s));
-                RUN(launch_cosine_attn_bwd(svB, TH, I5, svK, nullptr, gS, nullptr, gB, gK, b.nrows, T, H, s));
+                RUN(launch_cosine_attn_bwd_grouped(svB, svK, svSup, nullptr, gS, nullptr, I1, I2, gB, gK, gRs2, gStats, c, b.nrows, T, H, T, s));
                 RUN(dense_bwd(B, gK, b.nrows, 1, H, H, ws, H, H, I4, W.lk, gws, H, H, I4, 1));
                 RUN(mlp_tail(W.lv3, W.lv0, false));
                 break;

@@ -177,6 +177,83 @@ int launch_cosine_attn_bwd(const float *F, int64_t f_gs, const int32_t *f_idx, c
     return 0;
 }
 
+// Grouped form for Localize / Superlative, where ALL pairs of an instance share one private [T,H] tile: one block
+// per instance, no atomics.  The forward scores are saved (out = (cos+1)*0.49), so cos is recovered from them and
+// only the row norms are recomputed:
+//   dF[t][:] = sum_a sa[a][t] k_a  -  (sum_a sb[a][t]) f_t ;   dK[a][:] = sum_t sa[a][t] f_t  -  (sum_t sc[a][t]) k_a / nk_a^2
+// with sa = dcos/(nf nk), sb = dcos*cos/nf^2, sc = dcos*cos, dcos = 0.49 * dscore.  (The per-pair kernel above
+// issues Ka*T*H atomic adds per instance -- half a billion for a batch of Superlatives with Ka = T = 64.)
+__global__ void rownorm_kernel(const float *X, int64_t rows, int H, float *out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float4 *x = reinterpret_cast<const float4 *>(X + row * H);
+    float ss = 0.f;
+    for (int c = lane; c < H / 4; c += 64) { const float4 v = x[c]; ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
+    ss = wave_sum(ss);
+    if (lane == 0) out[row] = fmaxf(sqrtf(ss), 1e-8f);
+}
+
+// grid (instance, 64-column chunk); the chunk's K [Ka][64] and F [T][64] slices and the pair scalars live in LDS
+__global__ void cosine_attn_bwd_grouped_kernel(const float *F, const float *Kmat, const float *nf_all, const float *nk_all,
+                                               const float *score, int64_t s_stride, const int32_t *score_idx,
+                                               const float *dscore, const int32_t *dscore_idx, const int32_t *pair_start,
+                                               const int32_t *pair_cnt, float *dF, float *dK, int n, int T, int H, int ka_max) {
+    extern __shared__ float sm[];          // sa [Ka][T] | kt [Ka][64] | ft [T][64] | sbsum [T] | scsum [Ka]
+    const int i = blockIdx.x, c0 = blockIdx.y * 64;
+    const int p0 = pair_start[i], Ka = pair_cnt[i];
+    float *sa = sm, *kt = sa + ka_max * T, *ft = kt + ka_max * 64, *sbsum = ft + T * 64, *scsum = sbsum + T;
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;      // 4 waves: lane = column, part = row quarter
+    const float *f = F + (int64_t)i * T * H;
+    const float *nf = nf_all + (int64_t)i * T, *nk = nk_all + p0;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) sbsum[t] = 0.f;
+    for (int a = threadIdx.x; a < Ka; a += blockDim.x) scsum[a] = 0.f;
+    for (int t = part; t < T; t += 4) ft[t * 64 + lane] = f[(int64_t)t * H + c0 + lane];
+    for (int a = part; a < Ka; a += 4) kt[a * 64 + lane] = Kmat[(int64_t)(p0 + a) * H + c0 + lane];
+    __syncthreads();
+    for (int e = threadIdx.x; e < Ka * T; e += blockDim.x) {
+        const int a = e / T, t = e - a * T;
+        const int64_t so = (int64_t)(score_idx ? score_idx[p0 + a] : p0 + a) * s_stride + t;
+        const int64_t go = (int64_t)(dscore_idx ? dscore_idx[p0 + a] : p0 + a) * s_stride + t;
+        const float cosv = score[so] / 0.49f - 1.0f;
+        const float dcos = 0.49f * dscore[go];
+        sa[e] = dcos / (nf[t] * nk[a]);
+        atomicAdd(&sbsum[t], dcos * cosv / (nf[t] * nf[t]));
+        atomicAdd(&scsum[a], dcos * cosv);
+    }
+    __syncthreads();
+    for (int t = part; t < T; t += 4) {
+        float acc = 0.f;
+        for (int a = 0; a < Ka; ++a) acc += sa[a * T + t] * kt[a * 64 + lane];
+        dF[((int64_t)i * T + t) * H + c0 + lane] = acc - sbsum[t] * ft[t * 64 + lane];
+    }
+    for (int a = part; a < Ka; a += 4) {
+        float acc = 0.f;
+        for (int t = 0; t < T; ++t) acc += sa[a * T + t] * ft[t * 64 + lane];
+        dK[(int64_t)(p0 + a) * H + c0 + lane] = acc - scsum[a] * kt[a * 64 + lane] / (nk[a] * nk[a]);
+    }
+}
+int launch_cosine_attn_bwd_grouped(const float *F, const float *Kmat, const float *score, const int32_t *score_idx,
+                                   const float *dscore, const int32_t *dscore_idx, const int32_t *pair_start,
+                                   const int32_t *pair_cnt, float *dF, float *dK, float *nf_ws, float *nk_ws, int n, int npairs,
+                                   int T, int H, int ka_max, hipStream_t s) {
+    if (n == 0) return 0;
+    STAIR_CHECK(H % 64 == 0, "H must be a multiple of 64");
+    const int64_t frows = (int64_t)n * T;
+    hipLaunchKernelGGL(rownorm_kernel, dim3((unsigned)((frows + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, s, F, frows, H, nf_ws);
+    hipLaunchKernelGGL(rownorm_kernel, dim3((npairs + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlock), 0, s, Kmat, (int64_t)npairs, H, nk_ws);
+    STAIR_LAUNCH_CHECK();
+    const size_t shmem = ((size_t)ka_max * T + (size_t)ka_max * 64 + (size_t)T * 64 + T + ka_max) * sizeof(float);
+    STAIR_CHECK(shmem <= 160 * 1024, "cosine backward: Ka*T too large for LDS");
+    if (shmem > 48 * 1024)     // e.g. Superlative at T = 64: 16 + 16 + 16 KB; at max_video_length = 150 (args.py:29): 165 KB
+        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cosine_attn_bwd_grouped_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(cosine_attn_bwd_grouped_kernel, dim3(n, H / 64), dim3(256), shmem, s, F, Kmat, nf_ws, nk_ws, score, (int64_t)T,
+                       score_idx, dscore, dscore_idx, pair_start, pair_cnt, dF, dK, n, T, H, ka_max);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Temporal relate nets backward (recomputes the three layers in LDS).  dw[6] accumulate with atomics.
 struct RelateWB { const float *w[6]; float *dw[6]; };
