@@ -233,6 +233,188 @@ __global__ __launch_bounds__(NWAVES * 64) void lstm_rec_kernel(LstmRecParams p) 
 
 
 // =============================================================================================
+// split-precision recurrence (matmul mode bf16x3): same ownership and cell update as lstm_rec_kernel, but the
+// recurrent product h . W_hh^T runs on v_mfma_f32_16x16x32_bf16 with h and W_hh split into bf16 hi + lo
+// (hi*hi + hi*lo + lo*hi, fp32 accumulate; see csrc/gemm_bf16x3.hip).  W_hh is pre-split into a fragment-ordered
+// bf16 image (same bytes as the fp32 image); the matrix work per 32-wide k block drops from 8*NT fp32 MFMAs
+// (256 cycles each tile) to 3*NT bf16 MFMAs (48 cycles), so the kernel is purely a W_hh stream and the fragments of
+// a WHOLE k block are prefetched while the previous block is multiplied.
+// =============================================================================================
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using gbf8p = const __attribute__((address_space(1))) bf16x8 *;
+
+// pack[dir][kb][tile][part][lane][j] (bf16): W_hh[dir][tile*16 + (lane&15)][32kb + 8(lane>>4) + j] split into part 0 = hi, 1 = lo
+__global__ void whh_pack_bf16_kernel(const float *w0, const float *w1, __bf16 *pack, int Hh) {
+    const int64_t per_dir = 8 * (int64_t)Hh * Hh;                 // bf16 elements per direction (hi + lo)
+    const int64_t e8 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one 8-element vector per thread
+    if (e8 * 8 >= 2 * per_dir) return;
+    const int dir = (int)(e8 * 8 / per_dir);
+    int64_t r = e8 - dir * (per_dir / 8);
+    const int lane = (int)(r & 63);
+    r >>= 6;
+    const int part = (int)(r & 1);
+    r >>= 1;
+    const int ntile = 4 * Hh / 16;
+    const int tile = (int)(r % ntile), kb = (int)(r / ntile);
+    const float *w = (dir == 0 ? w0 : w1) + (int64_t)(tile * 16 + (lane & 15)) * Hh + 32 * kb + 8 * (lane >> 4);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 hi = (__bf16)w[j];
+        o[j] = part == 0 ? hi : (__bf16)(w[j] - (float)hi);
+    }
+    *reinterpret_cast<bf16x8 *>(pack + e8 * 8) = o;
+}
+
+template <int NCT, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void lstm_rec_x3_kernel(LstmRecParams p) {
+    extern __shared__ __attribute__((aligned(16))) float hbuf[];  // [2][16][Hh+4]
+    constexpr int NT = NCT * 4;
+    const int Hh = p.Hh, ldh = Hh + 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cl = lane & 15, g4 = lane >> 4;
+    const int dir = blockIdx.y;
+    const int s0 = blockIdx.x * 16;
+    const int ntiles = Hh >> 4, nkb = Hh >> 5;          // nkb is even (launcher guarantees Hh % 64 == 0)
+    const int ntile4 = 4 * ntiles;
+    const __attribute__((address_space(1))) __bf16 *wp =
+        (const __attribute__((address_space(1))) __bf16 *)p.w_pack + (int64_t)dir * 8 * Hh * Hh + lane * 8;
+    gfp xproj = (gfp)p.xproj;
+    __attribute__((address_space(1))) float *outp = (__attribute__((address_space(1))) float *)p.out;
+
+    int off4[4], len4[4];
+    int lmax = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int s = s0 + g4 * 4 + e;
+        off4[e] = 0; len4[e] = 0;
+        if (s < p.n) { off4[e] = p.seq_off[s]; len4[e] = p.seq_off[s + 1] - off4[e]; }
+    }
+    for (int s = s0; s < min(s0 + 16, p.n); ++s) lmax = max(lmax, p.seq_off[s + 1] - p.seq_off[s]);
+    for (int i = tid; i < 2 * 16 * ldh; i += NWAVES * 64) hbuf[i] = 0.0f;
+    float creg[NCT][4];          // h of a finished (inactive) sequence is carried in LDS, not in registers
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) creg[ct][e] = 0.0f;
+    bool own[NCT];
+    int unit[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        const int tile = wave * NCT + ct;
+        own[ct] = tile < ntiles;
+        unit[ct] = (own[ct] ? tile : 0) * 16 + cl;
+    }
+    // element offset of fragment ti (hi part) inside a k block: ((gate * ntiles) + column block) * 1024, recomputed
+    // where used (two adds) instead of living in NT registers
+    int cb[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) cb[ct] = (own[ct] ? wave * NCT + ct : 0) * 1024;
+    const int64_t ldx = 8 * (int64_t)Hh;
+    const int xcol = dir * 4 * Hh;
+
+    bf16x8 bA[NT][2], bB[NT][2];
+#define X3_LOADB(dst, kb)                                                              \
+    _Pragma("unroll") for (int t_ = 0; t_ < NT; ++t_) {                                 \
+        const int o_ = ((kb) * ntile4 + (t_ & 3) * ntiles) * 1024 + cb[t_ >> 2];        \
+        dst[t_][0] = *(gbf8p)(wp + o_);                                                 \
+        dst[t_][1] = *(gbf8p)(wp + o_ + 512);                                           \
+    }
+#define X3_MFMA(src, kb)                                                                                        \
+    {                                                                                                           \
+        const v4f a0_ = *reinterpret_cast<const v4f *>(hc + cl * ldh + (kb) * 32 + 8 * g4);                     \
+        const v4f a1_ = *reinterpret_cast<const v4f *>(hc + cl * ldh + (kb) * 32 + 8 * g4 + 4);                 \
+        bf16x8 ah_, al_;                                                                                        \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                      \
+            ah_[j_] = (__bf16)a0_[j_]; al_[j_] = (__bf16)(a0_[j_] - (float)ah_[j_]);                            \
+            ah_[4 + j_] = (__bf16)a1_[j_]; al_[4 + j_] = (__bf16)(a1_[j_] - (float)ah_[4 + j_]);                \
+        }                                                                                                       \
+        _Pragma("unroll") for (int t_ = 0; t_ < NT; ++t_) acc[t_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al_, src[t_][0], acc[t_], 0, 0, 0);   \
+        _Pragma("unroll") for (int t_ = 0; t_ < NT; ++t_) acc[t_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah_, src[t_][1], acc[t_], 0, 0, 0);   \
+        _Pragma("unroll") for (int t_ = 0; t_ < NT; ++t_) acc[t_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah_, src[t_][0], acc[t_], 0, 0, 0);   \
+    }
+
+    float xp[NCT][4][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const bool act = 0 < len4[e];
+        const int64_t row = off4[e] + (act ? (dir == 0 ? 0 : len4[e] - 1) : 0);
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int gate = 0; gate < 4; ++gate)
+                xp[ct][gate][e] = (act && own[ct]) ? xproj[row * ldx + xcol + gate * Hh + unit[ct]] : 0.0f;
+    }
+    X3_LOADB(bA, 0);
+    __syncthreads();
+
+    for (int tau = 0; tau < lmax; ++tau) {
+        const int cur = tau & 1;
+        const float *hc = hbuf + cur * 16 * ldh;
+        float *hn = hbuf + (cur ^ 1) * 16 * ldh;
+        v4f acc[NT];
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) acc[ti] = v4f{0.f, 0.f, 0.f, 0.f};
+        for (int kb = 0; kb < nkb; kb += 2) {
+            X3_LOADB(bB, kb + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            X3_MFMA(bA, kb);
+            const int kn = kb + 2 < nkb ? kb + 2 : 0;            // wraps to the next step's first block
+            X3_LOADB(bA, kn);
+            __builtin_amdgcn_sched_barrier(0);
+            X3_MFMA(bB, kb + 1);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool active = tau < len4[e];
+            const int t = dir == 0 ? tau : len4[e] - 1 - tau;
+            const int64_t row = off4[e] + (active ? t : 0);
+            const bool act_n = tau + 1 < len4[e];
+            const int64_t row_n = off4[e] + (act_n ? (dir == 0 ? tau + 1 : len4[e] - 2 - tau) : 0);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                if (!own[ct]) continue;
+                const float gi = acc[ct * 4 + 0][e] + xp[ct][0][e];
+                const float gf = acc[ct * 4 + 1][e] + xp[ct][1][e];
+                const float gg = acc[ct * 4 + 2][e] + xp[ct][2][e];
+                const float go = acc[ct * 4 + 3][e] + xp[ct][3][e];
+                const float si = sigmoid_fast(gi), sf = sigmoid_fast(gf), tg = tanh_fast(gg), so = sigmoid_fast(go);
+                const float cn = sf * creg[ct][e] + si * tg;
+                const float hv = so * tanh_fast(cn);
+                float hkeep = hc[(g4 * 4 + e) * ldh + unit[ct]];
+                if (active) {
+                    creg[ct][e] = cn;
+                    hkeep = hv;
+                    outp[row * p.ldo + dir * Hh + unit[ct]] = hv;
+                    if (p.cbuf) {
+                        float *gsave = const_cast<float *>(p.xproj) + row * ldx + xcol + unit[ct];
+                        gsave[0] = si; gsave[Hh] = sf; gsave[2 * Hh] = tg; gsave[3 * Hh] = so;
+                        p.cbuf[row * 2 * Hh + dir * Hh + unit[ct]] = cn;
+                    }
+                }
+                hn[(g4 * 4 + e) * ldh + unit[ct]] = hkeep;
+#pragma unroll
+                for (int gate = 0; gate < 4; ++gate)
+                    xp[ct][gate][e] = act_n ? xproj[row_n * ldx + xcol + gate * Hh + unit[ct]] : 0.0f;
+            }
+        }
+        __syncthreads();
+    }
+#undef X3_LOADB
+#undef X3_MFMA
+    const float *hl = hbuf + (lmax & 1) * 16 * ldh;       // buffer written by the last step (zeros if lmax == 0)
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        if (!own[ct]) continue;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int s = s0 + g4 * 4 + e;
+            if (s < p.n) p.h_n[(int64_t)s * 2 * Hh + dir * Hh + unit[ct]] = hl[(g4 * 4 + e) * ldh + unit[ct]];
+        }
+    }
+}
+
+// =============================================================================================
 // backward through time
 // =============================================================================================
 // pack^T image for the recurrent product of the backward pass, dh_prev = dgates . W_hh:
@@ -450,7 +632,13 @@ int launch_lstm(const stair_lstm_args &a, hipStream_t s) {
         if (int rc = launch_gemm(g, s)) return rc;
     }
     STAIR_CHECK(a.whh_pack_ws != nullptr, "whh_pack_ws missing");
-    {
+    const bool split = matmul_mode() == STAIR_MATMUL_BF16X3 && Hh % 64 == 0;     // the split kernel walks k blocks in pairs
+    if (split) {
+        const int64_t n8 = 2 * 8 * (int64_t)Hh * Hh / 8;
+        hipLaunchKernelGGL(whh_pack_bf16_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, a.w_hh[0], a.w_hh[1],
+                           reinterpret_cast<__bf16 *>(a.whh_pack_ws), Hh);
+        STAIR_LAUNCH_CHECK();
+    } else {
         const int64_t n4 = 2 * 4 * (int64_t)Hh * Hh / 4;
         hipLaunchKernelGGL(whh_pack_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a.w_hh[0], a.w_hh[1],
                            a.whh_pack_ws, Hh);
@@ -462,7 +650,11 @@ int launch_lstm(const stair_lstm_args &a, hipStream_t s) {
     const dim3 grid((a.n + 15) / 16, 2);
     const size_t shmem = 2 * 16 * (Hh + 4) * sizeof(float);
     const int tiles = Hh / 16;
-    if (tiles > 8) hipLaunchKernelGGL((lstm_rec_kernel<2, 8>), grid, dim3(512), shmem, s, p);
+    if (split) {
+        if (tiles > 8) hipLaunchKernelGGL((lstm_rec_x3_kernel<2, 8>), grid, dim3(512), shmem, s, p);
+        else if (tiles > 4) hipLaunchKernelGGL((lstm_rec_x3_kernel<1, 8>), grid, dim3(512), shmem, s, p);
+        else hipLaunchKernelGGL((lstm_rec_x3_kernel<1, 4>), grid, dim3(256), shmem, s, p);
+    } else if (tiles > 8) hipLaunchKernelGGL((lstm_rec_kernel<2, 8>), grid, dim3(512), shmem, s, p);
     else if (tiles > 4) hipLaunchKernelGGL((lstm_rec_kernel<1, 8>), grid, dim3(512), shmem, s, p);
     else if (tiles > 2) hipLaunchKernelGGL((lstm_rec_kernel<1, 4>), grid, dim3(256), shmem, s, p);
     else hipLaunchKernelGGL((lstm_rec_kernel<1, 2>), grid, dim3(128), shmem, s, p);
