@@ -570,13 +570,173 @@ __global__ __launch_bounds__(NWAVES * 64) void lstm_bwd_kernel(LstmBwdParams p) 
     }
 }
 
+// ---- split-precision reverse recurrence (matmul mode bf16x3) -------------------------------------------------
+// packT[dir][kb][colblk][part][lane][j] (bf16) = W_hh[dir][32kb + 8(lane>>4) + j][colblk*16 + (lane&15)], part 0 hi / 1 lo
+__global__ void whh_packT_bf16_kernel(const float *w0, const float *w1, __bf16 *pack, int Hh) {
+    const int64_t per_dir = 8 * (int64_t)Hh * Hh;
+    const int64_t e8 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e8 * 8 >= 2 * per_dir) return;
+    const int dir = (int)(e8 * 8 / per_dir);
+    int64_t r = e8 - dir * (per_dir / 8);
+    const int lane = (int)(r & 63);
+    r >>= 6;
+    const int part = (int)(r & 1);
+    r >>= 1;
+    const int ncol = Hh / 16;
+    const int colblk = (int)(r % ncol), kb = (int)(r / ncol);
+    const float *w = (dir == 0 ? w0 : w1) + (int64_t)(32 * kb + 8 * (lane >> 4)) * Hh + colblk * 16 + (lane & 15);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x = w[(int64_t)j * Hh];
+        const __bf16 hi = (__bf16)x;
+        o[j] = part == 0 ? hi : (__bf16)(x - (float)hi);
+    }
+    *reinterpret_cast<bf16x8 *>(pack + e8 * 8) = o;
+}
+
+// Same ownership as lstm_bwd_kernel.  The gate gradients are written to LDS ALREADY split (bf16 hi and lo images
+// [16][4Hh+8]), so the A fragments of dh_prev = dgates . W_hh are plain ds_read_b128 and the MFMA loop carries no
+// conversions; W_hh^T fragments are prefetched four k blocks (of 32 gate rows) at a time.
+template <int NCT, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void lstm_bwd_x3_kernel(LstmBwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 dgs16[];   // [2 parts][16][4Hh+8]
+    const int Hh = p.Hh, ldg = 4 * Hh + 8;
+    __bf16 *dg_hi = dgs16, *dg_lo = dgs16 + 16 * ldg;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cl = lane & 15, g4 = lane >> 4;
+    const int dir = blockIdx.y;
+    const int s0 = blockIdx.x * 16;
+    const int ntiles = Hh >> 4, nkb = (4 * Hh) >> 5;      // nkb is a multiple of 8 (Hh % 64 == 0)
+    const int64_t ldx = 8 * (int64_t)Hh;
+    const int xcol = dir * 4 * Hh;
+
+    int off4[4], len4[4];
+    int lmax = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int s = s0 + g4 * 4 + e;
+        off4[e] = 0; len4[e] = 0;
+        if (s < p.n) { off4[e] = p.seq_off[s]; len4[e] = p.seq_off[s + 1] - off4[e]; }
+    }
+    for (int s = s0; s < min(s0 + 16, p.n); ++s) lmax = max(lmax, p.seq_off[s + 1] - p.seq_off[s]);
+    bool own[NCT];
+    int unit[NCT], cb[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        const int tile = wave * NCT + ct;
+        own[ct] = tile < ntiles;
+        unit[ct] = (own[ct] ? tile : 0) * 16 + cl;
+        cb[ct] = (own[ct] ? tile : 0) * 1024;
+    }
+    const __attribute__((address_space(1))) __bf16 *wp =
+        (const __attribute__((address_space(1))) __bf16 *)p.w_packT + (int64_t)dir * 8 * Hh * Hh + lane * 8;
+
+    float dh[NCT][4], dc[NCT][4];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int s = s0 + g4 * 4 + e;
+            dc[ct][e] = 0.0f;
+            dh[ct][e] = (p.d_hn && s < p.n && own[ct]) ? p.d_hn[(int64_t)s * 2 * Hh + dir * Hh + unit[ct]] : 0.0f;
+        }
+    for (int i = tid; i < 2 * 16 * ldg; i += NWAVES * 64) dgs16[i] = (__bf16)0.0f;
+    __syncthreads();
+
+    bf16x8 bA[4][NCT][2], bB[4][NCT][2];
+#define B3_LOAD(dst, kb0)                                                                         \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                               \
+        _Pragma("unroll") for (int ct_ = 0; ct_ < NCT; ++ct_) {                                    \
+            const int o_ = (((kb0) + q_) * ntiles) * 1024 + cb[ct_];                               \
+            dst[q_][ct_][0] = *(gbf8p)(wp + o_);                                                   \
+            dst[q_][ct_][1] = *(gbf8p)(wp + o_ + 512);                                             \
+        }
+#define B3_MFMA(src, kb0)                                                                                          \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                              \
+        const bf16x8 ah_ = *reinterpret_cast<const bf16x8 *>(dg_hi + cl * ldg + ((kb0) + q_) * 32 + 8 * g4);        \
+        const bf16x8 al_ = *reinterpret_cast<const bf16x8 *>(dg_lo + cl * ldg + ((kb0) + q_) * 32 + 8 * g4);        \
+        _Pragma("unroll") for (int ct_ = 0; ct_ < NCT; ++ct_) {                                                     \
+            acc[ct_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al_, src[q_][ct_][0], acc[ct_], 0, 0, 0);            \
+            acc[ct_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah_, src[q_][ct_][1], acc[ct_], 0, 0, 0);            \
+            acc[ct_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah_, src[q_][ct_][0], acc[ct_], 0, 0, 0);            \
+        }                                                                                                           \
+    }
+    B3_LOAD(bA, 0);
+
+    for (int tau = lmax - 1; tau >= 0; --tau) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool active = tau < len4[e];
+            const int t = dir == 0 ? tau : len4[e] - 1 - tau;
+            const int64_t row = off4[e] + (active ? t : 0);
+            const int64_t rowp = row + (dir == 0 ? -1 : 1);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                if (!own[ct]) continue;
+                float di = 0.f, df = 0.f, dg = 0.f, dob = 0.f;
+                if (active) {
+                    float *g = p.G + row * ldx + xcol + unit[ct];
+                    const float gi = g[0], gf = g[Hh], gg = g[2 * Hh], go = g[3 * Hh];
+                    const float c = p.cbuf[row * 2 * Hh + dir * Hh + unit[ct]];
+                    const float cp = tau > 0 ? p.cbuf[rowp * 2 * Hh + dir * Hh + unit[ct]] : 0.0f;
+                    const float dht = dh[ct][e] + p.d_out[row * p.ldd + dir * Hh + unit[ct]];
+                    const float tc = tanh_fast(c);
+                    dob = dht * tc * go * (1.0f - go);
+                    const float dct = dc[ct][e] + dht * go * (1.0f - tc * tc);
+                    di = dct * gg * gi * (1.0f - gi);
+                    df = dct * cp * gf * (1.0f - gf);
+                    dg = dct * gi * (1.0f - gg * gg);
+                    dc[ct][e] = dct * gf;
+                    g[0] = di; g[Hh] = df; g[2 * Hh] = dg; g[3 * Hh] = dob;
+                }
+                const int o = (g4 * 4 + e) * ldg + unit[ct];
+                const float vals[4] = {di, df, dg, dob};
+#pragma unroll
+                for (int gate = 0; gate < 4; ++gate) {
+                    const __bf16 hi = (__bf16)vals[gate];
+                    dg_hi[o + gate * Hh] = hi;
+                    dg_lo[o + gate * Hh] = (__bf16)(vals[gate] - (float)hi);
+                }
+            }
+        }
+        __syncthreads();
+        v4f acc[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) acc[ct] = v4f{0.f, 0.f, 0.f, 0.f};
+        for (int kb = 0; kb < nkb; kb += 8) {
+            B3_LOAD(bB, kb + 4);
+            __builtin_amdgcn_sched_barrier(0);
+            B3_MFMA(bA, kb);
+            const int kn = kb + 8 < nkb ? kb + 8 : 0;        // wraps to the next step
+            B3_LOAD(bA, kn);
+            __builtin_amdgcn_sched_barrier(0);
+            B3_MFMA(bB, kb + 4);
+        }
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (tau < len4[e]) dh[ct][e] = acc[ct][e];
+        __syncthreads();
+    }
+#undef B3_LOAD
+#undef B3_MFMA
+}
+
 int launch_lstm_bwd(const stair_lstm_bwd_args &a, hipStream_t s) {
     STAIR_CHECK(a.n >= 0 && a.rows >= 0 && a.I > 0 && a.Hh > 0, "bad shape");
     STAIR_CHECK(a.Hh % 32 == 0 && a.Hh <= 256, "LSTM hidden size must be a multiple of 32, at most 256");
     STAIR_CHECK(a.gates && a.cbuf && a.out && a.d_out && a.whh_pack_ws && a.hprev_ws, "null buffer");
     if (a.n == 0 || a.rows == 0) return 0;
     const int Hh = a.Hh;
-    {
+    const bool split = matmul_mode() == STAIR_MATMUL_BF16X3 && Hh % 64 == 0;
+    if (split) {
+        const int64_t n8 = 2 * 8 * (int64_t)Hh * Hh / 8;
+        hipLaunchKernelGGL(whh_packT_bf16_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, a.w_hh[0], a.w_hh[1],
+                           reinterpret_cast<__bf16 *>(a.whh_pack_ws), Hh);
+        STAIR_LAUNCH_CHECK();
+    } else {
         const int64_t ne = 2 * 4 * (int64_t)Hh * Hh;
         hipLaunchKernelGGL(whh_packT_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, a.w_hh[0], a.w_hh[1],
                            a.whh_pack_ws, Hh);
@@ -586,13 +746,19 @@ int launch_lstm_bwd(const stair_lstm_bwd_args &a, hipStream_t s) {
     p.G = a.gates; p.cbuf = a.cbuf; p.d_out = a.d_out; p.ldd = a.ldd; p.d_hn = a.d_hn; p.w_packT = a.whh_pack_ws;
     p.seq_off = a.seq_off; p.n = a.n; p.Hh = Hh;
     const dim3 grid((a.n + 15) / 16, 2);
-    const size_t shmem = 16 * (4 * Hh + 4) * sizeof(float);
+    const size_t shmem = split ? 2 * 16 * (4 * Hh + 8) * sizeof(__bf16) : 16 * (4 * Hh + 4) * sizeof(float);
     const int tiles = Hh / 16;
     if (shmem > 48 * 1024) {   // 16 x (4*256+4) floats = 65.8 KB: above the default dynamic-LDS limit
         STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_bwd_kernel<2, 8>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_bwd_x3_kernel<2, 8>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     }
-    if (tiles > 8) hipLaunchKernelGGL((lstm_bwd_kernel<2, 8>), grid, dim3(512), shmem, s, p);
+    if (split) {
+        if (tiles > 8) hipLaunchKernelGGL((lstm_bwd_x3_kernel<2, 8>), grid, dim3(512), shmem, s, p);
+        else if (tiles > 4) hipLaunchKernelGGL((lstm_bwd_x3_kernel<1, 8>), grid, dim3(512), shmem, s, p);
+        else hipLaunchKernelGGL((lstm_bwd_x3_kernel<1, 4>), grid, dim3(256), shmem, s, p);
+    } else if (tiles > 8) hipLaunchKernelGGL((lstm_bwd_kernel<2, 8>), grid, dim3(512), shmem, s, p);
     else if (tiles > 4) hipLaunchKernelGGL((lstm_bwd_kernel<1, 8>), grid, dim3(512), shmem, s, p);
     else if (tiles > 2) hipLaunchKernelGGL((lstm_bwd_kernel<1, 4>), grid, dim3(256), shmem, s, p);
     else hipLaunchKernelGGL((lstm_bwd_kernel<1, 2>), grid, dim3(128), shmem, s, p);
