@@ -53,6 +53,14 @@ def make_batch(config, B, T, seed, device):
     return qs, video, question, q_lens
 
 
+# Memory-side bytes per launch of the dominant kernel from the PMC passes of tools/pmc_dominant.py
+# (profiles/r01_d_pmc_dominant.json): 2 x FETCH_SIZE (the gfx950 correction for 16-B-per-lane reads) + WRITE_SIZE, KiB.
+PMC_TRAFFIC_BYTES = {(131072, 1024, 2048): int((2 * 1558982.8 + 524288.0) * 1024)}
+PMC_TRAFFIC_NOTE = ('bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH doubled per the gfx950 '
+                    'correction; Infinity-Cache hits are counted, so the excess over the 1.62 GB algorithmic A+W+C is W tiles '
+                    're-read through L2 (8 MB of W per XCD > 4 MB L2); null for shapes that were not profiled')
+
+
 def time_dominant_kernel(model, B, T, device, iters=10):
     """HIP-event timing of the input-projection GEMM launch (M=B*T, N=4*Hh, K=V), same stream."""
     from stair_amd import ops
@@ -137,11 +145,18 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    # STAIR_DIST_BACKEND=gloo lets several ranks rehearse the N>1 path on one card (ranks wrap around the visible devices);
+    # the driver's runs use the default: nccl (= RCCL), one rank per GPU.
+    backend = os.environ.get('STAIR_DIST_BACKEND', 'nccl')
+    dev_index = local_rank if backend == 'nccl' else local_rank % max(1, torch.cuda.device_count())
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', dev_index))
+        else:
+            dist.init_process_group(backend)
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
 
     from stair_amd.module_net import VideoNMN      # raises if libstair_hip.so is missing
     config = dict(spec.DEFAULT_CONFIG)
@@ -223,7 +238,8 @@ def main():
             'roofline': {'bound': 'mfma', 'kernel': '%s (LSTM input projection, M=%d N=%d K=%d)' % (
                              'gemm_bf16x3_kernel' if split else 'gemm_f32_kernel', B * T, 2 * config['hidden_size'], config['video_size']),
                          'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / peak, 4), 'traffic': None, 'launch_ms': round(gemm_ms, 4),
+                         'frac': round(achieved / peak, 4), 'traffic': PMC_TRAFFIC_BYTES.get((B * T, 2 * config['hidden_size'], config['video_size'])),
+                         'traffic_note': PMC_TRAFFIC_NOTE, 'launch_ms': round(gemm_ms, 4),
                          'note': ('achieved = algorithmic 2MNK / launch time against the dense bf16 MFMA peak; the kernel executes 3 bf16 '
                                   'MFMAs per algorithmic product by design: executed %.0f TFLOP/s = %.3f of peak; the exact fp32-MFMA kernel '
                                   'peaks at 157.3' % (3 * achieved, 3 * achieved / peak)) if split else 'exact fp32 MFMA'},
@@ -234,7 +250,7 @@ def main():
         }
         if infer_qps is not None:
             line['inference_questions_per_s_per_gpu'] = round(infer_qps, 1)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:        # the CPU leg runs on rank 0 at N=1 only
             # the box gives one GPU a 16-core CPU share; more ATen threads than that only thrash
             ncores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
             torch.set_num_threads(ncores)

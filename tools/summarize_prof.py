@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 outputs under gpurun_out/ into the small summaries kept in profiles/.
+  summarize_prof.py stats <results.db> <out.csv>            per-kernel calls / total / average / share
+  summarize_prof.py pmc <counter_collection.csv>... <out.json>   mean counter value per kernel"""
+import sys, csv, json, sqlite3, collections
+
+
+def stats(db, out):
+    c = sqlite3.connect(db)
+    rows = c.execute('select name, total_calls, total_duration, average, percentage from top_kernels').fetchall()
+    with open(out, 'w', newline='') as f:
+        w = csv.writer(f)
+        w.writerow(['Name', 'Calls', 'TotalDurationUs', 'AverageUs', 'Percentage'])
+        for name, calls, tot, avg, pct in rows:
+            w.writerow([name[:160], calls, round(tot, 3), round(avg, 3), round(pct, 3)])
+
+
+def pmc(files, out):
+    res = []
+    for fn in files:
+        agg = collections.defaultdict(list)
+        grid = {}
+        for r in csv.DictReader(open(fn)):
+            if 'stair::' not in r['Kernel_Name']:
+                continue
+            k = (r['Kernel_Name'].split('(')[0], r['Counter_Name'])
+            agg[k].append(float(r['Counter_Value']))
+            grid[k] = int(r['Grid_Size'])
+        for (kern, ctr), v in agg.items():
+            res.append({'file': fn.split('/')[-2], 'kernel': kern, 'counter': ctr, 'dispatches': len(v), 'grid_threads': grid[(kern, ctr)],
+                        'mean_per_dispatch': sum(v) / len(v), 'min': min(v), 'max': max(v)})
+    json.dump(res, open(out, 'w'), indent=1)
+
+
+if __name__ == '__main__':
+    if sys.argv[1] == 'stats':
+        stats(sys.argv[2], sys.argv[3])
+    else:
+        pmc(sys.argv[2:-1], sys.argv[-1])
