@@ -201,6 +201,16 @@ int stair_l2normalize_fwd(const float *x, float *out, int32_t n, int32_t H, stai
 int stair_plan_build(stair_ctx *ctx, int32_t n, const int32_t *prog_off, const int32_t *tokens,
                      const int32_t *span_lo, const int32_t *span_hi, const int32_t *q_off, int32_t T,
                      int32_t flags, stair_plan **out);
+/* Same, for batches in which several questions ask about the same video (AGQA averages tens of questions per
+ * video, and module_net.py:74 re-encodes the video for each of them): `video` then holds n_videos distinct clips
+ * [n_videos, T, V] and video_of_question[q] names the clip of question q.  The video bi-LSTM (the largest single
+ * cost of the path) runs once per clip and every question's `video` token aliases the shared encoded map, so the
+ * results are those of stair_plan_build on the expanded batch.  video_of_question == NULL requires n_videos == n
+ * (identity).  Works for STAIR_PLAN_TRAIN too: gradients of all consumers accumulate into the clip's map. */
+int stair_plan_build_shared(stair_ctx *ctx, int32_t n, const int32_t *prog_off, const int32_t *tokens,
+                            const int32_t *span_lo, const int32_t *span_hi, const int32_t *q_off,
+                            int32_t n_videos, const int32_t *video_of_question, int32_t T,
+                            int32_t flags, stair_plan **out);
 void stair_plan_destroy(stair_plan *plan);
 
 /* Workspace the caller must provide to stair_plan_run (bytes, device) and its arena layout

@@ -210,7 +210,7 @@ struct Bucket {
 
 struct stair_plan {
     stair_config cfg;
-    int n = 0, T = 0, rows_q = 0, max_q = 0;
+    int n = 0, n_vid = 0, T = 0, rows_q = 0, max_q = 0;   // n_vid distinct videos (== n unless questions share them)
     std::vector<Node> nodes;
     std::vector<Bucket> buckets;
     std::vector<int32_t> roots;
@@ -265,8 +265,20 @@ std::string where(int q, int i, int tok) {
 extern "C" int stair_plan_build(stair_ctx *ctx, int32_t n, const int32_t *prog_off, const int32_t *tokens,
                                 const int32_t *span_lo, const int32_t *span_hi, const int32_t *q_off, int32_t T,
                                 int32_t flags, stair_plan **out) {
+    return stair_plan_build_shared(ctx, n, prog_off, tokens, span_lo, span_hi, q_off, n, nullptr, T, flags, out);
+}
+
+extern "C" int stair_plan_build_shared(stair_ctx *ctx, int32_t n, const int32_t *prog_off, const int32_t *tokens,
+                                       const int32_t *span_lo, const int32_t *span_hi, const int32_t *q_off,
+                                       int32_t n_videos, const int32_t *video_of_question, int32_t T,
+                                       int32_t flags, stair_plan **out) {
     STAIR_CHECK(ctx && prog_off && tokens && span_lo && span_hi && q_off && out, "null argument");
     STAIR_CHECK(n > 0 && T > 0, "n and T must be positive");
+    STAIR_CHECK(n_videos > 0 && (video_of_question || n_videos == n), "video_of_question is required when n_videos != n");
+    if (video_of_question)
+        for (int q = 0; q < n; ++q)
+            STAIR_CHECK(video_of_question[q] >= 0 && video_of_question[q] < n_videos,
+                        "video_of_question[" + std::to_string(q) + "] out of range");
     STAIR_CHECK(ctx->conv || T == ctx->cfg.max_video_length,
                 "Linear(T,T) Temporal nets need T == max_video_length (modules.py:266-277)");
     auto plp = std::make_unique<stair_plan>();
@@ -278,7 +290,8 @@ extern "C" int stair_plan_build(stair_ctx *ctx, int32_t n, const int32_t *prog_o
     const int ntok = prog_off[n];
     pl->nodes.assign(ntok, Node());
     pl->roots.assign(n, -1);
-    pl->n_map = n;   // map slot q = encoded video of question q
+    pl->n_vid = n_videos;
+    pl->n_map = n_videos;   // map slot v = encoded video v
     Builder B{pl};
     std::vector<int> stack;
 
@@ -470,7 +483,7 @@ extern "C" int stair_plan_build(stair_ctx *ctx, int32_t n, const int32_t *prog_o
                 }
             } else if (tok >= STAIR_KW_FORWARD && tok <= STAIR_KW_RELATIONS) {
                 if (tok == STAIR_KW_VIDEO) {        // module_net.py:103-104
-                    nd.kind = STAIR_VAL_MAP; nd.slot = q;
+                    nd.kind = STAIR_VAL_MAP; nd.slot = video_of_question ? video_of_question[q] : q;
                 } else {
                     nd.kind = STAIR_VAL_STR; nd.aux = tok;
                 }
@@ -524,8 +537,8 @@ extern "C" int stair_plan_build(stair_ctx *ctx, int32_t n, const int32_t *prog_o
         return off;
     };
     {
-        std::vector<int32_t> sv(n + 1), st(q_off, q_off + n + 1);
-        for (int q = 0; q <= n; ++q) sv[q] = q * T;
+        std::vector<int32_t> sv(pl->n_vid + 1), st(q_off, q_off + n + 1);
+        for (int v = 0; v <= pl->n_vid; ++v) sv[v] = v * T;
         pl->off_seqv = push(sv);
         pl->off_seqt = push(st);
         pl->off_roots = push(pl->roots);
@@ -557,8 +570,8 @@ extern "C" int stair_plan_build(stair_ctx *ctx, int32_t n, const int32_t *prog_o
     pl->o_att = take((int64_t)std::max(pl->n_att, 1) * T, 64);
     pl->o_tok = take((int64_t)pl->rows_q * H, 64);
     pl->o_qfeat = take((int64_t)n * H, 64);
-    pl->o_vhn = take((int64_t)n * H, 64);
-    pl->o_xpv = take((int64_t)n * T * 4 * H, 64);
+    pl->o_vhn = take((int64_t)pl->n_vid * H, 64);
+    pl->o_xpv = take((int64_t)pl->n_vid * T * 4 * H, 64);
     pl->o_xpt = take((int64_t)pl->rows_q * 4 * H, 64);
     pl->o_bias = take(2 * 4 * H, 64);
     pl->o_wpack = take(2 * 2 * H * H, 64);       // 8*Hh*Hh floats per encoder
@@ -598,9 +611,9 @@ extern "C" int stair_plan_build(stair_ctx *ctx, int32_t n, const int32_t *prog_o
     }
     if (pl->train) {
         const int64_t I = std::max(pl->maxI, 1), Vv = pl->maxV;
-        pl->o_cv = take((int64_t)n * T * H, 64);
+        pl->o_cv = take((int64_t)pl->n_vid * T * H, 64);
         pl->o_ct = take((int64_t)pl->rows_q * H, 64);
-        pl->o_hprev = take((int64_t)std::max(n * T, pl->rows_q) * H, 64);
+        pl->o_hprev = take((int64_t)std::max(pl->n_vid * T, pl->rows_q) * H, 64);
         pl->o_wt = take(ctx_weight_floats(ctx), 64);
         pl->o_gA = take(I * T * H, 64);
         pl->o_gB = take(I * T * H, 64);
@@ -802,7 +815,7 @@ extern "C" int stair_plan_run(stair_ctx *ctx, stair_plan *pl, const float *video
     // ---- encoders (module_net.py:74-75) ------------------------------------------------------
     {
         stair_lstm_args a = {};
-        a.x = video; a.ldx = V; a.rows = n * T; a.n = n; a.max_len = T; a.I = V; a.Hh = Hh;
+        a.x = video; a.ldx = V; a.rows = pl->n_vid * T; a.n = pl->n_vid; a.max_len = T; a.I = V; a.Hh = Hh;
         a.seq_off = didx + pl->off_seqv;
         for (int d = 0; d < 2; ++d) {
             a.w_ih[d] = W.enc[0][4 * d]; a.w_hh[d] = W.enc[0][4 * d + 1];
@@ -1165,7 +1178,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
     for (int e = 1; e >= 0; --e) {
         stair_lstm_bwd_args a = {};
         if (e == 0) {
-            a.x = video; a.ldx = V; a.rows = n * T; a.max_len = T; a.I = V; a.seq_off = didx + pl->off_seqv;
+            a.x = video; a.ldx = V; a.rows = pl->n_vid * T; a.max_len = T; a.I = V; a.seq_off = didx + pl->off_seqv;
             a.gates = ws + pl->o_xpv; a.cbuf = ws + pl->o_cv; a.out = map; a.d_out = g_map; a.d_hn = nullptr;
             a.whh_pack_ws = ws + pl->o_wpack;
         } else {
@@ -1173,7 +1186,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
             a.gates = ws + pl->o_xpt; a.cbuf = ws + pl->o_ct; a.out = ws + pl->o_tok; a.d_out = g_tok; a.d_hn = g_qfeat;
             a.whh_pack_ws = ws + pl->o_wpack + 2 * (int64_t)H * H;
         }
-        a.n = n; a.Hh = Hh; a.ldo = H; a.ldd = H; a.hprev_ws = ws + pl->o_hprev;
+        a.n = e == 0 ? pl->n_vid : n; a.Hh = Hh; a.ldo = H; a.ldd = H; a.hprev_ws = ws + pl->o_hprev;
         for (int d = 0; d < 2; ++d) {
             a.w_hh[d] = W.enc[e][4 * d + 1];
             a.dw_ih[d] = W.denc[e][4 * d]; a.dw_hh[d] = W.denc[e][4 * d + 1];
@@ -1264,8 +1277,8 @@ extern "C" int stair_plan_regions(stair_plan *pl, const stair_ctx *ctx, const ch
     add("att", pl->o_att, (int64_t)std::max(pl->n_att, 1) * T);
     add("tok", pl->o_tok, (int64_t)pl->rows_q * H);
     add("qfeat", pl->o_qfeat, n * H);
-    add("vhn", pl->o_vhn, n * H);
-    add("xpv", pl->o_xpv, n * T * 4 * H);
+    add("vhn", pl->o_vhn, (int64_t)pl->n_vid * H);
+    add("xpv", pl->o_xpv, (int64_t)pl->n_vid * T * 4 * H);
     add("xpt", pl->o_xpt, (int64_t)pl->rows_q * 4 * H);
     add("bias", pl->o_bias, 8 * H);
     add("wpack", pl->o_wpack, 4 * H * H);
@@ -1293,9 +1306,9 @@ extern "C" int stair_plan_regions(stair_plan *pl, const stair_ctx *ctx, const ch
             if (b.svExtra != pl->o_extra) add(p + "svExtra", b.svExtra, c);
         }
         const int64_t I = std::max(pl->maxI, 1), Vv = pl->maxV;
-        add("cv", pl->o_cv, n * T * H);
+        add("cv", pl->o_cv, (int64_t)pl->n_vid * T * H);
         add("ct", pl->o_ct, (int64_t)pl->rows_q * H);
-        add("hprev", pl->o_hprev, (int64_t)std::max<int64_t>(n * T, pl->rows_q) * H);
+        add("hprev", pl->o_hprev, (int64_t)std::max<int64_t>((int64_t)pl->n_vid * T, pl->rows_q) * H);
         add("wt", pl->o_wt, ctx_weight_floats(ctx));
         add("gA", pl->o_gA, I * T * H);
         add("gB", pl->o_gB, I * T * H);

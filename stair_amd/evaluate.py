@@ -20,6 +20,37 @@ def shard_indices(n, rank, world):
     return list(range(rank, n, world))
 
 
+def clip_key(d):
+    """What tells clips apart in a question list: `video_id` when present, else the feature buffer itself
+    (AGQADataset gives every question of a video the same tensor, dataset.py:183)."""
+    if 'video_id' in d:
+        return ('id', d['video_id'])
+    from .module_net import _clip_key
+    return _clip_key(d['video_features'])
+
+
+def shard_by_clip(questions, rank, world):
+    """Clip-aligned sharding for the per-video encoder cache: all questions of a clip go
+    to ONE rank, so no clip is encoded on two GPUs.  Clips are dealt largest-first to the least-loaded rank
+    (deterministic: ties by first appearance), which keeps the ranks within one clip's questions of each other.
+    Returns this rank's question indices, clip by clip."""
+    groups, order = {}, []
+    for i, d in enumerate(questions):
+        k = clip_key(d)
+        if k not in groups:
+            groups[k] = []
+            order.append(k)
+        groups[k].append(i)
+    load = [0] * world
+    mine = []
+    for k in sorted(order, key=lambda k: (-len(groups[k]), groups[k][0])):
+        r = min(range(world), key=lambda j: (load[j], j))
+        load[r] += len(groups[k])
+        if r == rank:
+            mine.append(groups[k])
+    return [i for g in sorted(mine, key=lambda g: g[0]) for i in g]
+
+
 def group_by_frames(batch):
     """The executor wants one frame count per launch batch; bucket a list of question dicts by T."""
     groups = {}
@@ -32,6 +63,11 @@ def predict(model, questions, batch_size=1024):
     """Top-1 answer ids (python ints) for a list of question dicts, in order."""
     preds = [None] * len(questions)
     for T, idxs in sorted(group_by_frames(questions).items()):
+        # questions of one clip next to each other, so a launch batch encodes each of its clips once
+        first = {}
+        for i in idxs:
+            first.setdefault(clip_key(questions[i]), i)
+        idxs = sorted(idxs, key=lambda i: (first[clip_key(questions[i])], i))
         for s in range(0, len(idxs), batch_size):
             chunk = idxs[s:s + batch_size]
             res = model.forward_batch([questions[i] for i in chunk])
@@ -48,11 +84,14 @@ def accuracy(preds, golds, unk_token_id):
 
 
 def evaluate(model, questions, unk_token_id, rank=0, world=1, batch_size=1024, predict_fn=None, preds_file=None,
-             id2word=None):
+             id2word=None, shard='round_robin'):
     """Sharded accuracy evaluation.  Every rank passes the SAME full question list; returns
     (accuracy, preds) on every rank.  `predict_fn(questions) -> list[int]` defaults to the HIP path
-    (tests substitute a CPU function to exercise the sharding logic without a GPU)."""
-    mine = shard_indices(len(questions), rank, world)
+    (tests substitute a CPU function to exercise the sharding logic without a GPU).
+    shard: 'round_robin'  or 'clip' (whole clips per rank, see shard_by_clip)."""
+    if shard not in ('round_robin', 'clip'):
+        raise ValueError("shard must be 'round_robin' or 'clip'")
+    mine = shard_indices(len(questions), rank, world) if shard == 'round_robin' else shard_by_clip(questions, rank, world)
     fn = predict_fn or (lambda qs: predict(model, qs, batch_size))
     local = fn([questions[i] for i in mine])
     if world > 1:

@@ -73,6 +73,15 @@ def _init_param(name, p, config):
             p.uniform_(-b, b)                                      # nn.Linear / nn.Conv1d default
 
 
+def _clip_key(x):
+    """Identity of a clip's feature buffer: same storage, offset and shape = same clip."""
+    if isinstance(x, torch.Tensor):
+        return ('t', x.untyped_storage().data_ptr(), x.storage_offset(), tuple(x.shape), tuple(x.stride()))
+    if isinstance(x, np.ndarray):
+        return ('n', x.__array_interface__['data'][0], x.shape, x.strides)
+    return ('o', id(x))
+
+
 class BatchResult:
     """Outputs of one batched pass plus read access to every intermediate program value."""
 
@@ -258,11 +267,21 @@ class VideoNMN(nn.Module):
         return hit
 
     # ---------------------------------------------------------------------------------------
-    def run_programs(self, programs, spans, video, question, q_lens, train=False):
+    def run_programs(self, programs, spans, video, question, q_lens, train=False, video_index=None):
         """Batched pass.  programs: list of token lists; spans: list of {pos: (lo, hi)}; video
-        [n,T,V] and question [sum(q_lens), E] float32 on the GPU.  Returns a BatchResult."""
+        [n,T,V] and question [sum(q_lens), E] float32 on the GPU.  Returns a BatchResult.
+
+        video_index (optional, [n] ints): question q asks about clip video[video_index[q]]; video is then
+        [n_videos,T,V] and each clip is encoded once instead of once per question (module_net.py:74 encodes per
+        question; the results are identical)."""
         n = len(programs)
-        if video.dim() != 3 or video.shape[0] != n:
+        if video_index is not None:
+            video_index = np.ascontiguousarray(np.asarray(video_index, dtype=np.int32))
+            if video_index.shape != (n,):
+                raise ValueError('video_index must have one entry per question')
+            if video.dim() != 3 or n == 0 or video_index.min() < 0 or video_index.max() >= video.shape[0]:
+                raise ValueError('video must be [n_videos, T, V] and video_index must point into it')
+        elif video.dim() != 3 or video.shape[0] != n:
             raise ValueError('video must be [n, T, V]')
         ops._req(video, 'video'); ops._req(question, 'question')
         T = video.shape[1]
@@ -289,7 +308,9 @@ class VideoNMN(nn.Module):
         def ip(a):
             return a.ctypes.data_as(C.POINTER(C.c_int32))
         plan = C.c_void_p()
-        check(lib.stair_plan_build(self._ctx, n, ip(prog_off), ip(tokens), ip(lo), ip(hi), ip(q_off), T, 1 if train else 0, C.byref(plan)))
+        check(lib.stair_plan_build_shared(self._ctx, n, ip(prog_off), ip(tokens), ip(lo), ip(hi), ip(q_off), video.shape[0],
+                                          ip(video_index) if video_index is not None else None, T, 1 if train else 0,
+                                          C.byref(plan)))
         try:
             info = PlanInfo()
             check(lib.stair_plan_get_info(plan, C.byref(info)))
@@ -307,16 +328,34 @@ class VideoNMN(nn.Module):
             raise
         return BatchResult(self, plan, info, ws, logits, pred, prog_off, programs, video, question)
 
-    def forward_batch(self, batch, train=False):
+    def forward_batch(self, batch, train=False, share_videos=True):
         """batch: list of question dicts in the reference layout (dataset.py:191-233), all with the
-        same number of frames.  Tensors may live on the host; they are moved once, packed."""
+        same number of frames.  Tensors may live on the host; they are moved once, packed.
+
+        Questions about the same clip share one encoder pass.  AGQADataset hands every question of a video the
+        same `self.video_feats[video_id]` tensor (dataset.py:183), so clips are told apart by the memory their
+        `video_features` occupy (or by a `video_id` entry, when every dict carries one)."""
         dev = next(self.parameters()).device
-        video = torch.stack([torch.as_tensor(d['video_features']) for d in batch]).to(dev, torch.float32).contiguous()
+        clips, index = [], None
+        if share_videos and len(batch) > 1:
+            by_id = all('video_id' in d for d in batch)
+            seen, index = {}, []
+            for d in batch:
+                key = d['video_id'] if by_id else _clip_key(d['video_features'])
+                if key not in seen:
+                    seen[key] = len(clips)
+                    clips.append(d['video_features'])
+                index.append(seen[key])
+            if len(clips) == len(batch):
+                index = None
+        else:
+            clips = [d['video_features'] for d in batch]
+        video = torch.stack([torch.as_tensor(c) for c in clips]).to(dev, torch.float32).contiguous()
         qs = [torch.as_tensor(d['question']) for d in batch]
         question = torch.cat(qs).to(dev, torch.float32).contiguous()
         return self.run_programs([d['nmn_program_list'] for d in batch],
                                  [d['prog_str_to_question_tokens'] for d in batch], video, question,
-                                 [q.shape[0] for q in qs], train=train)
+                                 [q.shape[0] for q in qs], train=train, video_index=index)
 
     # ---------------------------------------------------------------------------------------
     @torch.no_grad()

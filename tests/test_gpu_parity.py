@@ -202,6 +202,45 @@ def test_batch_composition_does_not_change_results(matmul):
     assert torch.equal(solo[0], full[5])
 
 
+def _questions_sharing_clips(config, seed, n, n_clips, T=None):
+    """n questions over n_clips clips: question q asks about clip q % n_clips and carries that clip's
+    feature tensor OBJECT, as AGQADataset does (dataset.py:183)."""
+    qs = synth.make_questions(config, seed, n, forms=synth.ALL_FORMS, T=T) if T else synth.make_questions(config, seed, n, forms=synth.ALL_FORMS)
+    clips = [torch.as_tensor(qs[c]['video_features']) for c in range(n_clips)]
+    for i, q in enumerate(qs):
+        q['video_features'] = clips[i % n_clips]
+    return qs
+
+
+def test_questions_sharing_a_clip_encode_it_once(matmul):
+    """the per-video encoder cache.  40 questions over 5 clips: the shared plan encodes 5 clips,
+    the expanded plan 40; logits are bit-identical, match the oracle run question by question, and the plan
+    really holds 35 fewer [T,H] maps."""
+    config = dict(spec.DEFAULT_CONFIG)
+    model = _model(config, 3)
+    w = oracle_weights(config, 3)
+    qs = _questions_sharing_clips(config, 21, 40, 5)
+    shared = model.forward_batch(qs)
+    expanded = model.forward_batch(qs, share_videos=False)
+    assert shared._video.shape[0] == 5 and expanded._video.shape[0] == 40
+    assert expanded.info.n_map - shared.info.n_map == 35
+    assert torch.equal(shared.logits.cpu(), expanded.logits.cpu())
+    assert torch.equal(shared.pred.cpu(), expanded.pred.cpu())
+    for qi in range(0, 40, 3):
+        r = O.forward(w, config, qs[qi])
+        assert _maxerr(shared.logits[qi], r['logits']) < 1e-4
+        assert int(shared.pred[qi]) == int(torch.argmax(r['logits']))
+    # explicit index form of the same call, clips in another order
+    video = torch.stack([qs[c]['video_features'] for c in (4, 3, 2, 1, 0)]).to(DEV)
+    question = torch.cat([torch.as_tensor(q['question']) for q in qs]).to(DEV)
+    res = model.run_programs([q['nmn_program_list'] for q in qs], [q['prog_str_to_question_tokens'] for q in qs], video,
+                             question, [q['question'].shape[0] for q in qs], video_index=[4 - (i % 5) for i in range(40)])
+    assert torch.equal(res.logits.cpu(), shared.logits.cpu())
+    with pytest.raises(ValueError):
+        model.run_programs([qs[0]['nmn_program_list']], [qs[0]['prog_str_to_question_tokens']], video, question[:qs[0]['question'].shape[0]],
+                           [qs[0]['question'].shape[0]], video_index=[5])
+
+
 def test_larger_batch_against_oracle(matmul):
     """128 random questions of all 12 forms vs the oracle run question by question."""
     config = dict(spec.DEFAULT_CONFIG)

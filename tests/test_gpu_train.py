@@ -92,6 +92,33 @@ def test_backward_matches_autograd_of_oracle(name, matmul):
     print('worst gradient error / tolerance:', worst)
 
 
+def test_shared_clip_gradients_equal_expanded_batch(matmul):
+    """Training plan over questions that share clips (stair_plan_build_shared): every consumer's gradient
+    accumulates into the one encoded map, so parameter gradients equal those of the expanded batch (up to the
+    order of the float atomics) -- including the video encoder's, which sees each clip once instead of 4 times."""
+    z, meta = load_golden('tiny_conv')
+    config = meta['config']
+    qs = [question_for(meta, q) for q in meta['questions']]
+    clips = [torch.as_tensor(qs[c]['video_features']) for c in range(3)]
+    for i, q in enumerate(qs):
+        q['video_features'] = clips[i % 3]
+    model = _model(config, meta['seed'])
+    grads = []
+    for share in (False, True):
+        for p in model.parameters():
+            p.grad = torch.zeros_like(p)
+        res = model.forward_batch(qs, train=True, share_videos=share)
+        assert res._video.shape[0] == (3 if share else len(qs))
+        answers = torch.tensor([q['answer'] for q in qs], dtype=torch.int32, device=DEV)
+        losses = res.backward(answers, 1.0 / len(qs))
+        grads.append(({n: p.grad.clone() for n, p in model.named_parameters()}, losses.clone()))
+    (ge, le), (gs, ls) = grads
+    assert torch.equal(le, ls)
+    for n in ge:
+        scale = max(float(ge[n].abs().max()), 1e-3)
+        assert float((ge[n] - gs[n]).abs().max()) < (2e-5 if matmul == 'f32' else 1e-4) * scale, n
+
+
 def test_trainer_steps_match_torch_adam(matmul):
     """Three optimizer steps (different program mixes per window, so some modules are untouched at first)
     against torch.optim.Adam + LambdaLR on the oracle's weights, zero_grad(set_to_none=False) = torch 1.13."""

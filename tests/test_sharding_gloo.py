@@ -68,6 +68,29 @@ def test_accuracy_rule_ignores_unk_gold():
     assert E.shard_indices(7, 1, 3) == [1, 4]
 
 
+def test_clip_aligned_sharding_keeps_clips_whole_and_ranks_balanced():
+    """shard_by_clip: disjoint cover, no clip on two ranks, loads within the largest clip."""
+    from stair_amd import evaluate as E
+    import numpy as np
+    rs = np.random.RandomState(0)
+    clips = [np.zeros((4, 8), dtype=np.float32) for _ in range(11)]
+    owner = [int(c) for c in rs.choice(11, size=97, p=np.arange(1, 12) / 66.0)]
+    qs = [{'video_features': clips[c], 'qid': i} for i, c in enumerate(owner)]
+    for world in (1, 2, 3, 8):
+        shards = [E.shard_by_clip(qs, r, world) for r in range(world)]
+        assert sorted(i for s in shards for i in s) == list(range(97))
+        clip_rank = {}
+        for r, s in enumerate(shards):
+            for i in s:
+                assert clip_rank.setdefault(owner[i], r) == r
+        biggest = max(owner.count(c) for c in set(owner))
+        assert max(map(len, shards)) - min(map(len, shards)) <= biggest
+    # explicit ids take precedence over buffer identity
+    qs2 = [{'video_features': np.zeros((4, 8), dtype=np.float32), 'video_id': 'v%d' % (i % 3)} for i in range(9)]
+    s0, s1 = E.shard_by_clip(qs2, 0, 2), E.shard_by_clip(qs2, 1, 2)
+    assert {i % 3 for i in s0}.isdisjoint({i % 3 for i in s1}) and len(s0) + len(s1) == 9
+
+
 def _grad_worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
