@@ -187,6 +187,15 @@ int stair_l2normalize_fwd(const float *x, float *out, int32_t n, int32_t H, stai
 
 /* ---- program plans: the batched stack interpreter (module_net.py:94-138) -------------------- */
 
+/* Rank C candidate representations by cosine similarity to each query row and keep the k best
+ * (/root/reference/evaluate.py:95-98: nn.CosineSimilarity()(result, filter_ans_reps), argsort descending, [:10]).
+ * queries: row q_idx[i] (or i when q_idx is NULL) of a matrix with leading dimension ldq, H floats each; keys [C,H]
+ * contiguous; key_invnorm_ws [C] scratch.  out_idx/out_sim [n,k], best first; equal similarities keep the lower index
+ * (torch's argsort leaves that order unspecified).  C <= 1024, 1 <= k <= C. */
+int stair_cosine_topk(const float *queries, int64_t ldq, const int32_t *q_idx, const float *keys,
+                      float *key_invnorm_ws, int32_t n, int32_t C, int32_t H, int32_t k, int32_t *out_idx,
+                      float *out_sim, stair_stream stream);
+
 /* Compile n questions' prefix programs into a launch plan: nodes are levelled as
  * utils/program_parser.py:307-321 (stat_module_levels) and all nodes of one (level, module,
  * keyword-variant) go into one packed launch.  Host arrays:

@@ -373,3 +373,37 @@ def module_levels(program):
             stack.append(lvl)
             levels.append(lvl)
     return levels[::-1]
+
+
+# ------------------------------------------------------------------------------------------
+# evaluate.py:65-117 get_filter_text_results -- pinned by tests/golden/filter_text.json (reference output)
+# ------------------------------------------------------------------------------------------
+def children_of(program):
+    """utils/program_parser.py:182-201: operand positions of every token, first positional argument first."""
+    children, stack = [[] for _ in program], []
+    for i in range(len(program) - 1, -1, -1):
+        if program[i] in ARITY:
+            children[i] = [stack.pop() for _ in range(ARITY[program[i]])]
+        stack.append(i)
+    return children
+
+
+def filter_text_results(w, config, questions, vocab, phrase_embeddings, pretrain_modules=frozenset(), top=10):
+    """{qa_id: {program_idx: (level, keyword text, top phrases)}} for every Filter node, question by question."""
+    reps = torch.stack([l2normalize(encode_question(w, torch.as_tensor(e))[1]) for e in phrase_embeddings])   # :66-76
+    out = {}
+    for n, d in enumerate(questions):
+        prog = d['nmn_program_list']
+        pidx = d.get('nmn_program_idx') or list(range(len(prog)))
+        steps = forward(w, config, d, return_res_by_step=False, return_result_of_each_step=True,
+                        pretrain_modules=pretrain_modules)['result_of_each_step']
+        levels, children = module_levels(prog), children_of(prog)
+        entry = {}
+        for i, tok in enumerate(prog):
+            if tok != 'Filter':
+                continue
+            sims = torch.nn.functional.cosine_similarity(steps[i][1].unsqueeze(0), reps)                      # :95
+            order = torch.argsort(sims, descending=True)[:top]
+            entry[pidx[i]] = (levels[i], prog[children[i][1]].replace('_', ' '), [vocab[int(c)] for c in order])
+        out[d.get('qa_id', n)] = entry
+    return out

@@ -92,6 +92,8 @@ SIGNATURES = [
     ('stair_temporal_relate_fwd', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                             C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p),
                                             C.c_void_p]),
+    ('stair_cosine_topk', C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                    C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     ('stair_l2normalize_fwd', C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     ('stair_plan_build', C.c_int, [C.c_void_p, C.c_int32, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p,
                                    C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),

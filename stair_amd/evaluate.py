@@ -111,3 +111,45 @@ def evaluate(model, questions, unk_token_id, rank=0, world=1, batch_size=1024, p
         json.dump({'preds': [w(p) for p in preds], 'golds': [w(g) for g in golds],
                    'qa_ids': [q.get('qa_id') for q in questions]}, open(preds_file, 'w'))
     return acc, preds
+
+
+def filter_text_results(model, questions, filter_vocab, phrase_embeddings, batch_size=1024, top=10):
+    """Batched counterpart of /root/reference/evaluate.py:65-117 (get_filter_text_results): for every `Filter`
+    node of every question, the `top` phrases of `filter_vocab` whose text-encoder representation is most similar
+    (cosine) to the node's output.  phrase_embeddings[i] = word embeddings [L_i, E] of filter_vocab[i] (the reference
+    gets them from the dataset's GloVe table, dataset.py:248-255).  Returns
+        {qa_id: {program_idx: (level, keyword_text, [top phrases])}}
+    with level as stat_module_levels and keyword_text the Filter's second operand, as the reference records them.
+    One stair_cosine_topk launch ranks all Filter nodes of a batch; questions whose program holds no Filter map to {}."""
+    from . import frontend, ops
+    import numpy as np
+    if len(filter_vocab) != len(phrase_embeddings):
+        raise ValueError('one embedding per vocabulary phrase')
+    reps = model.encode_phrases(phrase_embeddings)                      # [C, H]
+    H = model.config['hidden_size']
+    out = {}
+    for T, idxs in sorted(group_by_frames(questions).items()):
+        for s in range(0, len(idxs), batch_size):
+            chunk = [questions[i] for i in idxs[s:s + batch_size]]
+            res = model.forward_batch(chunk)
+            where, slots = [], []
+            for qi, d in enumerate(chunk):
+                prog = d['nmn_program_list']
+                out[d.get('qa_id', idxs[s + qi])] = {}
+                if 'Filter' not in prog:
+                    continue
+                levels = frontend.module_levels(prog)
+                children, _ = frontend.children_and_parents(prog)
+                pidx = d.get('nmn_program_idx') or list(range(len(prog)))
+                for i, tok in enumerate(prog):
+                    if tok == 'Filter':
+                        where.append((d.get('qa_id', idxs[s + qi]), pidx[i], levels[i], prog[children[i][1]].replace('_', ' ')))
+                        slots.append(res.node_info(qi, i)[1])
+            if not slots:
+                continue
+            vec = res._arena(res.info.vec_off, res.info.n_vec, H)
+            q_idx = torch.tensor(np.asarray(slots, dtype=np.int32), device=vec.device)
+            best, _ = ops.cosine_topk(vec, reps, min(top, len(filter_vocab)), q_idx=q_idx)
+            for (qa, pi, lvl, kw), row in zip(where, best.cpu().tolist()):
+                out[qa][pi] = (lvl, kw, [filter_vocab[c] for c in row])
+    return out

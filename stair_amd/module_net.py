@@ -22,7 +22,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from . import ops, spec
+from . import frontend, ops, spec
 from ._lib import PlanInfo, StairConfig, StairError, check, lib
 
 VAL_STR, VAL_VEC, VAL_MAP, VAL_ATT, VAL_FRAME, VAL_PAIR = range(6)
@@ -220,7 +220,7 @@ class VideoNMN(nn.Module):
         self._bound = {}
         self._gbound = {}
         self._ws = None
-        self._prog_cache = {}
+        self._programs = frontend.ProgramCache()
 
     def __del__(self):
         ctx = self.__dict__.get('_ctx')
@@ -257,15 +257,6 @@ class VideoNMN(nn.Module):
             self._ws = torch.empty(int(n * 1.25), dtype=torch.float32, device=device)
         return self._ws
 
-    def _encode_program(self, program):
-        key = tuple(program)
-        hit = self._prog_cache.get(key)
-        if hit is None:
-            codes = np.asarray(spec.encode_program(program), dtype=np.int32)
-            hit = (codes, np.nonzero(codes == spec.TOK_SPAN)[0])
-            self._prog_cache[key] = hit
-        return hit
-
     # ---------------------------------------------------------------------------------------
     def run_programs(self, programs, spans, video, question, q_lens, train=False, video_index=None):
         """Batched pass.  programs: list of token lists; spans: list of {pos: (lo, hi)}; video
@@ -286,22 +277,9 @@ class VideoNMN(nn.Module):
         ops._req(video, 'video'); ops._req(question, 'question')
         T = video.shape[1]
         self._bind_weights()
-        enc = [self._encode_program(p) for p in programs]
-        prog_off = np.zeros(n + 1, dtype=np.int32)
-        np.cumsum([len(e[0]) for e in enc], out=prog_off[1:])
-        tokens = np.concatenate([e[0] for e in enc])
-        lo = np.zeros(tokens.shape[0], dtype=np.int32)
-        hi = np.zeros(tokens.shape[0], dtype=np.int32)
-        for q, (codes, pos) in enumerate(enc):
-            sp, base = spans[q], prog_off[q]
-            for i in pos:
-                try:
-                    s, e = sp[int(i)]
-                except KeyError:
-                    raise KeyError(int(i))          # the reference fails the same way, module_net.py:127
-                lo[base + i], hi[base + i] = s, e
-        q_off = np.zeros(n + 1, dtype=np.int32)
-        np.cumsum(np.asarray(q_lens, dtype=np.int64), out=q_off[1:])
+        cache = self._programs
+        compiled = [cache.get(p, sp) for p, sp in zip(programs, spans)]       # packed once per distinct (program, spans)
+        prog_off, tokens, lo, hi, q_off = frontend.pack_batch(compiled, q_lens)
         if question.shape[0] != int(q_off[-1]):
             raise ValueError('question rows (%d) != sum(q_lens) (%d)' % (question.shape[0], int(q_off[-1])))
 
@@ -429,6 +407,19 @@ class VideoNMN(nn.Module):
         off = torch.tensor([0, x.shape[0]], dtype=torch.int32, device=dev)
         out, h_n = ops.lstm_bidir(x, off, x.shape[0], self._lstm_weights('text_encoder'))
         return out, h_n[0]
+
+    @torch.no_grad()
+    def encode_phrases(self, phrase_embeddings):
+        """Batched form of evaluate.py:66-76 (get_kw_representations): every phrase [L_i, E] through the text
+        encoder in one ragged pass, sentence feature -> contrastive_head.  Returns [C, H] L2-normalised reps."""
+        dev = next(self.parameters()).device
+        xs = [torch.as_tensor(p).to(dev, torch.float32).reshape(-1, self.config['text_size']) for p in phrase_embeddings]
+        lens = [int(x.shape[0]) for x in xs]
+        if not xs or min(lens) <= 0:
+            raise ValueError('every phrase needs at least one word embedding')
+        off = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32, device=dev)
+        _, h_n = ops.lstm_bidir(torch.cat(xs).contiguous(), off, max(lens), self._lstm_weights('text_encoder'))
+        return ops.l2normalize(h_n)
 
     def encode_video(self, video_feat):
         """module_net.py:160-163 -> [T,H]."""

@@ -162,6 +162,24 @@ def cosine_attn(F, f_idx, Kmat, k_idx, npairs, T, H, out=None, out_idx=None):
     return out
 
 
+def cosine_topk(queries, keys, k, q_idx=None, n=None):
+    """k best rows of `keys` [C,H] by cosine similarity for each query row (evaluate.py:95-98).  queries [rows,H];
+    q_idx (int32, optional) picks the rows to rank.  Returns (idx [n,k] int32, sim [n,k]) best first."""
+    _req(queries, 'queries'); _req(keys, 'keys')
+    if queries.dim() != 2 or keys.dim() != 2 or queries.shape[1] != keys.shape[1]:
+        raise ValueError('queries [rows,H] and keys [C,H] must share H')
+    if q_idx is not None:
+        _req(q_idx, 'q_idx', torch.int32)
+    n = (q_idx.shape[0] if q_idx is not None else queries.shape[0]) if n is None else n
+    Cn, H = keys.shape
+    idx = torch.empty(n, k, device=queries.device, dtype=torch.int32)
+    sim = torch.empty(n, k, device=queries.device, dtype=torch.float32)
+    ws = torch.empty(Cn, device=queries.device, dtype=torch.float32)
+    check(lib.stair_cosine_topk(_ptr(queries), queries.stride(0), _ptr(q_idx), _ptr(keys), _ptr(ws), n, Cn, H, k,
+                                _ptr(idx), _ptr(sim), _stream()))
+    return idx, sim
+
+
 def temporal_relate(att, att_idx, att_k, n, T, mode, conv, ksize, w6):
     """Temporal relate nets; att [rows,T]; returns r [n,T]."""
     _req(att, 'att')

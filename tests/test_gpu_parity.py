@@ -255,6 +255,73 @@ def test_larger_batch_against_oracle(matmul):
         assert int(res.pred[qi]) == int(torch.argmax(r['logits']))
 
 
+@pytest.mark.parametrize('n,C,H,k', [(1, 5, 64, 5), (37, 214, 512, 10), (300, 1024, 256, 3), (9, 70, 96, 10)])
+def test_cosine_topk_matches_torch(n, C, H, k):
+    """stair_cosine_topk == argsort(CosineSimilarity) (evaluate.py:95-97): indices exact, similarities to 2e-6;
+    row gather through q_idx; exact ties keep the lower index."""
+    from stair_amd import ops
+    g = torch.Generator().manual_seed(n + C)
+    rows = torch.randn(n + 3, H, generator=g)
+    keys = torch.randn(C, H, generator=g)
+    keys[C // 2] = keys[0]                                        # an exact tie between candidates 0 and C//2
+    keys[-1] = 0.0                                                # zero vector: cosine 0 through the eps clamp
+    pick = torch.randperm(n + 3, generator=g)[:n].to(torch.int32)
+    idx, sim = ops.cosine_topk(rows.to(DEV), keys.to(DEV), k, q_idx=pick.to(DEV))
+    ref = torch.nn.functional.cosine_similarity(rows[pick.long()].double().unsqueeze(1), keys.double().unsqueeze(0), dim=2)
+    idx, sim = idx.cpu().long(), sim.cpu().double()
+    assert float((sim - ref.gather(1, idx)).abs().max()) < 2e-6   # the reported similarity is that of the reported index
+    top = torch.sort(ref, dim=1, descending=True).values[:, :k]
+    assert float((sim - top).abs().max()) < 2e-6                  # ... and they are the k largest, best first
+    assert bool((sim[:, :-1] >= sim[:, 1:]).all()) if k > 1 else True
+    for r in range(n):
+        assert len(set(idx[r].tolist())) == k
+        row = idx[r].tolist()
+        if 0 in row and C // 2 in row:
+            assert row.index(0) + 1 == row.index(C // 2)          # tie: lower index first, adjacent
+    full, _ = ops.cosine_topk(rows.to(DEV), keys.to(DEV), k)     # without the gather
+    assert full.shape == (n + 3, k)
+    with pytest.raises(Exception):
+        ops.cosine_topk(rows.to(DEV), keys.to(DEV), C + 1)
+
+
+def test_filter_text_results_match_reference():
+    """stair_amd.evaluate.filter_text_results on the HIP path == the reference's get_filter_text_results output
+    (tests/golden/filter_text.json).  A rank may differ from the fixture only between phrases whose reference
+    similarities are closer than 1e-5 (none are, in this fixture)."""
+    import json, os
+    from stair_amd import evaluate as E
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'filter_text.json')))
+    z, meta = load_golden(gold['config'])
+    config = meta['config']
+    model = _model(config, meta['seed'], PRETRAIN_MODULES)
+    qs = []
+    for q in meta['questions']:
+        d = question_for(meta, q)
+        d['qa_id'] = 'q%d' % q['qid']
+        qs.append(d)
+    embs = [synth.class_embedding(config, meta['seed'], c) for c in range(len(gold['vocab']))]
+    got = E.filter_text_results(model, qs, gold['vocab'], embs, batch_size=5)
+    assert sorted(got) == sorted(gold['results'])
+    n = 0
+    for qa, entry in gold['results'].items():
+        assert sorted(str(k) for k in got[qa]) == sorted(entry)
+        for pidx, ref in entry.items():
+            level, kw, top = got[qa][int(pidx)]
+            assert (level, kw) == (ref['level'], ref['keyword'])
+            for a, b, in zip(top, ref['top']):
+                if a != b:
+                    sa, sb = ref['sims'][ref['top'].index(a)], ref['sims'][ref['top'].index(b)]
+                    assert abs(sa - sb) < 1e-5, (qa, pidx, a, b)
+            n += 1
+    assert n == 16
+    # phrase representations: batched ragged text-encoder pass == the reference's one-by-one loop (evaluate.py:66-76)
+    w = oracle_weights(config, meta['seed'])
+    reps = model.encode_phrases(embs).cpu()
+    for c in (0, 7, 29):
+        ref = O.l2normalize(O.encode_question(w, torch.as_tensor(embs[c]))[1])
+        assert _maxerr(reps[c], ref) < 1e-5          # unit vectors, split-precision GEMM in the input projection
+
+
 def test_missing_gpu_tensor_fails_loudly():
     from stair_amd import ops
     with pytest.raises(RuntimeError):
