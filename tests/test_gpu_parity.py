@@ -322,6 +322,37 @@ def test_filter_text_results_match_reference():
         assert _maxerr(reps[c], ref) < 1e-5          # unit vectors, split-precision GEMM in the input projection
 
 
+def test_on_disk_dataset_to_logits():
+    """tests/golden/agqa_mini (npy clips, question records, GloVe text, vocab) -> stair_amd.data -> packed batch ->
+    HIP path, against the oracle question by question; the packed path, forward_batch and evaluate.predict agree."""
+    import json, os
+    from stair_amd import data as D, evaluate as E
+    mini = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'agqa_mini')
+    recs = D.filter_records(D.load_question_records(os.path.join(mini, 'records.json')), 'valid')
+    clips = D.load_clip_features(os.path.join(mini, 'clips'), {r['video_id'] for r in recs}, 10)
+    vocab = D.load_answer_vocab(os.path.join(mini, 'vocab.json'))
+    ds = D.AGQAQuestions(recs, clips, D.load_glove(os.path.join(mini, 'glove.txt')), vocab, split='valid',
+                         video_secs=json.load(open(os.path.join(mini, 'video_secs.json'))), tokenize=str.split)
+    config = dict(spec.DEFAULT_CONFIG, hidden_size=64, video_size=16, text_size=8, answer_vocab_length=ds.answer_vocab_length(),
+                  max_video_length=40, object_types=10)
+    model = _model(config, 5)
+    w = oracle_weights(config, 5)
+    items = [ds[i] for i in range(len(ds))]
+    preds = E.predict(model, items, batch_size=4)
+    for T, idxs in E.group_by_frames(items).items():
+        group = [items[i] for i in idxs]
+        b = D.pack_questions(group, DEV)
+        res = model.run_programs(b.programs, b.spans, b.video, b.question, b.q_lens, video_index=b.video_index)
+        assert b.n_clips == 1 and tuple(b.video.shape) == (1, T, 16)
+        assert torch.equal(res.logits.cpu(), model.forward_batch(group).logits.cpu())
+        for j, i in enumerate(idxs):
+            r = O.forward(w, config, items[i])
+            assert _maxerr(res.logits[j], r['logits']) < 1e-4
+            assert preds[i] == int(torch.argmax(r['logits']))
+    acc, _ = E.evaluate(model, items, unk_token_id=vocab['word2id']['<UNK>'], batch_size=3, shard='clip')
+    assert acc == E.accuracy(preds, [int(it['answer']) for it in items], vocab['word2id']['<UNK>'])
+
+
 def test_missing_gpu_tensor_fails_loudly():
     from stair_amd import ops
     with pytest.raises(RuntimeError):
