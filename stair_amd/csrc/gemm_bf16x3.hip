@@ -14,6 +14,7 @@
 // fragments).  The TN variant (dW = dZ^T X) transposes 8x4 blocks in registers while staging, so its MFMA
 // phase is the same code.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -75,6 +76,27 @@ __device__ __forceinline__ void mfma_chunk(const __bf16 *lds, int buf, int wm, i
         acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh1, acc01, 0, 0, 0);
         acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh0, acc10, 0, 0, 0);
         acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh1, acc11, 0, 0, 0);
+    }
+}
+
+// the eight-wave kernel's chunk: wave tile 64 x 32 = two 32 x 32 tiles sharing the B fragments
+__device__ __forceinline__ void mfma_chunk_w8(const __bf16 *lds, int buf, int wm, int wn, int r, int h, f32x16 &acc00,
+                                              f32x16 &acc10) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int kq = 2 * s + h;
+        const bf16x8 ah0 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 0, 0, kq, wm * 64 + r));
+        const bf16x8 ah1 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 0, 0, kq, wm * 64 + 32 + r));
+        const bf16x8 al0 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 0, 1, kq, wm * 64 + r));
+        const bf16x8 al1 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 0, 1, kq, wm * 64 + 32 + r));
+        const bf16x8 bh0 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 1, 0, kq, wn * 32 + r));
+        const bf16x8 bl0 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 1, 1, kq, wn * 32 + r));
+        acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh0, acc00, 0, 0, 0);      // small terms first
+        acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh0, acc10, 0, 0, 0);
+        acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl0, acc00, 0, 0, 0);
+        acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl0, acc10, 0, 0, 0);
+        acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh0, acc00, 0, 0, 0);
+        acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh0, acc10, 0, 0, 0);
     }
 }
 
@@ -215,6 +237,142 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(XParams p) {
     }
 }
 
+// Eight-wave form of the same tile for large launches: waves 2 (M) x 4 (N), each 64 x 32 of the 128 x 128 tile,
+// so a wave carries 32 accumulator and 16 staging registers per set instead of 64 and 32.  At <= 128 VGPRs two
+// workgroups (16 waves, 4 per SIMD) share a CU, twice the four-wave kernel's, which is what hides the staging
+// stalls: rocprof counted the MFMA pipe 43 % busy with 2 waves per SIMD (profiles/r01_e_pmc_gemm.json).
+template <int ACT>
+__global__ __launch_bounds__(512, 2) void gemm_bf16x3_w8_kernel(XParams p) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 xlds[];
+    const stair_gemm_args &a = p.a;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int r = lane & 31, h = lane >> 5;
+
+    const int nb = p.tilesM * p.tilesN;
+    const int bid = blockIdx.x;
+    const int qd = nb >> 3, rm = nb & 7, xcd = bid & 7, loc = bid >> 3;
+    const int logical = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
+    const int tm = logical / p.tilesN, tn = logical - tm * p.tilesN;
+    const int m0 = tm * 128, n0 = tn * 128;
+    const int R = a.rows_per_group, K = a.K;
+
+    // staging units: (row, kq) with row = tid >> 2 (0..127), kq = tid & 3
+    const int kq = tid & 3, ra_ = tid >> 2;
+    const float *aptr[1];
+    const float *wptr[1];
+    float rs[1];
+#pragma unroll
+    for (int i = 0; i < 1; ++i) {
+        const int m = min(m0 + ra_ + 64 * i, p.M - 1);
+        const int g = m / R, rr = m - g * R;
+        const int64_t gi = a.a_gidx ? a.a_gidx[g] : g;
+        aptr[i] = a.A + gi * a.a_gstride + (int64_t)rr * a.lda;
+        rs[i] = 1.0f;
+        if (a.row_scale) rs[i] = a.row_scale[(a.rs_gidx ? a.rs_gidx[g] : g) * a.rs_gstride + rr];
+        const int n = min(n0 + ra_ + 64 * i, a.N - 1);
+        wptr[i] = a.W + (int64_t)n * a.ldw;
+    }
+
+    f32x16 acc00, acc10;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc00[e] = acc10[e] = 0.0f;
+
+    // Two staging register sets: the loads of chunks c+1 and c+2 are in flight while chunk c is multiplied
+    // (one chunk in flight left the kernel latency bound at ~2 us per chunk against ~0.7 us of MFMA work).
+    v4f va[2][1][2], vb[2][1][2];       // [set][row][k half]
+    float km[2][2];
+#define X_GLOAD(set, k0)                                                       \
+    {                                                                          \
+        const int kraw = (k0) + 8 * kq;                                        \
+        const int ka = max(0, min(kraw, K - 4)), kb = max(0, min(kraw + 4, K - 4));   \
+        km[set][0] = kraw < K ? 1.0f : 0.0f;                                   \
+        km[set][1] = kraw + 4 < K ? 1.0f : 0.0f;                               \
+        _Pragma("unroll") for (int i_ = 0; i_ < 1; ++i_) {                     \
+            va[set][i_][0] = *(gv4p)(aptr[i_] + ka); va[set][i_][1] = *(gv4p)(aptr[i_] + kb);   \
+            vb[set][i_][0] = *(gv4p)(wptr[i_] + ka); vb[set][i_][1] = *(gv4p)(wptr[i_] + kb);   \
+        }                                                                      \
+    }
+#define X_LSTORE(set, buf)                                                                              \
+    {                                                                                                   \
+        _Pragma("unroll") for (int i_ = 0; i_ < 1; ++i_) {                                              \
+            bf16x8 hi_, lo_;                                                                            \
+            split8(va[set][i_][0] * km[set][0], va[set][i_][1] * km[set][1], rs[i_], hi_, lo_);         \
+            *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, 0, 0, kq, ra_ + 64 * i_)) = hi_;            \
+            *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, 0, 1, kq, ra_ + 64 * i_)) = lo_;            \
+            split8(vb[set][i_][0], vb[set][i_][1], 1.0f, hi_, lo_);                                     \
+            *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, 1, 0, kq, ra_ + 64 * i_)) = hi_;            \
+            *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, 1, 1, kq, ra_ + 64 * i_)) = lo_;            \
+        }                                                                                               \
+    }
+
+    // Chunks past K are not skipped but zeroed (X_GLOAD clamps the address and sets the A mask to 0): every
+    // load stays unconditional, which lets hipcc keep counted vmcnt waits (a load inside a branch forces vmcnt(0)
+    // at the join and drains the second register set).
+    const int nchunks = (K + XBK - 1) / XBK;
+    X_GLOAD(0, 0);
+    X_GLOAD(1, XBK);
+    X_LSTORE(0, 0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; c += 2) {
+        // chunk c lives in LDS buffer 0, chunk c+1 in register set 1
+        X_GLOAD(0, (c + 2) * XBK);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_chunk_w8(xlds, 0, wm, wn, r, h, acc00, acc10);
+        __builtin_amdgcn_sched_barrier(0);
+        X_LSTORE(1, 1);
+        __syncthreads();
+        X_GLOAD(1, (c + 3) * XBK);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_chunk_w8(xlds, 1, wm, wn, r, h, acc00, acc10);
+        __builtin_amdgcn_sched_barrier(0);
+        X_LSTORE(0, 0);
+        __syncthreads();
+    }
+#undef X_GLOAD
+#undef X_LSTORE
+
+    long long *rowoff = reinterpret_cast<long long *>(xlds);
+    if (tid < 128) {
+        const int m = m0 + tid;
+        long long off = -1;
+        if (m < p.M) {
+            const int g = m / R, rr = m - g * R;
+            const int64_t gi = a.c_gidx ? a.c_gidx[g] : g;
+            off = gi * a.c_gstride + (int64_t)rr * a.ldc;
+        }
+        rowoff[tid] = off;
+    }
+    __syncthreads();
+    __attribute__((address_space(1))) float *Cg = (__attribute__((address_space(1))) float *)a.C;
+#pragma unroll
+    for (int nt = 0; nt < 1; ++nt) {
+        const int n = n0 + wn * 32 + r;
+        if (n >= a.N) continue;
+        const float b = a.bias ? a.bias[n] : 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const f32x16 &acc = mt == 0 ? acc00 : acc10;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rowl = wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const long long off = rowoff[rowl];
+                if (off < 0) continue;
+                float v = acc[e] + b;
+                if (ACT == 1) v = fmaxf(v, 0.0f);
+                if (ACT == 2) v = sigmoid_acc(v);
+                if (a.accumulate) unsafeAtomicAdd(a.C + off + n, v);
+                else Cg[off + n] = v;
+            }
+        }
+    }
+}
+
+static bool gemm_w8_enabled() {
+    static const bool on = [] { const char *e = getenv("STAIR_GEMM_W8"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 int launch_gemm_bf16x3(const stair_gemm_args &a, hipStream_t s) {
     XParams p;
     p.a = a;
@@ -225,6 +383,15 @@ int launch_gemm_bf16x3(const stair_gemm_args &a, hipStream_t s) {
     p.tilesN = (a.N + 127) / 128;
     const dim3 grid(p.tilesM * p.tilesN), block(256);
     const size_t shmem = 2 * 2 * 2 * IMG * sizeof(__bf16);
+    if (gemm_w8_enabled() && p.tilesM * p.tilesN >= 512) {          // enough tiles for two 8-wave workgroups on every CU
+        switch (a.act) {
+            case 0: hipLaunchKernelGGL(gemm_bf16x3_w8_kernel<0>, grid, dim3(512), shmem, s, p); break;
+            case 1: hipLaunchKernelGGL(gemm_bf16x3_w8_kernel<1>, grid, dim3(512), shmem, s, p); break;
+            default: hipLaunchKernelGGL(gemm_bf16x3_w8_kernel<2>, grid, dim3(512), shmem, s, p); break;
+        }
+        STAIR_LAUNCH_CHECK();
+        return 0;
+    }
     switch (a.act) {
         case 0: hipLaunchKernelGGL(gemm_bf16x3_kernel<0>, grid, block, shmem, s, p); break;
         case 1: hipLaunchKernelGGL(gemm_bf16x3_kernel<1>, grid, block, shmem, s, p); break;
