@@ -245,6 +245,18 @@ int stair_plan_run(stair_ctx *ctx, stair_plan *plan, const float *video, const f
                    void *workspace, int64_t workspace_bytes, float *logits, int32_t *argmax,
                    stair_stream stream);
 
+/* The same pass split for stream capture (BASELINE.json configs[3], "hipGraph-captured module chains"):
+ * stair_plan_upload copies the plan's index image (slot columns, sequence offsets) into the workspace ONCE, outside
+ * the capture; stair_plan_run_flags(..., STAIR_RUN_INDEX_RESIDENT, ...) then enqueues kernels only -- no host-to-device
+ * copy, no allocation, no synchronisation -- so it can be recorded between hipStreamBeginCapture / EndCapture (or
+ * torch.cuda.graph) and replayed while video / question / workspace / logits keep their addresses.  The caller must not
+ * let anything else write the workspace's index region in between (give a captured plan its own workspace). */
+#define STAIR_RUN_INDEX_RESIDENT 1
+int stair_plan_upload(stair_plan *plan, void *workspace, int64_t workspace_bytes, stair_stream stream);
+int stair_plan_run_flags(stair_ctx *ctx, stair_plan *plan, const float *video, const float *question,
+                         void *workspace, int64_t workspace_bytes, float *logits, int32_t *argmax, int32_t flags,
+                         stair_stream stream);
+
 /* Reverse pass of a STAIR_PLAN_TRAIN plan after stair_plan_run on the same workspace: decoder cross
  * entropy against answers[n] (train_module.py:193-194,376-380), d(loss_scale * sum_i CE_i) propagated
  * through decoder, every program level in reverse, and both encoders (BPTT); parameter gradients are

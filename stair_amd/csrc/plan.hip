@@ -787,9 +787,25 @@ struct Ptrs {     // workspace views shared by forward and backward
 
 }  // namespace
 
+extern "C" int stair_plan_upload(stair_plan *pl, void *workspace, int64_t workspace_bytes, stair_stream stream) {
+    STAIR_CHECK(pl && workspace, "null argument");
+    STAIR_CHECK(workspace_bytes >= pl->total * (int64_t)sizeof(float), "workspace too small");
+    STAIR_CHECK((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "workspace must be 256-byte aligned");
+    int32_t *didx = reinterpret_cast<int32_t *>(static_cast<float *>(workspace) + pl->o_idx);
+    STAIR_HIP(hipMemcpyAsync(didx, pl->idx.data(), pl->idx.size() * sizeof(int32_t), hipMemcpyHostToDevice,
+                             static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
 extern "C" int stair_plan_run(stair_ctx *ctx, stair_plan *pl, const float *video, const float *question,
                               void *workspace, int64_t workspace_bytes, float *logits, int32_t *argmax,
                               stair_stream stream) {
+    return stair_plan_run_flags(ctx, pl, video, question, workspace, workspace_bytes, logits, argmax, 0, stream);
+}
+
+extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float *video, const float *question,
+                                    void *workspace, int64_t workspace_bytes, float *logits, int32_t *argmax,
+                                    int32_t flags, stair_stream stream) {
     STAIR_CHECK(ctx && pl && video && question && workspace, "null argument");
     STAIR_CHECK(workspace_bytes >= pl->total * (int64_t)sizeof(float), "workspace too small");
     STAIR_CHECK((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "workspace must be 256-byte aligned");
@@ -809,7 +825,8 @@ extern "C" int stair_plan_run(stair_ctx *ctx, stair_plan *pl, const float *video
     if (pl->train) logits = ws + pl->o_logits;       // backward reads them from the workspace
     else if (!logits) logits = ws + pl->o_logits;
 
-    STAIR_HIP(hipMemcpyAsync(didx, pl->idx.data(), pl->idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    if (!(flags & STAIR_RUN_INDEX_RESIDENT))
+        STAIR_HIP(hipMemcpyAsync(didx, pl->idx.data(), pl->idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
 
 #define RUN(x) do { if (int rc_ = (x)) return rc_; } while (0)
     // ---- encoders (module_net.py:74-75) ------------------------------------------------------

@@ -119,6 +119,16 @@ class BatchResult:
                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         return loss
 
+    def capture_graph(self):
+        """Record this batch's forward pass (encoders, every program level, decoder, argmax) into a hipGraph and
+        return a CapturedPlan whose replay() re-runs it with ONE launch -- BASELINE.json configs[3].  The graph
+        reads self's video / question tensors and writes self.logits / self.pred in place: copy new inputs into
+        those tensors (same programs, spans and lengths -- i.e. the same plan) and replay.  The plan gets a
+        private workspace, because the model's shared one is rewritten by every other batch."""
+        if self.info.gvec_off >= 0:
+            raise StairError('capture_graph is for inference plans')
+        return CapturedPlan(self)
+
     def touched(self):
         """bool per canonical weight: does this batch's program mix send a gradient into it?"""
         n = len(self._model._weight_names)
@@ -173,6 +183,40 @@ class BatchResult:
     @property
     def question_feature(self):
         return self._arena(self.info.qfeat_off, self.info.n_questions, self._model.config['hidden_size'])
+
+
+class CapturedPlan:
+    """A plan's forward pass as a replayable hipGraph (torch.cuda.CUDAGraph on ROCm).  Holds the BatchResult (plan,
+    static input/output tensors) and its own workspace alive."""
+
+    def __init__(self, res):
+        self.result = res
+        model, info = res._model, res.info
+        dev = res._video.device
+        self._ws = torch.empty((info.workspace_bytes + 3) // 4, dtype=torch.float32, device=dev)
+        self.logits, self.pred = res.logits, res.pred
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            check(lib.stair_plan_upload(res._plan, C.c_void_p(self._ws.data_ptr()), self._ws.numel() * 4,
+                                        C.c_void_p(side.cuda_stream)))
+            self._enqueue(side)                       # warm-up outside the capture (lazy module loading, attributes)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._enqueue(torch.cuda.current_stream(dev))
+
+    def _enqueue(self, stream):
+        res = self.result
+        check(lib.stair_plan_run_flags(res._model._ctx, res._plan, C.c_void_p(res._video.data_ptr()),
+                                       C.c_void_p(res._question.data_ptr()), C.c_void_p(self._ws.data_ptr()),
+                                       self._ws.numel() * 4, C.c_void_p(self.logits.data_ptr()),
+                                       C.c_void_p(self.pred.data_ptr()), 1, C.c_void_p(stream.cuda_stream)))
+
+    def replay(self):
+        self.graph.replay()
+        return self.logits, self.pred
 
 
 class VideoNMN(nn.Module):

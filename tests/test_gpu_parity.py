@@ -353,6 +353,37 @@ def test_on_disk_dataset_to_logits():
     assert acc == E.accuracy(preds, [int(it['answer']) for it in items], vocab['word2id']['<UNK>'])
 
 
+def test_captured_plan_replays_bit_exactly(matmul):
+    """BASELINE configs[3]: a plan's forward pass recorded into a hipGraph.  Replay == eager run, bit for bit; new
+    inputs written into the static tensors (same programs and lengths) give the eager result for those inputs."""
+    config = dict(spec.DEFAULT_CONFIG)
+    model = _model(config, 4)
+    qs = synth.make_questions(config, 31, 24, forms=synth.ALL_FORMS)
+    eager = model.forward_batch(qs)
+    want = eager.logits.clone()
+    cap = model.forward_batch(qs).capture_graph()
+    cap.logits.zero_()
+    logits, pred = cap.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(logits, want) and torch.equal(pred, eager.pred)
+    # other clips and word embeddings under the same programs, spans and lengths (= the same plan)
+    g = torch.Generator().manual_seed(5)
+    other = []
+    for q in qs:
+        o = dict(q)
+        o['video_features'] = torch.randn(q['video_features'].shape, generator=g)
+        o['question'] = torch.randn(q['question'].shape, generator=g)
+        other.append(o)
+    fresh = model.forward_batch(other).logits.clone()
+    cap.result._video.copy_(torch.stack([torch.as_tensor(q['video_features']) for q in other]).to(DEV))
+    cap.result._question.copy_(torch.cat([torch.as_tensor(q['question']) for q in other]).to(DEV))
+    logits, _ = cap.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(logits, fresh)
+    with pytest.raises(Exception):
+        model.forward_batch(qs, train=True).capture_graph()
+
+
 def test_missing_gpu_tensor_fails_loudly():
     from stair_amd import ops
     with pytest.raises(RuntimeError):
