@@ -140,6 +140,7 @@ def main():
     ap.add_argument('--frames', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--mode', choices=['train', 'infer'], default='train')
+    ap.add_argument('--no-extras', action='store_true', help='skip the supplementary inference figures (clean kernel profiles)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -205,7 +206,7 @@ def main():
     qps = total_q / elapsed
 
     infer_qps = None
-    if args.mode == 'train':          # the forward-only rate in the same process, for reference
+    if args.mode == 'train' and not args.no_extras:          # the forward-only rate in the same process, for reference
         torch.cuda.synchronize()
         ti = time.perf_counter()
         for _ in range(3):
@@ -215,7 +216,7 @@ def main():
         res = r_inf
     # questions that share a clip encode it once.  Same B questions, 8 per clip (AGQA asks tens per video).
     shared_qps = None
-    if B % 8 == 0:
+    if B % 8 == 0 and not args.no_extras:
         vidx = [i // 8 for i in range(B)]
         vshared = video[:B // 8].contiguous()
         model.run_programs(programs, spans, vshared, question, q_lens, video_index=vidx)
@@ -225,6 +226,41 @@ def main():
             model.run_programs(programs, spans, vshared, question, q_lens, video_index=vidx)
         torch.cuda.synchronize()
         shared_qps = 3 * B / (time.perf_counter() - ti)
+
+    # Host-fed pipeline (SURVEY 8d "a second figure including H2D"): the batch's features start in pinned host memory;
+    # a copy stream stages batch i+1 into the other of two device buffers while batch i is computed.  Never `value`.
+    h2d_qps = None
+    if world == 1 and not args.no_extras:
+        host_v = video.cpu().pin_memory()
+        host_q = question.cpu().pin_memory()
+        dv = [torch.empty_like(video), torch.empty_like(video)]
+        dq = [torch.empty_like(question), torch.empty_like(question)]
+        copy_stream = torch.cuda.Stream(device=device)
+        ready = [torch.cuda.Event(), torch.cuda.Event()]
+        done = [torch.cuda.Event(), torch.cuda.Event()]
+        main_stream = torch.cuda.current_stream(device)
+
+        def stage(i):
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(done[i % 2])               # the compute that last read this buffer
+                dv[i % 2].copy_(host_v, non_blocking=True)
+                dq[i % 2].copy_(host_q, non_blocking=True)
+                ready[i % 2].record(copy_stream)
+        n_it = 4
+        for e in done:
+            e.record(main_stream)
+        torch.cuda.synchronize()
+        ti = time.perf_counter()
+        stage(0)
+        for i in range(n_it):
+            if i + 1 < n_it:
+                stage(i + 1)
+            main_stream.wait_event(ready[i % 2])
+            model.run_programs(programs, spans, dv[i % 2], dq[i % 2], q_lens)
+            done[i % 2].record(main_stream)
+        torch.cuda.synchronize()
+        h2d_qps = n_it * B / (time.perf_counter() - ti)
+        del host_v, host_q, dv, dq
 
     if rank == 0:
         from stair_amd import ops as _ops
@@ -262,6 +298,8 @@ def main():
         }
         if infer_qps is not None:
             line['inference_questions_per_s_per_gpu'] = round(infer_qps, 1)
+        if h2d_qps is not None:
+            line['inference_h2d_inclusive_questions_per_s_per_gpu'] = round(h2d_qps, 1)
         if shared_qps is not None:
             line['inference_8_questions_per_clip_questions_per_s_per_gpu'] = round(shared_qps, 1)
         if not args.no_cpu_baseline and world == 1:        # the CPU leg runs on rank 0 at N=1 only
