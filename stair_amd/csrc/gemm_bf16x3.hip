@@ -548,7 +548,11 @@ int launch_gemm_tn_bf16x3(const stair_gemm_tn_args &a, hipStream_t s) {
         }
     }
     const int tiles = p.tilesN * p.tilesK;
-    int slabs = std::max(1, std::min((a.M + 255) / 256, (1024 + tiles - 1) / tiles));
+    // M is split into slabs so that ~512 workgroups (2 per CU) exist; more slabs only add fp32 atomics (each slab adds
+    // its whole N x K tile set: measured 172 -> 205 TFLOP/s at M=32768, N=K=512 going from 1024 to 512 workgroups)
+    static const int target = [] { const char *e = getenv("STAIR_TN_BLOCKS"); return e ? std::max(8, atoi(e)) : 512; }();
+    static const int minrows = [] { const char *e = getenv("STAIR_TN_MINROWS"); return e ? std::max(32, atoi(e)) : 256; }();
+    int slabs = std::max(1, std::min((a.M + minrows - 1) / minrows, (target + tiles - 1) / tiles));
     slabs = (slabs + 7) / 8 * 8;                                   // a multiple of the XCD count
     p.mslab = ((a.M + slabs - 1) / slabs + 31) / 32 * 32;
     const size_t shmem = 2 * 2 * 2 * IMG * sizeof(__bf16);

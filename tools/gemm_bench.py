@@ -15,11 +15,15 @@ def timeit(fn, iters=5):
     return e0.elapsed_time(e1) / iters
 
 dev = 'cuda:0'
-shapes = [(131072, 1024, 2048), (131072, 1024, 256), (32768, 512, 512), (8192, 512, 512), (2048, 512, 1536)]
+shapes = [(131072, 1024, 2048), (131072, 1024, 256), (131072, 512, 512), (65536, 512, 512), (32768, 512, 512), (8192, 512, 512), (2048, 512, 1536), (2048, 1024, 1024), (34000, 1024, 300)]
+if len(sys.argv) > 1 and sys.argv[1] == 'tn':
+    MODES = ('bf16x3',)
+else:
+    MODES = ('f32', 'bf16x3')
 for (M, N, K) in shapes:
     x = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev); dz = torch.randn(M, N, device=dev)
     out = torch.empty(M, N, device=dev); dw = torch.zeros(N, K, device=dev)
-    for mode in ('f32', 'bf16x3'):
+    for mode in MODES:
         ops.set_matmul_mode(mode)
         t_nt = timeit(lambda: ops.gemm_grouped(x, K, None, w, None, out, N, None, M, 1, N, K))
         t_tn = timeit(lambda: ops.gemm_tn(dz, x, dw, M, N, K))
