@@ -50,6 +50,16 @@ __device__ __forceinline__ void split8(const v4f &x0, const v4f &x1, float scale
     }
 }
 
+__device__ __forceinline__ void split8p(const v4f &x0, const v4f &x1, bf16x8 &hi, bf16x8 &lo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        hi[j] = (__bf16)x0[j];
+        hi[4 + j] = (__bf16)x1[j];
+        lo[j] = (__bf16)(x0[j] - (float)hi[j]);
+        lo[4 + j] = (__bf16)(x1[j] - (float)hi[4 + j]);
+    }
+}
+
 // one chunk of MFMAs from LDS buffer `buf`: 2 k-steps x (2x2 tiles) x 3 products
 __device__ __forceinline__ void mfma_chunk(const __bf16 *lds, int buf, int wm, int wn, int r, int h, f32x16 &acc00,
                                            f32x16 &acc01, f32x16 &acc10, f32x16 &acc11) {
@@ -110,7 +120,9 @@ struct XParams {
 // ---------------------------------------------------------------------------------------------
 // NT: C[m][n] = act(sum_k rs[m] A[m][k] W[n][k] + b[n])
 // ---------------------------------------------------------------------------------------------
-template <int ACT>
+// PLAIN: K is a multiple of 64 and there is no row scale, so no staged element needs the K-tail mask or the scale
+// (a quarter of the staging VALU work otherwise); chunks past K are then staged but never multiplied.
+template <int ACT, bool PLAIN>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(XParams p) {
     extern __shared__ __attribute__((aligned(16))) __bf16 xlds[];
     const stair_gemm_args &a = p.a;
@@ -166,10 +178,11 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(XParams p) {
     {                                                                                                   \
         _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                              \
             bf16x8 hi_, lo_;                                                                            \
-            split8(va[set][i_][0] * km[set][0], va[set][i_][1] * km[set][1], rs[i_], hi_, lo_);         \
+            if (PLAIN) split8p(va[set][i_][0], va[set][i_][1], hi_, lo_);                               \
+            else split8(va[set][i_][0] * km[set][0], va[set][i_][1] * km[set][1], rs[i_], hi_, lo_);    \
             *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, 0, 0, kq, ra_ + 64 * i_)) = hi_;            \
             *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, 0, 1, kq, ra_ + 64 * i_)) = lo_;            \
-            split8(vb[set][i_][0], vb[set][i_][1], 1.0f, hi_, lo_);                                     \
+            split8p(vb[set][i_][0], vb[set][i_][1], hi_, lo_);                                          \
             *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, 1, 0, kq, ra_ + 64 * i_)) = hi_;            \
             *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, 1, 1, kq, ra_ + 64 * i_)) = lo_;            \
         }                                                                                               \
@@ -241,7 +254,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(XParams p) {
 // so a wave carries 32 accumulator and 16 staging registers per set instead of 64 and 32.  At <= 128 VGPRs two
 // workgroups (16 waves, 4 per SIMD) share a CU, twice the four-wave kernel's, which is what hides the staging
 // stalls: rocprof counted the MFMA pipe 43 % busy with 2 waves per SIMD (profiles/r01_e_pmc_gemm.json).
-template <int ACT>
+template <int ACT, bool PLAIN>
 __global__ __launch_bounds__(512, 2) void gemm_bf16x3_w8_kernel(XParams p) {
     extern __shared__ __attribute__((aligned(16))) __bf16 xlds[];
     const stair_gemm_args &a = p.a;
@@ -297,10 +310,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_w8_kernel(XParams p) {
     {                                                                                                   \
         _Pragma("unroll") for (int i_ = 0; i_ < 1; ++i_) {                                              \
             bf16x8 hi_, lo_;                                                                            \
-            split8(va[set][i_][0] * km[set][0], va[set][i_][1] * km[set][1], rs[i_], hi_, lo_);         \
+            if (PLAIN) split8p(va[set][i_][0], va[set][i_][1], hi_, lo_);                               \
+            else split8(va[set][i_][0] * km[set][0], va[set][i_][1] * km[set][1], rs[i_], hi_, lo_);    \
             *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, 0, 0, kq, ra_ + 64 * i_)) = hi_;            \
             *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, 0, 1, kq, ra_ + 64 * i_)) = lo_;            \
-            split8(vb[set][i_][0], vb[set][i_][1], 1.0f, hi_, lo_);                                     \
+            split8p(vb[set][i_][0], vb[set][i_][1], hi_, lo_);                                          \
             *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, 1, 0, kq, ra_ + 64 * i_)) = hi_;            \
             *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, 1, 1, kq, ra_ + 64 * i_)) = lo_;            \
         }                                                                                               \
@@ -383,20 +397,19 @@ int launch_gemm_bf16x3(const stair_gemm_args &a, hipStream_t s) {
     p.tilesN = (a.N + 127) / 128;
     const dim3 grid(p.tilesM * p.tilesN), block(256);
     const size_t shmem = 2 * 2 * 2 * IMG * sizeof(__bf16);
-    if (gemm_w8_enabled() && p.tilesM * p.tilesN >= 512) {          // enough tiles for two 8-wave workgroups on every CU
-        switch (a.act) {
-            case 0: hipLaunchKernelGGL(gemm_bf16x3_w8_kernel<0>, grid, dim3(512), shmem, s, p); break;
-            case 1: hipLaunchKernelGGL(gemm_bf16x3_w8_kernel<1>, grid, dim3(512), shmem, s, p); break;
-            default: hipLaunchKernelGGL(gemm_bf16x3_w8_kernel<2>, grid, dim3(512), shmem, s, p); break;
-        }
-        STAIR_LAUNCH_CHECK();
-        return 0;
-    }
+    const bool plain = a.K % 64 == 0 && !a.row_scale;
+    const bool w8 = gemm_w8_enabled() && p.tilesM * p.tilesN >= 512;   // enough tiles for two 8-wave workgroups on every CU
+#define X_LAUNCH(ACT_)                                                                                             \
+    if (w8 && plain) hipLaunchKernelGGL((gemm_bf16x3_w8_kernel<ACT_, true>), grid, dim3(512), shmem, s, p);         \
+    else if (w8) hipLaunchKernelGGL((gemm_bf16x3_w8_kernel<ACT_, false>), grid, dim3(512), shmem, s, p);            \
+    else if (plain) hipLaunchKernelGGL((gemm_bf16x3_kernel<ACT_, true>), grid, block, shmem, s, p);                 \
+    else hipLaunchKernelGGL((gemm_bf16x3_kernel<ACT_, false>), grid, block, shmem, s, p);
     switch (a.act) {
-        case 0: hipLaunchKernelGGL(gemm_bf16x3_kernel<0>, grid, block, shmem, s, p); break;
-        case 1: hipLaunchKernelGGL(gemm_bf16x3_kernel<1>, grid, block, shmem, s, p); break;
-        default: hipLaunchKernelGGL(gemm_bf16x3_kernel<2>, grid, block, shmem, s, p); break;
+        case 0: X_LAUNCH(0) break;
+        case 1: X_LAUNCH(1) break;
+        default: X_LAUNCH(2) break;
     }
+#undef X_LAUNCH
     STAIR_LAUNCH_CHECK();
     return 0;
 }
@@ -415,6 +428,9 @@ struct XTnParams {
     int M, N, K, mslab, tilesN, tilesK, fast8;
 };
 
+// PLAIN: no row scale and every slab holds a multiple of 64 rows, so no element needs a mask or a scale (columns past
+// N or K are computed from clamped addresses and never written).
+template <bool PLAIN>
 __global__ __launch_bounds__(256, 2) void gemm_tn_bf16x3_kernel(XTnParams p) {
     extern __shared__ __attribute__((aligned(16))) __bf16 xlds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -484,7 +500,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16x3_kernel(XTnParams p) {
         _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) {                                                  \
             bf16x8 hi_, lo_;                                                                                \
             _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) {                                              \
-                const float x_ = v[set][j_][c_] * sc[set][j_];                                              \
+                const float x_ = PLAIN ? v[set][j_][c_] : v[set][j_][c_] * sc[set][j_];                     \
                 hi_[j_] = (__bf16)x_;                                                                       \
                 lo_[j_] = (__bf16)(x_ - (float)hi_[j_]);                                                    \
             }                                                                                               \
@@ -554,9 +570,11 @@ int launch_gemm_tn_bf16x3(const stair_gemm_tn_args &a, hipStream_t s) {
     static const int minrows = [] { const char *e = getenv("STAIR_TN_MINROWS"); return e ? std::max(32, atoi(e)) : 256; }();
     int slabs = std::max(1, std::min((a.M + minrows - 1) / minrows, (target + tiles - 1) / tiles));
     slabs = (slabs + 7) / 8 * 8;                                   // a multiple of the XCD count
-    p.mslab = ((a.M + slabs - 1) / slabs + 31) / 32 * 32;
+    p.mslab = ((a.M + slabs - 1) / slabs + 63) / 64 * 64;
     const size_t shmem = 2 * 2 * 2 * IMG * sizeof(__bf16);
-    hipLaunchKernelGGL(gemm_tn_bf16x3_kernel, dim3(tiles * slabs), dim3(256), shmem, s, p);
+    const bool plain = !p.row_scale && a.M % 64 == 0 && p.mslab % 64 == 0;
+    if (plain) hipLaunchKernelGGL(gemm_tn_bf16x3_kernel<true>, dim3(tiles * slabs), dim3(256), shmem, s, p);
+    else hipLaunchKernelGGL(gemm_tn_bf16x3_kernel<false>, dim3(tiles * slabs), dim3(256), shmem, s, p);
     STAIR_LAUNCH_CHECK();
     return 0;
 }
