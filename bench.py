@@ -284,7 +284,7 @@ def main():
                        'parallelism': ('dp%d (questions sharded, one flat fp32 gradient all-reduce per step)' if args.mode == 'train'
                                        else 'dp%d (questions sharded, no collective)') % world},
             'roofline': {'bound': 'mfma', 'kernel': '%s (LSTM input projection, M=%d N=%d K=%d)' % (
-                             'gemm_bf16x3_kernel' if split else 'gemm_f32_kernel', B * T, 2 * config['hidden_size'], config['video_size']),
+                             'gemm_bf16x3_w8_kernel<0,true>' if split else 'gemm_f32_kernel', B * T, 2 * config['hidden_size'], config['video_size']),
                          'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': round(achieved / peak, 4), 'traffic': PMC_TRAFFIC_BYTES.get((B * T, 2 * config['hidden_size'], config['video_size'])),
                          'traffic_note': PMC_TRAFFIC_NOTE, 'launch_ms': round(gemm_ms, 4),

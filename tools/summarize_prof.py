@@ -13,6 +13,13 @@ def stats(db, out):
         w.writerow(['Name', 'Calls', 'TotalDurationUs', 'AverageUs', 'Percentage'])
         for name, calls, tot, avg, pct in rows:
             w.writerow([name[:160], calls, round(tot, 3), round(avg, 3), round(pct, 3)])
+        # the GEMM kernels serve many shapes: break them down by launch grid so that one shape's average can be read off
+        w.writerow([])
+        w.writerow(['Name', 'GridWorkgroups', 'Calls', 'TotalDurationUs', 'AverageUs'])
+        for name, wg, calls, tot in c.execute(
+                "select name, grid_x / workgroup_x, count(*), sum(end - start) / 1e3 from kernels where name like '%gemm%' "
+                "group by name, grid_x / workgroup_x order by 4 desc limit 24"):
+            w.writerow([name.split('(')[0][:80], wg, calls, round(tot, 3), round(tot / calls, 3)])
 
 
 def pmc(files, out):
