@@ -130,6 +130,8 @@ typedef struct stair_gemm_tn_args {
     const float *row_scale; int64_t rs_gstride; const int32_t *rs_gidx;
     float *C; int64_t ldc;
     int32_t M, rows_per_group, N, K;
+    float *colsum, *colsum2; /* optional [N]: += sum_m A[m][n] (the bias gradient db = colsum(dZ) of the same Linear;
+                                colsum2 receives the same sums: nn.LSTM's b_ih and b_hh), accumulated with atomics */
 } stair_gemm_tn_args;
 int stair_gemm_tn_f32(const stair_gemm_tn_args *args, stair_stream stream);
 

@@ -39,7 +39,8 @@ class GemmTnArgs(C.Structure):
                 ('B', C.c_void_p), ('ldb', C.c_int64), ('b_gstride', C.c_int64), ('b_gidx', C.c_void_p),
                 ('row_scale', C.c_void_p), ('rs_gstride', C.c_int64), ('rs_gidx', C.c_void_p),
                 ('C', C.c_void_p), ('ldc', C.c_int64),
-                ('M', C.c_int32), ('rows_per_group', C.c_int32), ('N', C.c_int32), ('K', C.c_int32)]
+                ('M', C.c_int32), ('rows_per_group', C.c_int32), ('N', C.c_int32), ('K', C.c_int32),
+                ('colsum', C.c_void_p), ('colsum2', C.c_void_p)]
 
 
 class LstmArgs(C.Structure):

@@ -318,6 +318,8 @@ __global__ __launch_bounds__(256) void gemm_tn_f32_kernel(GemmTnParams p) {
     }
 }
 
+int launch_colsum(const float *A, int64_t lda, float *out, int M, int N, hipStream_t s, float *out2);
+
 int launch_gemm_tn(const stair_gemm_tn_args &a, hipStream_t s) {
     STAIR_CHECK(a.M >= 0 && a.N > 0 && a.K > 0 && a.rows_per_group > 0, "bad shape");
     STAIR_CHECK(a.N % 4 == 0 && a.K % 4 == 0 && a.lda % 4 == 0 && a.ldb % 4 == 0 && a.b_gstride % 4 == 0,
@@ -336,6 +338,7 @@ int launch_gemm_tn(const stair_gemm_tn_args &a, hipStream_t s) {
     p.mslab = ((a.M + slabs - 1) / slabs + 31) / 32 * 32;
     hipLaunchKernelGGL(gemm_tn_f32_kernel, dim3(tiles * slabs), dim3(256), 0, s, p);
     STAIR_LAUNCH_CHECK();
+    if (a.colsum) return launch_colsum(a.A, a.lda, a.colsum, a.M, a.N, s, a.colsum2);   // fused only in the split kernel
     return 0;
 }
 

@@ -425,6 +425,7 @@ struct XTnParams {
     const float *B; int64_t ldb, b_gstride; const int32_t *b_gidx; int R;
     const float *row_scale; int64_t rs_gstride; const int32_t *rs_gidx;
     float *C; int64_t ldc;
+    float *colsum, *colsum2;
     int M, N, K, mslab, tilesN, tilesK, fast8;
 };
 
@@ -458,6 +459,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16x3_kernel(XTnParams p) {
 
     v4f v[2][8];
     float sc[2][8];
+    // bias gradient riding along: the workgroups of the first K tile already stage every dZ element of their (slab, N tile)
+    // once, so waves 0,1 add them up per column while splitting (colsum_kernel re-read all of dZ for this)
+    const bool do_colsum = p.colsum != nullptr && !isB && k0 == 0;
+    float csum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     // A thread's 8 rows (mfirst .. mfirst+7) lie inside ONE group whenever groups are multiples of 8 rows (R = T for
     // [T,H] tiles, or plain matrices passed as one group per 8 rows by the launcher): one group lookup and one 64-bit
     // base per chunk, then constant strides.  Otherwise (vectors gathered one row per group) every row is looked up.
@@ -472,7 +477,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16x3_kernel(XTnParams p) {
                 const int64_t ro_ = full_ ? (int64_t)j_ * p.lda : (int64_t)max(0, min(mfirst + j_, p.M - 1)) * p.lda;   \
                 v[set][j_] = *(gv4p)(base_ + ro_);                                                          \
             }                                                                                               \
-        } else if (p.fast8) {                                                                               \
+        } else if (p.fast8 == 1) {                                                                          \
             const int mc_ = max(0, min(mfirst, p.M - 8));                                                   \
             const int g_ = mc_ / p.R, rr_ = mc_ - g_ * p.R;                                                 \
             const float *base_ = p.B + (p.b_gidx ? (int64_t)p.b_gidx[g_] : (int64_t)g_) * p.b_gstride + (int64_t)rr_ * p.ldb + cc;   \
@@ -482,6 +487,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16x3_kernel(XTnParams p) {
                 sc[set][j_] = (in_ && mfirst + j_ < mend) ? cmask : 0.0f;                                   \
                 if (rsb_) sc[set][j_] *= rsb_[j_];                                                          \
                 v[set][j_] = *(gv4p)(base_ + (int64_t)j_ * p.ldb);                                          \
+            }                                                                                               \
+        } else if (p.fast8 == 2) {          /* plain matrix, any M: row m sits at B + m*ldb, no group arithmetic */   \
+            _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) {                                              \
+                const int mraw_ = mfirst + j_;                                                              \
+                const int m_ = max(0, min(mraw_, p.M - 1));                                                 \
+                sc[set][j_] = mraw_ < mend ? cmask : 0.0f;                                                  \
+                if (p.row_scale) sc[set][j_] *= p.row_scale[m_];                                            \
+                v[set][j_] = *(gv4p)(p.B + (int64_t)m_ * p.ldb + cc);                                       \
             }                                                                                               \
         } else {                                                                                            \
             _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) {                                              \
@@ -494,13 +507,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16x3_kernel(XTnParams p) {
             }                                                                                               \
         }                                                                                                   \
     }
-#define T_LSTORE(set, buf)                                                                                  \
+#define T_LSTORE(set, buf, chunk_)                                                                          \
     {                                                                                                       \
         const int operand_ = isB ? 1 : 0;                                                                   \
+        const bool sum_ = do_colsum && (chunk_) < nchunks;   /* a chunk past the slab is staged but belongs to nobody */ \
         _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) {                                                  \
             bf16x8 hi_, lo_;                                                                                \
             _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) {                                              \
                 const float x_ = PLAIN ? v[set][j_][c_] : v[set][j_][c_] * sc[set][j_];                     \
+                if (sum_) csum[c_] += x_;                                                                   \
                 hi_[j_] = (__bf16)x_;                                                                       \
                 lo_[j_] = (__bf16)(x_ - (float)hi_[j_]);                                                    \
             }                                                                                               \
@@ -513,25 +528,35 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16x3_kernel(XTnParams p) {
     if (nchunks > 0) {      // block-uniform; rows past mend are zeroed by sc, so every load below is unconditional
         T_GLOAD(0, mbeg);
         T_GLOAD(1, mbeg + XBK);
-        T_LSTORE(0, 0);
+        T_LSTORE(0, 0, 0);
         __syncthreads();
         for (int c = 0; c < nchunks; c += 2) {
             T_GLOAD(0, mbeg + (c + 2) * XBK);
             __builtin_amdgcn_sched_barrier(0);
             mfma_chunk(xlds, 0, wm, wn, r, h, acc00, acc01, acc10, acc11);
             __builtin_amdgcn_sched_barrier(0);
-            T_LSTORE(1, 1);
+            T_LSTORE(1, 1, c + 1);
             __syncthreads();
             T_GLOAD(1, mbeg + (c + 3) * XBK);
             __builtin_amdgcn_sched_barrier(0);
             mfma_chunk(xlds, 1, wm, wn, r, h, acc00, acc01, acc10, acc11);
             __builtin_amdgcn_sched_barrier(0);
-            T_LSTORE(0, 0);
+            T_LSTORE(0, 0, c + 2);
             __syncthreads();
         }
     }
 #undef T_GLOAD
 #undef T_LSTORE
+    if (do_colsum) {
+#pragma unroll
+        for (int c_ = 0; c_ < 4; ++c_) {
+            const int n = n0 + 4 * cq + c_;
+            if (n < p.N && csum[c_] != 0.0f) {
+                unsafeAtomicAdd(p.colsum + n, csum[c_]);
+                if (p.colsum2) unsafeAtomicAdd(p.colsum2 + n, csum[c_]);
+            }
+        }
+    }
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int k = k0 + wn * 64 + nt * 32 + r;
@@ -554,14 +579,18 @@ int launch_gemm_tn_bf16x3(const stair_gemm_tn_args &a, hipStream_t s) {
     p.A = a.A; p.lda = a.lda; p.B = a.B; p.ldb = a.ldb; p.b_gstride = a.b_gstride; p.b_gidx = a.b_gidx;
     p.R = a.rows_per_group; p.row_scale = a.row_scale; p.rs_gstride = a.rs_gstride; p.rs_gidx = a.rs_gidx;
     p.C = a.C; p.ldc = a.ldc; p.M = a.M; p.N = a.N; p.K = a.K;
+    p.colsum = a.colsum; p.colsum2 = a.colsum2;
     p.tilesN = (a.N + 127) / 128; p.tilesK = (a.K + 127) / 128;
     p.fast8 = 0;
+    const bool plain_matrix = !p.b_gidx && !p.rs_gidx && p.b_gstride == (int64_t)p.R * p.ldb && (!p.row_scale || p.rs_gstride == p.R);
     if (a.M % 8 == 0 && a.M >= 8) {
         if (p.R % 8 == 0) p.fast8 = 1;
-        else if (!p.b_gidx && !p.rs_gidx && p.b_gstride == (int64_t)p.R * p.ldb && (!p.row_scale || p.rs_gstride == p.R)) {
+        else if (plain_matrix) {
             // a plain contiguous matrix: regroup it as groups of 8 rows
             p.R = 8; p.b_gstride = 8 * p.ldb; p.rs_gstride = 8; p.fast8 = 1;
         }
+    } else if (plain_matrix) {
+        p.fast8 = 2;                  // ragged row count (e.g. the text encoder's sum of question lengths)
     }
     const int tiles = p.tilesN * p.tilesK;
     // M is split into slabs so that ~512 workgroups (2 per CU) exist; more slabs only add fp32 atomics (each slab adds

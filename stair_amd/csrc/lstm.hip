@@ -774,8 +774,8 @@ int launch_lstm_bwd(const stair_lstm_bwd_args &a, hipStream_t s) {
         if (int rc = launch_gemm_tn(g, s)) return rc;
         g.B = a.hprev_ws + dir * Hh; g.ldb = 2 * (int64_t)Hh; g.b_gstride = 2 * (int64_t)Hh;
         g.C = a.dw_hh[dir]; g.ldc = Hh; g.K = Hh;
+        g.colsum = a.db_ih[dir]; g.colsum2 = a.db_hh[dir];     // db_ih = db_hh = colsum(dG), with the smaller of the two products
         if (int rc = launch_gemm_tn(g, s)) return rc;
-        if (int rc = launch_colsum(a.gates + dir * 4 * Hh, 8 * (int64_t)Hh, a.db_ih[dir], a.rows, 4 * Hh, s, a.db_hh[dir])) return rc;
     }
     return 0;
 }

@@ -992,8 +992,8 @@ int dense_bwd(const BwdCtx &B, const float *dZ, int groups, int R, int N, int K,
     t.A = dZ; t.lda = N; t.B = X; t.ldb = ldx; t.b_gstride = x_gs; t.b_gidx = x_gidx;
     t.row_scale = rs; t.rs_gstride = rs_gs; t.rs_gidx = rs_gidx;
     t.C = l.dw; t.ldc = K; t.M = M; t.rows_per_group = R; t.N = N; t.K = K;
+    t.colsum = l.db;                 // db += colsum(dZ), summed while the TN kernel stages dZ
     if (int rc = launch_gemm_tn(t, B.s)) return rc;
-    if (int rc = launch_colsum(dZ, N, l.db, M, N, B.s)) return rc;
     if (dX) {
         stair_gemm_args g = {};
         g.A = dZ; g.lda = N; g.a_gstride = (int64_t)R * N;

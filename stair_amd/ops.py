@@ -75,8 +75,9 @@ def gemm_grouped(A, a_gstride, a_gidx, W, bias, Cmat, c_gstride, c_gidx, groups,
 
 
 def gemm_tn(A, B, Cmat, M, N, K, rows_per_group=1, b_gstride=None, b_gidx=None, row_scale=None, rs_gstride=0,
-            rs_gidx=None):
-    """Cmat[N,K] += A[M,N]^T @ (rs * B[M,K]) -- weight gradients (see stair_gemm_tn_args)."""
+            rs_gidx=None, colsum=None, colsum2=None):
+    """Cmat[N,K] += A[M,N]^T @ (rs * B[M,K]) -- weight gradients (see stair_gemm_tn_args); colsum[N] (and
+    colsum2) += column sums of A, the bias gradient of the same layer."""
     a = GemmTnArgs()
     a.A, a.lda = A.data_ptr(), N
     a.B, a.ldb, a.b_gstride = B.data_ptr(), K, (b_gstride if b_gstride is not None else K * rows_per_group)
@@ -85,6 +86,8 @@ def gemm_tn(A, B, Cmat, M, N, K, rows_per_group=1, b_gstride=None, b_gidx=None, 
     a.rs_gstride, a.rs_gidx = rs_gstride, (rs_gidx.data_ptr() if rs_gidx is not None else None)
     a.C, a.ldc = Cmat.data_ptr(), K
     a.M, a.rows_per_group, a.N, a.K = M, rows_per_group, N, K
+    a.colsum = colsum.data_ptr() if colsum is not None else None
+    a.colsum2 = colsum2.data_ptr() if colsum2 is not None else None
     check(lib.stair_gemm_tn_f32(C.byref(a), _stream()))
 
 

@@ -437,6 +437,24 @@ def test_gemm_tn_weight_gradient(M, N, K, R, matmul):
     assert _maxerr(Cm, ref) < _tol(matmul, 1e-4, 4e-4) * max(1.0, (M / 1000) ** 0.5 * 3)
 
 
+@pytest.mark.parametrize('M,N,K', [(64, 16, 64), (4096, 512, 512), (1001, 1024, 300), (333, 36, 512), (8192 + 64, 128, 2048)])
+def test_gemm_tn_bias_gradient_rides_along(M, N, K, matmul):
+    """stair_gemm_tn_args.colsum / colsum2: db += colsum(dZ) out of the same launch as dW (fused into the staging of
+    the split-precision kernel, a second kernel in f32 mode), on top of existing contents, ragged M included."""
+    from stair_amd import ops
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    X = torch.randn(M, K, generator=g)
+    dZ = torch.randn(M, N, generator=g)
+    b0 = torch.randn(N, generator=g)
+    d = lambda t: t.to(DEV)
+    Cm, b1, b2 = torch.zeros(N, K, device=DEV), d(b0.clone()), d(b0.clone() * 2)
+    ops.gemm_tn(d(dZ), d(X), Cm, M, N, K, rows_per_group=1, colsum=b1, colsum2=b2)
+    ref = dZ.double().sum(0)
+    tol = 2e-5 * max(1.0, (M / 100) ** 0.5)
+    assert _maxerr(b1, b0.double() + ref) < tol and _maxerr(b2, 2 * b0.double() + ref) < tol
+    assert _maxerr(Cm, dZ.double().t() @ X.double()) < _tol(matmul, 1e-4, 4e-4) * max(1.0, (M / 1000) ** 0.5 * 3)
+
+
 def test_gemm_accumulate_scatter_add(matmul):
     """dX products: two groups writing the same output slot must add up (atomic epilogue)."""
     from stair_amd import ops
