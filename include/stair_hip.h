@@ -273,7 +273,9 @@ int stair_plan_zero_grads(stair_plan *plan, void *workspace, stair_stream stream
 
 /* ---- per-module intermediate-supervision losses (train_module.py:33-194, CriterionByModule) -------------------
  * Each call evaluates `n` loss items, writes the unscaled loss of item i to loss[i] and ADDS scale * dloss/dresult
- * into the gradient arena at the result's slot; head parameters' gradients are added to dW/db.  All arrays device. */
+ * into the gradient arena at the result's slot; head parameters' gradients are added to dW/db.  All arrays device.
+ * The gradient pointers (d_att / d_vec / dW / db) may be NULL: the call then only evaluates the losses, which is how the
+ * validation loop (train_module.py:219-270) scores an inference plan. */
 
 /* attention_score_criterion (:83-90) on att rows slot[i] .. slot[i]+K[i]-1 against the soft interval masks of
  * span_to_attention (:67-81); intervals[2*(iv_off[i]+r)] = (start, end) of row r in frames (double, like the

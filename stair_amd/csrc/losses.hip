@@ -40,7 +40,7 @@ __global__ void loss_attention_kernel(const float *att, float *d_att, const int3
         const int64_t o = ((int64_t)slot[i] + r) * T + t;
         const float p = att[o];
         acc += -(g * logf(p) + (1.f - g) * logf(1.f - p));
-        unsafeAtomicAdd(d_att + o, scale * inv * (-g / p + (1.f - g) / (1.f - p)));
+        if (d_att) unsafeAtomicAdd(d_att + o, scale * inv * (-g / p + (1.f - g) / (1.f - p)));
     }
     acc = wave_sum(acc);
     if (threadIdx.x == 0) loss[i] = acc * inv;       // blockDim == 64: one wave
@@ -88,13 +88,14 @@ __global__ void loss_head_kernel(const float *vec, float *d_vec, const int32_t *
 #pragma unroll
         for (int j = 0; j < NOUT; ++j) {
             dx += dz[j] * W[(int64_t)j * H + c];
-            unsafeAtomicAdd(dW + (int64_t)j * H + c, dz[j] * x[c]);
+            if (dW) unsafeAtomicAdd(dW + (int64_t)j * H + c, dz[j] * x[c]);
         }
-        unsafeAtomicAdd(d_vec + (int64_t)slot[i] * H + c, dx);
+        if (d_vec) unsafeAtomicAdd(d_vec + (int64_t)slot[i] * H + c, dx);
     }
     if (lane == 0) {
 #pragma unroll
-        for (int j = 0; j < NOUT; ++j) unsafeAtomicAdd(db + j, dz[j]);
+        for (int j = 0; j < NOUT; ++j)
+            if (db) unsafeAtomicAdd(db + j, dz[j]);
         loss[i] = l;
     }
 }
@@ -163,8 +164,9 @@ __global__ void loss_contrastive_kernel(const float *vec, float *d_vec, const in
     if (lane == 0) atomicAdd(&s_dot, part);
     __syncthreads();
     const float dot = s_dot;       // pred . dpred
-    for (int h = threadIdx.x; h < H; h += blockDim.x)
-        unsafeAtomicAdd(d_vec + (int64_t)slot[i] * H + h, (dpred[h] - x[h] * inv * dot) * inv);
+    if (d_vec)
+        for (int h = threadIdx.x; h < H; h += blockDim.x)
+            unsafeAtomicAdd(d_vec + (int64_t)slot[i] * H + h, (dpred[h] - x[h] * inv * dot) * inv);
 }
 int launch_loss_contrastive(const float *vec, float *d_vec, const int32_t *slot, const int32_t *pos, const int32_t *win_start,
                             const int32_t *win_cnt, const float *G, int n, int H, int max_classes, float scale, float *loss,

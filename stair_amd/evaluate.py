@@ -153,3 +153,34 @@ def filter_text_results(model, questions, filter_vocab, phrase_embeddings, batch
             for (qa, pi, lvl, kw), row in zip(where, best.cpu().tolist()):
                 out[qa][pi] = (lvl, kw, [filter_vocab[c] for c in row])
     return out
+
+
+def evaluate_by_module(model, questions, unk_token_id, batch_size=1024, module_loss_weight=1.0, preds_file=None, id2word=None):
+    """Batched counterpart of /root/reference/train_module.py:219-270 (`evaluate_by_module`, the validation pass of the
+    training loop): returns (accuracy, {module: mean validation loss}).  Supervised nodes are those of
+    `model.pretrain_modules` whose program_idx has a gold value in the question's `sg_res_by_step`; contrastive modules
+    are scored with the 'cont-valid' cosine metric, the decoder with cross entropy against `answer`; a module without
+    any scored node reports +inf, as the reference does.  module_loss_weight == 0 skips the module scores (:232)."""
+    from . import losses as L
+    modules = set(model.pretrain_modules) | {'decoder'}
+    losses = {m: [] for m in L.CRITERION_MODULES}
+    preds = [None] * len(questions)
+    for T, idxs in sorted(group_by_frames(questions).items()):
+        for s in range(0, len(idxs), batch_size):
+            chunk_idx = idxs[s:s + batch_size]
+            chunk = [questions[i] for i in chunk_idx]
+            res = model.forward_batch(chunk)
+            if module_loss_weight != 0:
+                for m, vals in L.evaluate_module_losses(model, res, chunk, modules & L.CRITERION_MODULES).items():
+                    losses[m].extend(vals)
+            answers = torch.tensor([int(q['answer']) for q in chunk], dtype=torch.long, device=res.logits.device)
+            losses['decoder'].extend(torch.nn.functional.cross_entropy(res.logits, answers, reduction='none').cpu().tolist())
+            for i, p in zip(chunk_idx, res.pred.cpu().tolist()):
+                preds[i] = int(p)
+    golds = [int(q['answer']) for q in questions]
+    valid = {m: (sum(v) / len(v) if v else float('inf')) for m, v in losses.items()}
+    if preds_file is not None:
+        w = (lambda i: id2word[i] if id2word and i in id2word else i)
+        json.dump({'preds': [w(p) for p in preds], 'golds': [w(g) for g in golds],
+                   'qa_ids': [q.get('qa_id') for q in questions]}, open(preds_file, 'w'))
+    return accuracy(preds, golds, unk_token_id), valid

@@ -129,3 +129,78 @@ def apply_module_losses(model, res, questions, scale, pretrain_modules=CRITERION
                                          C.c_float(scale), C.c_void_p(out.data_ptr()), stream))
         losses['contrastive'] = out
     return losses, touched
+
+
+def evaluate_module_losses(model, res, questions, pretrain_modules=CRITERION_MODULES):
+    """Validation-time scores of every supervised node of a batch, {module: [loss, ...]} in question order -- the
+    inner loop of train_module.py:231-243 (`evaluate_by_module`).  Works on an inference plan: the stair_loss_*
+    kernels run with NULL gradient pointers.  Contrastive modules are scored with the reference's 'cont-valid'
+    metric (:127-132), the cosine between the node's output and the mean of the question's own gold class
+    representations; that one reduction (a few hundred [H] rows) is plain torch on the device."""
+    dev = res.logits.device
+    H, T = model.config['hidden_size'], res.info.T
+    att_items, head_items, cont_items, embs = [], {'Exists': [], 'Xor': [], 'Equals': []}, [], []
+    out = {m: [] for m in sorted(pretrain_modules)}
+    for qi, q in enumerate(questions):
+        sg = q.get('sg_res_by_step') or {}
+        prog = q['nmn_program_list']
+        for step, i in supervised_nodes(q, pretrain_modules).items():
+            module = prog[i]
+            if step not in sg or sg[step] is None or module == 'decoder':
+                continue
+            gold = sg[step]
+            kind, slot, aux, _, rel = res.node_info(qi, i)
+            if module == 'Localize':
+                att_items.append((slot, aux, [tuple(map(float, gold[r])) for r in range(aux)], module))
+            elif module == 'Temporal':
+                att_items.append((rel, 1, [tuple(map(float, gold))], module))
+            elif module == 'ExistsFrame':
+                att_items.append((slot, 1, [tuple(map(float, gold))], module))
+            elif module in head_items:
+                head_items[module].append((slot, int(bool(gold))))
+            elif module in CONTRASTIVE:
+                if len(gold) == 0:
+                    out[module].append(0.0)                               # "no results found" (:129-130)
+                    continue
+                cont_items.append((module, slot, len(embs), len(gold), len(out[module])))
+                out[module].append(None)
+                embs.extend(torch.as_tensor(e, dtype=torch.float32) for _, e in gold)
+            else:
+                raise NotImplementedError('validation loss for %s (FilterFrame needs the object vocabulary of '
+                                          'train_module.py:141-155, not built)' % module)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    vec = res._arena(res.info.vec_off, res.info.n_vec, H)
+    att = res._arena(res.info.att_off, res.info.n_att, T)
+    i32 = lambda a: torch.tensor(a, dtype=torch.int32, device=dev)
+    if att_items:
+        slot = i32([a[0] for a in att_items]); K = i32([a[1] for a in att_items])
+        off = i32(np.concatenate([[0], np.cumsum([a[1] for a in att_items])]).tolist())
+        iv = torch.tensor([p for a in att_items for p in a[2]], dtype=torch.float64, device=dev)
+        val = torch.empty(len(att_items), device=dev)
+        check(lib.stair_loss_attention(C.c_void_p(att.data_ptr()), None, C.c_void_p(slot.data_ptr()), C.c_void_p(K.data_ptr()),
+                                       C.c_void_p(off.data_ptr()), C.c_void_p(iv.data_ptr()), len(att_items), T,
+                                       C.c_float(0.0), C.c_void_p(val.data_ptr()), stream))
+        for a, v in zip(att_items, val.cpu().tolist()):
+            out[a[3]].append(v)
+    for module, items in head_items.items():
+        if not items:
+            continue
+        if not model.config['have_pretrain_head']:
+            raise RuntimeError('%s loss needs have_pretrain_head (modules.py)' % module)
+        head = model.submodules[module].pretrain_head
+        slot = i32([a[0] for a in items]); lab = i32([a[1] for a in items])
+        val = torch.empty(len(items), device=dev)
+        check(lib.stair_loss_head(head.weight.shape[0], C.c_void_p(vec.data_ptr()), None, C.c_void_p(slot.data_ptr()),
+                                  C.c_void_p(lab.data_ptr()), C.c_void_p(head.weight.data_ptr()), C.c_void_p(head.bias.data_ptr()),
+                                  None, None, len(items), H, C.c_float(0.0), C.c_void_p(val.data_ptr()), stream))
+        out[module].extend(val.cpu().tolist())
+    if cont_items:
+        reps = model.encode_phrases(embs)                                  # [sum of gold sizes, H], L2-normalised
+        seg = torch.repeat_interleave(torch.arange(len(cont_items), device=dev), i32([c[3] for c in cont_items]).long())
+        mean = torch.zeros(len(cont_items), H, device=dev).index_add_(0, seg, reps)
+        mean /= torch.tensor([c[3] for c in cont_items], dtype=torch.float32, device=dev).unsqueeze(1)
+        pred = vec[i32([c[1] for c in cont_items]).long()]
+        cos = torch.nn.functional.cosine_similarity(pred, mean, dim=1).cpu().tolist()
+        for c, v in zip(cont_items, cos):
+            out[c[0]][c[4]] = v
+    return out

@@ -81,15 +81,16 @@ class Trainer:
         start, end, total = self.sched
         return end if self.iters > total else start + (end - start) / total * self.iters
 
-    def step(self, programs, spans, video, question, q_lens, answers, global_batch=None, questions=None):
+    def step(self, programs, spans, video, question, q_lens, answers, global_batch=None, questions=None, video_index=None):
         """One optimizer step over this rank's shard of a window.  `questions` (the dicts, with
         'sg_res_by_step') switches the per-module intermediate losses on (train_module.py:351-373, 388-406).
+        video_index: questions that share a clip (see VideoNMN.run_programs).
         Returns (per-question decoder CE of the local shard, BatchResult)."""
         from . import losses as L
         n = len(programs)
         G = global_batch or n * self.world
         self.flat_g.zero_()                                   # optimizer.zero_grad()
-        res = self.model.run_programs(programs, spans, video, question, q_lens, train=True)
+        res = self.model.run_programs(programs, spans, video, question, q_lens, train=True, video_index=video_index)
         extra = set()
         if questions is not None and self.module_loss_weight != 0:
             res.zero_grad_arenas()

@@ -284,3 +284,32 @@ def test_intermediate_supervision_losses_and_gradients(name, window, matmul):
         assert err < tol, (n, err, float(ref.abs().max()))
     assert w['submodules.Exists.pretrain_head.weight'].grad is not None and 'submodules.Exists.pretrain_head.weight' in extra
     print('worst gradient error / tolerance with intermediate supervision:', worst)
+
+
+def test_validation_loop_matches_reference(matmul):
+    """stair_amd.evaluate.evaluate_by_module on the HIP path == the reference's evaluate_by_module output
+    (tests/golden/validation.json): accuracy, every module's mean validation loss ('cont-valid' cosine for the
+    contrastive modules, attention criteria, head criteria, decoder CE); modules with no scored node report inf."""
+    import json, os
+    from stair_amd import evaluate as E
+    from stair_amd.module_net import VideoNMN
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'validation.json')))
+    z, meta = load_golden(gold['config'])
+    config = meta['config']
+    from helpers import PRETRAIN_MODULES
+    m = VideoNMN(config, pretrain_modules=set(PRETRAIN_MODULES))
+    w = synth.make_weights(config, meta['seed'])
+    m.load_state_dict({k: torch.from_numpy(w[k].copy()) for k in spec.state_dict_keys(config)})
+    m = m.to(DEV)
+    qs = []
+    for q in meta['questions']:
+        d = question_for(meta, q)
+        d['sg_res_by_step'] = synth.make_gold(config, meta['seed'], d, T=meta['T'], keep=1.0)
+        qs.append(d)
+    acc, valid = E.evaluate_by_module(m, qs, gold['unk_token_id'], batch_size=5)
+    assert acc == pytest.approx(gold['accuracy'])
+    for module, ref in gold['valid_losses'].items():
+        if ref is None:
+            assert valid[module] == float('inf'), module
+        else:
+            assert valid[module] == pytest.approx(ref, rel=1e-4, abs=2e-5), module
