@@ -295,6 +295,15 @@ int stair_loss_contrastive(const float *vec, float *d_vec, const int32_t *slot, 
                            const int32_t *win_start, const int32_t *win_cnt, const float *G, int32_t n, int32_t H,
                            int32_t max_classes, float scale, float *loss, stair_stream stream);
 
+/* FilterFrame (:141-155): pretrain head W [O,H], b [O] on the T frames of map tile slot[i] (rows (slot*T + t) of the map
+ * arena), softmax over the O object classes, BCELoss against gold [n,T,O] = the row-normalised interval masks the host
+ * builds from the gold {entity: (start, end)} dict (0 rows where no entity is present), mean over T*O.  Gradients go
+ * to d_map (the map gradient arena), dW, db.  The reference leaves this loss out of training by default (args.py:62)
+ * but scores it in validation. */
+int stair_loss_filterframe(const float *map, float *d_map, const int32_t *slot, const float *gold, const float *W,
+                           const float *b, float *dW, float *db, int32_t n, int32_t T, int32_t H, int32_t O,
+                           float scale, float *loss, stair_stream stream);
+
 /* Test hook: every region of the workspace layout as (name, begin, end) float offsets; returns the region count.
  * Regions must be pairwise disjoint (tests/test_abi.py checks it for inference and training plans). */
 int stair_plan_regions(stair_plan *plan, const stair_ctx *ctx, const char **names, int64_t *beg, int64_t *end, int32_t cap);

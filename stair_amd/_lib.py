@@ -102,6 +102,8 @@ SIGNATURES = [
                                           C.c_int32, c_int32_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     ('stair_plan_backward', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                       C.c_float, C.c_void_p, C.c_int32, C.c_void_p]),
+    ('stair_loss_filterframe', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     ('stair_plan_zero_grads', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ('stair_loss_attention', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                        C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),

@@ -178,6 +178,105 @@ int launch_loss_contrastive(const float *vec, float *d_vec, const int32_t *slot,
     return 0;
 }
 
+// FilterFrame criterion (:141-155): pretrain head Lin(H -> O) on every frame of map tile slot[i] (modules.py:381-414),
+// softmax over the O object classes, BCELoss against the row-normalised interval masks gold [n][T][O] (built by the host
+// from the gold dict: one span_to_attention column per entity), mean over T*O.  One workgroup (4 waves) per item:
+//   phase 1  wave per frame: x[t][:] in registers, one butterfly reduction per class -> z[t][o] in LDS
+//   phase 2  thread per frame: softmax, loss terms, dz = softmax' . dBCE (torch's backward: (p-g)/max(p(1-p),1e-12))
+//   phase 3  dx[t][:] += dz[t][:] W  (wave per frame),  dW[o][:] += dz[:,o]^T x  (wave per class),  db += colsum(dz)
+__global__ __launch_bounds__(256) void loss_filterframe_kernel(const float *map, float *d_map, const int32_t *slot,
+                                                               const float *gold, const float *W, const float *b, float *dW,
+                                                               float *db, int T, int H, int O, float scale, float *loss) {
+    extern __shared__ float z[];                 // [T][O]
+    __shared__ float s_loss;
+    const int i = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float *x = map + (int64_t)slot[i] * T * H;
+    const float *g = gold + (int64_t)i * T * O;
+    const int nh = H >> 6;                       // floats per lane (H % 64 == 0, H <= 512)
+    if (threadIdx.x == 0) s_loss = 0.f;
+    for (int t = wave; t < T; t += 4) {
+        float xr[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xr[j] = j < nh ? x[(int64_t)t * H + j * 64 + lane] : 0.f;
+        for (int o = 0; o < O; ++o) {
+            float d = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < nh) d += xr[j] * W[(int64_t)o * H + j * 64 + lane];
+            d = wave_sum(d);
+            if (lane == 0) z[t * O + o] = d + b[o];
+        }
+    }
+    __syncthreads();
+    const float inv = 1.0f / (float)(T * O);
+    float part = 0.f;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+        float m = -INFINITY;
+        for (int o = 0; o < O; ++o) m = fmaxf(m, z[t * O + o]);
+        float sum = 0.f;
+        for (int o = 0; o < O; ++o) sum += expf(z[t * O + o] - m);
+        float dot = 0.f;                          // sum_j p_j dL/dp_j
+        for (int o = 0; o < O; ++o) {
+            const float p = expf(z[t * O + o] - m) / sum, gg = g[t * O + o];
+            part += -(gg * fmaxf(logf(p), -100.f) + (1.f - gg) * fmaxf(logf(1.f - p), -100.f));
+            dot += p * (p - gg) / fmaxf(p * (1.f - p), 1e-12f);
+        }
+        for (int o = 0; o < O; ++o) {
+            const float p = expf(z[t * O + o] - m) / sum, gg = g[t * O + o];
+            z[t * O + o] = scale * inv * p * ((p - gg) / fmaxf(p * (1.f - p), 1e-12f) - dot);     // d loss / d logit
+        }
+    }
+    part = wave_sum(part);
+    if (lane == 0 && part != 0.f) atomicAdd(&s_loss, part);
+    __syncthreads();
+    if (threadIdx.x == 0) loss[i] = s_loss * inv;
+    if (d_map) {
+        float *dx = d_map + (int64_t)slot[i] * T * H;
+        for (int t = wave; t < T; t += 4) {
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int o = 0; o < O; ++o) {
+                const float dz = z[t * O + o];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (j < nh) acc[j] += dz * W[(int64_t)o * H + j * 64 + lane];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < nh) unsafeAtomicAdd(dx + (int64_t)t * H + j * 64 + lane, acc[j]);
+        }
+    }
+    if (dW) {
+        for (int o = wave; o < O; o += 4) {
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < T; ++t) {
+                const float dz = z[t * O + o];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (j < nh) acc[j] += dz * x[(int64_t)t * H + j * 64 + lane];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < nh) unsafeAtomicAdd(dW + (int64_t)o * H + j * 64 + lane, acc[j]);
+        }
+    }
+    if (db)
+        for (int o = threadIdx.x; o < O; o += blockDim.x) {
+            float sdz = 0.f;
+            for (int t = 0; t < T; ++t) sdz += z[t * O + o];
+            unsafeAtomicAdd(db + o, sdz);
+        }
+}
+int launch_loss_filterframe(const float *map, float *d_map, const int32_t *slot, const float *gold, const float *W, const float *b,
+                            float *dW, float *db, int n, int T, int H, int O, float scale, float *loss, hipStream_t s) {
+    STAIR_CHECK(H % 64 == 0 && H <= 512, "hidden size must be a multiple of 64, at most 512");
+    STAIR_CHECK(T > 0 && O > 0 && (int64_t)T * O * 4 <= 60 * 1024, "T * object_types too large for the LDS tile");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(loss_filterframe_kernel, dim3(n), dim3(256), (size_t)T * O * sizeof(float), s, map, d_map, slot, gold, W, b,
+                       dW, db, T, H, O, scale, loss);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace stair
 
 extern "C" int stair_loss_attention(const float *att, float *d_att, const int32_t *slot, const int32_t *K,
@@ -194,5 +293,11 @@ extern "C" int stair_loss_contrastive(const float *vec, float *d_vec, const int3
                                       const int32_t *win_start, const int32_t *win_cnt, const float *G, int32_t n, int32_t H,
                                       int32_t max_classes, float scale, float *loss, stair_stream stream) {
     return stair::launch_loss_contrastive(vec, d_vec, slot, pos, win_start, win_cnt, G, n, H, max_classes, scale, loss,
+                                          static_cast<hipStream_t>(stream));
+}
+extern "C" int stair_loss_filterframe(const float *map, float *d_map, const int32_t *slot, const float *gold, const float *W,
+                                      const float *b, float *dW, float *db, int32_t n, int32_t T, int32_t H, int32_t O,
+                                      float scale, float *loss, stair_stream stream) {
+    return stair::launch_loss_filterframe(map, d_map, slot, gold, W, b, dW, db, n, T, H, O, scale, loss,
                                           static_cast<hipStream_t>(stream));
 }

@@ -9,7 +9,8 @@ Gold values per question live in ``q['sg_res_by_step'] = {program_idx: gold}`` e
     Temporal / ExistsFrame  -> one (start, end)
     Exists / Xor / Equals   -> bool
     Filter / ToAction / Superlative -> list of (class_name, GloVe embedding [L,300])
-    FilterFrame             -> dict (excluded by default: args.py:62 modules_no_intermediate_train)
+    FilterFrame             -> {entity: (start, end)} (left out of training by default, args.py:62
+                               modules_no_intermediate_train, but scored in validation); needs model.object_index
 """
 from __future__ import annotations
 
@@ -24,6 +25,65 @@ from ._lib import check, lib
 CONTRASTIVE = ('Filter', 'Superlative', 'ToAction')
 CRITERION_MODULES = frozenset({'Exists', 'Xor', 'Equals', 'Filter', 'ToAction', 'FilterFrame', 'ExistsFrame',
                                'Superlative', 'Localize', 'Temporal', 'decoder'})     # train_module.py:36-48
+
+
+def object_index(word2id):
+    """{word: column of the FilterFrame head} from the reference's IDX-style {word: id} table: several words may share
+    an id and the column is the rank of the id (train_module.py:49-54)."""
+    rank = {i: n for n, i in enumerate(sorted(set(word2id.values())))}
+    return {w: rank[i] for w, i in word2id.items()}
+
+
+def _span_mask(start, end, T):
+    """train_module.py:67-81 span_to_attention, float32 like the reference's tensor."""
+    import math
+    g = np.zeros(T, dtype=np.float32)
+    start = min(T - 0.002, max(0.001, start))
+    end = min(T - 0.001, end)
+    si, ei = math.ceil(start), math.floor(end)
+    if si < ei:
+        g[si:ei] += 1
+    if si <= ei:
+        g[si - 1] += np.float32(si - start)
+        g[ei] += np.float32(end - ei)
+    else:
+        g[ei] += np.float32(end - start)
+    return g
+
+
+def filterframe_target(gold, T, O, word2index):
+    """train_module.py:147-154: one interval mask per gold entity in its object column, rows normalised to sum 1."""
+    g = np.zeros((T, O), dtype=np.float32)
+    for name, interval in gold.items():
+        g[:, word2index[name]] = _span_mask(float(interval[0]), float(interval[1]), T)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        g = g / g.sum(axis=1, keepdims=True)
+    g[~np.isfinite(g)] = 0.0
+    return g
+
+
+def _filterframe_launch(model, res, items, scale, grads):
+    """items: [(map slot, gold dict)].  Returns the per-item losses (device tensor)."""
+    dev = res.logits.device
+    H, T, O = model.config['hidden_size'], res.info.T, model.config['object_types']
+    index = getattr(model, 'object_index', None)
+    if index is None:
+        raise RuntimeError('FilterFrame loss needs model.object_index = losses.object_index(json.load(open(word2id_filename)))')
+    head = model.submodules['FilterFrame'].pretrain_head
+    if grads and head.weight.grad is None:
+        raise RuntimeError('pretrain head of FilterFrame has no .grad buffer (use stair_amd.train.Trainer)')
+    gold = torch.from_numpy(np.stack([filterframe_target(g, T, O, index) for _, g in items])).to(dev)
+    slot = torch.tensor([a[0] for a in items], dtype=torch.int32, device=dev)
+    out = torch.empty(len(items), device=dev)
+    inf = res.info
+    mp = res._ws[inf.map_off: inf.map_off + inf.n_map * T * H]
+    gmap = res.grad_arena('map') if grads else None
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    check(lib.stair_loss_filterframe(p(mp), p(gmap), p(slot), p(gold), p(head.weight), p(head.bias),
+                                     p(head.weight.grad) if grads else None, p(head.bias.grad) if grads else None,
+                                     len(items), T, H, O, C.c_float(scale), p(out),
+                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return out
 
 
 def supervised_nodes(question, pretrain_modules):
@@ -45,7 +105,7 @@ def apply_module_losses(model, res, questions, scale, pretrain_modules=CRITERION
     Returns ({loss_kind: per-item losses tensor}, set of extra parameter names that received a gradient)."""
     dev = res.logits.device
     H, T = model.config['hidden_size'], res.info.T
-    att_items, head_items, cont_items = [], {'Exists': [], 'Xor': [], 'Equals': []}, []
+    att_items, head_items, cont_items, ff_items = [], {'Exists': [], 'Xor': [], 'Equals': []}, [], []
     windows = {}                      # window id -> {class_name: embedding}
     for qi, q in enumerate(questions):
         sg = q.get('sg_res_by_step') or {}
@@ -71,8 +131,10 @@ def apply_module_losses(model, res, questions, scale, pretrain_modules=CRITERION
                 for class_name, emb in gold:
                     w[class_name] = emb
                     cont_items.append((slot, qi // window if window else 0, class_name))
+            elif module == 'FilterFrame':
+                ff_items.append((slot, gold))
             else:
-                raise NotImplementedError('intermediate loss for %s (the reference excludes it by default, args.py:62)' % module)
+                raise NotImplementedError('intermediate loss for %s' % module)
 
     losses, touched = {}, set()
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -106,6 +168,9 @@ def apply_module_losses(model, res, questions, scale, pretrain_modules=CRITERION
                                   C.c_void_p(out.data_ptr()), stream))
         losses[module] = out
         touched.update({'submodules.%s.pretrain_head.weight' % module, 'submodules.%s.pretrain_head.bias' % module})
+    if ff_items:
+        losses['FilterFrame'] = _filterframe_launch(model, res, ff_items, scale, True)
+        touched.update({'submodules.FilterFrame.pretrain_head.weight', 'submodules.FilterFrame.pretrain_head.bias'})
     if cont_items:
         # class representations of every window: text encoder without gradient + L2Normalize (module_net.py:78-89)
         table, embs, win_range = {}, [], {}
@@ -139,7 +204,7 @@ def evaluate_module_losses(model, res, questions, pretrain_modules=CRITERION_MOD
     representations; that one reduction (a few hundred [H] rows) is plain torch on the device."""
     dev = res.logits.device
     H, T = model.config['hidden_size'], res.info.T
-    att_items, head_items, cont_items, embs = [], {'Exists': [], 'Xor': [], 'Equals': []}, [], []
+    att_items, head_items, cont_items, embs, ff_items = [], {'Exists': [], 'Xor': [], 'Equals': []}, [], [], []
     out = {m: [] for m in sorted(pretrain_modules)}
     for qi, q in enumerate(questions):
         sg = q.get('sg_res_by_step') or {}
@@ -165,9 +230,10 @@ def evaluate_module_losses(model, res, questions, pretrain_modules=CRITERION_MOD
                 cont_items.append((module, slot, len(embs), len(gold), len(out[module])))
                 out[module].append(None)
                 embs.extend(torch.as_tensor(e, dtype=torch.float32) for _, e in gold)
+            elif module == 'FilterFrame':
+                ff_items.append((slot, gold))
             else:
-                raise NotImplementedError('validation loss for %s (FilterFrame needs the object vocabulary of '
-                                          'train_module.py:141-155, not built)' % module)
+                raise NotImplementedError('validation loss for %s' % module)
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     vec = res._arena(res.info.vec_off, res.info.n_vec, H)
     att = res._arena(res.info.att_off, res.info.n_att, T)
@@ -194,6 +260,8 @@ def evaluate_module_losses(model, res, questions, pretrain_modules=CRITERION_MOD
                                   C.c_void_p(lab.data_ptr()), C.c_void_p(head.weight.data_ptr()), C.c_void_p(head.bias.data_ptr()),
                                   None, None, len(items), H, C.c_float(0.0), C.c_void_p(val.data_ptr()), stream))
         out[module].extend(val.cpu().tolist())
+    if ff_items:
+        out['FilterFrame'].extend(_filterframe_launch(model, res, ff_items, 0.0, False).cpu().tolist())
     if cont_items:
         reps = model.encode_phrases(embs)                                  # [sum of gold sizes, H], L2-normalised
         seg = torch.repeat_interleave(torch.arange(len(cont_items), device=dev), i32([c[3] for c in cont_items]).long())

@@ -286,6 +286,115 @@ def test_intermediate_supervision_losses_and_gradients(name, window, matmul):
     print('worst gradient error / tolerance with intermediate supervision:', worst)
 
 
+WORD2ID = {'cup': 'o1', 'glass': 'o1', 'dish': 'o2', 'door': 'o5', 'phone': 'o3', 'sofa': 'o9', 'blanket': 'o4',
+           'window': 'o7', 'food': 'o8', 'bag': 'o6'}
+
+
+def test_filterframe_loss_kernel_matches_reference_fixture():
+    """stair_loss_filterframe against tests/golden/criteria_filterframe.npz (the reference's CriterionByModule):
+    with head W = [I | 0], b = 0 the head's logits ARE the fixture's predictions, so the kernel's loss and the first O
+    columns of d_map must equal the reference's loss and d loss / d pred; then a random head vs autograd of the oracle."""
+    import ctypes as C, json, os
+    from oracle import nmn_losses as OL
+    from stair_amd import losses as L
+    from stair_amd._lib import lib, check
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'criteria_filterframe.npz'))
+    meta = json.loads(bytes(z['meta']).decode())
+    O, H = meta['O'], 64
+    index = L.object_index(meta['word2id'])
+    assert index == meta['word2index']
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for i, case in enumerate(meta['cases']):
+        T = case['T']
+        pred = torch.from_numpy(z['c%d/pred' % i])
+        gold = {k: tuple(v) for k, v in case['gold'].items()}
+        tgt = torch.from_numpy(L.filterframe_target(gold, T, O, index)).unsqueeze(0).to(DEV)
+        x = torch.zeros(3, T, H); x[1, :, :O] = pred                      # the item reads map slot 1
+        W = torch.zeros(O, H); W[:, :O] = torch.eye(O)
+        xd, Wd, bd = x.to(DEV), W.to(DEV), torch.zeros(O, device=DEV)
+        dmap, dW, db = torch.zeros_like(xd), torch.zeros_like(Wd), torch.zeros_like(bd)
+        slot = torch.tensor([1], dtype=torch.int32, device=DEV)
+        loss = torch.empty(1, device=DEV)
+        check(lib.stair_loss_filterframe(p(xd), p(dmap), p(slot), p(tgt), p(Wd), p(bd), p(dW), p(db), 1, T, H, O,
+                                         C.c_float(1.0), p(loss), stream))
+        assert float(loss) == pytest.approx(float(z['c%d/loss' % i]), abs=2e-6)
+        assert float((dmap[1, :, :O].cpu() - torch.from_numpy(z['c%d/dpred' % i])).abs().max()) < 2e-6
+        assert float(dmap[0].abs().max()) == 0.0 and float(dmap[2].abs().max()) == 0.0
+        # values only (NULL gradients), as the validation loop calls it
+        loss2 = torch.empty(1, device=DEV)
+        check(lib.stair_loss_filterframe(p(xd), None, p(slot), p(tgt), p(Wd), p(bd), None, None, 1, T, H, O,
+                                         C.c_float(0.0), p(loss2), stream))
+        assert float(loss2) == float(loss)
+    # random head, two items sharing a slot, scale != 1: vs torch autograd of the oracle criterion
+    g = torch.Generator().manual_seed(3)
+    T = 40
+    x = torch.randn(4, T, H, generator=g).requires_grad_(True)
+    W = (torch.randn(O, H, generator=g) * 0.2).requires_grad_(True)
+    b = torch.randn(O, generator=g).requires_grad_(True)
+    golds = [{'cup': (3.2, 17.9), 'door': (10.0, 30.5)}, {'phone': (0.0, 40.0)}, {'sofa': (5.5, 6.5), 'bag': (20.0, 21.0)}]
+    slots = [2, 0, 2]
+    total = sum(OL.criterion_filterframe(x[s] @ W.t() + b, gd, index) for s, gd in zip(slots, golds)) * 0.25
+    total.backward()
+    tgt = torch.from_numpy(np.stack([L.filterframe_target(gd, T, O, index) for gd in golds])).to(DEV)
+    xd, Wd, bd = x.detach().to(DEV), W.detach().to(DEV), b.detach().to(DEV)
+    dmap, dW, db = torch.zeros_like(xd), torch.zeros_like(Wd), torch.zeros_like(bd)
+    loss = torch.empty(3, device=DEV)
+    check(lib.stair_loss_filterframe(p(xd), p(dmap), p(torch.tensor(slots, dtype=torch.int32, device=DEV)), p(tgt), p(Wd), p(bd),
+                                     p(dW), p(db), 3, T, H, O, C.c_float(0.25), p(loss), stream))
+    for got, ref in ((dmap, x.grad), (dW, W.grad), (db, b.grad)):
+        assert float((got.cpu() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_training_with_filterframe_supervision(matmul):
+    """The FilterFrame criterion switched ON (no_intermediate=()): window loss and every parameter gradient vs
+    autograd of the oracle, whose criterion is pinned to the reference by criteria_filterframe.npz."""
+    from oracle import nmn_losses as OL
+    from stair_amd import losses as L
+    z, meta = load_golden('tiny_conv')
+    config, T = meta['config'], meta['T']
+    qs = _with_gold(config, 3, [question_for(meta, q) for q in meta['questions']], T)
+    index = L.object_index(WORD2ID)
+    words = sorted(WORD2ID)
+    n_ff = 0
+    for qi, q in enumerate(qs):
+        for i, tok in enumerate(q['nmn_program_list']):
+            if tok == 'FilterFrame' and i != 0 and q['nmn_program_idx'][i] is not None:
+                a, b = words[(qi + i) % len(words)], words[(qi + 2 * i + 3) % len(words)]
+                q['sg_res_by_step'][q['nmn_program_idx'][i]] = {a: (0.1 * T, 0.5 * T), b: (0.3 * T + qi, 0.9 * T)}
+                n_ff += 1
+    assert n_ff >= 3
+    Gw = len(qs)
+    names, w = _oracle_params(config, meta['seed'])
+    total, det = OL.window_loss(w, config, [_oracle_view(q) for q in qs], L.CRITERION_MODULES, gradient_accumulation=Gw,
+                                no_intermediate=(), explicit_lstm=True, word2index=index)
+    total.backward()
+    model = _model(config, meta['seed'])
+    model.pretrain_modules = set(L.CRITERION_MODULES)
+    model.object_index = index
+    for p in model.parameters():
+        p.grad = torch.zeros_like(p)
+    progs, spans, video, question, q_lens, answers = _pack(model, qs)
+    res = model.run_programs(progs, spans, video, question, q_lens, train=True)
+    res.zero_grad_arenas()
+    losses, extra = L.apply_module_losses(model, res, qs, 1.0 / Gw, no_intermediate=())
+    res.backward(answers, 1.0 / Gw, keep_arenas=True)
+    ref_ff = sorted(x[3] for x in det['module'] if x[2] == 'FilterFrame')
+    assert len(ref_ff) == n_ff and np.allclose(sorted(losses['FilterFrame'].cpu().tolist()), ref_ff, rtol=2e-5, atol=2e-6)
+    assert 'submodules.FilterFrame.pretrain_head.weight' in extra
+    got = dict(model.named_parameters())
+    for n in names:
+        ref = w[n].grad
+        if ref is None:
+            continue
+        tol = 2e-4 * max(float(ref.abs().max()), 1e-3)
+        assert float((got[n].grad.cpu() - ref).abs().max()) < tol, n
+    assert float(w['submodules.FilterFrame.pretrain_head.weight'].grad.abs().max()) > 0
+    model.object_index = None
+    with pytest.raises(RuntimeError, match='object_index'):
+        L.apply_module_losses(model, res, qs, 1.0 / Gw, no_intermediate=())
+
+
 def test_validation_loop_matches_reference(matmul):
     """stair_amd.evaluate.evaluate_by_module on the HIP path == the reference's evaluate_by_module output
     (tests/golden/validation.json): accuracy, every module's mean validation loss ('cont-valid' cosine for the
