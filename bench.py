@@ -175,7 +175,7 @@ def main():
     trainer = None
     if args.mode == 'train':
         from stair_amd.train import Trainer
-        trainer = Trainer(model, world=world)
+        trainer = Trainer(model, world=world, rank=rank)
 
     def step():
         if trainer is not None:

@@ -263,7 +263,8 @@ int stair_plan_run_flags(stair_ctx *ctx, stair_plan *plan, const float *video, c
  * entropy against answers[n] (train_module.py:193-194,376-380), d(loss_scale * sum_i CE_i) propagated
  * through decoder, every program level in reverse, and both encoders (BPTT); parameter gradients are
  * accumulated into the buffers given to stair_ctx_set_grad.  loss_out [n] (device, may be NULL)
- * receives the unscaled per-question CE.  What torch autograd does for train_module.py:408. */
+ * receives the unscaled per-question CE.  answers[i] < 0 leaves question i without a decoder loss (its CE is
+ * reported as 0): the train_decoder_after_iters gate of train_module.py:376.  What torch autograd does for :408. */
 int stair_plan_backward(stair_ctx *ctx, stair_plan *plan, const float *video, const float *question,
                         void *workspace, int64_t workspace_bytes, const int32_t *answers, float loss_scale,
                         float *loss_out, int32_t flags, stair_stream stream);

@@ -704,6 +704,12 @@ __global__ void ce_loss_kernel(const float *logits, const int32_t *answers, floa
     for (int c = lane; c < A; c += 64) sum += expf(x[c] - m);
     sum = wave_sum(sum);
     const int ans = answers[i];
+    if (ans < 0) {                 // question without a decoder loss (train_module.py:376: global_steps <= train_decoder_after_iters)
+        if (lane == 0 && loss) loss[i] = 0.f;
+        if (dlogits)
+            for (int c = lane; c < A; c += 64) dlogits[(int64_t)i * A + c] = 0.f;
+        return;
+    }
     if (lane == 0 && loss) loss[i] = logf(sum) + m - x[ans];
     if (dlogits)
         for (int c = lane; c < A; c += 64) dlogits[(int64_t)i * A + c] = scale * (expf(x[c] - m) / sum - (c == ans ? 1.f : 0.f));

@@ -37,10 +37,15 @@ class Trainer:
     def __init__(self, model, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decoder_loss_weight=1.0,
                  module_loss_weight=1.0, contrastive_window=32, no_intermediate=('FilterFrame',),
                  scheduler_start_factor=1.0, scheduler_end_factor=0.1, scheduler_total_iters=200000, world=1,
-                 skip_untouched='ever'):
+                 skip_untouched='ever', train_module_before_iters=1e10, train_decoder_after_iters=0, rank=0):
         """skip_untouched: 'ever'   -- a parameter is skipped by Adam until the first window that sends it a gradient
                                       (torch 1.13, which the reference pins: zero_grad() keeps zero tensors afterwards);
                            'window' -- skipped in every window that does not touch it (torch >= 2.0, set_to_none=True)."""
+        # train_module.py:350,376 gate the two loss families by the reference's global_steps (one per QUESTION there):
+        # intermediate losses while global_steps < train_module_before_iters, decoder loss once global_steps >
+        # train_decoder_after_iters.  Question i of a rank's shard has global step seen + 1 + rank + i * world.
+        self.before_iters, self.after_iters, self.rank = train_module_before_iters, train_decoder_after_iters, rank
+        self.questions_seen = 0
         assert skip_untouched in ('ever', 'window')
         self.skip_untouched = skip_untouched
         self.model, self.world = model, world
@@ -90,6 +95,13 @@ class Trainer:
         n = len(programs)
         G = global_batch or n * self.world
         self.flat_g.zero_()                                   # optimizer.zero_grad()
+        gstep = [self.questions_seen + 1 + self.rank + i * self.world for i in range(n)]
+        self.questions_seen += G
+        if gstep[0] <= self.after_iters:                      # some questions still without decoder loss
+            answers = torch.where(torch.tensor([g > self.after_iters for g in gstep], device=answers.device), answers,
+                                  torch.full_like(answers, -1))
+        if questions is not None and gstep[-1] >= self.before_iters:
+            questions = [q if g < self.before_iters else dict(q, sg_res_by_step={}) for q, g in zip(questions, gstep)]
         res = self.model.run_programs(programs, spans, video, question, q_lens, train=True, video_index=video_index)
         extra = set()
         if questions is not None and self.module_loss_weight != 0:

@@ -286,6 +286,37 @@ def test_intermediate_supervision_losses_and_gradients(name, window, matmul):
     print('worst gradient error / tolerance with intermediate supervision:', worst)
 
 
+def test_trainer_loss_gates_follow_the_global_step():
+    """train_module.py:350,376: intermediate losses only while global_steps < train_module_before_iters, decoder loss
+    only once global_steps > train_decoder_after_iters, with one global step per QUESTION.  A 12-question window that
+    straddles both thresholds: questions 1..4 carry no decoder loss, questions 9.. no intermediate loss."""
+    from stair_amd.train import Trainer
+    from stair_amd import losses as L
+    z, meta = load_golden('tiny_conv')
+    config, T = meta['config'], meta['T']
+    qs = _with_gold(config, 3, [question_for(meta, q) for q in meta['questions']], T)
+    model = _model(config, meta['seed'])
+    model.pretrain_modules = set(L.CRITERION_MODULES)
+    tr = Trainer(model, train_module_before_iters=9, train_decoder_after_iters=4)
+    progs, spans, video, question, q_lens, answers = _pack(model, qs)
+    dec, res = tr.step(progs, spans, video, question, q_lens, answers, questions=qs)
+    dec = dec.cpu()
+    assert float(dec[:4].abs().max()) == 0.0 and float(dec[4:].min()) > 0.0          # global steps 1..4 vs 5..12
+    supervised = [i for i, q in enumerate(qs) if q['sg_res_by_step']]
+    assert any(i >= 8 for i in supervised) and any(i < 8 for i in supervised)
+    n_items = sum(int(v.numel()) for v in tr.module_losses.values())
+    model2 = _model(config, meta['seed'])
+    model2.pretrain_modules = set(L.CRITERION_MODULES)
+    tr2 = Trainer(model2)
+    tr2.step(progs, spans, video, question, q_lens, answers, questions=qs)
+    n_all = sum(int(v.numel()) for v in tr2.module_losses.values())
+    assert 0 < n_items < n_all
+    assert tr.questions_seen == 12 and tr2.questions_seen == 12
+    # second window: every question is past both thresholds -> decoder loss everywhere, no intermediate loss at all
+    dec, _ = tr.step(progs, spans, video, question, q_lens, answers, questions=qs)
+    assert float(dec.min()) > 0.0 and sum(int(v.numel()) for v in tr.module_losses.values()) == 0
+
+
 WORD2ID = {'cup': 'o1', 'glass': 'o1', 'dish': 'o2', 'door': 'o5', 'phone': 'o3', 'sofa': 'o9', 'blanket': 'o4',
            'window': 'o7', 'food': 'o8', 'bag': 'o6'}
 
