@@ -382,6 +382,162 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_w8_kernel(XParams p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// 256 x 256 tile for the large PLAIN launches.  Ablations of the 128 x 128 kernels showed the
+// data-movement skeleton -- fp32 rows pulled through the vector L1 into registers, then pushed into LDS by
+// ds_write_b128 -- costing more than the MFMAs and NOT overlapping with them.  That cost is bytes per flop: a
+// 256 x 256 tile stages half as many bytes per MFMA (and its 128 x 64 wave tile reads half as many LDS fragments per
+// MFMA).  8 waves 2 (M) x 4 (N); 128 accumulator registers per lane; ONE staging register set (the 48 MFMAs of a
+// chunk, 1536 cycles, cover the load latency on their own); LDS 2 buffers x 64 KB; one workgroup per CU.
+// ---------------------------------------------------------------------------------------------
+namespace {
+constexpr int IMG2 = XKQ * 256 * 8;      // bf16 elements of one 256-row image (16 KB)
+__device__ __forceinline__ int img2_off(int buf, int operand, int part, int kq, int row) {
+    return (((buf * 2 + operand) * 2 + part) * IMG2) + (kq * 256 + ((row ^ ((row >> 3) & 3)) ^ (2 * kq))) * 8;
+}
+}  // namespace
+
+template <int ACT>
+__global__ __launch_bounds__(512, 1) void gemm_bf16x3_t256_kernel(XParams p) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 xlds[];
+    const stair_gemm_args &a = p.a;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int r = lane & 31, h = lane >> 5;
+
+    const int nb = p.tilesM * p.tilesN;
+    const int bid = blockIdx.x;
+    const int qd = nb >> 3, rm = nb & 7, xcd = bid & 7, loc = bid >> 3;
+    const int logical = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
+    const int tm = logical / p.tilesN, tn = logical - tm * p.tilesN;
+    const int m0 = tm * 256, n0 = tn * 256;
+    const int R = a.rows_per_group, K = a.K;
+
+    // staging units: (row, kq), rows tid/4 and 128 + tid/4 of each operand
+    const int kq = tid & 3, ra_ = tid >> 2;
+    const float *aptr[2];
+    const float *wptr[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = min(m0 + ra_ + 128 * i, p.M - 1);
+        const int g = m / R, rr = m - g * R;
+        const int64_t gi = a.a_gidx ? a.a_gidx[g] : g;
+        aptr[i] = a.A + gi * a.a_gstride + (int64_t)rr * a.lda;
+        const int n = min(n0 + ra_ + 128 * i, a.N - 1);
+        wptr[i] = a.W + (int64_t)n * a.ldw;
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    v4f va[2][2], vb[2][2];       // [row half][k half]
+#define Y_GLOAD(k0)                                                            \
+    {                                                                          \
+        const int ka = min((k0) + 8 * kq, K - 8);                              \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                     \
+            va[i_][0] = *(gv4p)(aptr[i_] + ka); va[i_][1] = *(gv4p)(aptr[i_] + ka + 4);   \
+            vb[i_][0] = *(gv4p)(wptr[i_] + ka); vb[i_][1] = *(gv4p)(wptr[i_] + ka + 4);   \
+        }                                                                      \
+    }
+#define Y_LSTORE(buf)                                                                                   \
+    {                                                                                                   \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                              \
+            bf16x8 hi_, lo_;                                                                            \
+            split8p(va[i_][0], va[i_][1], hi_, lo_);                                                    \
+            *reinterpret_cast<bf16x8 *>(xlds + img2_off(buf, 0, 0, kq, ra_ + 128 * i_)) = hi_;          \
+            *reinterpret_cast<bf16x8 *>(xlds + img2_off(buf, 0, 1, kq, ra_ + 128 * i_)) = lo_;          \
+            split8p(vb[i_][0], vb[i_][1], hi_, lo_);                                                    \
+            *reinterpret_cast<bf16x8 *>(xlds + img2_off(buf, 1, 0, kq, ra_ + 128 * i_)) = hi_;          \
+            *reinterpret_cast<bf16x8 *>(xlds + img2_off(buf, 1, 1, kq, ra_ + 128 * i_)) = lo_;          \
+        }                                                                                               \
+    }
+#define Y_MFMA(buf)                                                                                                  \
+    {                                                                                                                \
+        _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                           \
+            const int kq_ = 2 * s_ + h;                                                                              \
+            bf16x8 bh_[2], bl_[2];                                                                                   \
+            _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                       \
+                bh_[j_] = *reinterpret_cast<const bf16x8 *>(xlds + img2_off(buf, 1, 0, kq_, wn * 64 + 32 * j_ + r)); \
+                bl_[j_] = *reinterpret_cast<const bf16x8 *>(xlds + img2_off(buf, 1, 1, kq_, wn * 64 + 32 * j_ + r)); \
+            }                                                                                                        \
+            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                       \
+                const bf16x8 ah_ = *reinterpret_cast<const bf16x8 *>(xlds + img2_off(buf, 0, 0, kq_, wm * 128 + 32 * i_ + r)); \
+                const bf16x8 al_ = *reinterpret_cast<const bf16x8 *>(xlds + img2_off(buf, 0, 1, kq_, wm * 128 + 32 * i_ + r)); \
+                _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                   \
+                    acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al_, bh_[j_], acc[i_][j_], 0, 0, 0);       \
+                    acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, bl_[j_], acc[i_][j_], 0, 0, 0);       \
+                    acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, bh_[j_], acc[i_][j_], 0, 0, 0);       \
+                }                                                                                                    \
+            }                                                                                                        \
+        }                                                                                                            \
+    }
+
+    // K % 64 == 0 (PLAIN launches only): chunks come in pairs, no tail; the load past K re-reads the last chunk into
+    // a buffer nobody multiplies.  (Running the two waves of a SIMD in opposite phase order -- one multiplying while the
+    // other splits and stores -- and raising the MFMA phase's priority were both measured: no change.)
+    const int nchunks = K / XBK;
+    Y_GLOAD(0);
+    Y_LSTORE(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; c += 2) {
+        Y_GLOAD((c + 1) * XBK);
+        __builtin_amdgcn_sched_barrier(0);
+        Y_MFMA(0);
+        __builtin_amdgcn_sched_barrier(0);
+        Y_LSTORE(1);
+        __syncthreads();
+        Y_GLOAD((c + 2) * XBK);
+        __builtin_amdgcn_sched_barrier(0);
+        Y_MFMA(1);
+        __builtin_amdgcn_sched_barrier(0);
+        Y_LSTORE(0);
+        __syncthreads();
+    }
+#undef Y_GLOAD
+#undef Y_LSTORE
+#undef Y_MFMA
+
+    long long *rowoff = reinterpret_cast<long long *>(xlds);
+    if (tid < 256) {
+        const int m = m0 + tid;
+        long long off = -1;
+        if (m < p.M) {
+            const int g = m / R, rr = m - g * R;
+            const int64_t gi = a.c_gidx ? a.c_gidx[g] : g;
+            off = gi * a.c_gstride + (int64_t)rr * a.ldc;
+        }
+        rowoff[tid] = off;
+    }
+    __syncthreads();
+    __attribute__((address_space(1))) float *Cg = (__attribute__((address_space(1))) float *)a.C;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + r;
+        if (n >= a.N) continue;
+        const float b = a.bias ? a.bias[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rowl = wm * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const long long off = rowoff[rowl];
+                if (off < 0) continue;
+                float v = acc[i][j][e] + b;
+                if (ACT == 1) v = fmaxf(v, 0.0f);
+                if (ACT == 2) v = sigmoid_acc(v);
+                if (a.accumulate) unsafeAtomicAdd(a.C + off + n, v);
+                else Cg[off + n] = v;
+            }
+        }
+    }
+}
+
 static bool gemm_w8_enabled() {
     static const bool on = [] { const char *e = getenv("STAIR_GEMM_W8"); return !(e && e[0] == '0'); }();
     return on;
@@ -398,6 +554,31 @@ int launch_gemm_bf16x3(const stair_gemm_args &a, hipStream_t s) {
     const dim3 grid(p.tilesM * p.tilesN), block(256);
     const size_t shmem = 2 * 2 * 2 * IMG * sizeof(__bf16);
     const bool plain = a.K % 64 == 0 && !a.row_scale;
+    static const int t256_min = [] { const char *e = getenv("STAIR_GEMM_T256"); return e ? atoi(e) : 256; }();   // 0 = off
+    const int t2m = (p.M + 255) / 256, t2n = (a.N + 255) / 256;
+    // one 256 x 256 workgroup per CU: the launch runs in rounds of 256 tiles, so it only pays when the last round is
+    // (nearly) full -- 266 tiles took 1.4x the time of the 128 x 128 kernel's 1064, 2048 tiles 0.85x.
+    const int t2 = t2m * t2n, rounds = (t2 + 255) / 256;
+    if (plain && t256_min > 0 && t2 >= t256_min && a.K >= 64 && (t256_min == 1 || rounds * 256 * 100 <= t2 * 108)) {
+        XParams q = p;
+        q.tilesM = t2m; q.tilesN = t2n;
+        const size_t shmem2 = 2 * 2 * 2 * IMG2 * sizeof(__bf16);       // 128 KB
+        const dim3 grid2(t2m * t2n);
+        static bool attr_set = false;
+        if (!attr_set) {
+            STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_bf16x3_t256_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem2));
+            STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_bf16x3_t256_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem2));
+            STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_bf16x3_t256_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem2));
+            attr_set = true;
+        }
+        switch (a.act) {
+            case 0: hipLaunchKernelGGL(gemm_bf16x3_t256_kernel<0>, grid2, dim3(512), shmem2, s, q); break;
+            case 1: hipLaunchKernelGGL(gemm_bf16x3_t256_kernel<1>, grid2, dim3(512), shmem2, s, q); break;
+            default: hipLaunchKernelGGL(gemm_bf16x3_t256_kernel<2>, grid2, dim3(512), shmem2, s, q); break;
+        }
+        STAIR_LAUNCH_CHECK();
+        return 0;
+    }
     const bool w8 = gemm_w8_enabled() && p.tilesM * p.tilesN >= 512;   // enough tiles for two 8-wave workgroups on every CU
 #define X_LAUNCH(ACT_)                                                                                             \
     if (w8 && plain) hipLaunchKernelGGL((gemm_bf16x3_w8_kernel<ACT_, true>), grid, dim3(512), shmem, s, p);         \
