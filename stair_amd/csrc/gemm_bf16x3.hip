@@ -754,6 +754,134 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16x3_kernel(XTnParams p) {
     }
 }
 
+
+// 256 x 256 tile form of the TN kernel for the largest weight gradient (dW_ih of the video encoder: N = 1024, K = 2048,
+// 32 tiles): PLAIN launches whose B rows come in groups of 8 (fast8 == 1).  Waves 0-3 stage A (256 columns of dZ),
+// waves 4-7 stage B; same LDS images and MFMA phase as gemm_bf16x3_t256_kernel; one staging register set.
+__global__ __launch_bounds__(512, 1) void gemm_tn_bf16x3_t256_kernel(XTnParams p) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 xlds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int r = lane & 31, h = lane >> 5;
+    const int tiles = p.tilesN * p.tilesK;
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int tile = jb % tiles, slab = (jb / tiles) * 8 + xcd;
+    const int n0 = (tile % p.tilesN) * 256, k0 = (tile / p.tilesN) * 256;
+    const int mbeg = min(slab * p.mslab, p.M), mend = min(p.M, mbeg + p.mslab);
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const bool isB = wave >= 4;
+    const int u = tid & 255;
+    const int cq = u & 63, mq = u >> 6;            // column quad (4 columns), m group (8 rows)
+    const int col0 = isB ? k0 : n0, ncols = isB ? p.K : p.N;
+    const int cc = min(col0 + 4 * cq, ncols - 4);
+    const bool do_colsum = p.colsum != nullptr && !isB && k0 == 0;
+    float csum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    v4f v[8];
+#define Z_GLOAD(m0_)                                                                                        \
+    {                                                                                                       \
+        const int mc_ = max(0, min((m0_) + 8 * mq, p.M - 8));                                               \
+        const float *base_;                                                                                 \
+        int64_t ld_;                                                                                        \
+        if (!isB) { base_ = p.A + (int64_t)mc_ * p.lda + cc; ld_ = p.lda; }                                 \
+        else {                                                                                              \
+            const int g_ = mc_ / p.R, rr_ = mc_ - g_ * p.R;                                                 \
+            base_ = p.B + (p.b_gidx ? (int64_t)p.b_gidx[g_] : (int64_t)g_) * p.b_gstride + (int64_t)rr_ * p.ldb + cc;   \
+            ld_ = p.ldb;                                                                                    \
+        }                                                                                                   \
+        _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) v[j_] = *(gv4p)(base_ + j_ * ld_);                 \
+    }
+#define Z_LSTORE(buf, chunk_)                                                                               \
+    {                                                                                                       \
+        const int operand_ = isB ? 1 : 0;                                                                   \
+        const bool sum_ = do_colsum && (chunk_) < nchunks;                                                  \
+        _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) {                                                  \
+            bf16x8 hi_, lo_;                                                                                \
+            _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) {                                              \
+                const float x_ = v[j_][c_];                                                                 \
+                if (sum_) csum[c_] += x_;                                                                   \
+                hi_[j_] = (__bf16)x_;                                                                       \
+                lo_[j_] = (__bf16)(x_ - (float)hi_[j_]);                                                    \
+            }                                                                                               \
+            *reinterpret_cast<bf16x8 *>(xlds + img2_off(buf, operand_, 0, mq, 4 * cq + c_)) = hi_;          \
+            *reinterpret_cast<bf16x8 *>(xlds + img2_off(buf, operand_, 1, mq, 4 * cq + c_)) = lo_;          \
+        }                                                                                                   \
+    }
+#define Z_MFMA(buf)                                                                                                  \
+    {                                                                                                                \
+        _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                           \
+            const int kq_ = 2 * s_ + h;                                                                              \
+            bf16x8 bh_[2], bl_[2];                                                                                   \
+            _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                       \
+                bh_[j_] = *reinterpret_cast<const bf16x8 *>(xlds + img2_off(buf, 1, 0, kq_, wn * 64 + 32 * j_ + r)); \
+                bl_[j_] = *reinterpret_cast<const bf16x8 *>(xlds + img2_off(buf, 1, 1, kq_, wn * 64 + 32 * j_ + r)); \
+            }                                                                                                        \
+            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                       \
+                const bf16x8 ah_ = *reinterpret_cast<const bf16x8 *>(xlds + img2_off(buf, 0, 0, kq_, wm * 128 + 32 * i_ + r)); \
+                const bf16x8 al_ = *reinterpret_cast<const bf16x8 *>(xlds + img2_off(buf, 0, 1, kq_, wm * 128 + 32 * i_ + r)); \
+                _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                   \
+                    acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al_, bh_[j_], acc[i_][j_], 0, 0, 0);       \
+                    acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, bl_[j_], acc[i_][j_], 0, 0, 0);       \
+                    acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, bh_[j_], acc[i_][j_], 0, 0, 0);       \
+                }                                                                                                    \
+            }                                                                                                        \
+        }                                                                                                            \
+    }
+    const int nchunks = (mend - mbeg) / XBK;           // even: every slab holds a multiple of 64 rows (PLAIN)
+    if (nchunks > 0) {
+        Z_GLOAD(mbeg);
+        Z_LSTORE(0, 0);
+        __syncthreads();
+        for (int c = 0; c < nchunks; c += 2) {
+            Z_GLOAD(mbeg + (c + 1) * XBK);
+            __builtin_amdgcn_sched_barrier(0);
+            Z_MFMA(0);
+            __builtin_amdgcn_sched_barrier(0);
+            Z_LSTORE(1, c + 1);
+            __syncthreads();
+            Z_GLOAD(mbeg + (c + 2) * XBK);
+            __builtin_amdgcn_sched_barrier(0);
+            Z_MFMA(1);
+            __builtin_amdgcn_sched_barrier(0);
+            Z_LSTORE(0, c + 2);
+            __syncthreads();
+        }
+    }
+#undef Z_GLOAD
+#undef Z_LSTORE
+#undef Z_MFMA
+    if (do_colsum) {
+#pragma unroll
+        for (int c_ = 0; c_ < 4; ++c_) {
+            const int n = n0 + 4 * cq + c_;
+            if (n < p.N && csum[c_] != 0.0f) {
+                unsafeAtomicAdd(p.colsum + n, csum[c_]);
+                if (p.colsum2) unsafeAtomicAdd(p.colsum2 + n, csum[c_]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int k = k0 + wn * 64 + j * 32 + r;
+        if (k >= p.K) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = n0 + wm * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (n < p.N) unsafeAtomicAdd(p.C + (int64_t)n * p.ldc + k, acc[i][j][e]);
+            }
+        }
+    }
+}
+
 int launch_gemm_tn_bf16x3(const stair_gemm_tn_args &a, hipStream_t s) {
     if (a.M == 0) return 0;
     XTnParams p;
@@ -772,6 +900,27 @@ int launch_gemm_tn_bf16x3(const stair_gemm_tn_args &a, hipStream_t s) {
         }
     } else if (plain_matrix) {
         p.fast8 = 2;                  // ragged row count (e.g. the text encoder's sum of question lengths)
+    }
+    {   // 256 x 256 tiles where the output is large enough (>= 16 of them) and the staging is the simple case
+        static const int tn256 = [] { const char *e = getenv("STAIR_GEMM_TN256"); return e ? atoi(e) : 16; }();   // 0 = off
+        const int t2n = (a.N + 255) / 256, t2k = (a.K + 255) / 256, t2 = t2n * t2k;
+        if (tn256 > 0 && t2 >= tn256 && p.fast8 == 1 && !p.row_scale && a.M % 64 == 0 && a.M >= 64) {
+            XTnParams q = p;
+            q.tilesN = t2n; q.tilesK = t2k;
+            int slabs = std::max(1, std::min(a.M / 64, (512 + t2 - 1) / t2));
+            slabs = (slabs + 7) / 8 * 8;
+            q.mslab = ((a.M + slabs - 1) / slabs + 63) / 64 * 64;
+            const size_t shmem2 = 2 * 2 * 2 * IMG2 * sizeof(__bf16);
+            static bool attr_set = false;
+            if (!attr_set) {
+                STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tn_bf16x3_t256_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem2));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(gemm_tn_bf16x3_t256_kernel, dim3(t2 * slabs), dim3(512), shmem2, s, q);
+            STAIR_LAUNCH_CHECK();
+            return 0;
+        }
     }
     const int tiles = p.tilesN * p.tilesK;
     // M is split into slabs so that ~512 workgroups (2 per CU) exist; more slabs only add fp32 atomics (each slab adds
