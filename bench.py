@@ -54,11 +54,11 @@ def make_batch(config, B, T, seed, device):
 
 
 # Memory-side bytes per launch of the dominant kernel from the PMC passes of tools/pmc_dominant.py
-# (profiles/r01_d_pmc_dominant.json): 2 x FETCH_SIZE (the gfx950 correction for 16-B-per-lane reads) + WRITE_SIZE, KiB.
-PMC_TRAFFIC_BYTES = {(131072, 1024, 2048): int((2 * 1558982.8 + 524288.0) * 1024)}
+# (profiles/r01_g_pmc_dominant_t256.json): 2 x FETCH_SIZE (the gfx950 correction for 16-B-per-lane reads) + WRITE_SIZE, KiB.
+PMC_TRAFFIC_BYTES = {(131072, 1024, 2048): int((2 * 787070.0 + 524288.0) * 1024)}
 PMC_TRAFFIC_NOTE = ('bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH doubled per the gfx950 '
                     'correction; Infinity-Cache hits are counted, so the excess over the 1.62 GB algorithmic A+W+C is W tiles '
-                    're-read through L2 (8 MB of W per XCD > 4 MB L2); null for shapes that were not profiled')
+                    're-read through L2 (8 MB of W per XCD > 4 MB L2; 3.73 GB with the 128 x 128 tile); null for shapes that were not profiled')
 
 
 def time_dominant_kernel(model, B, T, device, iters=10):
@@ -284,7 +284,7 @@ def main():
                        'parallelism': ('dp%d (questions sharded, one flat fp32 gradient all-reduce per step)' if args.mode == 'train'
                                        else 'dp%d (questions sharded, no collective)') % world},
             'roofline': {'bound': 'mfma', 'kernel': '%s (LSTM input projection, M=%d N=%d K=%d)' % (
-                             'gemm_bf16x3_w8_kernel<0,true>' if split else 'gemm_f32_kernel', B * T, 2 * config['hidden_size'], config['video_size']),
+                             'gemm_bf16x3_t256_kernel<0>' if split else 'gemm_f32_kernel', B * T, 2 * config['hidden_size'], config['video_size']),
                          'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': round(achieved / peak, 4), 'traffic': PMC_TRAFFIC_BYTES.get((B * T, 2 * config['hidden_size'], config['video_size'])),
                          'traffic_note': PMC_TRAFFIC_NOTE, 'launch_ms': round(gemm_ms, 4),
