@@ -88,6 +88,36 @@ def test_gemm_group_gather_scatter_rowscale(matmul):
     assert float(Cm.cpu()[3].min()) == -7.0 and float(Cm.cpu()[5].max()) == -7.0     # untouched slots stay untouched
 
 
+@pytest.mark.parametrize('G,N,gather', [(1100, 512, True), (1030, 256, False), (2048, 128, True)])
+def test_gemm_bench_sized_launch_paths(G, N, gather, matmul):
+    """Launches as large as the benchmark's (>= 65 536 rows), which take the 8-wave 128 x 128 kernel (G=1100, 1030:
+    ragged last round) or the 256 x 256 tiles (G=2048: whole rounds of CUs), gathered by slot index or contiguous,
+    bias + ReLU epilogue -- every output row against fp64."""
+    from stair_amd import ops
+    g = torch.Generator().manual_seed(G + N)
+    T, K = 64, 128
+    slots = G + 5
+    arena = torch.randn(slots, T, K, generator=g)
+    w = torch.randn(N, K, generator=g) / 8
+    b = torch.randn(N, generator=g)
+    a_idx = torch.randperm(slots, generator=g)[:G].to(torch.int32)
+    c_idx = torch.randperm(slots, generator=g)[:G].to(torch.int32)
+    out = torch.full((slots, T, N), -7.0, device=DEV)
+    d = lambda t: t.to(DEV)
+    if gather:
+        ops.gemm_grouped(d(arena), T * K, d(a_idx), d(w), d(b), out, T * N, d(c_idx), G, T, N, K, act='relu', lda=K, ldc=N)
+        ref = (arena[a_idx.long()].double() @ w.double().t() + b.double()).relu()
+        got = out.cpu()[c_idx.long()]
+        untouched = sorted(set(range(slots)) - set(c_idx.tolist()))
+        assert float(out.cpu()[untouched].min()) == -7.0 and float(out.cpu()[untouched].max()) == -7.0
+    else:
+        ops.gemm_grouped(d(arena), T * K, None, d(w), d(b), out, T * N, None, G, T, N, K, act='relu', lda=K, ldc=N)
+        ref = (arena[:G].double() @ w.double().t() + b.double()).relu()
+        got = out.cpu()[:G]
+        assert float(out.cpu()[G:].min()) == -7.0
+    assert _maxerr(got, ref) < _tol(matmul, 1e-5, 1e-4)
+
+
 @pytest.mark.parametrize('Hh,I,lens', [(32, 128, [5, 1, 9, 9, 3]), (32, 300, [17] * 33), (256, 2048, [64] * 3),
                                        (256, 300, [8, 25, 12, 19, 25, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 20]),
                                        (64, 64, [4, 6]), (128, 64, [10, 3, 7])])
