@@ -247,6 +247,19 @@ int stair_plan_run(stair_ctx *ctx, stair_plan *plan, const float *video, const f
                    void *workspace, int64_t workspace_bytes, float *logits, int32_t *argmax,
                    stair_stream stream);
 
+/* Training-mode dropout (nn.Dropout(config['dropout']) at the `D` positions of video_nmn/modules.py, active in the
+ * reference whenever model.train() is: after the ReLU of every hidden Linear of Filter / FilterFrame / Localize /
+ * Exists / HasItem / ToAction / the decoder, after the dense layers of FilterFrame and Temporal, after HasItem's
+ * sigmoid).  Call on a STAIR_PLAN_TRAIN plan before stair_plan_run; p = 0 switches it off again.  The masks are a
+ * counter-based hash of (seed, position, element) -- torch's Philox stream cannot be reproduced -- so a step is
+ * replayable and stair_plan_backward needs no stored masks.  Inference plans never drop. */
+int stair_plan_set_dropout(stair_plan *plan, float p, uint64_t seed);
+/* The mask generator on its own (building block / test hook): in place on `groups` rows of `rowlen` floats, row g at
+ * x + (gidx ? gidx[g] : g) * gstride; element e of the launch is kept iff hash24(seed, site, e) >= p * 2^24 and then
+ * divided by (1 - p). */
+int stair_dropout_fwd(float *x, int64_t gstride, const int32_t *gidx, int32_t groups, int64_t rowlen, float p,
+                      uint64_t seed, uint32_t site, stair_stream stream);
+
 /* The same pass split for stream capture (BASELINE.json configs[3], "hipGraph-captured module chains"):
  * stair_plan_upload copies the plan's index image (slot columns, sequence offsets) into the workspace ONCE, outside
  * the capture; stair_plan_run_flags(..., STAIR_RUN_INDEX_RESIDENT, ...) then enqueues kernels only -- no host-to-device

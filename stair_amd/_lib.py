@@ -120,6 +120,9 @@ SIGNATURES = [
     ('stair_plan_node', C.c_int, [C.c_void_p, C.c_int32, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p]),
     ('stair_plan_run', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                  C.c_void_p, C.c_void_p]),
+    ('stair_dropout_fwd', C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_uint32,
+                                   C.c_void_p]),
+    ('stair_plan_set_dropout', C.c_int, [C.c_void_p, C.c_float, C.c_uint64]),
     ('stair_plan_upload', C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     ('stair_plan_run_flags', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                        C.c_void_p, C.c_int32, C.c_void_p]),

@@ -59,8 +59,9 @@ int launch_l2norm(const float *x, float *out, int n, int H, hipStream_t s);
 
 // ---- backward kernels (csrc/rowops_bwd.hip) --------------------------------------------------
 int launch_mask_relu(float *dst, const float *G, int64_t g_gs, const int32_t *g_idx, const float *Y, int64_t y_gs,
-                     const int32_t *y_idx, int groups, int rowlen, hipStream_t s);
-int launch_bcast_mask_relu(float *dst, const float *dsum, const float *Y, int groups, int T, int H, hipStream_t s);
+                     const int32_t *y_idx, int groups, int rowlen, hipStream_t s, float scale = 1.0f);
+int launch_bcast_mask_relu(float *dst, const float *dsum, const float *Y, int groups, int T, int H, hipStream_t s,
+                           float scale = 1.0f);
 int launch_scatter_add_rows(float *dst, const int32_t *dst_idx, const float *src, int n, int len, float scale, hipStream_t s);
 int launch_pack_bwd(int mode, const float *A, const int32_t *ia, const float *B, const int32_t *ib, const float *g,
                     float *dA, float *dB, int n, int H, hipStream_t s);
@@ -77,12 +78,17 @@ int launch_temporal_relate_bwd(const float *att, const int32_t *att_idx, const i
                                const int32_t *rel_idx, float *datt, int n, int T, int mode, int conv, int ksize,
                                const float *const w[6], float *const dw[6], hipStream_t s);
 int launch_layernorm_bwd(const float *dOut, int64_t g_gs, const int32_t *g_idx, const float *Y, int n, int T, int H,
-                         const float *gamma, float eps, float *dZ, float *stats, float *dgamma, float *dbeta, hipStream_t s);
+                         const float *gamma, float eps, float *dZ, float *stats, float *dgamma, float *dbeta, hipStream_t s,
+                         float scale = 1.0f);
 int launch_rowscale_bwd(const float *G, const float *X, int64_t x_gs, const int32_t *x_idx, const float *rs, int64_t rs_gs,
                         const int32_t *rs_idx, float *dX, float *drs, int n, int T, int H, hipStream_t s);
 int launch_rowdot_sigmoid_bwd(const float *dOut, int64_t o_gs, const int32_t *o_idx, const float *A, int64_t a_gs,
                               const int32_t *a_idx, const float *w, float *dXdst, int add_mode, float *dpre_out,
-                              float *dextra, int n, int T, int H, hipStream_t s);
+                              float *dextra, int n, int T, int H, hipStream_t s, float keep = 1.0f);
+// training-mode nn.Dropout(p) applied in place to `groups` rows of `rowlen` floats (row g at X + idx[g] * gstride):
+// x <- keep(seed, site, element) ? x / (1 - p) : 0 with a counter-based hash, so the mask is a pure function of the seed
+int launch_dropout_rows(float *X, int64_t gstride, const int32_t *gidx, int groups, int64_t rowlen, float p, uint64_t seed,
+                        uint32_t site, hipStream_t s);
 int launch_weighted_colsum(const float *X, int64_t ld, const int32_t *x_idx, const float *scale, float *out, int rows, int H,
                            hipStream_t s);
 int launch_axpy_rows(float *dV, const int32_t *idx, const float *scale, const float *w, int n, int H, hipStream_t s);

@@ -224,6 +224,8 @@ struct stair_plan {
             o_logits = 0, total = 0;
     // training only
     bool train = false;
+    float drop_p = 0.0f;            // training-mode dropout (stair_plan_set_dropout); 0 = off
+    uint64_t drop_seed = 0;
     int64_t o_cv = 0, o_ct = 0, o_hprev = 0, o_gblock = 0, o_gatt = 0, o_gtok = 0, o_gqfeat = 0, o_gA = 0, o_gB = 0,
             o_gK = 0, o_gV0 = 0, o_gV1 = 0, o_gCat = 0, o_gS = 0, o_gRs = 0, o_gRs2 = 0, o_gExtra = 0, o_gStats = 0,
             o_wt = 0, o_dlogits = 0, o_loss = 0, o_zero_beg = 0, o_zero_end = 0;
@@ -787,6 +789,15 @@ struct Ptrs {     // workspace views shared by forward and backward
 
 }  // namespace
 
+extern "C" int stair_plan_set_dropout(stair_plan *pl, float p, uint64_t seed) {
+    STAIR_CHECK(pl, "null plan");
+    STAIR_CHECK(p >= 0.0f && p < 1.0f, "dropout probability must be in [0, 1)");
+    STAIR_CHECK(p == 0.0f || pl->train, "dropout needs a STAIR_PLAN_TRAIN plan (model.eval() has none, modules.py)");
+    pl->drop_p = p;
+    pl->drop_seed = seed;
+    return 0;
+}
+
 extern "C" int stair_plan_upload(stair_plan *pl, void *workspace, int64_t workspace_bytes, stair_stream stream) {
     STAIR_CHECK(pl && workspace, "null argument");
     STAIR_CHECK(workspace_bytes >= pl->total * (int64_t)sizeof(float), "workspace too small");
@@ -829,6 +840,13 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
         STAIR_HIP(hipMemcpyAsync(didx, pl->idx.data(), pl->idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
 
 #define RUN(x) do { if (int rc_ = (x)) return rc_; } while (0)
+    // nn.Dropout at the `D` positions of modules.py, training plans only; site = bucket * 8 + position (decoder: 0xffff)
+    const float dp = pl->train ? pl->drop_p : 0.0f;
+    int bucket_no = -1;
+    auto drop = [&](float *X, int64_t gs, const int32_t *gidx, int groups, int64_t rowlen, int pos) -> int {
+        if (dp <= 0.0f) return 0;
+        return launch_dropout_rows(X, gs, gidx, groups, rowlen, dp, pl->drop_seed, (uint32_t)(bucket_no * 8 + pos), s);
+    };
     // ---- encoders (module_net.py:74-75) ------------------------------------------------------
     {
         stair_lstm_args a = {};
@@ -859,6 +877,7 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
 
     // ---- program levels ----------------------------------------------------------------------
     for (const Bucket &b : pl->buckets) {
+        ++bucket_no;
         if (b.cnt == 0) continue;
         const int c = b.cnt;
         const int32_t *I0 = didx + b.off[0], *I1 = didx + b.off[1], *I2 = didx + b.off[2], *I3 = didx + b.off[3],
@@ -895,12 +914,15 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
             case STAIR_OP_TOACTION:     // modules.py:102-120: cat[action, keyword]
                 RUN(launch_pack(PACK_CAT2, vec, I0, vec, I1, cat, c, H, s));
                 RUN(dense(s, cat, 2 * H, 2 * H, nullptr, W.ta0, 2 * H, hid, H, H, nullptr, c, 1, H, 2 * H, 1));
+                RUN(drop(hid, H, nullptr, c, H, 0));
                 RUN(dense(s, hid, H, H, nullptr, W.ta3, H, vec, H, H, I2, c, 1, H, H, 1));
                 break;
             case STAIR_OP_EXISTS:       // modules.py:141-159: Exists(keyword, feat) -> cat[feat, keyword, feat*keyword]
                 RUN(launch_pack(PACK_EXISTS, vec, I1, vec, I0, cat, c, H, s));
                 RUN(dense(s, cat, 3 * H, 3 * H, nullptr, W.exists0, 3 * H, hid, H, H, nullptr, c, 1, H, 3 * H, 1));
+                RUN(drop(hid, H, nullptr, c, H, 0));
                 RUN(dense(s, hid, H, H, nullptr, W.exists3, H, vec, H, H, I2, c, 1, H, H, 1));
+                RUN(drop(vec, H, I2, c, H, 1));
                 break;
             case STAIR_OP_EXISTSFRAME:  // modules.py:162-178
                 RUN(launch_cosine_attn(map, TH, I1, vec, I0, att, I2, c, T, H, s));
@@ -908,7 +930,9 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
             case STAIR_OP_FILTER: {     // modules.py:343-378 (attention == 1 exactly, see oracle op_filter)
                 const int v = b.variant;
                 RUN(dense(s, map, H, TH, I0, W.f0[v], H, tmpA, H, TH, nullptr, c, T, H, H, 1));
+                RUN(drop(tmpA, TH, nullptr, c, TH, 0));
                 RUN(dense(s, tmpA, H, TH, nullptr, W.f3[v], H, tmpB, H, TH, nullptr, c, T, H, H, 1));
+                RUN(drop(tmpB, TH, nullptr, c, TH, 1));
                 RUN(launch_sum_rows(tmpB, cat, c, T, H, s));
                 RUN(dense(s, cat, H, H, nullptr, W.fdense, H, vec, H, H, I1, c, 1, H, H, 1));
                 break;
@@ -916,7 +940,9 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
             case STAIR_OP_FILTERFRAME: {   // modules.py:381-414
                 const int v = b.variant;
                 RUN(dense(s, map, H, TH, I0, W.ff0[v], H, tmpA, H, TH, nullptr, c, T, H, H, 1));
+                RUN(drop(tmpA, TH, nullptr, c, TH, 0));
                 RUN(dense(s, tmpA, H, TH, nullptr, W.ff3[v], H, tmpB, H, TH, nullptr, c, T, H, H, 1));
+                RUN(drop(tmpB, TH, nullptr, c, TH, 1));
                 if (v == 0) {
                     // sigmoid(Lin(2H->1)(cat[f_t, kw])) = sigmoid(w[:H].f_t + w[H:].kw + b)
                     RUN(launch_vecdot(vec, I1, W.ffatt.w + H, extra, c, H, s));
@@ -925,14 +951,18 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
                 } else {
                     RUN(dense(s, tmpB, H, TH, nullptr, W.ffdense, H, map, H, TH, I2, c, T, H, H, 1));
                 }
+                RUN(drop(map, TH, I2, c, TH, 2));
                 break;
             }
             case STAIR_OP_HASITEM:      // modules.py:123-138
                 RUN(dense(s, map, H, TH, I0, W.hi0, H, tmpA, H, TH, nullptr, c, T, H, H, 1));
+                RUN(drop(tmpA, TH, nullptr, c, TH, 0));
                 RUN(launch_rowdot_sigmoid(tmpA, c, T, H, W.hi3.w, W.hi3.b, nullptr, att, I1, T, s));
+                RUN(drop(att, T, I1, c, T, 1));
                 break;
             case STAIR_OP_LOCALIZE:     // modules.py:181-217
                 RUN(dense(s, map, H, TH, I0, W.lv0, H, tmpA, H, TH, nullptr, c, T, H, H, 1));
+                RUN(drop(tmpA, TH, nullptr, c, TH, 0));
                 RUN(dense(s, tmpA, H, TH, nullptr, W.lv3, H, tmpB, H, TH, nullptr, c, T, H, H, 0));
                 RUN(dense(s, vec, H, H, I2, W.lk, H, kbuf, H, H, nullptr, b.nrows, 1, H, H, 0));
                 RUN(launch_cosine_attn(tmpB, TH, I1, kbuf, nullptr, att, I3, b.nrows, T, H, s));
@@ -942,6 +972,7 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
                 break;
             case STAIR_OP_SUPERLATIVE:  // modules.py:220-248 (shares Localize's weights, module_net.py:31-32)
                 RUN(dense(s, map, H, TH, I0, W.lv0, H, tmpA, H, TH, nullptr, c, T, H, H, 1));
+                RUN(drop(tmpA, TH, nullptr, c, TH, 0));
                 RUN(dense(s, tmpA, H, TH, nullptr, W.lv3, H, tmpB, H, TH, nullptr, c, T, H, H, 0));
                 RUN(dense(s, ws, H, H, I4, W.lk, H, kbuf, H, H, nullptr, b.nrows, 1, H, H, 0));
                 RUN(launch_cosine_attn(tmpB, TH, I5, kbuf, nullptr, sup, nullptr, b.nrows, T, H, s));
@@ -953,6 +984,7 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
                 RUN(launch_temporal_relate(att, I1, I2, att, I3, c, T, mode, ctx->conv ? 1 : 0, ctx->ksize,
                                            mode ? W.relate[mode - 1] : nullptr, s));
                 RUN(dense(s, map, H, TH, I0, W.tdense, H, tmpA, H, TH, nullptr, c, T, H, H, 1, att, T, I3));
+                RUN(drop(tmpA, TH, nullptr, c, TH, 0));
                 RUN(launch_layernorm(tmpA, map, TH, I4, c, T, H, W.ln_w, W.ln_b, 1e-5f, s));
                 break;
             }
@@ -965,6 +997,8 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
     float *cat = ws + pl->o_cat, *hid = ws + pl->o_hid;
     RUN(launch_pack(PACK_CAT2, vec, didx + pl->off_roots, qfeat, nullptr, cat, n, H, s));
     RUN(dense(s, cat, 2 * H, 2 * H, nullptr, W.dec0, 2 * H, hid, 2 * H, 2 * H, nullptr, n, 1, 2 * H, 2 * H, 1));
+    bucket_no = 0x1fff;
+    RUN(drop(hid, 2 * H, nullptr, n, 2 * H, 7));
     RUN(dense(s, hid, 2 * H, 2 * H, nullptr, W.dec3, 2 * H, logits, A, A, nullptr, n, 1, A, 2 * H, 0));
     if (argmax) RUN(launch_argmax(logits, argmax, n, A, s));
     return 0;
@@ -1019,6 +1053,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
 
     const stair_config &g = ctx->cfg;
     const int H = g.hidden_size, Hh = H / 2, V = g.video_size, E = g.text_size, A = g.answer_vocab_length;
+    const float inv_keep = 1.0f / (1.0f - pl->drop_p);      // gradient factor of every ReLU -> Dropout pair (1 when dropout is off)
     const int n = pl->n, T = pl->T;
     const int64_t TH = (int64_t)T * H;
     float *ws = static_cast<float *>(workspace);
@@ -1060,7 +1095,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
     {
         const float *cat = ws + pl->o_cat, *hid = ws + pl->o_hid;     // decoder buffers are never reused by buckets in training
         RUN(dense_bwd(B, dlogits, n, 1, A, 2 * H, hid, 2 * H, 2 * H, nullptr, W.dec3, gV0, 2 * H, 2 * H, nullptr, 0));
-        RUN(launch_mask_relu(gV0, gV0, 2 * H, nullptr, hid, 2 * H, nullptr, n, 2 * H, s));
+        RUN(launch_mask_relu(gV0, gV0, 2 * H, nullptr, hid, 2 * H, nullptr, n, 2 * H, s, inv_keep));
         RUN(dense_bwd(B, gV0, n, 1, 2 * H, 2 * H, cat, 2 * H, 2 * H, nullptr, W.dec0, gCat, 2 * H, 2 * H, nullptr, 0));
         RUN(launch_pack_bwd(PACK_CAT2, vec, didx + pl->off_roots, qfeat, nullptr, gCat, g_vec, g_qfeat, n, H, s));
     }
@@ -1076,9 +1111,9 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
         const float *svRs = ws + b.svRs, *svSup = ws + b.svSup;
         // tail shared by Filter / FilterFrame / Localize / Superlative: gB = d(second linear output)
         auto mlp_tail = [&](const Lin &l3, const Lin &l0, bool relu_second) -> int {
-            if (relu_second) RUN(launch_mask_relu(gB, gB, TH, nullptr, svB, TH, nullptr, c, (int)TH, s));
+            if (relu_second) RUN(launch_mask_relu(gB, gB, TH, nullptr, svB, TH, nullptr, c, (int)TH, s, inv_keep));
             RUN(dense_bwd(B, gB, c, T, H, H, svA, H, TH, nullptr, l3, gA, H, TH, nullptr, 0));
-            RUN(launch_mask_relu(gA, gA, TH, nullptr, svA, TH, nullptr, c, (int)TH, s));
+            RUN(launch_mask_relu(gA, gA, TH, nullptr, svA, TH, nullptr, c, (int)TH, s, inv_keep));
             RUN(dense_bwd(B, gA, c, T, H, H, map, H, TH, I0, l0, g_map, H, TH, I0, 1));
             return 0;
         };
@@ -1114,9 +1149,9 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
             case STAIR_OP_EXISTS: {
                 const bool ex = b.op == STAIR_OP_EXISTS;
                 const int K = ex ? 3 * H : 2 * H;
-                RUN(launch_mask_relu(gV0, g_vec, H, I2, vec, H, I2, c, H, s));
+                RUN(launch_mask_relu(gV0, g_vec, H, I2, vec, H, I2, c, H, s, ex ? inv_keep : 1.0f));     // only Exists ends in ReLU . Dropout
                 RUN(dense_bwd(B, gV0, c, 1, H, H, svHid, H, H, nullptr, ex ? W.exists3 : W.ta3, gV1, H, H, nullptr, 0));
-                RUN(launch_mask_relu(gV1, gV1, H, nullptr, svHid, H, nullptr, c, H, s));
+                RUN(launch_mask_relu(gV1, gV1, H, nullptr, svHid, H, nullptr, c, H, s, inv_keep));
                 RUN(dense_bwd(B, gV1, c, 1, H, K, svCat, K, K, nullptr, ex ? W.exists0 : W.ta0, gCat, K, K, nullptr, 0));
                 if (ex) RUN(launch_pack_bwd(PACK_EXISTS, vec, I1, vec, I0, gCat, g_vec, g_vec, c, H, s));
                 else RUN(launch_pack_bwd(PACK_CAT2, vec, I0, vec, I1, gCat, g_vec, g_vec, c, H, s));
@@ -1129,13 +1164,13 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
                 const int v = b.variant;
                 RUN(launch_mask_relu(gV0, g_vec, H, I1, vec, H, I1, c, H, s));
                 RUN(dense_bwd(B, gV0, c, 1, H, H, svCat, H, H, nullptr, W.fdense, gV1, H, H, nullptr, 0));
-                RUN(launch_bcast_mask_relu(gB, gV1, svB, c, T, H, s));
+                RUN(launch_bcast_mask_relu(gB, gV1, svB, c, T, H, s, inv_keep));
                 RUN(mlp_tail(W.f3[v], W.f0[v], false));
                 break;
             }
             case STAIR_OP_FILTERFRAME: {
                 const int v = b.variant;
-                RUN(launch_mask_relu(gA, g_map, TH, I2, map, TH, I2, c, (int)TH, s));        // dZ of the dense layer
+                RUN(launch_mask_relu(gA, g_map, TH, I2, map, TH, I2, c, (int)TH, s, inv_keep));        // dZ of the dense layer
                 if (v == 0) {
                     // dense input is a_t * f_t: weight grads see the scaled input, G = dZ.W is d(a*f)
                     RUN(dense_bwd(B, gA, c, T, H, H, svB, H, TH, nullptr, W.ffdense, gB, H, TH, nullptr, 0, svRs, T, nullptr));
@@ -1155,10 +1190,10 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
                 break;
             }
             case STAIR_OP_HASITEM:
-                RUN(launch_rowdot_sigmoid_bwd(g_att, T, I1, att, T, I1, W.hi3.w, gA, 0, gRs2, nullptr, c, T, H, s));
+                RUN(launch_rowdot_sigmoid_bwd(g_att, T, I1, att, T, I1, W.hi3.w, gA, 0, gRs2, nullptr, c, T, H, s, 1.0f / inv_keep));
                 RUN(launch_weighted_colsum(svA, H, nullptr, gRs2, W.hi3.dw, c * T, H, s));
                 RUN(launch_sum_all(gRs2, W.hi3.db, c * T, s));
-                RUN(launch_mask_relu(gA, gA, TH, nullptr, svA, TH, nullptr, c, (int)TH, s));
+                RUN(launch_mask_relu(gA, gA, TH, nullptr, svA, TH, nullptr, c, (int)TH, s, inv_keep));
                 RUN(dense_bwd(B, gA, c, T, H, H, map, H, TH, I0, W.hi0, g_map, H, TH, I0, 1));
                 break;
             case STAIR_OP_LOCALIZE:
@@ -1179,7 +1214,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
                 break;
             case STAIR_OP_TEMPORAL: {
                 const int mode = b.variant;
-                RUN(launch_layernorm_bwd(g_map, TH, I4, svA, c, T, H, W.ln_w, 1e-5f, gA, gStats, W.dln_w, W.dln_b, s));
+                RUN(launch_layernorm_bwd(g_map, TH, I4, svA, c, T, H, W.ln_w, 1e-5f, gA, gStats, W.dln_w, W.dln_b, s, inv_keep));
                 RUN(dense_bwd(B, gA, c, T, H, H, map, H, TH, I0, W.tdense, gB, H, TH, nullptr, 0, att, T, I3));
                 RUN(launch_rowscale_bwd(gB, map, TH, I0, att, T, I3, g_map, g_att, c, T, H, s));
                 RUN(launch_temporal_relate_bwd(att, I1, I2, g_att, I3, g_att, c, T, mode, ctx->conv ? 1 : 0, ctx->ksize,

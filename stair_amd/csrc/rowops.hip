@@ -445,6 +445,42 @@ int launch_l2norm(const float *x, float *out, int n, int H, hipStream_t s) {
     return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// nn.Dropout in training mode (the `D` positions of modules.py: after the ReLU of every hidden Linear, after the dense
+// layers of FilterFrame / Temporal, after HasItem's Sigmoid; p = config['dropout'], args.py:31).  torch draws its mask
+// from a Philox stream that cannot be reproduced here; the mask below is a counter-based hash of (seed, site,
+// element), i.e. a pure function: the backward pass needs no stored mask (a dropped element is an exact zero of the
+// saved activation) and a step can be replayed.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t drop_hash(uint64_t seed, uint32_t site, uint64_t e) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (e + 1) + ((uint64_t)site << 40);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return (uint32_t)((z ^ (z >> 31)) >> 40);          // 24 uniform bits
+}
+__global__ void dropout_rows_kernel(float *X, int64_t gstride, const int32_t *gidx, int groups, int64_t rowlen, uint32_t thresh,
+                                    float inv_keep, uint64_t seed, uint32_t site) {
+    const int64_t total = (int64_t)groups * rowlen;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(e / rowlen);
+        const int64_t r = e - (int64_t)g * rowlen;
+        float *x = X + (int64_t)idx_or_id(gidx, g) * gstride + r;
+        *x = drop_hash(seed, site, (uint64_t)e) >= thresh ? *x * inv_keep : 0.0f;
+    }
+}
+int launch_dropout_rows(float *X, int64_t gstride, const int32_t *gidx, int groups, int64_t rowlen, float p, uint64_t seed,
+                        uint32_t site, hipStream_t s) {
+    if (groups == 0 || rowlen == 0 || p <= 0.0f) return 0;
+    STAIR_CHECK(p < 1.0f, "dropout probability must be below 1");
+    const int64_t total = (int64_t)groups * rowlen;
+    const uint32_t thresh = (uint32_t)(p * 16777216.0f);         // drop when the 24-bit hash is below p * 2^24
+    hipLaunchKernelGGL(dropout_rows_kernel, dim3((unsigned)std::min<int64_t>((total + kBlock - 1) / kBlock, 8192)), dim3(kBlock), 0,
+                       s, X, gstride, gidx, groups, rowlen, thresh, 1.0f / (1.0f - p), seed, site);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace stair
 
 extern "C" int stair_l2normalize_fwd(const float *x, float *out, int32_t n, int32_t H, stair_stream stream) {
@@ -463,4 +499,10 @@ extern "C" int stair_temporal_relate_fwd(const float *att, const int32_t *att_id
                                          int32_t ksize, const float *const w[6], stair_stream stream) {
     return stair::launch_temporal_relate(att, att_idx, att_k, out, out_idx, n, T, mode, conv, ksize, w,
                                          static_cast<hipStream_t>(stream));
+}
+
+extern "C" int stair_dropout_fwd(float *x, int64_t gstride, const int32_t *gidx, int32_t groups, int64_t rowlen, float p,
+                                 uint64_t seed, uint32_t site, stair_stream stream) {
+    STAIR_CHECK(x != nullptr && groups >= 0 && rowlen >= 0 && p >= 0.0f, "bad argument");
+    return stair::launch_dropout_rows(x, gstride, gidx, groups, rowlen, p, seed, site, static_cast<hipStream_t>(stream));
 }

@@ -17,40 +17,40 @@ __device__ __forceinline__ float sgn(float x) { return x > 0.f ? 1.f : (x < 0.f 
 
 // dst[g][:] = G[gi][:] * (Y[yi][:] > 0)      (ReLU backward with optional gathers; rowlen floats per group)
 __global__ void mask_relu_kernel(float *dst, const float *G, int64_t g_gs, const int32_t *g_idx, const float *Y,
-                                 int64_t y_gs, const int32_t *y_idx, int groups, int rowlen) {
+                                 int64_t y_gs, const int32_t *y_idx, int groups, int rowlen, float scale) {
     const int64_t total = (int64_t)groups * rowlen;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int g = (int)(e / rowlen);
         const int64_t r = e - (int64_t)g * rowlen;
         const float gv = G[(int64_t)idx_or_id(g_idx, g) * g_gs + r];
         const float yv = Y[(int64_t)idx_or_id(y_idx, g) * y_gs + r];
-        dst[e] = yv > 0.f ? gv : 0.f;
+        dst[e] = yv > 0.f ? gv * scale : 0.f;      // scale = 1/(1-p) where a dropout follows the ReLU (Y is the dropped tensor)
     }
 }
 int launch_mask_relu(float *dst, const float *G, int64_t g_gs, const int32_t *g_idx, const float *Y, int64_t y_gs,
-                     const int32_t *y_idx, int groups, int rowlen, hipStream_t s) {
+                     const int32_t *y_idx, int groups, int rowlen, hipStream_t s, float scale) {
     if (groups == 0) return 0;
     const int64_t total = (int64_t)groups * rowlen;
     hipLaunchKernelGGL(mask_relu_kernel, dim3((unsigned)std::min<int64_t>((total + kBlock - 1) / kBlock, 4096)), dim3(kBlock), 0,
-                       s, dst, G, g_gs, g_idx, Y, y_gs, y_idx, groups, rowlen);
+                       s, dst, G, g_gs, g_idx, Y, y_gs, y_idx, groups, rowlen, scale);
     STAIR_LAUNCH_CHECK();
     return 0;
 }
 
 // Filter's sum over frames, backward + ReLU mask: dst[g][t][:] = dsum[g][:] * (Y[g][t][:] > 0)
-__global__ void bcast_mask_relu_kernel(float *dst, const float *dsum, const float *Y, int groups, int T, int H) {
+__global__ void bcast_mask_relu_kernel(float *dst, const float *dsum, const float *Y, int groups, int T, int H, float scale) {
     const int64_t total = (int64_t)groups * T * H;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int g = (int)(e / ((int64_t)T * H));
         const int c = (int)(e % H);
-        dst[e] = Y[e] > 0.f ? dsum[(int64_t)g * H + c] : 0.f;
+        dst[e] = Y[e] > 0.f ? dsum[(int64_t)g * H + c] * scale : 0.f;
     }
 }
-int launch_bcast_mask_relu(float *dst, const float *dsum, const float *Y, int groups, int T, int H, hipStream_t s) {
+int launch_bcast_mask_relu(float *dst, const float *dsum, const float *Y, int groups, int T, int H, hipStream_t s, float scale) {
     if (groups == 0) return 0;
     const int64_t total = (int64_t)groups * T * H;
     hipLaunchKernelGGL(bcast_mask_relu_kernel, dim3((unsigned)std::min<int64_t>((total + kBlock - 1) / kBlock, 4096)), dim3(kBlock),
-                       0, s, dst, dsum, Y, groups, T, H);
+                       0, s, dst, dsum, Y, groups, T, H, scale);
     STAIR_LAUNCH_CHECK();
     return 0;
 }
@@ -358,7 +358,7 @@ int launch_temporal_relate_bwd(const float *att, const int32_t *att_idx, const i
 //   y = relu(z) saved; out = LN(y).  dz = relu'(y) * rstd * (dxh - mean(dxh) - xh * mean(dxh*xh)), dxh = dout*gamma
 // stats[row] = (mean, rstd) for the parameter-gradient pass.
 __global__ void layernorm_bwd_kernel(const float *dOut, int64_t g_gs, const int32_t *g_idx, const float *Y, int n, int T,
-                                     int H, const float *gamma, float eps, float *dZ, float *stats) {
+                                     int H, const float *gamma, float eps, float *dZ, float *stats, float scale) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (row >= (int64_t)n * T) return;
@@ -380,7 +380,7 @@ __global__ void layernorm_bwd_kernel(const float *dOut, int64_t g_gs, const int3
     for (int c = lane; c < H; c += 64) {
         const float dxh = go[c] * gamma[c], xh = (y[c] - mean) * rstd;
         const float dy = rstd * (dxh - s1 - xh * s2);
-        dZ[row * H + c] = y[c] > 0.f ? dy : 0.f;
+        dZ[row * H + c] = y[c] > 0.f ? dy * scale : 0.f;
     }
     if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
 }
@@ -400,11 +400,12 @@ __global__ void layernorm_param_grad_kernel(const float *dOut, int64_t g_gs, con
     unsafeAtomicAdd(dbeta + c, ab);
 }
 int launch_layernorm_bwd(const float *dOut, int64_t g_gs, const int32_t *g_idx, const float *Y, int n, int T, int H,
-                         const float *gamma, float eps, float *dZ, float *stats, float *dgamma, float *dbeta, hipStream_t s) {
+                         const float *gamma, float eps, float *dZ, float *stats, float *dgamma, float *dbeta, hipStream_t s,
+                         float scale) {
     if (n == 0) return 0;
     const int64_t rows = (int64_t)n * T;
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)((rows + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0,
-                       s, dOut, g_gs, g_idx, Y, n, T, H, gamma, eps, dZ, stats);
+                       s, dOut, g_gs, g_idx, Y, n, T, H, gamma, eps, dZ, stats, scale);
     STAIR_LAUNCH_CHECK();
     const int slab = (int)std::max<int64_t>(64, (rows + 255) / 256);
     hipLaunchKernelGGL(layernorm_param_grad_kernel, dim3((H + 255) / 256, (unsigned)((rows + slab - 1) / slab)), dim3(256), 0, s,
@@ -451,13 +452,15 @@ int launch_rowscale_bwd(const float *G, const float *X, int64_t x_gs, const int3
 // add_mode: 0 store into dXdst, 1 add (non-atomic read-modify-write: rows are private to this launch)
 __global__ void rowdot_sigmoid_bwd_kernel(const float *dOut, int64_t o_gs, const int32_t *o_idx, const float *A, int64_t a_gs,
                                           const int32_t *a_idx, const float *w, float *dXdst, int add_mode, float *dpre_out,
-                                          float *dextra, int n, int T, int H) {
+                                          float *dextra, int n, int T, int H, float keep) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (row >= (int64_t)n * T) return;
     const int g = (int)(row / T), t = (int)(row - (int64_t)g * T);
-    const float a = A[(int64_t)idx_or_id(a_idx, g) * a_gs + t];
-    const float dpre = dOut[(int64_t)idx_or_id(o_idx, g) * o_gs + t] * a * (1.f - a);
+    // keep < 1: A holds sigmoid * mask / keep (HasItem's Sigmoid -> Dropout, modules.py:129-131): sigmoid = A * keep where
+    // the element was kept and the factor 1/keep multiplies the incoming gradient; a dropped element (A == 0) gets none
+    const float a = A[(int64_t)idx_or_id(a_idx, g) * a_gs + t] * keep;
+    const float dpre = dOut[(int64_t)idx_or_id(o_idx, g) * o_gs + t] / keep * a * (1.f - a);
     float *dx = dXdst + row * H;
     for (int c = lane; c < H; c += 64) dx[c] = (add_mode ? dx[c] : 0.f) + dpre * w[c];
     if (lane == 0) {
@@ -467,11 +470,11 @@ __global__ void rowdot_sigmoid_bwd_kernel(const float *dOut, int64_t o_gs, const
 }
 int launch_rowdot_sigmoid_bwd(const float *dOut, int64_t o_gs, const int32_t *o_idx, const float *A, int64_t a_gs,
                               const int32_t *a_idx, const float *w, float *dXdst, int add_mode, float *dpre_out,
-                              float *dextra, int n, int T, int H, hipStream_t s) {
+                              float *dextra, int n, int T, int H, hipStream_t s, float keep) {
     if (n == 0) return 0;
     const int64_t rows = (int64_t)n * T;
     hipLaunchKernelGGL(rowdot_sigmoid_bwd_kernel, dim3((unsigned)((rows + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock),
-                       0, s, dOut, o_gs, o_idx, A, a_gs, a_idx, w, dXdst, add_mode, dpre_out, dextra, n, T, H);
+                       0, s, dOut, o_gs, o_idx, A, a_gs, a_idx, w, dXdst, add_mode, dpre_out, dextra, n, T, H, keep);
     STAIR_LAUNCH_CHECK();
     return 0;
 }

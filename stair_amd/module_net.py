@@ -302,10 +302,13 @@ class VideoNMN(nn.Module):
         return self._ws
 
     # ---------------------------------------------------------------------------------------
-    def run_programs(self, programs, spans, video, question, q_lens, train=False, video_index=None):
+    def run_programs(self, programs, spans, video, question, q_lens, train=False, video_index=None, dropout=None):
         """Batched pass.  programs: list of token lists; spans: list of {pos: (lo, hi)}; video
         [n,T,V] and question [sum(q_lens), E] float32 on the GPU.  Returns a BatchResult.
 
+        dropout (optional, training plans only): (p, seed) applies nn.Dropout(p) at the reference's positions with
+        masks derived from `seed` (stair_plan_set_dropout); None or p = 0 is the eval / dropout=0 arithmetic that every
+        parity test pins.
         video_index (optional, [n] ints): question q asks about clip video[video_index[q]]; video is then
         [n_videos,T,V] and each clip is encoded once instead of once per question (module_net.py:74 encodes per
         question; the results are identical)."""
@@ -336,6 +339,10 @@ class VideoNMN(nn.Module):
         try:
             info = PlanInfo()
             check(lib.stair_plan_get_info(plan, C.byref(info)))
+            if dropout is not None and dropout[0] > 0:
+                if not train:
+                    raise ValueError('dropout is a training-mode operation (train=True)')
+                check(lib.stair_plan_set_dropout(plan, C.c_float(float(dropout[0])), C.c_uint64(int(dropout[1]) & (2 ** 64 - 1))))
             ws = self._workspace(info.workspace_bytes, video.device)
             A = self.config['answer_vocab_length']
             logits = torch.empty(n, A, dtype=torch.float32, device=video.device)
@@ -350,7 +357,7 @@ class VideoNMN(nn.Module):
             raise
         return BatchResult(self, plan, info, ws, logits, pred, prog_off, programs, video, question)
 
-    def forward_batch(self, batch, train=False, share_videos=True):
+    def forward_batch(self, batch, train=False, share_videos=True, dropout=None):
         """batch: list of question dicts in the reference layout (dataset.py:191-233), all with the
         same number of frames.  Tensors may live on the host; they are moved once, packed.
 
@@ -377,7 +384,7 @@ class VideoNMN(nn.Module):
         question = torch.cat(qs).to(dev, torch.float32).contiguous()
         return self.run_programs([d['nmn_program_list'] for d in batch],
                                  [d['prog_str_to_question_tokens'] for d in batch], video, question,
-                                 [q.shape[0] for q in qs], train=train, video_index=index)
+                                 [q.shape[0] for q in qs], train=train, video_index=index, dropout=dropout)
 
     # ---------------------------------------------------------------------------------------
     @torch.no_grad()

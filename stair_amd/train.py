@@ -37,7 +37,8 @@ class Trainer:
     def __init__(self, model, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decoder_loss_weight=1.0,
                  module_loss_weight=1.0, contrastive_window=32, no_intermediate=('FilterFrame',),
                  scheduler_start_factor=1.0, scheduler_end_factor=0.1, scheduler_total_iters=200000, world=1,
-                 skip_untouched='ever', train_module_before_iters=1e10, train_decoder_after_iters=0, rank=0):
+                 skip_untouched='ever', train_module_before_iters=1e10, train_decoder_after_iters=0, rank=0,
+                 dropout=0.0, dropout_seed=0):
         """skip_untouched: 'ever'   -- a parameter is skipped by Adam until the first window that sends it a gradient
                                       (torch 1.13, which the reference pins: zero_grad() keeps zero tensors afterwards);
                            'window' -- skipped in every window that does not touch it (torch >= 2.0, set_to_none=True)."""
@@ -46,6 +47,10 @@ class Trainer:
         # train_decoder_after_iters.  Question i of a rank's shard has global step seen + 1 + rank + i * world.
         self.before_iters, self.after_iters, self.rank = train_module_before_iters, train_decoder_after_iters, rank
         self.questions_seen = 0
+        # nn.Dropout(config['dropout']) of the reference's model.train() (modules.py `D` positions).  Off by default: the
+        # parity pins are defined at dropout = 0; pass dropout=model.config['dropout'] to train the way the reference does.
+        # Every step and rank draws fresh masks: seed = dropout_seed + step * world + rank.
+        self.dropout, self.dropout_seed = float(dropout), int(dropout_seed)
         assert skip_untouched in ('ever', 'window')
         self.skip_untouched = skip_untouched
         self.model, self.world = model, world
@@ -102,7 +107,8 @@ class Trainer:
                                   torch.full_like(answers, -1))
         if questions is not None and gstep[-1] >= self.before_iters:
             questions = [q if g < self.before_iters else dict(q, sg_res_by_step={}) for q, g in zip(questions, gstep)]
-        res = self.model.run_programs(programs, spans, video, question, q_lens, train=True, video_index=video_index)
+        drop = (self.dropout, self.dropout_seed + self.iters * self.world + self.rank) if self.dropout > 0 else None
+        res = self.model.run_programs(programs, spans, video, question, q_lens, train=True, video_index=video_index, dropout=drop)
         extra = set()
         if questions is not None and self.module_loss_weight != 0:
             res.zero_grad_arenas()

@@ -317,6 +317,101 @@ def test_trainer_loss_gates_follow_the_global_step():
     assert float(dec.min()) > 0.0 and sum(int(v.numel()) for v in tr.module_losses.values()) == 0
 
 
+def test_dropout_mask_generator():
+    """stair_dropout_fwd: kept fraction ~ 1 - p, kept values scaled by 1/(1-p), dropped ones exactly 0, the mask a pure
+    function of (seed, site, element) -- same call twice gives the same tensor, another seed or site another mask --
+    and row gathering through gidx touches only the listed rows."""
+    import ctypes as C
+    from stair_amd._lib import lib, check
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    x = torch.randn(300, 512, device=DEV) + 3.0                       # no zeros in the input
+    def run(p, seed, site, idx=None, groups=300):
+        y = x.clone()
+        check(lib.stair_dropout_fwd(C.c_void_p(y.data_ptr()), 512, C.c_void_p(idx.data_ptr()) if idx is not None else None, groups, 512,
+                                    C.c_float(p), C.c_uint64(seed), C.c_uint32(site), stream))
+        return y
+    for p in (0.25, 0.5, 0.9):
+        y = run(p, 7, 3)
+        kept = y != 0
+        assert abs(float(kept.float().mean()) - (1 - p)) < 0.01
+        assert torch.allclose(y[kept], x[kept] / (1 - p), rtol=1e-6)
+        assert abs(float(y.mean()) / float(x.mean()) - 1.0) < 0.03      # expectation preserved
+    a, b = run(0.25, 7, 3), run(0.25, 7, 3)
+    assert torch.equal(a, b)
+    assert not torch.equal(a != 0, run(0.25, 8, 3) != 0) and not torch.equal(a != 0, run(0.25, 7, 4) != 0)
+    assert torch.equal(run(0.0, 7, 3), x)
+    idx = torch.tensor([5, 299, 17], dtype=torch.int32, device=DEV)
+    g = run(0.5, 1, 0, idx, 3)
+    untouched = [i for i in range(300) if i not in (5, 299, 17)]
+    assert torch.equal(g[untouched], x[untouched]) and float((g[[5, 299, 17]] == 0).float().mean()) > 0.4
+
+
+def test_dropout_training_forward_and_gradients():
+    """Training-mode dropout at the reference's `D` positions (stair_plan_set_dropout).  torch's masks cannot be matched,
+    so what is checked: (a) p = 0 and inference are the pinned arithmetic, bit for bit; (b) a seed fixes the step
+    (replay is bit-identical), another seed changes it; (c) with the masks held fixed the loss is an ordinary function
+    of the weights, and stair_plan_backward is its gradient: directional derivative by central differences along a
+    random direction over ALL parameters, exact-fp32 products, every program form in the batch."""
+    from stair_amd import ops
+    ops.set_matmul_mode('f32')
+    try:
+        z, meta = load_golden('tiny_conv')
+        config = meta['config']
+        qs = [question_for(meta, q) for q in meta['questions']]
+        model = _model(config, meta['seed'])
+        for p in model.parameters():
+            p.grad = torch.zeros_like(p)
+        progs, spans, video, question, q_lens, answers = _pack(model, qs)
+        plain = model.run_programs(progs, spans, video, question, q_lens, train=True).logits.clone()
+        assert torch.equal(model.run_programs(progs, spans, video, question, q_lens, train=True, dropout=(0.0, 5)).logits, plain)
+        d1 = model.run_programs(progs, spans, video, question, q_lens, train=True, dropout=(0.25, 5)).logits.clone()
+        d2 = model.run_programs(progs, spans, video, question, q_lens, train=True, dropout=(0.25, 5)).logits.clone()
+        d3 = model.run_programs(progs, spans, video, question, q_lens, train=True, dropout=(0.25, 6)).logits.clone()
+        assert torch.equal(d1, d2) and not torch.equal(d1, d3) and not torch.equal(d1, plain)
+        assert float((d1 - plain).abs().max()) < 5.0                   # a perturbation, not garbage
+        with pytest.raises(ValueError):
+            model.run_programs(progs, spans, video, question, q_lens, dropout=(0.25, 5))
+
+        ans = answers.long()
+        for drop in ((0.25, 11), None):                                 # None calibrates the method on the pinned path
+            def loss_at():
+                lg = model.run_programs(progs, spans, video, question, q_lens, train=True, dropout=drop).logits
+                return float(torch.nn.functional.cross_entropy(lg.double(), ans, reduction='mean'))
+            for p in model.parameters():
+                p.grad.zero_()
+            res = model.run_programs(progs, spans, video, question, q_lens, train=True, dropout=drop)
+            res.backward(answers, 1.0 / len(qs))
+            # one check per module: step along THAT module's gradient (largest signal over fp32 noise), so that a wrong
+            # factor at any single dropout site shows up instead of drowning in the other modules' gradient
+            groups = {}
+            for n, p in model.named_parameters():
+                groups.setdefault(n.split('.')[1], []).append((n, p))
+            total = sum(float((p.grad.double() ** 2).sum()) for p in model.parameters()) ** 0.5
+            checked = 0
+            for gname, plist in sorted(groups.items()):
+                gn = sum(float((p.grad.double() ** 2).sum()) for _, p in plist) ** 0.5
+                if gn < 0.02 * total:
+                    continue                                             # too little signal for a finite difference in fp32
+                wn = sum(float((p.detach().double() ** 2).sum()) for _, p in plist) ** 0.5
+                direction = {n: p.grad.clone() / gn for n, p in plist}
+                eps = 5e-4 * wn                                          # 2e-3 already bends the loss by up to 8 %
+                with torch.no_grad():
+                    for n, p in plist:
+                        p.add_(direction[n], alpha=eps)
+                    up = loss_at()
+                    for n, p in plist:
+                        p.add_(direction[n], alpha=-2 * eps)
+                    down = loss_at()
+                    for n, p in plist:
+                        p.add_(direction[n], alpha=eps)
+                numeric = (up - down) / (2 * eps)
+                assert abs(numeric - gn) < 0.03 * gn, (drop, gname, numeric, gn)
+                checked += 1
+            assert checked >= 6, checked
+    finally:
+        ops.set_matmul_mode('bf16x3')
+
+
 WORD2ID = {'cup': 'o1', 'glass': 'o1', 'dish': 'o2', 'door': 'o5', 'phone': 'o3', 'sofa': 'o9', 'blanket': 'o4',
            'window': 'o7', 'food': 'o8', 'bag': 'o6'}
 
