@@ -271,6 +271,21 @@ def test_questions_sharing_a_clip_encode_it_once(matmul):
                            [qs[0]['question'].shape[0]], video_index=[5])
 
 
+def test_appearance_feature_config_against_oracle(matmul):
+    """The README's ResNet/ResNeXt setting (README.md:180-183, BASELINE configs[0]): 8 frames of 4096 features,
+    max_video_length 8 -> Linear(T,T) Temporal nets at full hidden size.  24 questions of all forms vs the oracle."""
+    config = dict(spec.DEFAULT_CONFIG, video_size=4096, max_video_length=8)
+    model = _model(config, 6)
+    w = oracle_weights(config, 6)
+    qs = synth.make_questions(config, 13, 24, forms=synth.ALL_FORMS)
+    assert qs[0]['video_features'].shape == (8, 4096)
+    res = model.forward_batch(qs)
+    for qi in range(0, 24, 2):
+        r = O.forward(w, config, qs[qi])
+        assert _maxerr(res.logits[qi], r['logits']) < 1e-4
+        assert int(res.pred[qi]) == int(torch.argmax(r['logits']))
+
+
 def test_larger_batch_against_oracle(matmul):
     """128 random questions of all 12 forms vs the oracle run question by question."""
     config = dict(spec.DEFAULT_CONFIG)
