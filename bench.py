@@ -150,13 +150,13 @@ def main():
     # the driver's runs use the default: nccl (= RCCL), one rank per GPU.
     backend = os.environ.get('STAIR_DIST_BACKEND', 'nccl')
     dev_index = local_rank if backend == 'nccl' else local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)                 # before the process group: RCCL binds the communicator to this device
     if world > 1:
         import torch.distributed as dist
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device('cuda', dev_index))
         else:
             dist.init_process_group(backend)
-    torch.cuda.set_device(dev_index)
     device = torch.device('cuda', dev_index)
 
     from stair_amd.module_net import VideoNMN      # raises if libstair_hip.so is missing
