@@ -482,7 +482,8 @@ def test_gemm_tn_weight_gradient(M, N, K, R, matmul):
     assert _maxerr(Cm, ref) < _tol(matmul, 1e-4, 4e-4) * max(1.0, (M / 1000) ** 0.5 * 3)
 
 
-@pytest.mark.parametrize('M,N,K', [(64, 16, 64), (4096, 512, 512), (1001, 1024, 300), (333, 36, 512), (8192 + 64, 128, 2048)])
+@pytest.mark.parametrize('M,N,K', [(64, 16, 64), (4096, 512, 512), (1001, 1024, 300), (333, 36, 512), (8192 + 64, 128, 2048),
+                                   (4096, 1024, 2048)])      # the last one takes the 256 x 256 tile kernel (32 output tiles)
 def test_gemm_tn_bias_gradient_rides_along(M, N, K, matmul):
     """stair_gemm_tn_args.colsum / colsum2: db += colsum(dZ) out of the same launch as dW (fused into the staging of
     the split-precision kernel, a second kernel in f32 mode), on top of existing contents, ragged M included."""
