@@ -192,7 +192,7 @@ static int g_matmul_mode = -1;
 int matmul_mode() {
     if (g_matmul_mode < 0) {
         const char *e = getenv("STAIR_MATMUL");
-        g_matmul_mode = (e && std::string(e) == "f32") ? STAIR_MATMUL_F32 : STAIR_MATMUL_BF16X3;
+        g_matmul_mode = (e && std::string(e) == "f32") ? STAIR_MATMUL_F32 : (e && std::string(e) == "bf16") ? STAIR_MATMUL_BF16 : STAIR_MATMUL_BF16X3;
     }
     return g_matmul_mode;
 }
@@ -217,7 +217,7 @@ int launch_gemm(const stair_gemm_args &a, hipStream_t s) {
     const int64_t M = (int64_t)a.groups * a.rows_per_group;
     if (M == 0) return 0;
     STAIR_CHECK(M < (1ll << 31), "M too large");
-    if (matmul_mode() == STAIR_MATMUL_BF16X3 && M >= kSplitMinRows) return launch_gemm_bf16x3(a, s);
+    if (matmul_mode() != STAIR_MATMUL_F32 && M >= kSplitMinRows) return launch_gemm_bf16x3(a, s);
     p.M = (int)M;
     p.tilesM = (p.M + BM - 1) / BM;
     p.tilesN = (a.N + BN - 1) / BN;
@@ -325,7 +325,7 @@ int launch_gemm_tn(const stair_gemm_tn_args &a, hipStream_t s) {
     STAIR_CHECK(a.N % 4 == 0 && a.K % 4 == 0 && a.lda % 4 == 0 && a.ldb % 4 == 0 && a.b_gstride % 4 == 0,
                 "N, K, lda, ldb, b_gstride must be multiples of 4 floats");
     if (a.M == 0) return 0;
-    if (matmul_mode() == STAIR_MATMUL_BF16X3 && a.M >= kSplitMinRows) return launch_gemm_tn_bf16x3(a, s);
+    if (matmul_mode() != STAIR_MATMUL_F32 && a.M >= kSplitMinRows) return launch_gemm_tn_bf16x3(a, s);
     GemmTnParams p;
     p.A = a.A; p.lda = a.lda; p.B = a.B; p.ldb = a.ldb; p.b_gstride = a.b_gstride; p.b_gidx = a.b_gidx;
     p.R = a.rows_per_group; p.row_scale = a.row_scale; p.rs_gstride = a.rs_gstride; p.rs_gidx = a.rs_gidx;
@@ -406,8 +406,8 @@ extern "C" int stair_gemm_tn_f32(const stair_gemm_tn_args *args, stair_stream st
 }
 
 extern "C" int stair_set_matmul_mode(int32_t mode) {
-    if (mode != STAIR_MATMUL_F32 && mode != STAIR_MATMUL_BF16X3) {
-        stair::set_error("stair_set_matmul_mode: mode must be STAIR_MATMUL_F32 or STAIR_MATMUL_BF16X3");
+    if (mode != STAIR_MATMUL_F32 && mode != STAIR_MATMUL_BF16X3 && mode != STAIR_MATMUL_BF16) {
+        stair::set_error("stair_set_matmul_mode: mode must be STAIR_MATMUL_F32, STAIR_MATMUL_BF16X3 or STAIR_MATMUL_BF16");
         return 1;
     }
     stair::set_matmul_mode(mode);

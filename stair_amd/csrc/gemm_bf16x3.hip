@@ -61,6 +61,7 @@ __device__ __forceinline__ void split8p(const v4f &x0, const v4f &x1, bf16x8 &hi
 }
 
 // one chunk of MFMAs from LDS buffer `buf`: 2 k-steps x (2x2 tiles) x 3 products
+template <int NP>
 __device__ __forceinline__ void mfma_chunk(const __bf16 *lds, int buf, int wm, int wn, int r, int h, f32x16 &acc00,
                                            f32x16 &acc01, f32x16 &acc10, f32x16 &acc11) {
 #pragma unroll
@@ -68,20 +69,22 @@ __device__ __forceinline__ void mfma_chunk(const __bf16 *lds, int buf, int wm, i
         const int kq = 2 * s + h;
         const bf16x8 ah0 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 0, 0, kq, wm * 64 + r));
         const bf16x8 ah1 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 0, 0, kq, wm * 64 + 32 + r));
-        const bf16x8 al0 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 0, 1, kq, wm * 64 + r));
-        const bf16x8 al1 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 0, 1, kq, wm * 64 + 32 + r));
         const bf16x8 bh0 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 1, 0, kq, wn * 64 + r));
         const bf16x8 bh1 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 1, 0, kq, wn * 64 + 32 + r));
-        const bf16x8 bl0 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 1, 1, kq, wn * 64 + r));
-        const bf16x8 bl1 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 1, 1, kq, wn * 64 + 32 + r));
-        acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh0, acc00, 0, 0, 0);      // small terms first
-        acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh1, acc01, 0, 0, 0);
-        acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh0, acc10, 0, 0, 0);
-        acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh1, acc11, 0, 0, 0);
-        acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl0, acc00, 0, 0, 0);
-        acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl1, acc01, 0, 0, 0);
-        acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl0, acc10, 0, 0, 0);
-        acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl1, acc11, 0, 0, 0);
+        if constexpr (NP == 3) {                     // the two cross terms (NP == 1: plain bf16 products, hi * hi only)
+            const bf16x8 al0 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 0, 1, kq, wm * 64 + r));
+            const bf16x8 al1 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 0, 1, kq, wm * 64 + 32 + r));
+            const bf16x8 bl0 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 1, 1, kq, wn * 64 + r));
+            const bf16x8 bl1 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 1, 1, kq, wn * 64 + 32 + r));
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh0, acc00, 0, 0, 0);      // small terms first
+            acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh1, acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh0, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh1, acc11, 0, 0, 0);
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl0, acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl1, acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl0, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl1, acc11, 0, 0, 0);
+        }
         acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh0, acc00, 0, 0, 0);
         acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh1, acc01, 0, 0, 0);
         acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh0, acc10, 0, 0, 0);
@@ -90,6 +93,7 @@ __device__ __forceinline__ void mfma_chunk(const __bf16 *lds, int buf, int wm, i
 }
 
 // the eight-wave kernel's chunk: wave tile 64 x 32 = two 32 x 32 tiles sharing the B fragments
+template <int NP>
 __device__ __forceinline__ void mfma_chunk_w8(const __bf16 *lds, int buf, int wm, int wn, int r, int h, f32x16 &acc00,
                                               f32x16 &acc10) {
 #pragma unroll
@@ -97,14 +101,16 @@ __device__ __forceinline__ void mfma_chunk_w8(const __bf16 *lds, int buf, int wm
         const int kq = 2 * s + h;
         const bf16x8 ah0 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 0, 0, kq, wm * 64 + r));
         const bf16x8 ah1 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 0, 0, kq, wm * 64 + 32 + r));
-        const bf16x8 al0 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 0, 1, kq, wm * 64 + r));
-        const bf16x8 al1 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 0, 1, kq, wm * 64 + 32 + r));
         const bf16x8 bh0 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 1, 0, kq, wn * 32 + r));
-        const bf16x8 bl0 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 1, 1, kq, wn * 32 + r));
-        acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh0, acc00, 0, 0, 0);      // small terms first
-        acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh0, acc10, 0, 0, 0);
-        acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl0, acc00, 0, 0, 0);
-        acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl0, acc10, 0, 0, 0);
+        if constexpr (NP == 3) {
+            const bf16x8 al0 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 0, 1, kq, wm * 64 + r));
+            const bf16x8 al1 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 0, 1, kq, wm * 64 + 32 + r));
+            const bf16x8 bl0 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 1, 1, kq, wn * 32 + r));
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh0, acc00, 0, 0, 0);      // small terms first
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh0, acc10, 0, 0, 0);
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl0, acc00, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl0, acc10, 0, 0, 0);
+        }
         acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh0, acc00, 0, 0, 0);
         acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh0, acc10, 0, 0, 0);
     }
@@ -122,7 +128,7 @@ struct XParams {
 // ---------------------------------------------------------------------------------------------
 // PLAIN: K is a multiple of 64 and there is no row scale, so no staged element needs the K-tail mask or the scale
 // (a quarter of the staging VALU work otherwise); chunks past K are then staged but never multiplied.
-template <int ACT, bool PLAIN>
+template <int ACT, bool PLAIN, int NP>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(XParams p) {
     extern __shared__ __attribute__((aligned(16))) __bf16 xlds[];
     const stair_gemm_args &a = p.a;
@@ -181,10 +187,10 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(XParams p) {
             if (PLAIN) split8p(va[set][i_][0], va[set][i_][1], hi_, lo_);                               \
             else split8(va[set][i_][0] * km[set][0], va[set][i_][1] * km[set][1], rs[i_], hi_, lo_);    \
             *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, 0, 0, kq, ra_ + 64 * i_)) = hi_;            \
-            *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, 0, 1, kq, ra_ + 64 * i_)) = lo_;            \
+            if (NP == 3) *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, 0, 1, kq, ra_ + 64 * i_)) = lo_;            \
             split8p(vb[set][i_][0], vb[set][i_][1], hi_, lo_);                                          \
             *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, 1, 0, kq, ra_ + 64 * i_)) = hi_;            \
-            *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, 1, 1, kq, ra_ + 64 * i_)) = lo_;            \
+            if (NP == 3) *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, 1, 1, kq, ra_ + 64 * i_)) = lo_;            \
         }                                                                                               \
     }
 
@@ -200,13 +206,13 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(XParams p) {
         // chunk c lives in LDS buffer 0, chunk c+1 in register set 1
         X_GLOAD(0, (c + 2) * XBK);
         __builtin_amdgcn_sched_barrier(0);
-        mfma_chunk(xlds, 0, wm, wn, r, h, acc00, acc01, acc10, acc11);
+        mfma_chunk<NP>(xlds, 0, wm, wn, r, h, acc00, acc01, acc10, acc11);
         __builtin_amdgcn_sched_barrier(0);
         X_LSTORE(1, 1);
         __syncthreads();
         X_GLOAD(1, (c + 3) * XBK);
         __builtin_amdgcn_sched_barrier(0);
-        mfma_chunk(xlds, 1, wm, wn, r, h, acc00, acc01, acc10, acc11);
+        mfma_chunk<NP>(xlds, 1, wm, wn, r, h, acc00, acc01, acc10, acc11);
         __builtin_amdgcn_sched_barrier(0);
         X_LSTORE(0, 0);
         __syncthreads();
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(XParams p) {
 // so a wave carries 32 accumulator and 16 staging registers per set instead of 64 and 32.  At <= 128 VGPRs two
 // workgroups (16 waves, 4 per SIMD) share a CU, twice the four-wave kernel's, which is what hides the staging
 // stalls: rocprof counted the MFMA pipe 43 % busy with 2 waves per SIMD (profiles/r01_e_pmc_gemm.json).
-template <int ACT, bool PLAIN>
+template <int ACT, bool PLAIN, int NP>
 __global__ __launch_bounds__(512, 2) void gemm_bf16x3_w8_kernel(XParams p) {
     extern __shared__ __attribute__((aligned(16))) __bf16 xlds[];
     const stair_gemm_args &a = p.a;
@@ -313,10 +319,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_w8_kernel(XParams p) {
             if (PLAIN) split8p(va[set][i_][0], va[set][i_][1], hi_, lo_);                               \
             else split8(va[set][i_][0] * km[set][0], va[set][i_][1] * km[set][1], rs[i_], hi_, lo_);    \
             *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, 0, 0, kq, ra_ + 64 * i_)) = hi_;            \
-            *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, 0, 1, kq, ra_ + 64 * i_)) = lo_;            \
+            if (NP == 3) *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, 0, 1, kq, ra_ + 64 * i_)) = lo_;            \
             split8p(vb[set][i_][0], vb[set][i_][1], hi_, lo_);                                          \
             *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, 1, 0, kq, ra_ + 64 * i_)) = hi_;            \
-            *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, 1, 1, kq, ra_ + 64 * i_)) = lo_;            \
+            if (NP == 3) *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, 1, 1, kq, ra_ + 64 * i_)) = lo_;            \
         }                                                                                               \
     }
 
@@ -332,13 +338,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3_w8_kernel(XParams p) {
         // chunk c lives in LDS buffer 0, chunk c+1 in register set 1
         X_GLOAD(0, (c + 2) * XBK);
         __builtin_amdgcn_sched_barrier(0);
-        mfma_chunk_w8(xlds, 0, wm, wn, r, h, acc00, acc10);
+        mfma_chunk_w8<NP>(xlds, 0, wm, wn, r, h, acc00, acc10);
         __builtin_amdgcn_sched_barrier(0);
         X_LSTORE(1, 1);
         __syncthreads();
         X_GLOAD(1, (c + 3) * XBK);
         __builtin_amdgcn_sched_barrier(0);
-        mfma_chunk_w8(xlds, 1, wm, wn, r, h, acc00, acc10);
+        mfma_chunk_w8<NP>(xlds, 1, wm, wn, r, h, acc00, acc10);
         __builtin_amdgcn_sched_barrier(0);
         X_LSTORE(0, 0);
         __syncthreads();
@@ -398,7 +404,7 @@ __device__ __forceinline__ int img2_off(int buf, int operand, int part, int kq, 
 }
 }  // namespace
 
-template <int ACT>
+template <int ACT, int NP>
 __global__ __launch_bounds__(512, 1) void gemm_bf16x3_t256_kernel(XParams p) {
     extern __shared__ __attribute__((aligned(16))) __bf16 xlds[];
     const stair_gemm_args &a = p.a;
@@ -451,10 +457,10 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16x3_t256_kernel(XParams p) {
             bf16x8 hi_, lo_;                                                                            \
             split8p(va[i_][0], va[i_][1], hi_, lo_);                                                    \
             *reinterpret_cast<bf16x8 *>(xlds + img2_off(buf, 0, 0, kq, ra_ + 128 * i_)) = hi_;          \
-            *reinterpret_cast<bf16x8 *>(xlds + img2_off(buf, 0, 1, kq, ra_ + 128 * i_)) = lo_;          \
+            if (NP == 3) *reinterpret_cast<bf16x8 *>(xlds + img2_off(buf, 0, 1, kq, ra_ + 128 * i_)) = lo_;          \
             split8p(vb[i_][0], vb[i_][1], hi_, lo_);                                                    \
             *reinterpret_cast<bf16x8 *>(xlds + img2_off(buf, 1, 0, kq, ra_ + 128 * i_)) = hi_;          \
-            *reinterpret_cast<bf16x8 *>(xlds + img2_off(buf, 1, 1, kq, ra_ + 128 * i_)) = lo_;          \
+            if (NP == 3) *reinterpret_cast<bf16x8 *>(xlds + img2_off(buf, 1, 1, kq, ra_ + 128 * i_)) = lo_;          \
         }                                                                                               \
     }
 #define Y_MFMA(buf)                                                                                                  \
@@ -464,14 +470,17 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16x3_t256_kernel(XParams p) {
             bf16x8 bh_[2], bl_[2];                                                                                   \
             _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                       \
                 bh_[j_] = *reinterpret_cast<const bf16x8 *>(xlds + img2_off(buf, 1, 0, kq_, wn * 64 + 32 * j_ + r)); \
-                bl_[j_] = *reinterpret_cast<const bf16x8 *>(xlds + img2_off(buf, 1, 1, kq_, wn * 64 + 32 * j_ + r)); \
+                if (NP == 3) bl_[j_] = *reinterpret_cast<const bf16x8 *>(xlds + img2_off(buf, 1, 1, kq_, wn * 64 + 32 * j_ + r)); \
             }                                                                                                        \
             _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                       \
                 const bf16x8 ah_ = *reinterpret_cast<const bf16x8 *>(xlds + img2_off(buf, 0, 0, kq_, wm * 128 + 32 * i_ + r)); \
-                const bf16x8 al_ = *reinterpret_cast<const bf16x8 *>(xlds + img2_off(buf, 0, 1, kq_, wm * 128 + 32 * i_ + r)); \
+                bf16x8 al_ = ah_;                                                                                    \
+                if (NP == 3) al_ = *reinterpret_cast<const bf16x8 *>(xlds + img2_off(buf, 0, 1, kq_, wm * 128 + 32 * i_ + r)); \
                 _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                   \
-                    acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al_, bh_[j_], acc[i_][j_], 0, 0, 0);       \
-                    acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, bl_[j_], acc[i_][j_], 0, 0, 0);       \
+                    if (NP == 3) {                                                                                   \
+                        acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al_, bh_[j_], acc[i_][j_], 0, 0, 0);   \
+                        acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, bl_[j_], acc[i_][j_], 0, 0, 0);   \
+                    }                                                                                                \
                     acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, bh_[j_], acc[i_][j_], 0, 0, 0);       \
                 }                                                                                                    \
             }                                                                                                        \
@@ -554,6 +563,7 @@ int launch_gemm_bf16x3(const stair_gemm_args &a, hipStream_t s) {
     const dim3 grid(p.tilesM * p.tilesN), block(256);
     const size_t shmem = 2 * 2 * 2 * IMG * sizeof(__bf16);
     const bool plain = a.K % 64 == 0 && !a.row_scale;
+    const bool one = matmul_mode() == STAIR_MATMUL_BF16;        // single product per operand pair (top-1 identity only)
     static const int t256_min = [] { const char *e = getenv("STAIR_GEMM_T256"); return e ? atoi(e) : 256; }();   // 0 = off
     const int t2m = (p.M + 255) / 256, t2n = (a.N + 255) / 256;
     // one 256 x 256 workgroup per CU: the launch runs in rounds of 256 tiles, so it only pays when the last round is
@@ -566,31 +576,38 @@ int launch_gemm_bf16x3(const stair_gemm_args &a, hipStream_t s) {
         const dim3 grid2(t2m * t2n);
         static bool attr_set = false;
         if (!attr_set) {
-            STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_bf16x3_t256_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem2));
-            STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_bf16x3_t256_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem2));
-            STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_bf16x3_t256_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem2));
+            const void *fns[6] = {reinterpret_cast<const void *>(&gemm_bf16x3_t256_kernel<0, 3>), reinterpret_cast<const void *>(&gemm_bf16x3_t256_kernel<1, 3>),
+                                  reinterpret_cast<const void *>(&gemm_bf16x3_t256_kernel<2, 3>), reinterpret_cast<const void *>(&gemm_bf16x3_t256_kernel<0, 1>),
+                                  reinterpret_cast<const void *>(&gemm_bf16x3_t256_kernel<1, 1>), reinterpret_cast<const void *>(&gemm_bf16x3_t256_kernel<2, 1>)};
+            for (const void *f : fns) STAIR_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem2));
             attr_set = true;
         }
+#define T_LAUNCH(ACT_)                                                                                              \
+    if (one) hipLaunchKernelGGL((gemm_bf16x3_t256_kernel<ACT_, 1>), grid2, dim3(512), shmem2, s, q);                 \
+    else hipLaunchKernelGGL((gemm_bf16x3_t256_kernel<ACT_, 3>), grid2, dim3(512), shmem2, s, q);
         switch (a.act) {
-            case 0: hipLaunchKernelGGL(gemm_bf16x3_t256_kernel<0>, grid2, dim3(512), shmem2, s, q); break;
-            case 1: hipLaunchKernelGGL(gemm_bf16x3_t256_kernel<1>, grid2, dim3(512), shmem2, s, q); break;
-            default: hipLaunchKernelGGL(gemm_bf16x3_t256_kernel<2>, grid2, dim3(512), shmem2, s, q); break;
+            case 0: T_LAUNCH(0) break;
+            case 1: T_LAUNCH(1) break;
+            default: T_LAUNCH(2) break;
         }
+#undef T_LAUNCH
         STAIR_LAUNCH_CHECK();
         return 0;
     }
     const bool w8 = gemm_w8_enabled() && p.tilesM * p.tilesN >= 512;   // enough tiles for two 8-wave workgroups on every CU
-#define X_LAUNCH(ACT_)                                                                                             \
-    if (w8 && plain) hipLaunchKernelGGL((gemm_bf16x3_w8_kernel<ACT_, true>), grid, dim3(512), shmem, s, p);         \
-    else if (w8) hipLaunchKernelGGL((gemm_bf16x3_w8_kernel<ACT_, false>), grid, dim3(512), shmem, s, p);            \
-    else if (plain) hipLaunchKernelGGL((gemm_bf16x3_kernel<ACT_, true>), grid, block, shmem, s, p);                 \
-    else hipLaunchKernelGGL((gemm_bf16x3_kernel<ACT_, false>), grid, block, shmem, s, p);
+#define X_LAUNCH1(ACT_, NP_)                                                                                       \
+    if (w8 && plain) hipLaunchKernelGGL((gemm_bf16x3_w8_kernel<ACT_, true, NP_>), grid, dim3(512), shmem, s, p);    \
+    else if (w8) hipLaunchKernelGGL((gemm_bf16x3_w8_kernel<ACT_, false, NP_>), grid, dim3(512), shmem, s, p);       \
+    else if (plain) hipLaunchKernelGGL((gemm_bf16x3_kernel<ACT_, true, NP_>), grid, block, shmem, s, p);            \
+    else hipLaunchKernelGGL((gemm_bf16x3_kernel<ACT_, false, NP_>), grid, block, shmem, s, p);
+#define X_LAUNCH(ACT_) if (one) { X_LAUNCH1(ACT_, 1) } else { X_LAUNCH1(ACT_, 3) }
     switch (a.act) {
         case 0: X_LAUNCH(0) break;
         case 1: X_LAUNCH(1) break;
         default: X_LAUNCH(2) break;
     }
 #undef X_LAUNCH
+#undef X_LAUNCH1
     STAIR_LAUNCH_CHECK();
     return 0;
 }
@@ -612,7 +629,7 @@ struct XTnParams {
 
 // PLAIN: no row scale and every slab holds a multiple of 64 rows, so no element needs a mask or a scale (columns past
 // N or K are computed from clamped addresses and never written).
-template <bool PLAIN>
+template <bool PLAIN, int NP>
 __global__ __launch_bounds__(256, 2) void gemm_tn_bf16x3_kernel(XTnParams p) {
     extern __shared__ __attribute__((aligned(16))) __bf16 xlds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -701,7 +718,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16x3_kernel(XTnParams p) {
                 lo_[j_] = (__bf16)(x_ - (float)hi_[j_]);                                                    \
             }                                                                                               \
             *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, operand_, 0, mq, 4 * cq + c_)) = hi_;           \
-            *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, operand_, 1, mq, 4 * cq + c_)) = lo_;           \
+            if (NP == 3) *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, operand_, 1, mq, 4 * cq + c_)) = lo_;           \
         }                                                                                                   \
     }
 
@@ -714,13 +731,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16x3_kernel(XTnParams p) {
         for (int c = 0; c < nchunks; c += 2) {
             T_GLOAD(0, mbeg + (c + 2) * XBK);
             __builtin_amdgcn_sched_barrier(0);
-            mfma_chunk(xlds, 0, wm, wn, r, h, acc00, acc01, acc10, acc11);
+            mfma_chunk<NP>(xlds, 0, wm, wn, r, h, acc00, acc01, acc10, acc11);
             __builtin_amdgcn_sched_barrier(0);
             T_LSTORE(1, 1, c + 1);
             __syncthreads();
             T_GLOAD(1, mbeg + (c + 3) * XBK);
             __builtin_amdgcn_sched_barrier(0);
-            mfma_chunk(xlds, 1, wm, wn, r, h, acc00, acc01, acc10, acc11);
+            mfma_chunk<NP>(xlds, 1, wm, wn, r, h, acc00, acc01, acc10, acc11);
             __builtin_amdgcn_sched_barrier(0);
             T_LSTORE(0, 0, c + 2);
             __syncthreads();
@@ -758,6 +775,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16x3_kernel(XTnParams p) {
 // 256 x 256 tile form of the TN kernel for the largest weight gradient (dW_ih of the video encoder: N = 1024, K = 2048,
 // 32 tiles): PLAIN launches whose B rows come in groups of 8 (fast8 == 1).  Waves 0-3 stage A (256 columns of dZ),
 // waves 4-7 stage B; same LDS images and MFMA phase as gemm_bf16x3_t256_kernel; one staging register set.
+template <int NP>
 __global__ __launch_bounds__(512, 1) void gemm_tn_bf16x3_t256_kernel(XTnParams p) {
     extern __shared__ __attribute__((aligned(16))) __bf16 xlds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -811,7 +829,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_bf16x3_t256_kernel(XTnParams p
                 lo_[j_] = (__bf16)(x_ - (float)hi_[j_]);                                                    \
             }                                                                                               \
             *reinterpret_cast<bf16x8 *>(xlds + img2_off(buf, operand_, 0, mq, 4 * cq + c_)) = hi_;          \
-            *reinterpret_cast<bf16x8 *>(xlds + img2_off(buf, operand_, 1, mq, 4 * cq + c_)) = lo_;          \
+            if (NP == 3) *reinterpret_cast<bf16x8 *>(xlds + img2_off(buf, operand_, 1, mq, 4 * cq + c_)) = lo_;          \
         }                                                                                                   \
     }
 #define Z_MFMA(buf)                                                                                                  \
@@ -821,14 +839,17 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_bf16x3_t256_kernel(XTnParams p
             bf16x8 bh_[2], bl_[2];                                                                                   \
             _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                       \
                 bh_[j_] = *reinterpret_cast<const bf16x8 *>(xlds + img2_off(buf, 1, 0, kq_, wn * 64 + 32 * j_ + r)); \
-                bl_[j_] = *reinterpret_cast<const bf16x8 *>(xlds + img2_off(buf, 1, 1, kq_, wn * 64 + 32 * j_ + r)); \
+                if (NP == 3) bl_[j_] = *reinterpret_cast<const bf16x8 *>(xlds + img2_off(buf, 1, 1, kq_, wn * 64 + 32 * j_ + r)); \
             }                                                                                                        \
             _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                       \
                 const bf16x8 ah_ = *reinterpret_cast<const bf16x8 *>(xlds + img2_off(buf, 0, 0, kq_, wm * 128 + 32 * i_ + r)); \
-                const bf16x8 al_ = *reinterpret_cast<const bf16x8 *>(xlds + img2_off(buf, 0, 1, kq_, wm * 128 + 32 * i_ + r)); \
+                bf16x8 al_ = ah_;                                                                                    \
+                if (NP == 3) al_ = *reinterpret_cast<const bf16x8 *>(xlds + img2_off(buf, 0, 1, kq_, wm * 128 + 32 * i_ + r)); \
                 _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                   \
-                    acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al_, bh_[j_], acc[i_][j_], 0, 0, 0);       \
-                    acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, bl_[j_], acc[i_][j_], 0, 0, 0);       \
+                    if (NP == 3) {                                                                                   \
+                        acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al_, bh_[j_], acc[i_][j_], 0, 0, 0);   \
+                        acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, bl_[j_], acc[i_][j_], 0, 0, 0);   \
+                    }                                                                                                \
                     acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, bh_[j_], acc[i_][j_], 0, 0, 0);       \
                 }                                                                                                    \
             }                                                                                                        \
@@ -884,6 +905,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_bf16x3_t256_kernel(XTnParams p
 
 int launch_gemm_tn_bf16x3(const stair_gemm_tn_args &a, hipStream_t s) {
     if (a.M == 0) return 0;
+    const bool one = matmul_mode() == STAIR_MATMUL_BF16;
     XTnParams p;
     p.A = a.A; p.lda = a.lda; p.B = a.B; p.ldb = a.ldb; p.b_gstride = a.b_gstride; p.b_gidx = a.b_gidx;
     p.R = a.rows_per_group; p.row_scale = a.row_scale; p.rs_gstride = a.rs_gstride; p.rs_gidx = a.rs_gidx;
@@ -913,11 +935,14 @@ int launch_gemm_tn_bf16x3(const stair_gemm_tn_args &a, hipStream_t s) {
             const size_t shmem2 = 2 * 2 * 2 * IMG2 * sizeof(__bf16);
             static bool attr_set = false;
             if (!attr_set) {
-                STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tn_bf16x3_t256_kernel),
+                STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tn_bf16x3_t256_kernel<3>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem2));
+                STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tn_bf16x3_t256_kernel<1>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem2));
                 attr_set = true;
             }
-            hipLaunchKernelGGL(gemm_tn_bf16x3_t256_kernel, dim3(t2 * slabs), dim3(512), shmem2, s, q);
+            if (one) hipLaunchKernelGGL(gemm_tn_bf16x3_t256_kernel<1>, dim3(t2 * slabs), dim3(512), shmem2, s, q);
+            else hipLaunchKernelGGL(gemm_tn_bf16x3_t256_kernel<3>, dim3(t2 * slabs), dim3(512), shmem2, s, q);
             STAIR_LAUNCH_CHECK();
             return 0;
         }
@@ -932,8 +957,10 @@ int launch_gemm_tn_bf16x3(const stair_gemm_tn_args &a, hipStream_t s) {
     p.mslab = ((a.M + slabs - 1) / slabs + 63) / 64 * 64;
     const size_t shmem = 2 * 2 * 2 * IMG * sizeof(__bf16);
     const bool plain = !p.row_scale && a.M % 64 == 0 && p.mslab % 64 == 0;
-    if (plain) hipLaunchKernelGGL(gemm_tn_bf16x3_kernel<true>, dim3(tiles * slabs), dim3(256), shmem, s, p);
-    else hipLaunchKernelGGL(gemm_tn_bf16x3_kernel<false>, dim3(tiles * slabs), dim3(256), shmem, s, p);
+    if (plain && one) hipLaunchKernelGGL((gemm_tn_bf16x3_kernel<true, 1>), dim3(tiles * slabs), dim3(256), shmem, s, p);
+    else if (plain) hipLaunchKernelGGL((gemm_tn_bf16x3_kernel<true, 3>), dim3(tiles * slabs), dim3(256), shmem, s, p);
+    else if (one) hipLaunchKernelGGL((gemm_tn_bf16x3_kernel<false, 1>), dim3(tiles * slabs), dim3(256), shmem, s, p);
+    else hipLaunchKernelGGL((gemm_tn_bf16x3_kernel<false, 3>), dim3(tiles * slabs), dim3(256), shmem, s, p);
     STAIR_LAUNCH_CHECK();
     return 0;
 }

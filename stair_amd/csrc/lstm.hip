@@ -730,7 +730,7 @@ int launch_lstm_bwd(const stair_lstm_bwd_args &a, hipStream_t s) {
     STAIR_CHECK(a.gates && a.cbuf && a.out && a.d_out && a.whh_pack_ws && a.hprev_ws, "null buffer");
     if (a.n == 0 || a.rows == 0) return 0;
     const int Hh = a.Hh;
-    const bool split = matmul_mode() == STAIR_MATMUL_BF16X3 && Hh % 64 == 0;
+    const bool split = matmul_mode() != STAIR_MATMUL_F32 && Hh % 64 == 0;
     if (split) {
         const int64_t n8 = 2 * 8 * (int64_t)Hh * Hh / 8;
         hipLaunchKernelGGL(whh_packT_bf16_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, a.w_hh[0], a.w_hh[1],
@@ -798,7 +798,7 @@ int launch_lstm(const stair_lstm_args &a, hipStream_t s) {
         if (int rc = launch_gemm(g, s)) return rc;
     }
     STAIR_CHECK(a.whh_pack_ws != nullptr, "whh_pack_ws missing");
-    const bool split = matmul_mode() == STAIR_MATMUL_BF16X3 && Hh % 64 == 0;     // the split kernel walks k blocks in pairs
+    const bool split = matmul_mode() != STAIR_MATMUL_F32 && Hh % 64 == 0;     // the split kernel walks k blocks in pairs
     if (split) {
         const int64_t n8 = 2 * 8 * (int64_t)Hh * Hh / 8;
         hipLaunchKernelGGL(whh_pack_bf16_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, a.w_hh[0], a.w_hh[1],

@@ -13,11 +13,12 @@ import torch
 from ._lib import GemmArgs, GemmTnArgs, LstmArgs, LstmBwdArgs, check, lib
 
 ACT = {None: 0, 'none': 0, 'relu': 1, 'sigmoid': 2}
-MATMUL_MODES = {'f32': 0, 'bf16x3': 1}
+MATMUL_MODES = {'f32': 0, 'bf16x3': 1, 'bf16': 2}
 
 
 def set_matmul_mode(mode, split_min_rows=1):
-    """'f32' (exact fp32 MFMA) or 'bf16x3' (split-precision bf16 MFMA, the default)."""
+    """'f32' (exact fp32 MFMA), 'bf16x3' (split-precision bf16 MFMA, the default, inside the 1e-4 logit budget) or
+    'bf16' (one bf16 product per operand pair: BASELINE configs[1]'s precision, top-1 identity only)."""
     check(lib.stair_set_matmul_mode(MATMUL_MODES[mode]))
     check(lib.stair_set_split_min_rows(split_min_rows))
 

@@ -63,6 +63,44 @@ def test_gemm_matches_fp64(M, N, K, act, matmul):
     assert _maxerr(y, ref) < _tol(matmul, 2e-5, 1e-4)          # fp32 accumulation over K <= 1536 terms of O(1)
 
 
+def test_single_product_bf16_mode():
+    """STAIR_MATMUL_BF16 (BASELINE configs[1]'s "bf16"): one bf16 product per operand pair.  GEMMs land where bf16
+    rounding of both operands puts them (relative error ~3e-3 of the row scale, far outside the 1e-4 budget, which is why
+    the mode is opt-in); on the full-size model the logits move by ~1e-3 and the top-1 answers of 64 questions stay those
+    of the oracle."""
+    from stair_amd import ops
+    ops.set_matmul_mode('bf16')
+    try:
+        assert ops.get_matmul_mode() == 'bf16'
+        g = torch.Generator().manual_seed(2)
+        for (M, N, K) in ((1000, 512, 1536), (70000, 512, 128), (4096, 1024, 2048)):
+            x = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) / K ** 0.5; b = torch.randn(N, generator=g)
+            y = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), 'relu').cpu().double()
+            ref = (x.double() @ w.double().t() + b.double()).relu()
+            rounded = (x.bfloat16().double() @ w.bfloat16().double().t() + b.double()).relu()
+            assert float((y - rounded).abs().max()) < 2e-4                 # exactly the bf16-operand product, fp32 accumulation
+            assert 1e-4 < float((y - ref).abs().max()) < 5e-2              # and measurably not the fp32 one
+            dz = torch.randn(M, N, generator=g)
+            dw = torch.zeros(N, K, device=DEV)
+            ops.gemm_tn(dz.to(DEV), x.to(DEV), dw, M, N, K)
+            refw = dz.bfloat16().double().t() @ x.bfloat16().double()
+            assert float((dw.cpu().double() - refw).abs().max()) < 2e-3 * max(1.0, (M / 1000) ** 0.5)
+        config = dict(spec.DEFAULT_CONFIG)
+        model = _model(config, 2)
+        w = oracle_weights(config, 2)
+        qs = synth.make_questions(config, 11, 64, forms=synth.ALL_FORMS)
+        res = model.forward_batch(qs)
+        worst = 0.0
+        for qi in range(0, 64, 4):
+            r = O.forward(w, config, qs[qi])
+            worst = max(worst, _maxerr(res.logits[qi], r['logits']))
+            assert int(res.pred[qi]) == int(torch.argmax(r['logits']))
+        assert 1e-5 < worst < 2e-2
+        print('bf16 mode: max |logit - oracle| =', worst)
+    finally:
+        ops.set_matmul_mode('bf16x3')
+
+
 def test_gemm_group_gather_scatter_rowscale(matmul):
     """The packed-launch form: tiles gathered/scattered by slot index, rows scaled before the product."""
     from stair_amd import ops
