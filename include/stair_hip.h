@@ -271,7 +271,9 @@ int stair_dropout_fwd(float *x, int64_t gstride, const int32_t *gidx, int32_t gr
  * the capture; stair_plan_run_flags(..., STAIR_RUN_INDEX_RESIDENT, ...) then enqueues kernels only -- no host-to-device
  * copy, no allocation, no synchronisation -- so it can be recorded between hipStreamBeginCapture / EndCapture (or
  * torch.cuda.graph) and replayed while video / question / workspace / logits keep their addresses.  The caller must not
- * let anything else write the workspace's index region in between (give a captured plan its own workspace). */
+ * let anything else write the workspace's index region in between (give a captured plan its own workspace), and must
+ * have run the plan once un-captured first: kernels with more than 64 KB of LDS set their function attribute on first
+ * use, which is not a stream operation. */
 #define STAIR_RUN_INDEX_RESIDENT 1
 int stair_plan_upload(stair_plan *plan, void *workspace, int64_t workspace_bytes, stair_stream stream);
 int stair_plan_run_flags(stair_ctx *ctx, stair_plan *plan, const float *video, const float *question,
