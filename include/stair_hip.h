@@ -123,6 +123,9 @@ typedef struct stair_gemm_args {
     int32_t groups, rows_per_group, N, K, act;
     int32_t accumulate; /* 0: C = ...; 1: C += ... with fp32 atomics (act must be 0) -- the dX products of the
                            backward pass, where several program nodes may read the same slot */
+    float *splitk_ws; int64_t splitk_ws_floats; /* optional scratch: launches of <= 64 output tiles split their K loop over
+                           128-wide pieces when ceil(K / 128) * M * N floats are available here (partials reduced in a fixed order:
+                           deterministic, and the same for every batch that takes this path); NULL = never split a forward product */
 } stair_gemm_args;
 int stair_gemm_f32(const stair_gemm_args *args, stair_stream stream);
 

@@ -31,7 +31,8 @@ class GemmArgs(C.Structure):
                 ('C', C.c_void_p), ('ldc', C.c_int64), ('c_gstride', C.c_int64), ('c_gidx', C.c_void_p),
                 ('row_scale', C.c_void_p), ('rs_gstride', C.c_int64), ('rs_gidx', C.c_void_p),
                 ('groups', C.c_int32), ('rows_per_group', C.c_int32), ('N', C.c_int32), ('K', C.c_int32),
-                ('act', C.c_int32), ('accumulate', C.c_int32)]
+                ('act', C.c_int32), ('accumulate', C.c_int32),
+                ('splitk_ws', C.c_void_p), ('splitk_ws_floats', C.c_int64)]
 
 
 class GemmTnArgs(C.Structure):

@@ -119,6 +119,8 @@ __device__ __forceinline__ void mfma_chunk_w8(const __bf16 *lds, int buf, int wm
 struct XParams {
     stair_gemm_args a;
     int M, tilesM, tilesN;
+    int ksplit = 1, kchunk = 0;      // split-K of small launches (4-wave kernel): blockIdx.y takes K range [y*kchunk, +kchunk)
+    float *part = nullptr;           // [ksplit][M][N] partial sums (deterministic reduction); nullptr: atomic adds into C
 };
 
 }  // namespace
@@ -143,6 +145,10 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(XParams p) {
     const int tm = logical / p.tilesN, tn = logical - tm * p.tilesN;
     const int m0 = tm * 128, n0 = tn * 128;
     const int R = a.rows_per_group, K = a.K;
+    // split-K: this workgroup multiplies k in [kbeg, Kend) and ADDS its raw partial sums (bias / activation are applied by
+    // a later pass); Kend also bounds the tail masks below, so an odd trailing chunk of the range is zeroed, not borrowed
+    const int kbeg = p.ksplit > 1 ? (int)blockIdx.y * p.kchunk : 0;
+    const int Kend = p.ksplit > 1 ? min(K, kbeg + p.kchunk) : K;
 
     // staging units: (row, kq) with row = u >> 2, kq = u & 3, u = tid + 256 i  ->  rows tid/4 and 64 + tid/4
     const int kq = tid & 3, ra_ = tid >> 2;
@@ -173,8 +179,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(XParams p) {
     {                                                                          \
         const int kraw = (k0) + 8 * kq;                                        \
         const int ka = max(0, min(kraw, K - 4)), kb = max(0, min(kraw + 4, K - 4));   \
-        km[set][0] = kraw < K ? 1.0f : 0.0f;                                   \
-        km[set][1] = kraw + 4 < K ? 1.0f : 0.0f;                               \
+        km[set][0] = kraw < Kend ? 1.0f : 0.0f;                                \
+        km[set][1] = kraw + 4 < Kend ? 1.0f : 0.0f;                            \
         _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                     \
             va[set][i_][0] = *(gv4p)(aptr[i_] + ka); va[set][i_][1] = *(gv4p)(aptr[i_] + kb);   \
             vb[set][i_][0] = *(gv4p)(wptr[i_] + ka); vb[set][i_][1] = *(gv4p)(wptr[i_] + kb);   \
@@ -197,20 +203,20 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(XParams p) {
     // Chunks past K are not skipped but zeroed (X_GLOAD clamps the address and sets the A mask to 0): every
     // load stays unconditional, which lets hipcc keep counted vmcnt waits (a load inside a branch forces vmcnt(0)
     // at the join and drains the second register set).
-    const int nchunks = (K + XBK - 1) / XBK;
-    X_GLOAD(0, 0);
-    X_GLOAD(1, XBK);
+    const int nchunks = (Kend - kbeg + XBK - 1) / XBK;
+    X_GLOAD(0, kbeg);
+    X_GLOAD(1, kbeg + XBK);
     X_LSTORE(0, 0);
     __syncthreads();
     for (int c = 0; c < nchunks; c += 2) {
         // chunk c lives in LDS buffer 0, chunk c+1 in register set 1
-        X_GLOAD(0, (c + 2) * XBK);
+        X_GLOAD(0, kbeg + (c + 2) * XBK);
         __builtin_amdgcn_sched_barrier(0);
         mfma_chunk<NP>(xlds, 0, wm, wn, r, h, acc00, acc01, acc10, acc11);
         __builtin_amdgcn_sched_barrier(0);
         X_LSTORE(1, 1);
         __syncthreads();
-        X_GLOAD(1, (c + 3) * XBK);
+        X_GLOAD(1, kbeg + (c + 3) * XBK);
         __builtin_amdgcn_sched_barrier(0);
         mfma_chunk<NP>(xlds, 1, wm, wn, r, h, acc00, acc01, acc10, acc11);
         __builtin_amdgcn_sched_barrier(0);
@@ -246,6 +252,11 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(XParams p) {
                 const int rowl = wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 const long long off = rowoff[rowl];
                 if (off < 0) continue;
+                if (p.ksplit > 1) {
+                    if (p.part) p.part[((int64_t)blockIdx.y * p.M + m0 + rowl) * a.N + n] = acc[e];
+                    else unsafeAtomicAdd(a.C + off + n, acc[e]);
+                    continue;
+                }
                 float v = acc[e] + b;
                 if (ACT == 1) v = fmaxf(v, 0.0f);
                 if (ACT == 2) v = sigmoid_acc(v);
@@ -547,6 +558,22 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16x3_t256_kernel(XParams p) {
     }
 }
 
+// split-K companion: C[row mapping] = act(sum over the splits, in order, of part[y][m][n] + bias[n])
+__global__ void c_rows_reduce_kernel(float *C, int64_t ldc, int64_t gs, const int32_t *gidx, int M, int R, int N, const float *part,
+                                     int ksplit, const float *bias, int act) {
+    const int64_t total = (int64_t)M * N;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(e / N), n = (int)(e - (int64_t)m * N);
+        const int g = m / R, rr = m - g * R;
+        float v = 0.0f;
+        for (int y = 0; y < ksplit; ++y) v += part[(int64_t)y * total + e];
+        if (bias) v += bias[n];
+        if (act == 1) v = fmaxf(v, 0.0f);
+        if (act == 2) v = sigmoid_acc(v);
+        C[(gidx ? (int64_t)gidx[g] : (int64_t)g) * gs + (int64_t)rr * ldc + n] = v;
+    }
+}
+
 static bool gemm_w8_enabled() {
     static const bool on = [] { const char *e = getenv("STAIR_GEMM_W8"); return !(e && e[0] == '0'); }();
     return on;
@@ -593,6 +620,36 @@ int launch_gemm_bf16x3(const stair_gemm_args &a, hipStream_t s) {
 #undef T_LAUNCH
         STAIR_LAUNCH_CHECK();
         return 0;
+    }
+    // Small launches (the vector-level MLPs: 8..64 tiles, K up to 1536) leave most CUs idle and are bound by the latency
+    // of their serial K loop, so they are split over K into ~256 workgroups.  Products that already accumulate without
+    // bias or activation (the dX products of training) add their partial sums with the atomics they use anyway; forward
+    // products write partials to the caller's scratch (stair_gemm_args.splitk_ws) and a second kernel reduces them in
+    // a fixed order and applies bias + activation -- results stay deterministic and independent of the batch.
+    static const bool splitk_on = [] { const char *e = getenv("STAIR_GEMM_SPLITK"); return !(e && e[0] == '0'); }();
+    const int tiles128 = p.tilesM * p.tilesN;
+    if (splitk_on && tiles128 <= 64 && a.K >= 256 && a.K <= 128 * 16) {
+        const int kchunk = 128;                         // fixed, so the order of the partial sums does not depend on the batch
+        const int ksplit = (a.K + kchunk - 1) / kchunk;
+        const bool direct = a.accumulate && a.act == 0 && !a.bias;
+        const bool staged = !a.accumulate && a.splitk_ws && a.splitk_ws_floats >= (int64_t)ksplit * M * a.N;
+        if (ksplit > 1 && (direct || staged)) {
+            p.ksplit = ksplit; p.kchunk = kchunk;
+            p.part = staged ? a.splitk_ws : nullptr;
+            const dim3 gridk(tiles128, ksplit);
+            if (plain && one) hipLaunchKernelGGL((gemm_bf16x3_kernel<0, true, 1>), gridk, block, shmem, s, p);
+            else if (plain) hipLaunchKernelGGL((gemm_bf16x3_kernel<0, true, 3>), gridk, block, shmem, s, p);
+            else if (one) hipLaunchKernelGGL((gemm_bf16x3_kernel<0, false, 1>), gridk, block, shmem, s, p);
+            else hipLaunchKernelGGL((gemm_bf16x3_kernel<0, false, 3>), gridk, block, shmem, s, p);
+            STAIR_LAUNCH_CHECK();
+            if (staged) {
+                const int zb = (int)std::min<int64_t>((M * a.N + 255) / 256, 1024);
+                hipLaunchKernelGGL(c_rows_reduce_kernel, dim3(zb), dim3(256), 0, s, a.C, a.ldc, a.c_gstride, a.c_gidx, p.M,
+                                   a.rows_per_group, a.N, a.splitk_ws, ksplit, a.bias, a.act);
+                STAIR_LAUNCH_CHECK();
+            }
+            return 0;
+        }
     }
     const bool w8 = gemm_w8_enabled() && p.tilesM * p.tilesN >= 512;   // enough tiles for two 8-wave workgroups on every CU
 #define X_LAUNCH1(ACT_, NP_)                                                                                       \

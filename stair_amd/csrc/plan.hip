@@ -185,6 +185,9 @@ extern "C" int stair_ctx_set_grad(stair_ctx *ctx, int id, float *dev_ptr, int64_
 // =============================================================================================
 namespace {
 
+constexpr int64_t kSplitKFloats = 16ll * 64 * 128 * 128;     // split-K scratch: 16 K pieces x 64 output tiles of 128 x 128
+
+
 constexpr int OP_SPAN = 50;      // pseudo op: span mean (level 0)
 const int kArity[STAIR_OP_COUNT] = {2, 2, 3, 2, 2, 2, 2, 2, 2, 1, 2, 2, 3, 3, 2, 2, 2, 2};
 const char *kOpName[STAIR_OP_COUNT] = {"And", "AttnVideo", "Choose", "Compare", "Equals", "Exists", "ExistsFrame",
@@ -220,7 +223,7 @@ struct stair_plan {
     int maxI = 0, maxV = 0, maxK = 0, maxSupRows = 0, n_levels = 0;
     // workspace layout (float offsets)
     int64_t o_idx = 0, o_vec = 0, o_map = 0, o_att = 0, o_tok = 0, o_qfeat = 0, o_vhn = 0, o_xpv = 0, o_xpt = 0,
-            o_bias = 0, o_wpack = 0, o_tmpA = 0, o_tmpB = 0, o_kbuf = 0, o_cat = 0, o_hid = 0, o_rs = 0, o_sup = 0, o_extra = 0,
+            o_bias = 0, o_wpack = 0, o_splitk = 0, o_tmpA = 0, o_tmpB = 0, o_kbuf = 0, o_cat = 0, o_hid = 0, o_rs = 0, o_sup = 0, o_extra = 0,
             o_logits = 0, total = 0;
     // training only
     bool train = false;
@@ -577,6 +580,7 @@ extern "C" int stair_plan_build_shared(stair_ctx *ctx, int32_t n, const int32_t 
     pl->o_xpt = take((int64_t)pl->rows_q * 4 * H, 64);
     pl->o_bias = take(2 * 4 * H, 64);
     pl->o_wpack = take(2 * 2 * H * H, 64);       // 8*Hh*Hh floats per encoder
+    pl->o_splitk = take(kSplitKFloats, 64);      // partial sums of split-K launches (<= 64 output tiles x 16 pieces)
     pl->o_tmpA = take((int64_t)std::max(pl->maxI, 1) * T * H, 64);
     pl->o_tmpB = take((int64_t)std::max(pl->maxI, 1) * T * H, 64);
     pl->o_kbuf = take((int64_t)std::max(pl->maxK, 1) * H, 64);
@@ -770,10 +774,13 @@ int resolve(const stair_ctx *ctx, Weights &W, bool grads) {
 }
 
 // dense helper: C[g][r] = act(rs * A[g][r] W^T + b)
+float *g_splitk_ws = nullptr;      // set by stair_plan_run for the duration of the call (one ctx per process, not thread-safe)
+
 int dense(hipStream_t s, const float *A, int64_t lda, int64_t a_gs, const int32_t *a_gidx, const Lin &l, int64_t ldw,
           float *C, int64_t ldc, int64_t c_gs, const int32_t *c_gidx, int groups, int R, int N, int K, int act,
           const float *rs = nullptr, int64_t rs_gs = 0, const int32_t *rs_gidx = nullptr) {
     stair_gemm_args g = {};
+    g.splitk_ws = g_splitk_ws; g.splitk_ws_floats = g_splitk_ws ? kSplitKFloats : 0;
     g.A = A; g.lda = lda; g.a_gstride = a_gs; g.a_gidx = a_gidx;
     g.W = l.w; g.ldw = ldw; g.bias = l.b;
     g.C = C; g.ldc = ldc; g.c_gstride = c_gs; g.c_gidx = c_gidx;
@@ -838,6 +845,11 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
 
     if (!(flags & STAIR_RUN_INDEX_RESIDENT))
         STAIR_HIP(hipMemcpyAsync(didx, pl->idx.data(), pl->idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+
+    struct SplitKScope {            // forward products of this call may stage split-K partials in the workspace
+        explicit SplitKScope(float *p) { g_splitk_ws = p; }
+        ~SplitKScope() { g_splitk_ws = nullptr; }
+    } splitk_scope(ws + pl->o_splitk);
 
 #define RUN(x) do { if (int rc_ = (x)) return rc_; } while (0)
     // nn.Dropout at the `D` positions of modules.py, training plans only; site = bucket * 8 + position (decoder: 0xffff)
@@ -1334,6 +1346,7 @@ extern "C" int stair_plan_regions(stair_plan *pl, const stair_ctx *ctx, const ch
     add("xpt", pl->o_xpt, (int64_t)pl->rows_q * 4 * H);
     add("bias", pl->o_bias, 8 * H);
     add("wpack", pl->o_wpack, 4 * H * H);
+    add("splitk", pl->o_splitk, kSplitKFloats);
     add("tmpA", pl->o_tmpA, (int64_t)std::max(pl->maxI, 1) * T * H);
     add("tmpB", pl->o_tmpB, (int64_t)std::max(pl->maxI, 1) * T * H);
     add("kbuf", pl->o_kbuf, (int64_t)std::max(pl->maxK, 1) * H);

@@ -43,8 +43,16 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
-def linear(x, weight, bias=None, act=None):
-    """act(x @ weight.T + bias) through stair_gemm_f32.  x [..., K] -> [..., N]."""
+def _splitk_scratch(args, M, N, K, device):
+    """Scratch that lets a small launch split its K loop (stair_gemm_args.splitk_ws); kept alive by the caller."""
+    ws = torch.empty(max(1, -(-K // 128)) * M * N, device=device, dtype=torch.float32)
+    args.splitk_ws, args.splitk_ws_floats = ws.data_ptr(), ws.numel()
+    return ws
+
+
+def linear(x, weight, bias=None, act=None, splitk=False):
+    """act(x @ weight.T + bias) through stair_gemm_f32.  x [..., K] -> [..., N].  splitk: hand the launch the scratch a
+    plan gives its vector-level layers (small launches then split K; deterministic)."""
     _req(x, 'x'); _req(weight, 'weight')
     K = x.shape[-1]
     N = weight.shape[0]
@@ -57,12 +65,13 @@ def linear(x, weight, bias=None, act=None):
     a.C, a.ldc, a.c_gstride, a.c_gidx = out.data_ptr(), N, N, None
     a.row_scale, a.rs_gstride, a.rs_gidx = None, 0, None
     a.groups, a.rows_per_group, a.N, a.K, a.act = x2.shape[0], 1, N, K, ACT[act]
+    ws = _splitk_scratch(a, x2.shape[0], N, K, x.device) if splitk else None
     check(lib.stair_gemm_f32(C.byref(a), _stream()))
     return out.reshape(*x.shape[:-1], N)
 
 
 def gemm_grouped(A, a_gstride, a_gidx, W, bias, Cmat, c_gstride, c_gidx, groups, rows_per_group, N, K, act=None,
-                 lda=None, ldc=None, row_scale=None, rs_gstride=0, rs_gidx=None, accumulate=False):
+                 lda=None, ldc=None, row_scale=None, rs_gstride=0, rs_gidx=None, accumulate=False, splitk=False):
     """Raw grouped form (see stair_gemm_args)."""
     a = GemmArgs()
     a.A, a.lda, a.a_gstride, a.a_gidx = A.data_ptr(), lda or K, a_gstride, (a_gidx.data_ptr() if a_gidx is not None else None)
@@ -72,6 +81,7 @@ def gemm_grouped(A, a_gstride, a_gidx, W, bias, Cmat, c_gstride, c_gidx, groups,
     a.rs_gstride, a.rs_gidx = rs_gstride, (rs_gidx.data_ptr() if rs_gidx is not None else None)
     a.groups, a.rows_per_group, a.N, a.K, a.act = groups, rows_per_group, N, K, ACT[act]
     a.accumulate = 1 if accumulate else 0
+    ws = _splitk_scratch(a, groups * rows_per_group, N, K, A.device) if splitk else None
     check(lib.stair_gemm_f32(C.byref(a), _stream()))
 
 

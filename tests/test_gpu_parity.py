@@ -101,6 +101,29 @@ def test_single_product_bf16_mode():
         ops.set_matmul_mode('bf16x3')
 
 
+@pytest.mark.parametrize('M,N,K', [(1, 512, 512), (7, 172, 1024), (300, 512, 1536), (1000, 512, 1536), (2048, 1024, 1024), (130, 512, 300)])
+@pytest.mark.parametrize('act', [None, 'relu'])
+def test_small_launches_split_k_deterministically(M, N, K, act, matmul):
+    """The vector-level layers (<= 64 output tiles) split their K loop into 128-wide pieces when the caller provides
+    scratch (a plan does): result == fp64 reference to the mode's tolerance, identical from run to run, and a row's
+    output does not depend on which other rows are in the launch (same pieces, same order)."""
+    from stair_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) / K ** 0.5; b = torch.randn(N, generator=g)
+    d = lambda t: t.to(DEV)
+    y1 = ops.linear(d(x), d(w), d(b), act, splitk=True)
+    y2 = ops.linear(d(x), d(w), d(b), act, splitk=True)
+    assert torch.equal(y1, y2)
+    ref = x.double() @ w.double().t() + b.double()
+    ref = ref.relu() if act else ref
+    assert _maxerr(y1, ref) < _tol(matmul, 2e-5, 1e-4)
+    if ((M + 127) // 128) * ((N + 127) // 128) <= 64:           # both launches split (the 2048 x 1024 case is not small)
+        solo = ops.linear(d(x[:1]), d(w), d(b), act, splitk=True)
+        assert torch.equal(solo[0], y1[0])
+    plain = ops.linear(d(x), d(w), d(b), act)                    # the unsplit kernel: same numbers up to summation order
+    assert _maxerr(plain, y1.cpu()) < _tol(matmul, 2e-5, 1e-4)
+
+
 def test_gemm_group_gather_scatter_rowscale(matmul):
     """The packed-launch form: tiles gathered/scattered by slot index, rows scaled before the product."""
     from stair_amd import ops
