@@ -983,7 +983,9 @@ int launch_gemm_tn_bf16x3(const stair_gemm_tn_args &a, hipStream_t s) {
     {   // 256 x 256 tiles where the output is large enough (>= 16 of them) and the staging is the simple case
         static const int tn256 = [] { const char *e = getenv("STAIR_GEMM_TN256"); return e ? atoi(e) : 16; }();   // 0 = off
         const int t2n = (a.N + 255) / 256, t2k = (a.K + 255) / 256, t2 = t2n * t2k;
-        if (tn256 > 0 && t2 >= tn256 && p.fast8 == 1 && !p.row_scale && a.M % 64 == 0 && a.M >= 64) {
+        // (a short reduction dimension gives each of the 512 workgroups a handful of chunks and a 256 x 256 atomic epilogue:
+        // the decoder's dW at M = 2048 took 122 us here against ~40 us on the 128 x 128 kernel, so M must be long)
+        if (tn256 > 0 && t2 >= tn256 && p.fast8 == 1 && !p.row_scale && a.M % 64 == 0 && (a.M >= 16384 || tn256 == 1)) {
             XTnParams q = p;
             q.tilesN = t2n; q.tilesK = t2k;
             int slabs = std::max(1, std::min(a.M / 64, (512 + t2 - 1) / t2));
