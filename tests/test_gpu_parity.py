@@ -557,7 +557,7 @@ def test_gemm_tn_bias_gradient_rides_along(M, N, K, matmul):
     Cm, b1, b2 = torch.zeros(N, K, device=DEV), d(b0.clone()), d(b0.clone() * 2)
     ops.gemm_tn(d(dZ), d(X), Cm, M, N, K, rows_per_group=1, colsum=b1, colsum2=b2)
     ref = dZ.double().sum(0)
-    tol = 2e-5 * max(1.0, (M / 100) ** 0.5)
+    tol = 4e-5 * max(1.0, (M / 100) ** 0.5)          # fp32 accumulation of M terms of unit variance
     assert _maxerr(b1, b0.double() + ref) < tol and _maxerr(b2, 2 * b0.double() + ref) < tol
     refw = (d(dZ).double().t() @ d(X).double()).cpu()             # fp64 on the device: the largest case is 69 GFLOP
     assert _maxerr(Cm, refw) < _tol(matmul, 1e-4, 4e-4) * max(1.0, (M / 1000) ** 0.5 * 3)
