@@ -347,6 +347,23 @@ def test_appearance_feature_config_against_oracle(matmul):
         assert int(res.pred[qi]) == int(torch.argmax(r['logits']))
 
 
+@pytest.mark.parametrize('H,V,L,T', [(64, 128, 40, 2), (64, 260, 40, 33), (128, 128, 2, 2), (128, 260, 64, 63), (256, 128, 100, 100),
+                                     (256, 260, 40, 7), (512, 128, 8, 8), (512, 260, 40, 33), (512, 128, 100, 100)])
+def test_odd_shapes_against_oracle(H, V, L, T):
+    """Hidden sizes 64..512, feature sizes that are not multiples of 64, frame counts 2..100 incl. odd ones, T below and
+    at max_video_length, Conv1d and Linear(T,T) Temporal nets: all 12 program forms in one batch, every other question
+    against the oracle."""
+    config = dict(spec.DEFAULT_CONFIG, hidden_size=H, video_size=V, answer_vocab_length=16, max_video_length=L, object_types=10)
+    model = _model(config, 1)
+    w = oracle_weights(config, 1)
+    qs = synth.make_questions(config, 5, 12, forms=synth.ALL_FORMS, T=T)
+    res = model.forward_batch(qs)
+    for qi in range(0, 12, 2):
+        r = O.forward(w, config, qs[qi])
+        assert _maxerr(res.logits[qi], r['logits']) < 1e-4
+        assert int(res.pred[qi]) == int(torch.argmax(r['logits']))
+
+
 def test_larger_batch_against_oracle(matmul):
     """128 random questions of all 12 forms vs the oracle run question by question."""
     config = dict(spec.DEFAULT_CONFIG)

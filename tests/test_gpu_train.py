@@ -92,6 +92,33 @@ def test_backward_matches_autograd_of_oracle(name, matmul):
     print('worst gradient error / tolerance:', worst)
 
 
+@pytest.mark.parametrize('H,L,T', [(64, 40, 7), (128, 40, 33), (128, 2, 2), (512, 8, 8), (512, 40, 33), (64, 100, 100)])
+def test_backward_on_odd_shapes(H, L, T):
+    """Every parameter gradient vs autograd of the oracle for odd frame counts / hidden sizes, exact-fp32 products (in
+    split mode single ReLU masks flip at H = 512, see test_full_size_backward_sample)."""
+    from stair_amd import ops
+    ops.set_matmul_mode('f32')
+    try:
+        config = dict(spec.DEFAULT_CONFIG, hidden_size=H, video_size=128, answer_vocab_length=16, max_video_length=L, object_types=10)
+        qs = synth.make_questions(config, 5, 12, forms=synth.ALL_FORMS, T=T)
+        names, w = _oracle_params(config, 1)
+        loss, _ = _oracle_loss(w, config, qs, 1.0 / len(qs))
+        loss.backward()
+        model = _model(config, 1)
+        for p in model.parameters():
+            p.grad = torch.zeros_like(p)
+        res = model.forward_batch(qs, train=True)
+        res.backward(torch.tensor([q['answer'] for q in qs], dtype=torch.int32, device=DEV), 1.0 / len(qs))
+        got = dict(model.named_parameters())
+        for n in names:
+            ref = w[n].grad
+            if ref is None:
+                continue
+            assert float((got[n].grad.cpu() - ref).abs().max()) < 2e-4 * max(float(ref.abs().max()), 1e-3), n
+    finally:
+        ops.set_matmul_mode('bf16x3')
+
+
 def test_shared_clip_gradients_equal_expanded_batch(matmul):
     """Training plan over questions that share clips (stair_plan_build_shared): every consumer's gradient
     accumulates into the one encoded map, so parameter gradients equal those of the expanded batch (up to the
