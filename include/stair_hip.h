@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STAIR_ABI_VERSION 1
+#define STAIR_ABI_VERSION 2
 
 typedef struct stair_ctx stair_ctx;
 typedef struct stair_plan stair_plan;
@@ -141,8 +141,35 @@ typedef struct stair_gemm_tn_args {
     int32_t M, rows_per_group, N, K;
     float *colsum, *colsum2; /* optional [N]: += sum_m A[m][n] (the bias gradient db = colsum(dZ) of the same Linear;
                                 colsum2 receives the same sums: nn.LSTM's b_ih and b_hh), accumulated with atomics */
+    int32_t b_is_bf16; /* 1: B points to bf16 rows (exact values: stored clip features), ldb / b_gstride in ELEMENTS; needs a plain
+                          row matrix (rows_per_group = 1, no index, no row scale), K % 8 == 0 and a split matmul mode */
 } stair_gemm_tn_args;
 int stair_gemm_tn_f32(const stair_gemm_tn_args *args, stair_stream stream);
+
+/* ---- pre-split operands: bf16 planes staged by LDS-DMA (csrc/gemm_planes.hip) -----------------------------------
+ * x [n] fp32 -> hi[i] = bf16(x[i]) (round to nearest even), lo[i] = bf16(x[i] - hi[i]); x = hi + lo + O(2^-17 |x|).
+ * lo may be NULL (plain rounding to bf16: how a loader produces the bf16 clip-feature format of BASELINE.json
+ * configs[1] from the fp32 .npy rows of /root/reference/video_nmn/dataset.py:134-143).  n % 8 == 0, 16-byte aligned. */
+int stair_split_planes(const float *x, void *hi, void *lo, int64_t n, stair_stream stream);
+/* The same split of a [rows, cols] row-major matrix (an nn.Linear / nn.LSTM weight) written in the TILED layout
+ * [cols/32][rows][32]: the 32 k-values a GEMM stage needs from 16 consecutive rows are then 1 KB of contiguous memory,
+ * one whole LDS-DMA instruction.  cols % 32 == 0; both planes required. */
+int stair_split_planes_tiled(const float *x, void *hi, void *lo, int32_t rows, int32_t cols, stair_stream stream);
+
+/* C[m][n] = act( sum_k A[m][k] * W[n][k] + bias[n] ) with A = A_hi (+ A_lo) and W = W_hi + W_lo given as bf16 planes
+ * (row-major, lda / ldw in ELEMENTS, multiples of 8), fp32 accumulation and output.  A_lo == NULL means A is exact in
+ * bf16 (stored clip features): two MFMA products per operand pair instead of three.  K % 32 == 0, M, N >= 1.  Same contraction as
+ * stair_gemm_f32 for the nn.Linear / nn.LSTM input projections of module_net.py:39-47; used by the plan runner when
+ * the clip features arrive in bf16 (STAIR_RUN_VIDEO_BF16). */
+typedef struct stair_gemm_planes_args {
+    const void *A_hi, *A_lo; int64_t lda;
+    const void *W_hi, *W_lo; int64_t ldw;
+    const float *bias;
+    float *C; int64_t ldc;
+    int32_t M, N, K, act;
+    int32_t w_tiled; /* 0: W planes row-major [N, ldw]; 1: tiled [K/32][N][32] (stair_split_planes_tiled; ldw ignored) */
+} stair_gemm_planes_args;
+int stair_gemm_planes(const stair_gemm_planes_args *args, stair_stream stream);
 
 /* Bidirectional single-layer LSTM over n ragged sequences (nn.LSTM as used at
  * module_net.py:39-47,151-163).  x [rows, I] with sequence s at rows seq_off[s]..seq_off[s+1]-1
@@ -158,6 +185,11 @@ typedef struct stair_lstm_args {
     float *out; int64_t ldo; float *h_n;
     float *cbuf; /* NULL for inference.  Training: [rows, 2*Hh] cell states are saved here and xproj_ws is left
                     holding the ACTIVATED gates (i, f, g, o) of every step, both consumed by stair_lstm_bidir_bwd */
+    const void *x_bf16; /* optional: the same input rows stored as bf16 [rows, ldx] (the clip-feature format of BASELINE.json
+                    configs[1]).  When set, x may be NULL and the input projection runs as a plane GEMM (stair_gemm_planes: A
+                    exact in bf16, W_ih split once into hi/lo planes, two MFMA products per pair); needs I % 32 == 0 and a
+                    split matmul mode. */
+    void *wih_planes_ws; /* scratch for the W_ih planes when x_bf16 is set: 2 planes x [8*Hh, I] bf16 = 32*Hh*I bytes */
 } stair_lstm_args;
 int stair_lstm_bidir_fwd(const stair_lstm_args *args, stair_stream stream);
 
@@ -175,6 +207,7 @@ typedef struct stair_lstm_bwd_args {
     const float *d_out; int64_t ldd; const float *d_hn;
     float *whh_pack_ws, *hprev_ws;
     float *dw_ih[2], *dw_hh[2], *db_ih[2], *db_hh[2];
+    const void *x_bf16; /* optional, as in stair_lstm_args: dW_ih = dG^T X then reads X as exact bf16 (two products per pair) */
 } stair_lstm_bwd_args;
 int stair_lstm_bidir_bwd(const stair_lstm_bwd_args *args, stair_stream stream);
 
@@ -278,6 +311,9 @@ int stair_dropout_fwd(float *x, int64_t gstride, const int32_t *gidx, int32_t gr
  * have run the plan once un-captured first: kernels with more than 64 KB of LDS set their function attribute on first
  * use, which is not a stream operation. */
 #define STAIR_RUN_INDEX_RESIDENT 1
+#define STAIR_RUN_VIDEO_BF16 2 /* `video` points to bf16 [n_videos, T, V] (V % 32 == 0): the stored clip-feature format of
+                                  BASELINE.json configs[1]; results equal the fp32 path fed the same (rounded) values up to
+                                  the split-product error.  Also a flag of stair_plan_backward. */
 int stair_plan_upload(stair_plan *plan, void *workspace, int64_t workspace_bytes, stair_stream stream);
 int stair_plan_run_flags(stair_ctx *ctx, stair_plan *plan, const float *video, const float *question,
                          void *workspace, int64_t workspace_bytes, float *logits, int32_t *argmax, int32_t flags,
@@ -293,7 +329,8 @@ int stair_plan_backward(stair_ctx *ctx, stair_plan *plan, const float *video, co
                         void *workspace, int64_t workspace_bytes, const int32_t *answers, float loss_scale,
                         float *loss_out, int32_t flags, stair_stream stream);
 #define STAIR_BWD_KEEP_ARENAS 1 /* flags: the gradient arenas were cleared by stair_plan_zero_grads and already hold
-                                   the gradients injected by the stair_loss_* functions below */
+                                   the gradients injected by the stair_loss_* functions below.  STAIR_RUN_VIDEO_BF16 (2) must be
+                                   repeated here when the forward pass ran on bf16 clip features. */
 int stair_plan_zero_grads(stair_plan *plan, void *workspace, stair_stream stream);
 
 /* ---- per-module intermediate-supervision losses (train_module.py:33-194, CriterionByModule) -------------------

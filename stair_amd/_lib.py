@@ -16,6 +16,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('STAIR_LIB_PATH') or os.path.join(_HERE, 'lib', 'libstair_hip.so')   # override: kernel experiments
 
+ABI_VERSION = 2
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)
 
@@ -41,7 +42,14 @@ class GemmTnArgs(C.Structure):
                 ('row_scale', C.c_void_p), ('rs_gstride', C.c_int64), ('rs_gidx', C.c_void_p),
                 ('C', C.c_void_p), ('ldc', C.c_int64),
                 ('M', C.c_int32), ('rows_per_group', C.c_int32), ('N', C.c_int32), ('K', C.c_int32),
-                ('colsum', C.c_void_p), ('colsum2', C.c_void_p)]
+                ('colsum', C.c_void_p), ('colsum2', C.c_void_p), ('b_is_bf16', C.c_int32)]
+
+
+class GemmPlanesArgs(C.Structure):
+    _fields_ = [('A_hi', C.c_void_p), ('A_lo', C.c_void_p), ('lda', C.c_int64),
+                ('W_hi', C.c_void_p), ('W_lo', C.c_void_p), ('ldw', C.c_int64),
+                ('bias', C.c_void_p), ('C', C.c_void_p), ('ldc', C.c_int64),
+                ('M', C.c_int32), ('N', C.c_int32), ('K', C.c_int32), ('act', C.c_int32), ('w_tiled', C.c_int32)]
 
 
 class LstmArgs(C.Structure):
@@ -49,7 +57,8 @@ class LstmArgs(C.Structure):
                 ('max_len', C.c_int32), ('I', C.c_int32), ('Hh', C.c_int32), ('seq_off', C.c_void_p),
                 ('w_ih', C.c_void_p * 2), ('w_hh', C.c_void_p * 2), ('b_ih', C.c_void_p * 2), ('b_hh', C.c_void_p * 2),
                 ('xproj_ws', C.c_void_p), ('bias_ws', C.c_void_p), ('whh_pack_ws', C.c_void_p),
-                ('out', C.c_void_p), ('ldo', C.c_int64), ('h_n', C.c_void_p), ('cbuf', C.c_void_p)]
+                ('out', C.c_void_p), ('ldo', C.c_int64), ('h_n', C.c_void_p), ('cbuf', C.c_void_p),
+                ('x_bf16', C.c_void_p), ('wih_planes_ws', C.c_void_p)]
 
 
 class LstmBwdArgs(C.Structure):
@@ -59,7 +68,8 @@ class LstmBwdArgs(C.Structure):
                 ('gates', C.c_void_p), ('cbuf', C.c_void_p), ('out', C.c_void_p), ('ldo', C.c_int64),
                 ('d_out', C.c_void_p), ('ldd', C.c_int64), ('d_hn', C.c_void_p),
                 ('whh_pack_ws', C.c_void_p), ('hprev_ws', C.c_void_p),
-                ('dw_ih', C.c_void_p * 2), ('dw_hh', C.c_void_p * 2), ('db_ih', C.c_void_p * 2), ('db_hh', C.c_void_p * 2)]
+                ('dw_ih', C.c_void_p * 2), ('dw_hh', C.c_void_p * 2), ('db_ih', C.c_void_p * 2), ('db_hh', C.c_void_p * 2),
+                ('x_bf16', C.c_void_p)]
 
 
 class PlanInfo(C.Structure):
@@ -87,6 +97,9 @@ SIGNATURES = [
     ('stair_set_split_min_rows', C.c_int, [C.c_int32]),
     ('stair_gemm_f32', C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     ('stair_gemm_tn_f32', C.c_int, [C.POINTER(GemmTnArgs), C.c_void_p]),
+    ('stair_split_planes', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    ('stair_split_planes_tiled', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    ('stair_gemm_planes', C.c_int, [C.POINTER(GemmPlanesArgs), C.c_void_p]),
     ('stair_lstm_bidir_fwd', C.c_int, [C.POINTER(LstmArgs), C.c_void_p]),
     ('stair_lstm_bidir_bwd', C.c_int, [C.POINTER(LstmBwdArgs), C.c_void_p]),
     ('stair_cosine_attn_fwd', C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -144,8 +157,8 @@ def _load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.stair_abi_version() != 1:
-        raise ImportError('libstair_hip.so ABI version %d, expected 1' % lib.stair_abi_version())
+    if lib.stair_abi_version() != ABI_VERSION:
+        raise ImportError('libstair_hip.so ABI version %d, expected %d' % (lib.stair_abi_version(), ABI_VERSION))
     return lib
 
 

@@ -55,6 +55,10 @@ int launch_lstm_bwd(const stair_lstm_bwd_args &a, hipStream_t s);
 int launch_gemm_bf16x3(const stair_gemm_args &a, hipStream_t s);
 int launch_gemm_tn_bf16x3(const stair_gemm_tn_args &a, hipStream_t s);
 int matmul_mode();
+int launch_split_planes(const float *x, void *hi, void *lo, int64_t n, hipStream_t s);
+int launch_split_planes_tiled(const float *x, void *hi, void *lo, int rows, int cols, hipStream_t s, int row_off = 0, int total_rows = 0);
+int launch_gemm_planes(const stair_gemm_planes_args &a, hipStream_t s);
+bool gemm_planes_supported(int64_t M, int N, int K);
 int launch_gemm_tn(const stair_gemm_tn_args &a, hipStream_t s);
 int launch_colsum(const float *A, int64_t lda, float *out, int M, int N, hipStream_t s, float *out2 = nullptr);
 int launch_transpose(const float *in, float *out, int rows, int cols, hipStream_t s);

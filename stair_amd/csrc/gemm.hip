@@ -325,6 +325,8 @@ int launch_gemm_tn(const stair_gemm_tn_args &a, hipStream_t s) {
     STAIR_CHECK(a.N % 4 == 0 && a.K % 4 == 0 && a.lda % 4 == 0 && a.ldb % 4 == 0 && a.b_gstride % 4 == 0,
                 "N, K, lda, ldb, b_gstride must be multiples of 4 floats");
     if (a.M == 0) return 0;
+    STAIR_CHECK(!a.b_is_bf16 || matmul_mode() == STAIR_MATMUL_BF16X3, "bf16 B rows (stored clip features) need the bf16x3 matmul mode");
+    if (a.b_is_bf16) return launch_gemm_tn_bf16x3(a, s);
     if (matmul_mode() != STAIR_MATMUL_F32 && a.M >= kSplitMinRows) return launch_gemm_tn_bf16x3(a, s);
     GemmTnParams p;
     p.A = a.A; p.lda = a.lda; p.B = a.B; p.ldb = a.ldb; p.b_gstride = a.b_gstride; p.b_gidx = a.b_gidx;

@@ -71,15 +71,17 @@ __device__ __forceinline__ void mfma_chunk(const __bf16 *lds, int buf, int wm, i
         const bf16x8 ah1 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 0, 0, kq, wm * 64 + 32 + r));
         const bf16x8 bh0 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 1, 0, kq, wn * 64 + r));
         const bf16x8 bh1 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 1, 0, kq, wn * 64 + 32 + r));
-        if constexpr (NP == 3) {                     // the two cross terms (NP == 1: plain bf16 products, hi * hi only)
+        if constexpr (NP >= 2) {                     // the cross terms (NP == 1: plain bf16 products, hi * hi only; NP == 2: B is exact in bf16, no B lo image)
             const bf16x8 al0 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 0, 1, kq, wm * 64 + r));
             const bf16x8 al1 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 0, 1, kq, wm * 64 + 32 + r));
-            const bf16x8 bl0 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 1, 1, kq, wn * 64 + r));
-            const bf16x8 bl1 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 1, 1, kq, wn * 64 + 32 + r));
             acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh0, acc00, 0, 0, 0);      // small terms first
             acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh1, acc01, 0, 0, 0);
             acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh0, acc10, 0, 0, 0);
             acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh1, acc11, 0, 0, 0);
+        }
+        if constexpr (NP == 3) {
+            const bf16x8 bl0 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 1, 1, kq, wn * 64 + r));
+            const bf16x8 bl1 = *reinterpret_cast<const bf16x8 *>(lds + img_off(buf, 1, 1, kq, wn * 64 + 32 + r));
             acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl0, acc00, 0, 0, 0);
             acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl1, acc01, 0, 0, 0);
             acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl0, acc10, 0, 0, 0);
@@ -114,6 +116,16 @@ __device__ __forceinline__ void mfma_chunk_w8(const __bf16 *lds, int buf, int wm
         acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh0, acc00, 0, 0, 0);
         acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh0, acc10, 0, 0, 0);
     }
+}
+
+// four consecutive bf16 values (8 bytes) widened to fp32 (exact)
+__device__ __forceinline__ v4f load4_bf16(const float *base, int64_t elem) {
+    using v2u = __attribute__((ext_vector_type(2))) unsigned;
+    const v2u w = *(const __attribute__((address_space(1))) v2u *)(reinterpret_cast<const char *>(base) + elem * 2);
+    v4f r;
+    r[0] = __uint_as_float(w[0] << 16); r[1] = __uint_as_float(w[0] & 0xffff0000u);
+    r[2] = __uint_as_float(w[1] << 16); r[3] = __uint_as_float(w[1] & 0xffff0000u);
+    return r;
 }
 
 struct XParams {
@@ -686,7 +698,9 @@ struct XTnParams {
 
 // PLAIN: no row scale and every slab holds a multiple of 64 rows, so no element needs a mask or a scale (columns past
 // N or K are computed from clamped addresses and never written).
-template <bool PLAIN, int NP>
+// BX: B holds bf16 values (stored clip features, exact): rows are read as 8-byte quads, no lo image of B is written and the
+// ah * bl product is dropped (NP == 3 -> two products per pair); plain row matrices only (fast8 == 1 or 2).
+template <bool PLAIN, int NP, bool BX = false>
 __global__ __launch_bounds__(256, 2) void gemm_tn_bf16x3_kernel(XTnParams p) {
     extern __shared__ __attribute__((aligned(16))) __bf16 xlds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -735,13 +749,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16x3_kernel(XTnParams p) {
         } else if (p.fast8 == 1) {                                                                          \
             const int mc_ = max(0, min(mfirst, p.M - 8));                                                   \
             const int g_ = mc_ / p.R, rr_ = mc_ - g_ * p.R;                                                 \
-            const float *base_ = p.B + (p.b_gidx ? (int64_t)p.b_gidx[g_] : (int64_t)g_) * p.b_gstride + (int64_t)rr_ * p.ldb + cc;   \
+            const int64_t boff_ = (p.b_gidx ? (int64_t)p.b_gidx[g_] : (int64_t)g_) * p.b_gstride + (int64_t)rr_ * p.ldb + cc;   \
             const float *rsb_ = p.row_scale ? p.row_scale + (p.rs_gidx ? (int64_t)p.rs_gidx[g_] : (int64_t)g_) * p.rs_gstride + rr_ : nullptr;   \
             const bool in_ = mfirst <= p.M - 8;                                                             \
             _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) {                                              \
                 sc[set][j_] = (in_ && mfirst + j_ < mend) ? cmask : 0.0f;                                   \
                 if (rsb_) sc[set][j_] *= rsb_[j_];                                                          \
-                v[set][j_] = *(gv4p)(base_ + (int64_t)j_ * p.ldb);                                          \
+                if (BX) v[set][j_] = load4_bf16(p.B, boff_ + (int64_t)j_ * p.ldb);                          \
+                else v[set][j_] = *(gv4p)(p.B + boff_ + (int64_t)j_ * p.ldb);                               \
             }                                                                                               \
         } else if (p.fast8 == 2) {          /* plain matrix, any M: row m sits at B + m*ldb, no group arithmetic */   \
             _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) {                                              \
@@ -749,7 +764,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16x3_kernel(XTnParams p) {
                 const int m_ = max(0, min(mraw_, p.M - 1));                                                 \
                 sc[set][j_] = mraw_ < mend ? cmask : 0.0f;                                                  \
                 if (p.row_scale) sc[set][j_] *= p.row_scale[m_];                                            \
-                v[set][j_] = *(gv4p)(p.B + (int64_t)m_ * p.ldb + cc);                                       \
+                if (BX) v[set][j_] = load4_bf16(p.B, (int64_t)m_ * p.ldb + cc);                             \
+                else v[set][j_] = *(gv4p)(p.B + (int64_t)m_ * p.ldb + cc);                                  \
             }                                                                                               \
         } else {                                                                                            \
             _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) {                                              \
@@ -775,7 +791,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16x3_kernel(XTnParams p) {
                 lo_[j_] = (__bf16)(x_ - (float)hi_[j_]);                                                    \
             }                                                                                               \
             *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, operand_, 0, mq, 4 * cq + c_)) = hi_;           \
-            if (NP == 3) *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, operand_, 1, mq, 4 * cq + c_)) = lo_;           \
+            if (NP == 3 && !(BX && isB)) *reinterpret_cast<bf16x8 *>(xlds + img_off(buf, operand_, 1, mq, 4 * cq + c_)) = lo_;           \
         }                                                                                                   \
     }
 
@@ -788,13 +804,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16x3_kernel(XTnParams p) {
         for (int c = 0; c < nchunks; c += 2) {
             T_GLOAD(0, mbeg + (c + 2) * XBK);
             __builtin_amdgcn_sched_barrier(0);
-            mfma_chunk<NP>(xlds, 0, wm, wn, r, h, acc00, acc01, acc10, acc11);
+            mfma_chunk<(BX && NP == 3) ? 2 : NP>(xlds, 0, wm, wn, r, h, acc00, acc01, acc10, acc11);
             __builtin_amdgcn_sched_barrier(0);
             T_LSTORE(1, 1, c + 1);
             __syncthreads();
             T_GLOAD(1, mbeg + (c + 3) * XBK);
             __builtin_amdgcn_sched_barrier(0);
-            mfma_chunk<NP>(xlds, 1, wm, wn, r, h, acc00, acc01, acc10, acc11);
+            mfma_chunk<(BX && NP == 3) ? 2 : NP>(xlds, 1, wm, wn, r, h, acc00, acc01, acc10, acc11);
             __builtin_amdgcn_sched_barrier(0);
             T_LSTORE(0, 0, c + 2);
             __syncthreads();
@@ -832,7 +848,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16x3_kernel(XTnParams p) {
 // 256 x 256 tile form of the TN kernel for the largest weight gradient (dW_ih of the video encoder: N = 1024, K = 2048,
 // 32 tiles): PLAIN launches whose B rows come in groups of 8 (fast8 == 1).  Waves 0-3 stage A (256 columns of dZ),
 // waves 4-7 stage B; same LDS images and MFMA phase as gemm_bf16x3_t256_kernel; one staging register set.
-template <int NP>
+template <int NP, bool BX = false>
 __global__ __launch_bounds__(512, 1) void gemm_tn_bf16x3_t256_kernel(XTnParams p) {
     extern __shared__ __attribute__((aligned(16))) __bf16 xlds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -863,15 +879,17 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_bf16x3_t256_kernel(XTnParams p
 #define Z_GLOAD(m0_)                                                                                        \
     {                                                                                                       \
         const int mc_ = max(0, min((m0_) + 8 * mq, p.M - 8));                                               \
-        const float *base_;                                                                                 \
-        int64_t ld_;                                                                                        \
-        if (!isB) { base_ = p.A + (int64_t)mc_ * p.lda + cc; ld_ = p.lda; }                                 \
-        else {                                                                                              \
+        if (!isB) {                                                                                         \
+            const float *base_ = p.A + (int64_t)mc_ * p.lda + cc;                                           \
+            _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) v[j_] = *(gv4p)(base_ + j_ * p.lda);           \
+        } else {                                                                                            \
             const int g_ = mc_ / p.R, rr_ = mc_ - g_ * p.R;                                                 \
-            base_ = p.B + (p.b_gidx ? (int64_t)p.b_gidx[g_] : (int64_t)g_) * p.b_gstride + (int64_t)rr_ * p.ldb + cc;   \
-            ld_ = p.ldb;                                                                                    \
+            const int64_t boff_ = (p.b_gidx ? (int64_t)p.b_gidx[g_] : (int64_t)g_) * p.b_gstride + (int64_t)rr_ * p.ldb + cc;   \
+            _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) {                                              \
+                if (BX) v[j_] = load4_bf16(p.B, boff_ + j_ * p.ldb);                                        \
+                else v[j_] = *(gv4p)(p.B + boff_ + j_ * p.ldb);                                             \
+            }                                                                                               \
         }                                                                                                   \
-        _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) v[j_] = *(gv4p)(base_ + j_ * ld_);                 \
     }
 #define Z_LSTORE(buf, chunk_)                                                                               \
     {                                                                                                       \
@@ -886,7 +904,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_bf16x3_t256_kernel(XTnParams p
                 lo_[j_] = (__bf16)(x_ - (float)hi_[j_]);                                                    \
             }                                                                                               \
             *reinterpret_cast<bf16x8 *>(xlds + img2_off(buf, operand_, 0, mq, 4 * cq + c_)) = hi_;          \
-            if (NP == 3) *reinterpret_cast<bf16x8 *>(xlds + img2_off(buf, operand_, 1, mq, 4 * cq + c_)) = lo_;          \
+            if (NP == 3 && !(BX && isB)) *reinterpret_cast<bf16x8 *>(xlds + img2_off(buf, operand_, 1, mq, 4 * cq + c_)) = lo_;          \
         }                                                                                                   \
     }
 #define Z_MFMA(buf)                                                                                                  \
@@ -896,7 +914,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_bf16x3_t256_kernel(XTnParams p
             bf16x8 bh_[2], bl_[2];                                                                                   \
             _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                       \
                 bh_[j_] = *reinterpret_cast<const bf16x8 *>(xlds + img2_off(buf, 1, 0, kq_, wn * 64 + 32 * j_ + r)); \
-                if (NP == 3) bl_[j_] = *reinterpret_cast<const bf16x8 *>(xlds + img2_off(buf, 1, 1, kq_, wn * 64 + 32 * j_ + r)); \
+                if (NP == 3 && !BX) bl_[j_] = *reinterpret_cast<const bf16x8 *>(xlds + img2_off(buf, 1, 1, kq_, wn * 64 + 32 * j_ + r)); \
             }                                                                                                        \
             _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                       \
                 const bf16x8 ah_ = *reinterpret_cast<const bf16x8 *>(xlds + img2_off(buf, 0, 0, kq_, wm * 128 + 32 * i_ + r)); \
@@ -905,7 +923,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_bf16x3_t256_kernel(XTnParams p
                 _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                   \
                     if (NP == 3) {                                                                                   \
                         acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al_, bh_[j_], acc[i_][j_], 0, 0, 0);   \
-                        acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, bl_[j_], acc[i_][j_], 0, 0, 0);   \
+                        if (!BX) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, bl_[j_], acc[i_][j_], 0, 0, 0);   \
                     }                                                                                                \
                     acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, bh_[j_], acc[i_][j_], 0, 0, 0);       \
                 }                                                                                                    \
@@ -970,6 +988,13 @@ int launch_gemm_tn_bf16x3(const stair_gemm_tn_args &a, hipStream_t s) {
     p.colsum = a.colsum; p.colsum2 = a.colsum2;
     p.tilesN = (a.N + 127) / 128; p.tilesK = (a.K + 127) / 128;
     p.fast8 = 0;
+    const bool bx = a.b_is_bf16 != 0;
+    if (bx) {
+        STAIR_CHECK(!one, "bf16 B rows need the bf16x3 matmul mode");
+        STAIR_CHECK(a.rows_per_group == 1 && !a.b_gidx && !a.row_scale && a.b_gstride == a.ldb && a.K % 8 == 0 && a.ldb % 4 == 0,
+                    "bf16 B rows: plain row matrix only (rows_per_group 1, no index, no row scale), K % 8 == 0");
+        STAIR_CHECK((reinterpret_cast<uintptr_t>(a.B) & 7) == 0, "bf16 B rows must be 8-byte aligned");
+    }
     const bool plain_matrix = !p.b_gidx && !p.rs_gidx && p.b_gstride == (int64_t)p.R * p.ldb && (!p.row_scale || p.rs_gstride == p.R);
     if (a.M % 8 == 0 && a.M >= 8) {
         if (p.R % 8 == 0) p.fast8 = 1;
@@ -998,9 +1023,12 @@ int launch_gemm_tn_bf16x3(const stair_gemm_tn_args &a, hipStream_t s) {
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem2));
                 STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tn_bf16x3_t256_kernel<1>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem2));
+                STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tn_bf16x3_t256_kernel<3, true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem2));
                 attr_set = true;
             }
-            if (one) hipLaunchKernelGGL(gemm_tn_bf16x3_t256_kernel<1>, dim3(t2 * slabs), dim3(512), shmem2, s, q);
+            if (bx) hipLaunchKernelGGL((gemm_tn_bf16x3_t256_kernel<3, true>), dim3(t2 * slabs), dim3(512), shmem2, s, q);
+            else if (one) hipLaunchKernelGGL(gemm_tn_bf16x3_t256_kernel<1>, dim3(t2 * slabs), dim3(512), shmem2, s, q);
             else hipLaunchKernelGGL(gemm_tn_bf16x3_t256_kernel<3>, dim3(t2 * slabs), dim3(512), shmem2, s, q);
             STAIR_LAUNCH_CHECK();
             return 0;
@@ -1016,7 +1044,11 @@ int launch_gemm_tn_bf16x3(const stair_gemm_tn_args &a, hipStream_t s) {
     p.mslab = ((a.M + slabs - 1) / slabs + 63) / 64 * 64;
     const size_t shmem = 2 * 2 * 2 * IMG * sizeof(__bf16);
     const bool plain = !p.row_scale && a.M % 64 == 0 && p.mslab % 64 == 0;
-    if (plain && one) hipLaunchKernelGGL((gemm_tn_bf16x3_kernel<true, 1>), dim3(tiles * slabs), dim3(256), shmem, s, p);
+    if (bx) {
+        STAIR_CHECK(p.fast8 != 0, "internal: bf16 B rows need a plain row matrix");
+        if (plain) hipLaunchKernelGGL((gemm_tn_bf16x3_kernel<true, 3, true>), dim3(tiles * slabs), dim3(256), shmem, s, p);
+        else hipLaunchKernelGGL((gemm_tn_bf16x3_kernel<false, 3, true>), dim3(tiles * slabs), dim3(256), shmem, s, p);
+    } else if (plain && one) hipLaunchKernelGGL((gemm_tn_bf16x3_kernel<true, 1>), dim3(tiles * slabs), dim3(256), shmem, s, p);
     else if (plain) hipLaunchKernelGGL((gemm_tn_bf16x3_kernel<true, 3>), dim3(tiles * slabs), dim3(256), shmem, s, p);
     else if (one) hipLaunchKernelGGL((gemm_tn_bf16x3_kernel<false, 1>), dim3(tiles * slabs), dim3(256), shmem, s, p);
     else hipLaunchKernelGGL((gemm_tn_bf16x3_kernel<false, 3>), dim3(tiles * slabs), dim3(256), shmem, s, p);

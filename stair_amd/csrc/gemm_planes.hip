@@ -1,0 +1,489 @@
+// Plane GEMMs: bf16 MFMA contractions whose operands ARRIVE as bf16 planes in HBM and are staged global -> LDS by
+// LDS-DMA (global_load_lds_dwordx4), with no register round trip.
+//
+// Round 1's split kernels (csrc/gemm_bf16x3.hip) load fp32 rows into VGPRs, split them into bf16 hi + lo on the VALU and
+// push them into LDS with ds_write_b128; ablations showed that skeleton costing as much as the MFMAs and not overlapping
+// with them.  Here the split happens ONCE, outside the contraction:
+//   * clip features are stored as bf16 (BASELINE.json configs[1]: "I3D rgb+flow [T=64,2048] feats, bf16"), so the A operand
+//     of the LSTM input projection (/root/reference/video_nmn/module_net.py:39-42,160-163) is a single exact plane;
+//   * weights are split into hi/lo bf16 planes once per plan run (stair_split_planes), W = hi + lo + O(2^-17 |W|);
+// and a product is  A * Whi + A * Wlo  (two v_mfma_f32_32x32x16_bf16, fp32 accumulate) when A is exact bf16, or
+// Ahi * Whi + Ahi * Wlo + Alo * Whi when A carries a lo plane as well.
+//
+// Kernel: 256 x 256 output tile, 8 waves as 2 (M) x 4 (N) of 128 x 64, K in steps of 32, ring of LDS stages
+// (3 x 48 KB for one A plane, 2 x 64 KB for two); one raw s_barrier per K step; the LDS-DMA of the stages ahead stays in
+// flight across the barrier behind a counted s_waitcnt vmcnt(N) (cdna_hip_programming.md section 5, "Pipelining across
+// barriers").  LDS image of a plane: [row 0..255][4 chunks of 8 bf16], chunk c of row R stored at slot c ^ ((R >> 2) & 3):
+// a 64-lane LDS-DMA instruction fills 16 rows x 64 B linearly (the swizzle is applied to the per-lane SOURCE address) and
+// the ds_read_b128 fragment reads (32 consecutive rows of one chunk) are bank-conflict free.
+#include <algorithm>
+#include <cstdlib>
+
+#include "common.h"
+
+namespace stair {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using v4f = __attribute__((ext_vector_type(4))) float;
+using v4u = __attribute__((ext_vector_type(4))) unsigned;
+
+namespace {
+
+constexpr int PBK = 32;                    // k per stage
+constexpr int PLANE_BYTES = 256 * 64;      // one plane of one stage: 256 rows x 32 bf16
+
+struct PlParams {
+    const __bf16 *A[2];      // hi, lo (lo unused when NPA == 1); [M, lda]
+    const __bf16 *W[2];      // hi, lo; [N, ldw]
+    int64_t lda, ldw;
+    const float *bias;
+    float *C;
+    int64_t ldc;
+    int M, N, K, tilesM, tilesN;
+};
+
+__device__ __forceinline__ void glds16(const __bf16 *src, __attribute__((address_space(3))) char *dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, dst, 16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else static_assert(N < 0, "add the count");
+}
+
+}  // namespace
+
+// swizzle of the LDS plane image: chunk c (8 bf16) of row R lives in slot c ^ swz(R) of the row's four 16-byte slots.
+// swz maps (R >> 2) & 3 = 0,1,2,3 to 0,2,3,1: any bijection makes the 32-row fragment reads of v_mfma_f32_32x32x16_bf16
+// conflict free; this one also does it for the 16-row x 4-chunk reads of v_mfma_f32_16x16x32_bf16.
+__device__ __forceinline__ int pl_swz(int R) {
+    const int q0 = (R >> 2) & 1, q1 = (R >> 3) & 1;
+    return ((q0 ^ q1) << 1) | q1;
+}
+
+// NPA: A planes (1: exact bf16 A, two products per pair; 2: hi + lo, three products).  ACT as stair_gemm_args.act.
+// WT: W planes in the tiled layout [K/32][N][32] written by stair_split_planes_tiled: one LDS-DMA instruction then reads
+// 1 KB of contiguous memory (16 rows x 64 B) instead of 16 half lines 2*ldw bytes apart.
+// MF: 0 = v_mfma_f32_32x32x16_bf16 (wave tile 4 x 2 blocks of 32 x 32, two k steps per stage, fragments of the next k
+//     step prefetched across the barrier); 1 = v_mfma_f32_16x16x32_bf16 (8 x 4 blocks of 16 x 16, one k step per stage).
+// The grid is at most one workgroup per CU and every workgroup walks its tiles itself, treating (tile, k step) as ONE
+// stream of stages: the LDS-DMA of the next tile's first stages is issued while the current tile's last stages are
+// multiplied, and the epilogue's stores drain behind the next tile's loads.
+// ABL: ablation builds for measurements (1: no LDS-DMA in the loop, 2: no fragment reads / MFMAs); 0 in the product.
+template <int NPA, int ACT, bool WT, int MF, int ABL = 0>
+__global__ __launch_bounds__(512, 1) void gemm_planes_kernel(PlParams p) {
+    extern __shared__ __attribute__((aligned(16))) char plds[];
+    constexpr int NPL = NPA + 2;                         // planes per stage: A hi [, A lo], W hi, W lo
+    constexpr int NST = NPA == 1 ? 3 : 2;                // ring depth (144 KB / 128 KB)
+    constexpr int STAGE_BYTES = NPL * PLANE_BYTES;
+    constexpr int LPS = NPL * 2;                         // LDS-DMA instructions per wave and stage
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int K = p.K;
+
+    // XCD-aware renumbering: workgroups with equal blockIdx % 8 share an XCD (speed only), and at any moment they hold
+    // consecutive tiles, i.e. all tilesN column tiles of the same A panels: the panel leaves HBM once, W stays in L2.
+    const int nb = p.tilesM * p.tilesN, G = gridDim.x;
+    const int bid = blockIdx.x;
+    const int qd = G >> 3, rm = G & 7, xcd = bid & 7, loc = bid >> 3;
+    const int first = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;     // bijective on [0, G)
+    const int my_tiles = (nb - first + G - 1) / G;      // tiles first, first + G, ... (>= 1: G <= nb)
+
+    // staging: instruction i (0, 1) of this wave fills units [(2 wave + i) * 64, +64) of a plane; unit u = row * 4 + slot
+    const int u0 = 2 * wave * 64 + lane;
+    const int srow[2] = {u0 >> 2, (u0 + 64) >> 2};
+    const int scol = ((u0 & 3) ^ pl_swz(u0 >> 2)) * 8;    // source chunk of this lane's slot (rows 16 apart share swz)
+    const int dst_off[2] = {2 * wave * 1024, (2 * wave + 1) * 1024};      // wave-uniform LDS byte offsets inside a plane
+    const int64_t wstep = WT ? p.N : 1;                   // W elements per unit of k0: tiled planes advance by N * 32 per stage
+    const __bf16 *srcA[NPA][2], *srcW[2][2];
+    auto set_src = [&](int tile) {
+        const int tm = tile / p.tilesN, tn = tile - tm * p.tilesN;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int64_t ra = min(tm * 256 + srow[i], p.M - 1), rw = min(tn * 256 + srow[i], p.N - 1);
+#pragma unroll
+            for (int q = 0; q < NPA; ++q) srcA[q][i] = p.A[q] + ra * p.lda + scol;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) srcW[q][i] = p.W[q] + rw * (WT ? PBK : p.ldw) + scol;
+        }
+    };
+    __attribute__((address_space(3))) char *lbase = (__attribute__((address_space(3))) char *)plds;
+
+#define PL_STAGE(buf, k0)                                                                                   \
+    {                                                                                                       \
+        __attribute__((address_space(3))) char *sb_ = lbase + (buf);                                        \
+        _Pragma("unroll") for (int q_ = 0; q_ < NPA; ++q_)                                                  \
+            _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                \
+                glds16(srcA[q_][i_] + (k0), sb_ + q_ * PLANE_BYTES + dst_off[i_]);                          \
+        _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_)                                                    \
+            _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                \
+                glds16(srcW[q_][i_] + (k0) * wstep, sb_ + (NPA + q_) * PLANE_BYTES + dst_off[i_]);          \
+    }
+
+    // The issue cursor (i_ord, i_k) runs NST-1 stages ahead of the multiply cursor and crosses into the next tile on its
+    // own; past the last stage it re-reads the last one into a buffer nobody multiplies, so the counted waits stay exact.
+    int i_ord = 0, i_k = 0;
+    set_src(first);
+    auto advance = [&]() {
+        i_k += PBK;
+        if (i_k == K) {
+            if (i_ord + 1 < my_tiles) { ++i_ord; i_k = 0; set_src(first + i_ord * G); }
+            else i_k = K - PBK;
+        }
+    };
+    const int nt = K / PBK;             // K % 32 == 0 (launcher)
+
+    if constexpr (MF == 0) {
+        const int r = lane & 31, h = lane >> 5;
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+        // fragment byte offsets inside a plane for chunk 0; chunk c flips the slot bits: ^ (c << 4)
+        int offA[4], offW[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int R = wm * 128 + 32 * i + r;
+            offA[i] = (R * 4 + pl_swz(R)) * 16;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int R = wn * 64 + 32 * j + r;
+            offW[j] = (R * 4 + pl_swz(R)) * 16;
+        }
+        // fragment sets: set 0 = k step 0 of a stage (k = 0..15), set 1 = k step 1 (k = 16..31)
+        bf16x8 fa[2][4], fal[2][4], fwh[2][2], fwl[2][2];
+#define PL_READ(buf, s_)                                                                                             \
+    {                                                                                                                \
+        const char *sb_ = plds + (buf);                                                                              \
+        const int cx_ = (2 * (s_) + h) << 4;                                                                         \
+        _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                           \
+            fwh[s_][j_] = *reinterpret_cast<const bf16x8 *>(sb_ + NPA * PLANE_BYTES + (offW[j_] ^ cx_));             \
+            fwl[s_][j_] = *reinterpret_cast<const bf16x8 *>(sb_ + (NPA + 1) * PLANE_BYTES + (offW[j_] ^ cx_));       \
+        }                                                                                                            \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                           \
+            fa[s_][i_] = *reinterpret_cast<const bf16x8 *>(sb_ + (offA[i_] ^ cx_));                                  \
+            if (NPA == 2) fal[s_][i_] = *reinterpret_cast<const bf16x8 *>(sb_ + PLANE_BYTES + (offA[i_] ^ cx_));     \
+        }                                                                                                            \
+    }
+#define PL_MUL(s_)                                                                                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                                 \
+        _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                           \
+            if (NPA == 2) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[s_][i_], fwh[s_][j_], acc[i_][j_], 0, 0, 0);   \
+            acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s_][i_], fwl[s_][j_], acc[i_][j_], 0, 0, 0);    \
+            acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s_][i_], fwh[s_][j_], acc[i_][j_], 0, 0, 0);    \
+        }
+        // Ring: at the top of a step, its stage is in LDS and visible to every wave, its k-step-0 fragments are already in
+        // registers, and the next NST-2 stages are in flight.  The step
+        //   issues the stage NST-1 ahead (into the buffer whose last reader was the previous step: every wave finished
+        //   those reads -- lgkmcnt(0) -- before it joined that step's barrier),
+        //   reads its k-step-1 fragments and multiplies k step 0 (the MFMAs cover the read latency),
+        //   waits for its reads and for its own share of the next stage's LDS-DMA (counted vmcnt: the stage after that
+        //   stays in flight across the barrier), joins the barrier,
+        //   reads the NEXT stage's k-step-0 fragments and multiplies k step 1.
+#pragma unroll
+        for (int q = 0; q < NST - 1; ++q) { PL_STAGE(q * STAGE_BYTES, i_k); advance(); }
+        wait_vm<(NST - 2) * LPS>();
+        __builtin_amdgcn_s_barrier();
+        int sbuf = 0, ibuf = (NST - 1) * STAGE_BYTES;
+        if (ABL != 2) PL_READ(sbuf, 0);
+        for (int ord = 0; ord < my_tiles; ++ord) {
+            for (int t = 0; t < nt; ++t) {
+                if (ABL != 1) PL_STAGE(ibuf, i_k);
+                if (ABL != 2) {
+                    PL_READ(sbuf, 1);
+                    PL_MUL(0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wait_vm<(NST - 2) * LPS>();
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                sbuf = sbuf + STAGE_BYTES == NST * STAGE_BYTES ? 0 : sbuf + STAGE_BYTES;
+                ibuf = ibuf + STAGE_BYTES == NST * STAGE_BYTES ? 0 : ibuf + STAGE_BYTES;
+                if (ABL != 2) {
+                    PL_READ(sbuf, 0);
+                    PL_MUL(1);
+                }
+                advance();                  // (the branches of the cursor sit at the end: the blocks above stay straight-line)
+            }
+            const int tile = first + ord * G;
+            const int tm = tile / p.tilesN, tn = tile - tm * p.tilesN;
+            const int m0 = tm * 256, n0 = tn * 256;
+            // uniform tile base + 32-bit per-lane offset: the stores take the SGPR-base form and need no 64-bit VGPR math
+            float *ctile = p.C + (int64_t)m0 * p.ldc + n0;
+            const unsigned loff = (unsigned)((wm * 128 + 4 * h) * (int)p.ldc + wn * 64 + r);
+            const bool full = m0 + 256 <= p.M && n0 + 256 <= p.N;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn * 64 + j * 32 + r;
+                const float b = (p.bias && n < p.N) ? p.bias[n] : 0.0f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int rl = i * 32 + (e & 3) + 8 * (e >> 2);            // + wm * 128 + 4 h inside loff
+                        float v = acc[i][j][e] + b;
+                        if (ACT == 1) v = fmaxf(v, 0.0f);
+                        if (ACT == 2) v = sigmoid_acc(v);
+                        __attribute__((address_space(1))) float *rowp =
+                            (__attribute__((address_space(1))) float *)(ctile + (int64_t)rl * p.ldc + j * 32);
+                        if (full || (n < p.N && m0 + wm * 128 + 4 * h + rl < p.M)) rowp[loff] = v;
+                        acc[i][j][e] = 0.0f;
+                    }
+                }
+            }
+        }
+#undef PL_READ
+#undef PL_MUL
+    } else {
+        // ---- 16 x 16 x 32: lane l holds A[row l & 15][k = 8 (l >> 4) + j], the whole 32-wide stage is ONE k step ----
+        const int r16 = lane & 15, c4 = lane >> 4;
+        v4f acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+        int offA[8], offW[4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int R = wm * 128 + 16 * i + r16;
+            offA[i] = (R * 4 + (c4 ^ pl_swz(R))) * 16;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int R = wn * 64 + 16 * j + r16;
+            offW[j] = (R * 4 + (c4 ^ pl_swz(R))) * 16;
+        }
+#define PL_STEP(buf)                                                                                                 \
+    {                                                                                                                \
+        const char *sb_ = plds + (buf);                                                                              \
+        bf16x8 wh_[4], wl_[4];                                                                                       \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                           \
+            wh_[j_] = *reinterpret_cast<const bf16x8 *>(sb_ + NPA * PLANE_BYTES + offW[j_]);                         \
+            wl_[j_] = *reinterpret_cast<const bf16x8 *>(sb_ + (NPA + 1) * PLANE_BYTES + offW[j_]);                   \
+        }                                                                                                            \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                                           \
+            const bf16x8 ah_ = *reinterpret_cast<const bf16x8 *>(sb_ + offA[i_]);                                    \
+            bf16x8 al_ = ah_;                                                                                        \
+            if (NPA == 2) al_ = *reinterpret_cast<const bf16x8 *>(sb_ + PLANE_BYTES + offA[i_]);                     \
+            _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                       \
+                if (NPA == 2) acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al_, wh_[j_], acc[i_][j_], 0, 0, 0);   \
+                acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah_, wl_[j_], acc[i_][j_], 0, 0, 0);           \
+                acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah_, wh_[j_], acc[i_][j_], 0, 0, 0);           \
+            }                                                                                                        \
+        }                                                                                                            \
+    }
+#pragma unroll
+        for (int q = 0; q < NST - 1; ++q) { PL_STAGE(q * STAGE_BYTES, i_k); advance(); }
+        wait_vm<(NST - 2) * LPS>();
+        __builtin_amdgcn_s_barrier();
+        int sbuf = 0, ibuf = (NST - 1) * STAGE_BYTES;
+        for (int ord = 0; ord < my_tiles; ++ord) {
+            for (int t = 0; t < nt; ++t) {
+                if (ABL != 1) PL_STAGE(ibuf, i_k);
+                if (ABL != 2) PL_STEP(sbuf);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every read of this stage done before its buffer is refilled
+                wait_vm<(NST - 2) * LPS>();
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                sbuf = sbuf + STAGE_BYTES == NST * STAGE_BYTES ? 0 : sbuf + STAGE_BYTES;
+                ibuf = ibuf + STAGE_BYTES == NST * STAGE_BYTES ? 0 : ibuf + STAGE_BYTES;
+                advance();
+            }
+            const int tile = first + ord * G;
+            const int tm = tile / p.tilesN, tn = tile - tm * p.tilesN;
+            const int m0 = tm * 256, n0 = tn * 256;
+            float *ctile = p.C + (int64_t)m0 * p.ldc + n0;
+            const unsigned loff = (unsigned)((wm * 128 + 4 * c4) * (int)p.ldc + wn * 64 + r16);
+            const bool full = m0 + 256 <= p.M && n0 + 256 <= p.N;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + j * 16 + r16;
+                const float b = (p.bias && n < p.N) ? p.bias[n] : 0.0f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int rl = i * 16 + e;                                  // + wm * 128 + 4 c4 inside loff
+                        float v = acc[i][j][e] + b;
+                        if (ACT == 1) v = fmaxf(v, 0.0f);
+                        if (ACT == 2) v = sigmoid_acc(v);
+                        __attribute__((address_space(1))) float *rowp =
+                            (__attribute__((address_space(1))) float *)(ctile + (int64_t)rl * p.ldc + j * 16);
+                        if (full || (n < p.N && m0 + wm * 128 + 4 * c4 + rl < p.M)) rowp[loff] = v;
+                        acc[i][j][e] = 0.0f;
+                    }
+                }
+            }
+        }
+#undef PL_STEP
+    }
+    wait_vm<0>();                       // the trailing (unused) stages must land before the LDS is given back
+#undef PL_STAGE
+}
+
+// x -> hi = bf16(x), lo = bf16(x - hi); 8 elements per thread (two 16-byte loads, two 16-byte stores)
+__global__ void split_planes_kernel(const float *x, __bf16 *hi, __bf16 *lo, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const v4f a = *reinterpret_cast<const v4f *>(x + 8 * i), b = *reinterpret_cast<const v4f *>(x + 8 * i + 4);
+        bf16x8 vh, vl;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            vh[j] = (__bf16)a[j]; vl[j] = (__bf16)(a[j] - (float)vh[j]);
+            vh[4 + j] = (__bf16)b[j]; vl[4 + j] = (__bf16)(b[j] - (float)vh[4 + j]);
+        }
+        *reinterpret_cast<bf16x8 *>(hi + 8 * i) = vh;
+        if (lo) *reinterpret_cast<bf16x8 *>(lo + 8 * i) = vl;
+    }
+}
+
+// tiled form for W operands: src [rows, cols] row-major fp32 -> planes [cols/32][rows][32]; one thread per 8 elements
+__global__ void split_planes_tiled_kernel(const float *x, __bf16 *hi, __bf16 *lo, int rows, int cols, int row_off, int total_rows) {
+    const int64_t n8 = (int64_t)rows * cols / 8;
+    const int c8 = cols / 8;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / c8), k8 = (int)(i - (int64_t)row * c8);          // source: row, columns 8 k8 .. 8 k8 + 7
+        const v4f a = *reinterpret_cast<const v4f *>(x + 8 * i), b = *reinterpret_cast<const v4f *>(x + 8 * i + 4);
+        bf16x8 vh, vl;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            vh[j] = (__bf16)a[j]; vl[j] = (__bf16)(a[j] - (float)vh[j]);
+            vh[4 + j] = (__bf16)b[j]; vl[4 + j] = (__bf16)(b[j] - (float)vh[4 + j]);
+        }
+        const int64_t o = ((int64_t)(k8 >> 2) * total_rows + row_off + row) * PBK + (k8 & 3) * 8;
+        *reinterpret_cast<bf16x8 *>(hi + o) = vh;
+        *reinterpret_cast<bf16x8 *>(lo + o) = vl;
+    }
+}
+
+int launch_split_planes_tiled(const float *x, void *hi, void *lo, int rows, int cols, hipStream_t s, int row_off, int total_rows) {
+    if (total_rows <= 0) total_rows = rows;
+    STAIR_CHECK(row_off >= 0 && row_off + rows <= total_rows, "row block outside the plane");
+    STAIR_CHECK(x && hi && lo, "null argument");
+    STAIR_CHECK(rows > 0 && cols > 0 && cols % PBK == 0, "cols must be a positive multiple of 32");
+    STAIR_CHECK(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(hi) | reinterpret_cast<uintptr_t>(lo)) & 15) == 0,
+                "pointers must be 16-byte aligned");
+    const int64_t n8 = (int64_t)rows * cols / 8;
+    const int blocks = (int)std::min<int64_t>((n8 + 255) / 256, 4096);
+    hipLaunchKernelGGL(split_planes_tiled_kernel, dim3(blocks), dim3(256), 0, s, x, static_cast<__bf16 *>(hi), static_cast<__bf16 *>(lo), rows, cols, row_off, total_rows);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_split_planes(const float *x, void *hi, void *lo, int64_t n, hipStream_t s) {
+    STAIR_CHECK(x && hi, "null argument");
+    STAIR_CHECK(n % 8 == 0, "element count must be a multiple of 8");
+    STAIR_CHECK(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(hi) | reinterpret_cast<uintptr_t>(lo)) & 15) == 0,
+                "pointers must be 16-byte aligned");
+    if (n == 0) return 0;
+    const int64_t n8 = n / 8;
+    const int blocks = (int)std::min<int64_t>((n8 + 255) / 256, 4096);
+    hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, s, x, static_cast<__bf16 *>(hi), static_cast<__bf16 *>(lo), n8);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
+bool gemm_planes_supported(int64_t M, int N, int K) {
+    return M >= 256 && N >= 256 && K >= 64 && K % PBK == 0;
+}
+
+int launch_gemm_planes(const stair_gemm_planes_args &a, hipStream_t s) {
+    STAIR_CHECK(a.A_hi && a.W_hi && a.W_lo && a.C, "null operand");
+    STAIR_CHECK(a.M > 0 && a.N > 0 && a.K > 0 && a.K % PBK == 0, "K must be a positive multiple of 32");
+    STAIR_CHECK(a.lda % 8 == 0 && (a.w_tiled || a.ldw % 8 == 0), "lda / ldw must be multiples of 8 bf16 (16-byte rows)");
+    STAIR_CHECK(((reinterpret_cast<uintptr_t>(a.A_hi) | reinterpret_cast<uintptr_t>(a.A_lo) | reinterpret_cast<uintptr_t>(a.W_hi) |
+                  reinterpret_cast<uintptr_t>(a.W_lo)) & 15) == 0, "plane pointers must be 16-byte aligned");
+    PlParams p;
+    p.A[0] = static_cast<const __bf16 *>(a.A_hi); p.A[1] = static_cast<const __bf16 *>(a.A_lo);
+    p.W[0] = static_cast<const __bf16 *>(a.W_hi); p.W[1] = static_cast<const __bf16 *>(a.W_lo);
+    p.lda = a.lda; p.ldw = a.ldw; p.bias = a.bias; p.C = a.C; p.ldc = a.ldc;
+    p.M = a.M; p.N = a.N; p.K = a.K;
+    p.tilesM = (a.M + 255) / 256; p.tilesN = (a.N + 255) / 256;
+    const int nb = p.tilesM * p.tilesN;
+    static const int ncu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+        return n > 0 ? n : 256;
+    }();
+    static const int ablate = [] { const char *e = getenv("STAIR_PLANES_ABLATE"); return e ? atoi(e) : 0; }();   // measurements only
+    const dim3 grid(std::min(nb, ncu)), block(512);
+    const size_t sh1 = 3 * 3 * PLANE_BYTES, sh2 = 2 * 4 * PLANE_BYTES;
+    static bool attr_set = false;       // one device per process (one ctx per GPU / process, see stair_hip.h)
+    // MFMA shape: measured equal for two products (0.95 ms either way on the dominant shape); with three the 16x16x32 form
+    // is 4 % faster (1.32 vs 1.37 ms) -- profiles/r02_a_planes_bench.txt.  STAIR_PLANES_MFMA = 0 / 1 forces one.
+    static const int mf_force = [] { const char *e = getenv("STAIR_PLANES_MFMA"); return e ? atoi(e) : -1; }();
+    const int mf_env = mf_force >= 0 ? mf_force : (a.A_lo ? 1 : 0);
+#define P_FOREACH(X) X(0, false, 0) X(1, false, 0) X(2, false, 0) X(0, true, 0) X(1, true, 0) X(2, true, 0) \
+                     X(0, false, 1) X(1, false, 1) X(2, false, 1) X(0, true, 1) X(1, true, 1) X(2, true, 1)
+    if (!attr_set) {
+#define P_ATTR(ACT_, WT_, MF_)                                                                                          \
+        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_planes_kernel<1, ACT_, WT_, MF_>),            \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh1));                            \
+        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_planes_kernel<2, ACT_, WT_, MF_>),            \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2));
+        P_FOREACH(P_ATTR)
+#undef P_ATTR
+#define P_ATTR_A(MF_, ABL_) STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_planes_kernel<1, 0, true, MF_, ABL_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh1));
+        P_ATTR_A(0, 1) P_ATTR_A(0, 2) P_ATTR_A(1, 1) P_ATTR_A(1, 2)
+#undef P_ATTR_A
+        attr_set = true;
+    }
+#define P_LAUNCH2(ACT_, WT_, MF_)                                                                                       \
+    {                                                                                                                   \
+        if (a.A_lo) hipLaunchKernelGGL((gemm_planes_kernel<2, ACT_, WT_, MF_>), grid, block, sh2, s, p);                 \
+        else hipLaunchKernelGGL((gemm_planes_kernel<1, ACT_, WT_, MF_>), grid, block, sh1, s, p);                        \
+    }
+#define P_LAUNCH(ACT_, WT_) { if (mf_env) P_LAUNCH2(ACT_, WT_, 1) else P_LAUNCH2(ACT_, WT_, 0) }
+    if (ablate && a.act == 0 && a.w_tiled && !a.A_lo) {
+        if (mf_env == 0 && ablate == 1) hipLaunchKernelGGL((gemm_planes_kernel<1, 0, true, 0, 1>), grid, block, sh1, s, p);
+        else if (mf_env == 0) hipLaunchKernelGGL((gemm_planes_kernel<1, 0, true, 0, 2>), grid, block, sh1, s, p);
+        else if (ablate == 1) hipLaunchKernelGGL((gemm_planes_kernel<1, 0, true, 1, 1>), grid, block, sh1, s, p);
+        else hipLaunchKernelGGL((gemm_planes_kernel<1, 0, true, 1, 2>), grid, block, sh1, s, p);
+    } else if (a.w_tiled) {
+        switch (a.act) {
+            case 0: P_LAUNCH(0, true) break;
+            case 1: P_LAUNCH(1, true) break;
+            default: P_LAUNCH(2, true) break;
+        }
+    } else {
+        switch (a.act) {
+            case 0: P_LAUNCH(0, false) break;
+            case 1: P_LAUNCH(1, false) break;
+            default: P_LAUNCH(2, false) break;
+        }
+    }
+#undef P_LAUNCH
+#undef P_LAUNCH2
+#undef P_FOREACH
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace stair
+
+extern "C" int stair_split_planes(const float *x, void *hi, void *lo, int64_t n, stair_stream stream) {
+    return stair::launch_split_planes(x, hi, lo, n, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int stair_split_planes_tiled(const float *x, void *hi, void *lo, int32_t rows, int32_t cols, stair_stream stream) {
+    return stair::launch_split_planes_tiled(x, hi, lo, rows, cols, static_cast<hipStream_t>(stream), 0, rows);
+}
+
+extern "C" int stair_gemm_planes(const stair_gemm_planes_args *args, stair_stream stream) {
+    if (!args) {
+        stair::set_error("stair_gemm_planes: null args");
+        return 1;
+    }
+    return stair::launch_gemm_planes(*args, static_cast<hipStream_t>(stream));
+}

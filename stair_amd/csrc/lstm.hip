@@ -769,9 +769,11 @@ int launch_lstm_bwd(const stair_lstm_bwd_args &a, hipStream_t s) {
     for (int dir = 0; dir < 2; ++dir) {
         stair_gemm_tn_args g = {};
         g.A = a.gates + dir * 4 * Hh; g.lda = 8 * (int64_t)Hh;
-        g.B = a.x; g.ldb = a.ldx; g.b_gstride = a.ldx; g.rows_per_group = 1;
+        g.B = a.x_bf16 ? static_cast<const float *>(a.x_bf16) : a.x; g.b_is_bf16 = a.x_bf16 ? 1 : 0;
+        g.ldb = a.ldx; g.b_gstride = a.ldx; g.rows_per_group = 1;
         g.C = a.dw_ih[dir]; g.ldc = a.I; g.M = a.rows; g.N = 4 * Hh; g.K = a.I;
         if (int rc = launch_gemm_tn(g, s)) return rc;
+        g.b_is_bf16 = 0;
         g.B = a.hprev_ws + dir * Hh; g.ldb = 2 * (int64_t)Hh; g.b_gstride = 2 * (int64_t)Hh;
         g.C = a.dw_hh[dir]; g.ldc = Hh; g.K = Hh;
         g.colsum = a.db_ih[dir]; g.colsum2 = a.db_hh[dir];     // db_ih = db_hh = colsum(dG), with the smaller of the two products
@@ -784,11 +786,28 @@ int launch_lstm(const stair_lstm_args &a, hipStream_t s) {
     STAIR_CHECK(a.n >= 0 && a.rows >= 0 && a.I > 0 && a.Hh > 0, "bad shape");
     STAIR_CHECK(a.Hh % 32 == 0 && a.Hh <= 256, "LSTM hidden size must be a multiple of 32, at most 256");
     STAIR_CHECK(a.I % 4 == 0 && a.ldx % 4 == 0, "LSTM input size / ldx must be multiples of 4");
+    STAIR_CHECK(a.x || a.x_bf16, "no input rows");
     if (a.n == 0 || a.rows == 0) return 0;
     const int Hh = a.Hh;
     hipLaunchKernelGGL(bias_sum_kernel, dim3((8 * Hh + 255) / 256), dim3(256), 0, s, a.b_ih[0], a.b_hh[0], a.b_ih[1],
                        a.b_hh[1], a.bias_ws, 4 * Hh);
     STAIR_LAUNCH_CHECK();
+    if (a.x_bf16) {
+        // stored bf16 features: ONE plane GEMM for both directions (N = 8 Hh: an A panel leaves HBM once for all gate
+        // columns), W_ih of both directions split into tiled hi/lo planes first (csrc/gemm_planes.hip)
+        STAIR_CHECK(matmul_mode() == STAIR_MATMUL_BF16X3, "bf16 input rows need the bf16x3 matmul mode (STAIR_MATMUL)");
+        STAIR_CHECK(a.I % 32 == 0 && a.ldx % 8 == 0, "bf16 input rows need I % 32 == 0 and ldx % 8 == 0");
+        STAIR_CHECK(a.wih_planes_ws != nullptr, "wih_planes_ws missing");
+        char *hi = static_cast<char *>(a.wih_planes_ws), *lo = hi + (size_t)8 * Hh * a.I * 2;
+        for (int dir = 0; dir < 2; ++dir)
+            if (int rc = launch_split_planes_tiled(a.w_ih[dir], hi, lo, 4 * Hh, a.I, s, dir * 4 * Hh, 8 * Hh)) return rc;
+        stair_gemm_planes_args g = {};
+        g.A_hi = a.x_bf16; g.A_lo = nullptr; g.lda = a.ldx;
+        g.W_hi = hi; g.W_lo = lo; g.ldw = 0; g.w_tiled = 1;
+        g.bias = a.bias_ws; g.C = a.xproj_ws; g.ldc = 8 * (int64_t)Hh;
+        g.M = a.rows; g.N = 8 * Hh; g.K = a.I; g.act = 0;
+        if (int rc = launch_gemm_planes(g, s)) return rc;
+    } else
     for (int dir = 0; dir < 2; ++dir) {
         stair_gemm_args g = {};
         g.A = a.x; g.lda = a.ldx; g.a_gstride = a.ldx;

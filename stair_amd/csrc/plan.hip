@@ -223,7 +223,7 @@ struct stair_plan {
     int maxI = 0, maxV = 0, maxK = 0, maxSupRows = 0, n_levels = 0;
     // workspace layout (float offsets)
     int64_t o_idx = 0, o_vec = 0, o_map = 0, o_att = 0, o_tok = 0, o_qfeat = 0, o_vhn = 0, o_xpv = 0, o_xpt = 0,
-            o_bias = 0, o_wpack = 0, o_splitk = 0, o_tmpA = 0, o_tmpB = 0, o_kbuf = 0, o_cat = 0, o_hid = 0, o_rs = 0, o_sup = 0, o_extra = 0,
+            o_bias = 0, o_wpack = 0, o_wplanes = 0, o_splitk = 0, o_tmpA = 0, o_tmpB = 0, o_kbuf = 0, o_cat = 0, o_hid = 0, o_rs = 0, o_sup = 0, o_extra = 0,
             o_logits = 0, total = 0;
     // training only
     bool train = false;
@@ -580,6 +580,7 @@ extern "C" int stair_plan_build_shared(stair_ctx *ctx, int32_t n, const int32_t 
     pl->o_xpt = take((int64_t)pl->rows_q * 4 * H, 64);
     pl->o_bias = take(2 * 4 * H, 64);
     pl->o_wpack = take(2 * 2 * H * H, 64);       // 8*Hh*Hh floats per encoder
+    pl->o_wplanes = ctx->cfg.video_size % 32 == 0 ? take(4 * H * ctx->cfg.video_size, 64) : 0;   // video W_ih hi/lo planes (bf16 features): 2 x [4H, V] bf16
     pl->o_splitk = take(kSplitKFloats, 64);      // partial sums of split-K launches (<= 64 output tiles x 16 pieces)
     pl->o_tmpA = take((int64_t)std::max(pl->maxI, 1) * T * H, 64);
     pl->o_tmpB = take((int64_t)std::max(pl->maxI, 1) * T * H, 64);
@@ -863,6 +864,10 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
     {
         stair_lstm_args a = {};
         a.x = video; a.ldx = V; a.rows = pl->n_vid * T; a.n = pl->n_vid; a.max_len = T; a.I = V; a.Hh = Hh;
+        if (flags & STAIR_RUN_VIDEO_BF16) {
+            STAIR_CHECK(V % 32 == 0, "bf16 clip features need video_size % 32 == 0");
+            a.x = nullptr; a.x_bf16 = video; a.wih_planes_ws = ws + pl->o_wplanes;
+        }
         a.seq_off = didx + pl->off_seqv;
         for (int d = 0; d < 2; ++d) {
             a.w_ih[d] = W.enc[0][4 * d]; a.w_hh[d] = W.enc[0][4 * d + 1];
@@ -1243,6 +1248,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
         stair_lstm_bwd_args a = {};
         if (e == 0) {
             a.x = video; a.ldx = V; a.rows = pl->n_vid * T; a.max_len = T; a.I = V; a.seq_off = didx + pl->off_seqv;
+            if (flags & STAIR_RUN_VIDEO_BF16) { a.x = nullptr; a.x_bf16 = video; }
             a.gates = ws + pl->o_xpv; a.cbuf = ws + pl->o_cv; a.out = map; a.d_out = g_map; a.d_hn = nullptr;
             a.whh_pack_ws = ws + pl->o_wpack;
         } else {
@@ -1346,6 +1352,7 @@ extern "C" int stair_plan_regions(stair_plan *pl, const stair_ctx *ctx, const ch
     add("xpt", pl->o_xpt, (int64_t)pl->rows_q * 4 * H);
     add("bias", pl->o_bias, 8 * H);
     add("wpack", pl->o_wpack, 4 * H * H);
+    if (ctx->cfg.video_size % 32 == 0) add("wplanes", pl->o_wplanes, 4 * H * ctx->cfg.video_size);
     add("splitk", pl->o_splitk, kSplitKFloats);
     add("tmpA", pl->o_tmpA, (int64_t)std::max(pl->maxI, 1) * T * H);
     add("tmpB", pl->o_tmpB, (int64_t)std::max(pl->maxI, 1) * T * H);

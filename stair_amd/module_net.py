@@ -26,6 +26,7 @@ from . import frontend, ops, spec
 from ._lib import PlanInfo, StairConfig, StairError, check, lib
 
 VAL_STR, VAL_VEC, VAL_MAP, VAL_ATT, VAL_FRAME, VAL_PAIR = range(6)
+RUN_INDEX_RESIDENT, RUN_VIDEO_BF16 = 1, 2          # stair_plan_run_flags / stair_plan_backward flags (include/stair_hip.h)
 
 
 class L2Normalize(nn.Module):
@@ -112,10 +113,11 @@ class BatchResult:
         ops._req(answers, 'answers', torch.int32)
         loss = torch.empty(self.info.n_questions, dtype=torch.float32, device=answers.device)
         self._model._bind_grads()
+        flags = (1 if keep_arenas else 0) | (RUN_VIDEO_BF16 if self._video.dtype == torch.bfloat16 else 0)
         check(lib.stair_plan_backward(self._model._ctx, self._plan, C.c_void_p(self._video.data_ptr()),
                                       C.c_void_p(self._question.data_ptr()), C.c_void_p(self._ws.data_ptr()),
                                       self._ws.numel() * 4, C.c_void_p(answers.data_ptr()), C.c_float(loss_scale),
-                                      C.c_void_p(loss.data_ptr()), 1 if keep_arenas else 0,
+                                      C.c_void_p(loss.data_ptr()), flags,
                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         return loss
 
@@ -212,7 +214,9 @@ class CapturedPlan:
         check(lib.stair_plan_run_flags(res._model._ctx, res._plan, C.c_void_p(res._video.data_ptr()),
                                        C.c_void_p(res._question.data_ptr()), C.c_void_p(self._ws.data_ptr()),
                                        self._ws.numel() * 4, C.c_void_p(self.logits.data_ptr()),
-                                       C.c_void_p(self.pred.data_ptr()), 1, C.c_void_p(stream.cuda_stream)))
+                                       C.c_void_p(self.pred.data_ptr()),
+                                       RUN_INDEX_RESIDENT | (RUN_VIDEO_BF16 if res._video.dtype == torch.bfloat16 else 0),
+                                       C.c_void_p(stream.cuda_stream)))
 
     def replay(self):
         self.graph.replay()
@@ -321,7 +325,12 @@ class VideoNMN(nn.Module):
                 raise ValueError('video must be [n_videos, T, V] and video_index must point into it')
         elif video.dim() != 3 or video.shape[0] != n:
             raise ValueError('video must be [n, T, V]')
-        ops._req(video, 'video'); ops._req(question, 'question')
+        # clip features: fp32, or the stored bf16 format of BASELINE.json configs[1] (video.dtype == torch.bfloat16): the
+        # input projection of the video encoder then runs on the bf16 rows directly (two MFMA products per operand pair)
+        ops._req(video, 'video', torch.bfloat16 if video.dtype == torch.bfloat16 else torch.float32)
+        ops._req(question, 'question')
+        if video.dtype == torch.bfloat16 and self.config['video_size'] % 32:
+            raise ValueError('bf16 clip features need video_size % 32 == 0')
         T = video.shape[1]
         self._bind_weights()
         cache = self._programs
@@ -347,9 +356,10 @@ class VideoNMN(nn.Module):
             A = self.config['answer_vocab_length']
             logits = torch.empty(n, A, dtype=torch.float32, device=video.device)
             pred = torch.empty(n, dtype=torch.int32, device=video.device)
-            check(lib.stair_plan_run(self._ctx, plan, C.c_void_p(video.data_ptr()), C.c_void_p(question.data_ptr()),
-                                     C.c_void_p(ws.data_ptr()), ws.numel() * 4, C.c_void_p(logits.data_ptr()),
-                                     C.c_void_p(pred.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            check(lib.stair_plan_run_flags(self._ctx, plan, C.c_void_p(video.data_ptr()), C.c_void_p(question.data_ptr()),
+                                           C.c_void_p(ws.data_ptr()), ws.numel() * 4, C.c_void_p(logits.data_ptr()),
+                                           C.c_void_p(pred.data_ptr()), RUN_VIDEO_BF16 if video.dtype == torch.bfloat16 else 0,
+                                           C.c_void_p(torch.cuda.current_stream().cuda_stream)))
             if train:       # a training plan keeps its logits inside the workspace for the backward pass
                 logits = ws[info.logits_off: info.logits_off + n * A].view(n, A)
         except Exception:
@@ -379,7 +389,10 @@ class VideoNMN(nn.Module):
                 index = None
         else:
             clips = [d['video_features'] for d in batch]
-        video = torch.stack([torch.as_tensor(c) for c in clips]).to(dev, torch.float32).contiguous()
+        clips = [torch.as_tensor(c) for c in clips]
+        # clips stored as bf16 (data.load_clip_features(..., dtype='bf16')) stay bf16 on the device
+        vdtype = torch.bfloat16 if all(c.dtype == torch.bfloat16 for c in clips) else torch.float32
+        video = torch.stack(clips).to(dev, vdtype).contiguous()
         qs = [torch.as_tensor(d['question']) for d in batch]
         question = torch.cat(qs).to(dev, torch.float32).contiguous()
         return self.run_programs([d['nmn_program_list'] for d in batch],

@@ -10,7 +10,7 @@ import ctypes as C
 
 import torch
 
-from ._lib import GemmArgs, GemmTnArgs, LstmArgs, LstmBwdArgs, check, lib
+from ._lib import GemmArgs, GemmPlanesArgs, GemmTnArgs, LstmArgs, LstmBwdArgs, check, lib
 
 ACT = {None: 0, 'none': 0, 'relu': 1, 'sigmoid': 2}
 MATMUL_MODES = {'f32': 0, 'bf16x3': 1, 'bf16': 2}
@@ -85,12 +85,59 @@ def gemm_grouped(A, a_gstride, a_gidx, W, bias, Cmat, c_gstride, c_gidx, groups,
     check(lib.stair_gemm_f32(C.byref(a), _stream()))
 
 
+def split_planes(x, lo=True):
+    """fp32 tensor -> (hi, lo) bf16 planes with x = hi + lo + O(2^-17 |x|) (stair_split_planes); lo=False: hi only,
+    i.e. plain round-to-nearest-even bf16 (the stored clip-feature format of BASELINE.json configs[1])."""
+    _req(x, 'x')
+    if x.numel() % 8:
+        raise ValueError('element count must be a multiple of 8')
+    hi = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+    lo_t = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16) if lo else None
+    check(lib.stair_split_planes(_ptr(x), _ptr(hi), _ptr(lo_t), x.numel(), _stream()))
+    return (hi, lo_t) if lo else hi
+
+
+def split_planes_tiled(w):
+    """[N, K] fp32 weight -> (hi, lo) bf16 planes in the tiled layout [K/32, N, 32] (stair_split_planes_tiled)."""
+    _req(w, 'w')
+    N, K = w.shape
+    if K % 32:
+        raise ValueError('K must be a multiple of 32')
+    hi = torch.empty(K // 32, N, 32, device=w.device, dtype=torch.bfloat16)
+    lo = torch.empty_like(hi)
+    check(lib.stair_split_planes_tiled(_ptr(w), _ptr(hi), _ptr(lo), N, K, _stream()))
+    return hi, lo
+
+
+def gemm_planes(a_hi, a_lo, w_hi, w_lo, bias=None, act=None, out=None):
+    """act((a_hi + a_lo) @ (w_hi + w_lo).T + bias) on bf16 planes staged by LDS-DMA (stair_gemm_planes).
+    a_hi [M,K] bf16, a_lo None (A exact in bf16: two MFMA products per pair) or [M,K]; w_hi, w_lo [N,K]."""
+    _req(a_hi, 'a_hi', torch.bfloat16); _req(w_hi, 'w_hi', torch.bfloat16); _req(w_lo, 'w_lo', torch.bfloat16)
+    if a_lo is not None:
+        _req(a_lo, 'a_lo', torch.bfloat16)
+    M, K = a_hi.shape
+    tiled = w_hi.dim() == 3
+    N = w_hi.shape[1] if tiled else w_hi.shape[0]
+    assert w_hi.shape == w_lo.shape == ((K // 32, N, 32) if tiled else (N, K))
+    if out is None:
+        out = torch.empty(M, N, device=a_hi.device, dtype=torch.float32)
+    a = GemmPlanesArgs()
+    a.A_hi, a.A_lo, a.lda = a_hi.data_ptr(), (a_lo.data_ptr() if a_lo is not None else None), K
+    a.W_hi, a.W_lo, a.ldw = w_hi.data_ptr(), w_lo.data_ptr(), K
+    a.bias = bias.data_ptr() if bias is not None else None
+    a.C, a.ldc = out.data_ptr(), out.stride(0)
+    a.M, a.N, a.K, a.act, a.w_tiled = M, N, K, ACT[act], 1 if tiled else 0
+    check(lib.stair_gemm_planes(C.byref(a), _stream()))
+    return out
+
+
 def gemm_tn(A, B, Cmat, M, N, K, rows_per_group=1, b_gstride=None, b_gidx=None, row_scale=None, rs_gstride=0,
             rs_gidx=None, colsum=None, colsum2=None):
     """Cmat[N,K] += A[M,N]^T @ (rs * B[M,K]) -- weight gradients (see stair_gemm_tn_args); colsum[N] (and
     colsum2) += column sums of A, the bias gradient of the same layer."""
     a = GemmTnArgs()
     a.A, a.lda = A.data_ptr(), N
+    a.b_is_bf16 = 1 if B.dtype == torch.bfloat16 else 0        # stored clip features: exact bf16 rows, two products per pair
     a.B, a.ldb, a.b_gstride = B.data_ptr(), K, (b_gstride if b_gstride is not None else K * rows_per_group)
     a.b_gidx = b_gidx.data_ptr() if b_gidx is not None else None
     a.row_scale = row_scale.data_ptr() if row_scale is not None else None
@@ -108,7 +155,8 @@ def lstm_bidir(x, seq_off, max_len, weights, save=False):
     x [rows, I]; seq_off int32 [n+1] (device); weights = (w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r).
     Returns (out [rows, 2*Hh], h_n [n, 2*Hh]); with save=True also (gates, cbuf) for lstm_bidir_bwd.
     """
-    _req(x, 'x'); _req(seq_off, 'seq_off', torch.int32)
+    bf = x.dtype == torch.bfloat16           # stored bf16 input rows (clip features): plane GEMM input projection
+    _req(x, 'x', torch.bfloat16 if bf else torch.float32); _req(seq_off, 'seq_off', torch.int32)
     for w in weights:
         _req(w, 'lstm weight')
     rows, I = x.shape
@@ -120,7 +168,10 @@ def lstm_bidir(x, seq_off, max_len, weights, save=False):
     bias_ws = torch.empty(8 * Hh, device=x.device, dtype=torch.float32)
     pack_ws = torch.empty(8 * Hh * Hh, device=x.device, dtype=torch.float32)
     a = LstmArgs()
-    a.x, a.ldx, a.rows, a.n, a.max_len, a.I, a.Hh = x.data_ptr(), I, rows, n, max_len, I, Hh
+    a.x, a.ldx, a.rows, a.n, a.max_len, a.I, a.Hh = (None if bf else x.data_ptr()), I, rows, n, max_len, I, Hh
+    if bf:
+        planes = torch.empty(2 * 8 * Hh * I, device=x.device, dtype=torch.bfloat16)
+        a.x_bf16, a.wih_planes_ws = x.data_ptr(), planes.data_ptr()
     a.seq_off = seq_off.data_ptr()
     for d in range(2):
         a.w_ih[d], a.w_hh[d] = weights[4 * d].data_ptr(), weights[4 * d + 1].data_ptr()
@@ -141,7 +192,10 @@ def lstm_bidir_bwd(x, seq_off, max_len, weights, out, gates, cbuf, d_out, d_hn=N
     Hh = weights[1].shape[1]
     grads = [torch.zeros_like(w) for w in weights]
     a = LstmBwdArgs()
-    a.x, a.ldx, a.rows, a.n, a.max_len, a.I, a.Hh = x.data_ptr(), I, rows, n, max_len, I, Hh
+    bf = x.dtype == torch.bfloat16
+    a.x, a.ldx, a.rows, a.n, a.max_len, a.I, a.Hh = (None if bf else x.data_ptr()), I, rows, n, max_len, I, Hh
+    if bf:
+        a.x_bf16 = x.data_ptr()
     a.seq_off = seq_off.data_ptr()
     pack_ws = torch.empty(8 * Hh * Hh, device=x.device, dtype=torch.float32)
     hprev = torch.empty(rows, 2 * Hh, device=x.device, dtype=torch.float32)
