@@ -190,7 +190,13 @@ typedef struct stair_lstm_args {
                     exact in bf16, W_ih split once into hi/lo planes, two MFMA products per pair); needs I % 32 == 0 and a
                     split matmul mode. */
     void *wih_planes_ws; /* scratch for the W_ih planes when x_bf16 is set: 2 planes x [8*Hh, I] bf16 = 32*Hh*I bytes */
+    void *coop_ws; int64_t coop_ws_bytes; /* optional scratch (>= stair_lstm_coop_ws_bytes(n), 256-byte aligned) for the
+                    cooperative recurrence (csrc/lstm_coop.hip: Hh = 256, split matmul modes): hidden units split over groups
+                    of 4 co-resident workgroups that exchange h every step, W_hh resident in registers.  NULL = the
+                    one-workgroup-per-16-sequences kernel.  The launch occupies up to one workgroup on every CU and its
+                    workgroups wait for each other: do not run two of them concurrently on different streams. */
 } stair_lstm_args;
+int64_t stair_lstm_coop_ws_bytes(int32_t n);
 int stair_lstm_bidir_fwd(const stair_lstm_args *args, stair_stream stream);
 
 /* Backward through time of the same layer (autograd of nn.LSTM in train_module.py:408).  gates = the

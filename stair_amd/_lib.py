@@ -58,7 +58,7 @@ class LstmArgs(C.Structure):
                 ('w_ih', C.c_void_p * 2), ('w_hh', C.c_void_p * 2), ('b_ih', C.c_void_p * 2), ('b_hh', C.c_void_p * 2),
                 ('xproj_ws', C.c_void_p), ('bias_ws', C.c_void_p), ('whh_pack_ws', C.c_void_p),
                 ('out', C.c_void_p), ('ldo', C.c_int64), ('h_n', C.c_void_p), ('cbuf', C.c_void_p),
-                ('x_bf16', C.c_void_p), ('wih_planes_ws', C.c_void_p)]
+                ('x_bf16', C.c_void_p), ('wih_planes_ws', C.c_void_p), ('coop_ws', C.c_void_p), ('coop_ws_bytes', C.c_int64)]
 
 
 class LstmBwdArgs(C.Structure):
@@ -100,6 +100,7 @@ SIGNATURES = [
     ('stair_split_planes', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     ('stair_split_planes_tiled', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     ('stair_gemm_planes', C.c_int, [C.POINTER(GemmPlanesArgs), C.c_void_p]),
+    ('stair_lstm_coop_ws_bytes', C.c_int64, [C.c_int32]),
     ('stair_lstm_bidir_fwd', C.c_int, [C.POINTER(LstmArgs), C.c_void_p]),
     ('stair_lstm_bidir_bwd', C.c_int, [C.POINTER(LstmBwdArgs), C.c_void_p]),
     ('stair_cosine_attn_fwd', C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

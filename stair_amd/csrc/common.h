@@ -43,8 +43,13 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 __device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
 // fast forms for the LSTM cell (absolute error ~1e-7, far inside the 1e-4 logit budget)
-__device__ __forceinline__ float sigmoid_fast(float x) { return __frcp_rn(1.0f + __expf(-x)); }
-__device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
+// (v_exp_f32 and v_rcp_f32 are 1-ulp instructions; __frcp_rn would expand to a 12-instruction IEEE division)
+__device__ __forceinline__ float sigmoid_fast(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float tanh_fast(float x) {
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+}
 
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
@@ -52,6 +57,9 @@ static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * 
 int launch_gemm(const stair_gemm_args &a, hipStream_t s);
 int launch_lstm(const stair_lstm_args &a, hipStream_t s);
 int launch_lstm_bwd(const stair_lstm_bwd_args &a, hipStream_t s);
+int launch_lstm_rec_coop(const stair_lstm_args &a, hipStream_t s);
+bool lstm_coop_usable(int Hh);
+int64_t lstm_coop_ws_bytes(int n);
 int launch_gemm_bf16x3(const stair_gemm_args &a, hipStream_t s);
 int launch_gemm_tn_bf16x3(const stair_gemm_tn_args &a, hipStream_t s);
 int matmul_mode();

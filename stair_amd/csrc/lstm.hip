@@ -817,6 +817,7 @@ int launch_lstm(const stair_lstm_args &a, hipStream_t s) {
         if (int rc = launch_gemm(g, s)) return rc;
     }
     STAIR_CHECK(a.whh_pack_ws != nullptr, "whh_pack_ws missing");
+    if (a.coop_ws && lstm_coop_usable(Hh)) return launch_lstm_rec_coop(a, s);   // hidden units split over co-resident workgroups
     const bool split = matmul_mode() != STAIR_MATMUL_F32 && Hh % 64 == 0;     // the split kernel walks k blocks in pairs
     if (split) {
         const int64_t n8 = 2 * 8 * (int64_t)Hh * Hh / 8;

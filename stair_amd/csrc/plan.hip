@@ -221,9 +221,10 @@ struct stair_plan {
     int64_t off_seqv = 0, off_seqt = 0, off_roots = 0;
     int n_vec = 0, n_map = 0, n_att = 0;
     int maxI = 0, maxV = 0, maxK = 0, maxSupRows = 0, n_levels = 0;
+    int64_t coop_bytes = 0;
     // workspace layout (float offsets)
     int64_t o_idx = 0, o_vec = 0, o_map = 0, o_att = 0, o_tok = 0, o_qfeat = 0, o_vhn = 0, o_xpv = 0, o_xpt = 0,
-            o_bias = 0, o_wpack = 0, o_wplanes = 0, o_splitk = 0, o_tmpA = 0, o_tmpB = 0, o_kbuf = 0, o_cat = 0, o_hid = 0, o_rs = 0, o_sup = 0, o_extra = 0,
+            o_bias = 0, o_wpack = 0, o_wplanes = 0, o_coop = 0, o_splitk = 0, o_tmpA = 0, o_tmpB = 0, o_kbuf = 0, o_cat = 0, o_hid = 0, o_rs = 0, o_sup = 0, o_extra = 0,
             o_logits = 0, total = 0;
     // training only
     bool train = false;
@@ -581,6 +582,8 @@ extern "C" int stair_plan_build_shared(stair_ctx *ctx, int32_t n, const int32_t 
     pl->o_bias = take(2 * 4 * H, 64);
     pl->o_wpack = take(2 * 2 * H * H, 64);       // 8*Hh*Hh floats per encoder
     pl->o_wplanes = ctx->cfg.video_size % 32 == 0 ? take(4 * H * ctx->cfg.video_size, 64) : 0;   // video W_ih hi/lo planes (bf16 features): 2 x [4H, V] bf16
+    pl->coop_bytes = lstm_coop_usable((int)(H / 2)) || true ? std::max(lstm_coop_ws_bytes(pl->n_vid), lstm_coop_ws_bytes(n)) : 0;
+    pl->o_coop = take((pl->coop_bytes + 3) / 4, 64);   // h exchange slabs + flags of the cooperative recurrence (both encoders, in turn)
     pl->o_splitk = take(kSplitKFloats, 64);      // partial sums of split-K launches (<= 64 output tiles x 16 pieces)
     pl->o_tmpA = take((int64_t)std::max(pl->maxI, 1) * T * H, 64);
     pl->o_tmpB = take((int64_t)std::max(pl->maxI, 1) * T * H, 64);
@@ -875,6 +878,7 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
         }
         a.xproj_ws = ws + pl->o_xpv; a.bias_ws = ws + pl->o_bias; a.whh_pack_ws = ws + pl->o_wpack;
         a.out = map; a.ldo = H; a.h_n = ws + pl->o_vhn;
+        a.coop_ws = ws + pl->o_coop; a.coop_ws_bytes = pl->coop_bytes;
         a.cbuf = pl->train ? ws + pl->o_cv : nullptr;
         RUN(launch_lstm(a, s));
     }
@@ -888,6 +892,7 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
         }
         a.xproj_ws = ws + pl->o_xpt; a.bias_ws = ws + pl->o_bias + 4 * H; a.whh_pack_ws = ws + pl->o_wpack + 2 * (int64_t)H * H;
         a.out = tok; a.ldo = H; a.h_n = qfeat;
+        a.coop_ws = ws + pl->o_coop; a.coop_ws_bytes = pl->coop_bytes;
         a.cbuf = pl->train ? ws + pl->o_ct : nullptr;
         RUN(launch_lstm(a, s));
     }
@@ -1353,6 +1358,7 @@ extern "C" int stair_plan_regions(stair_plan *pl, const stair_ctx *ctx, const ch
     add("bias", pl->o_bias, 8 * H);
     add("wpack", pl->o_wpack, 4 * H * H);
     if (ctx->cfg.video_size % 32 == 0) add("wplanes", pl->o_wplanes, 4 * H * ctx->cfg.video_size);
+    add("coop", pl->o_coop, (pl->coop_bytes + 3) / 4);
     add("splitk", pl->o_splitk, kSplitKFloats);
     add("tmpA", pl->o_tmpA, (int64_t)std::max(pl->maxI, 1) * T * H);
     add("tmpB", pl->o_tmpB, (int64_t)std::max(pl->maxI, 1) * T * H);

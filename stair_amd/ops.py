@@ -149,7 +149,7 @@ def gemm_tn(A, B, Cmat, M, N, K, rows_per_group=1, b_gstride=None, b_gidx=None, 
     check(lib.stair_gemm_tn_f32(C.byref(a), _stream()))
 
 
-def lstm_bidir(x, seq_off, max_len, weights, save=False):
+def lstm_bidir(x, seq_off, max_len, weights, save=False, coop=True):
     """Bidirectional LSTM over packed ragged sequences.
 
     x [rows, I]; seq_off int32 [n+1] (device); weights = (w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r).
@@ -173,6 +173,9 @@ def lstm_bidir(x, seq_off, max_len, weights, save=False):
         planes = torch.empty(2 * 8 * Hh * I, device=x.device, dtype=torch.bfloat16)
         a.x_bf16, a.wih_planes_ws = x.data_ptr(), planes.data_ptr()
     a.seq_off = seq_off.data_ptr()
+    if coop and Hh == 256:       # scratch for the cooperative recurrence (hidden units split over co-resident workgroups)
+        coop_ws = torch.empty(int(lib.stair_lstm_coop_ws_bytes(n)), device=x.device, dtype=torch.uint8)
+        a.coop_ws, a.coop_ws_bytes = coop_ws.data_ptr(), coop_ws.numel()
     for d in range(2):
         a.w_ih[d], a.w_hh[d] = weights[4 * d].data_ptr(), weights[4 * d + 1].data_ptr()
         a.b_ih[d], a.b_hh[d] = weights[4 * d + 2].data_ptr(), weights[4 * d + 3].data_ptr()

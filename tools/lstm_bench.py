@@ -30,3 +30,34 @@ for _ in range(a.iters):
     ops.lstm_bidir(x, off, a.T, ws)
 e1.record(); torch.cuda.synchronize()
 print('lstm_bidir n=%d T=%d V=%d Hh=%d: %.3f ms per call (input proj + recurrence)' % (a.n, a.T, a.V, a.Hh, e0.elapsed_time(e1) / a.iters))
+
+if os.environ.get('STAIR_LSTM_COOP_PROF') == '1':
+    # diagnostic build: re-run once with our own scratch so the phase sums (cycles of wave 0, workgroup 0) can be read back
+    from stair_amd._lib import LstmArgs, lib, check
+    import ctypes as C
+    rows, I = x.shape
+    out = torch.empty(rows, 2 * a.Hh, device=dev); h_n = torch.empty(a.n, 2 * a.Hh, device=dev)
+    xproj = torch.empty(rows, 8 * a.Hh, device=dev); bias_ws = torch.empty(8 * a.Hh, device=dev); pack = torch.empty(8 * a.Hh * a.Hh, device=dev)
+    nb = int(lib.stair_lstm_coop_ws_bytes(a.n)); coop = torch.zeros(nb, device=dev, dtype=torch.uint8)
+    A = LstmArgs()
+    A.x, A.ldx, A.rows, A.n, A.max_len, A.I, A.Hh = x.data_ptr(), I, rows, a.n, a.T, I, a.Hh
+    A.seq_off = off.data_ptr()
+    for d in range(2):
+        A.w_ih[d], A.w_hh[d], A.b_ih[d], A.b_hh[d] = (ws[4 * d + i].data_ptr() for i in range(4))
+    A.xproj_ws, A.bias_ws, A.whh_pack_ws = xproj.data_ptr(), bias_ws.data_ptr(), pack.data_ptr()
+    A.out, A.ldo, A.h_n = out.data_ptr(), 2 * a.Hh, h_n.data_ptr()
+    A.coop_ws, A.coop_ws_bytes = coop.data_ptr(), nb
+    check(lib.stair_lstm_bidir_fwd(C.byref(A), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    import numpy as np
+    raw = coop.cpu().numpy()
+    # the flag block follows the slabs; err word + 8 words in, 8 uint64 sums.  Geometry mirrors coop_geometry().
+    nt = int(os.environ.get('STAIR_LSTM_COOP_TILES', '0')) or (3 if a.n > 2048 else (2 if a.n > 32 else 1))
+    gpd = max(1, min((a.n + 32 * nt - 1) // (32 * nt), 32)); G = 2 * gpd
+    base = 2 * G * nt * 32768 + (G * nt * 4 * 16) * 4
+    sums = raw[base + 32: base + 32 + 64].view(np.uint64)
+    names = ['xproj issue + MFMA chain', 'vmcnt(0)', 'mid barrier', 'flag/peek/cell/out stores', 'publish', 'slab wait + ds_write', 'land barrier', 'poll + slab issue']
+    tot = float(sums.sum())
+    print('phase cycles of wave 0 / workgroup 0 (err word %d):' % int(raw[base: base + 4].view(np.uint32)[0]))
+    for nme, v in zip(names, sums):
+        print('  %-28s %12d  %5.1f %%' % (nme, int(v), 100.0 * float(v) / max(tot, 1.0)))
