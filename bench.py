@@ -175,7 +175,7 @@ def main():
     trainer = None
     if args.mode == 'train':
         from stair_amd.train import Trainer
-        trainer = Trainer(model, world=world, rank=rank)
+        trainer = Trainer(model, world=world, rank=rank, dropout=args.dropout)
 
     def step():
         if trainer is not None:

@@ -288,6 +288,11 @@ int stair_plan_get_info(const stair_plan *plan, stair_plan_info *info);
 int stair_plan_node(const stair_plan *plan, int32_t tok, int32_t *kind, int32_t *slot, int32_t *aux,
                     int32_t *level, int32_t *rel_slot);
 
+/* The same for every token at once: host arrays of stair_plan_info.n_nodes int32 (any may be NULL).  What a loss driver
+ * needs to address the supervised nodes of a whole batch without one call per node. */
+int stair_plan_nodes(const stair_plan *plan, int32_t *kind, int32_t *slot, int32_t *aux, int32_t *level,
+                     int32_t *rel_slot, int32_t count);
+
 /* Run the whole path for the batch: encode_video, encode_question, every program level, decoder,
  * argmax.  video [n,T,V], question [q_off[n],E] device fp32; logits [n,A]; argmax [n] int32
  * (either may be NULL).  Everything is enqueued on `stream`. */

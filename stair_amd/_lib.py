@@ -133,6 +133,7 @@ SIGNATURES = [
     ('stair_plan_destroy', None, [C.c_void_p]),
     ('stair_plan_get_info', C.c_int, [C.c_void_p, C.POINTER(PlanInfo)]),
     ('stair_plan_node', C.c_int, [C.c_void_p, C.c_int32, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p]),
+    ('stair_plan_nodes', C.c_int, [C.c_void_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p, C.c_int32]),
     ('stair_plan_run', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                  C.c_void_p, C.c_void_p]),
     ('stair_dropout_fwd', C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_uint32,

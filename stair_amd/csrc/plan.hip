@@ -685,6 +685,22 @@ extern "C" int stair_plan_node(const stair_plan *pl, int32_t tok, int32_t *kind,
     return 0;
 }
 
+// the whole node table in one call (host arrays of n_nodes int32 each; any of them may be NULL)
+extern "C" int stair_plan_nodes(const stair_plan *pl, int32_t *kind, int32_t *slot, int32_t *aux, int32_t *level, int32_t *rel_slot,
+                                int32_t count) {
+    STAIR_CHECK(pl, "null plan");
+    STAIR_CHECK(count == (int32_t)pl->nodes.size(), "count must equal stair_plan_info.n_nodes");
+    for (int32_t i = 0; i < count; ++i) {
+        const Node &nd = pl->nodes[i];
+        if (kind) kind[i] = nd.kind;
+        if (slot) slot[i] = nd.slot;
+        if (aux) aux[i] = nd.aux;
+        if (level) level[i] = nd.level;
+        if (rel_slot) rel_slot[i] = nd.rel;
+    }
+    return 0;
+}
+
 // =============================================================================================
 // runner
 // =============================================================================================

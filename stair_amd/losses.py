@@ -98,98 +98,171 @@ def supervised_nodes(question, pretrain_modules):
     return out
 
 
+class GoldPack:
+    """The supervised nodes of ONE question in array form -- what a data-loader worker prepares once per question (the
+    reference does the equivalent in AGQADataset.__getitem__, dataset.py:200-221, inside its DataLoader workers), so
+    that the training loop only concatenates arrays.  Token positions are relative to the question's program.
+      att_pos / att_kind (0 Localize: K rows at the node's slot, 1 Temporal: the related_attn row, 2 ExistsFrame) /
+      att_iv [n, 2, 2] float64 gold (start, end) intervals (row 1 only for Localize with two keywords) / att_mod
+      head[module] = (pos, label)                      Exists, Xor (2-way CE), Equals (MSE)
+      cont = [(pos, module, [(class_name, emb)])]     Filter, ToAction, Superlative
+      ff = [(pos, {entity: (start, end)})]             FilterFrame"""
+    __slots__ = ('att_pos', 'att_kind', 'att_iv', 'att_mod', 'head', 'cont', 'ff')
+
+    def __init__(self, question, pretrain_modules, no_intermediate):
+        sg = question.get('sg_res_by_step') or {}
+        prog = question['nmn_program_list']
+        ap, ak, aiv, am = [], [], [], []
+        self.head, self.cont, self.ff = {}, [], []
+        if sg:
+            for step, i in supervised_nodes(question, pretrain_modules).items():
+                module = prog[i]
+                if step not in sg or module in no_intermediate or module == 'decoder' or sg[step] is None:
+                    continue
+                gold = sg[step]
+                if module == 'Localize':
+                    iv = [tuple(map(float, g)) for g in gold][:2]
+                    ap.append(i); ak.append(0); aiv.append(iv + [(0.0, 0.0)] * (2 - len(iv))); am.append(module)
+                elif module in ('Temporal', 'ExistsFrame'):
+                    ap.append(i); ak.append(1 if module == 'Temporal' else 2)
+                    aiv.append([tuple(map(float, gold)), (0.0, 0.0)]); am.append(module)
+                elif module in ('Exists', 'Xor', 'Equals'):
+                    h = self.head.setdefault(module, ([], []))
+                    h[0].append(i); h[1].append(int(bool(gold)))
+                elif module in CONTRASTIVE:
+                    self.cont.append((i, module, list(gold)))
+                elif module == 'FilterFrame':
+                    self.ff.append((i, gold))
+                else:
+                    raise NotImplementedError('intermediate loss for %s' % module)
+        self.att_pos = np.asarray(ap, dtype=np.int64)
+        self.att_kind = np.asarray(ak, dtype=np.int64)
+        self.att_iv = np.asarray(aiv, dtype=np.float64).reshape(-1, 2, 2)
+        self.att_mod = am
+        self.head = {m: (np.asarray(p, dtype=np.int64), np.asarray(l, dtype=np.int32)) for m, (p, l) in self.head.items()}
+
+
+def compile_gold(question, pretrain_modules=CRITERION_MODULES, no_intermediate=('FilterFrame',)):
+    """GoldPack of a question, cached on the dict (key '_gold_pack') as long as its sg_res_by_step object is the same."""
+    key = (id(question.get('sg_res_by_step')), frozenset(pretrain_modules), tuple(no_intermediate))
+    hit = question.get('_gold_pack')
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    pack = GoldPack(question, pretrain_modules, no_intermediate)
+    question['_gold_pack'] = (key, pack)
+    return pack
+
+
+def contrastive_windows(entries, window, world=1):
+    """The class pools of train_module.py:386-402 over the GLOBAL accumulation window.
+    entries: [(global question position, class_name, embedding)] of this rank's contrastive golds; with world > 1 every
+    rank contributes its entries (all_gather_object: a few KB of host data) and builds the same table, so that a
+    data-parallel step pools exactly the classes the single-process window of the reference pools.
+    Returns ({window id: {class_name: row}}, [embedding per row], {window id: (first row, count)})."""
+    if world > 1:
+        import torch.distributed as dist
+        gathered = [None] * world
+        dist.all_gather_object(gathered, [(g, n, np.asarray(e, dtype=np.float32)) for g, n, e in entries])
+        entries = [t for part in gathered for t in part]
+    pools = {}
+    for gpos, name, emb in sorted(entries, key=lambda t: (t[0], t[1])):
+        pools.setdefault(gpos // window if window else 0, {}).setdefault(name, emb)
+    table, embs, rng = {}, [], {}
+    for wid in sorted(pools):
+        start = len(embs)
+        table[wid] = {}
+        for name, emb in pools[wid].items():
+            table[wid][name] = len(embs)
+            embs.append(torch.as_tensor(np.asarray(emb), dtype=torch.float32))
+        rng[wid] = (start, len(embs) - start)
+    return table, embs, rng
+
+
 def apply_module_losses(model, res, questions, scale, pretrain_modules=CRITERION_MODULES,
-                        no_intermediate=('FilterFrame',), window=32):
+                        no_intermediate=('FilterFrame',), window=32, world=1, rank=0, window_base=0):
     """Evaluate every intermediate loss of the batch and add scale * gradient into res's gradient arenas
     (call res.zero_grad_arenas() first and res.backward(..., keep_arenas=True) afterwards).
+    Local question i sits at global position window_base + rank + i * world of the accumulation window (the round-robin
+    sharding of Trainer.step); contrastive classes are pooled per `window` GLOBAL questions (contrastive_windows).
     Returns ({loss_kind: per-item losses tensor}, set of extra parameter names that received a gradient)."""
     dev = res.logits.device
     H, T = model.config['hidden_size'], res.info.T
-    att_items, head_items, cont_items, ff_items = [], {'Exists': [], 'Xor': [], 'Equals': []}, [], []
-    windows = {}                      # window id -> {class_name: embedding}
-    for qi, q in enumerate(questions):
-        sg = q.get('sg_res_by_step') or {}
-        if not sg:
-            continue
-        prog = q['nmn_program_list']
-        for step, i in supervised_nodes(q, pretrain_modules).items():
-            module = prog[i]
-            if step not in sg or module in no_intermediate or module == 'decoder' or sg[step] is None:
-                continue
-            gold = sg[step]
-            kind, slot, aux, _, rel = res.node_info(qi, i)
-            if module == 'Localize':
-                att_items.append((slot, aux, [tuple(map(float, gold[r])) for r in range(aux)]))
-            elif module == 'Temporal':
-                att_items.append((rel, 1, [tuple(map(float, gold))]))
-            elif module == 'ExistsFrame':
-                att_items.append((slot, 1, [tuple(map(float, gold))]))
-            elif module in head_items:
-                head_items[module].append((slot, int(bool(gold))))
-            elif module in CONTRASTIVE:
-                w = windows.setdefault(qi // window if window else 0, {})
-                for class_name, emb in gold:
-                    w[class_name] = emb
-                    cont_items.append((slot, qi // window if window else 0, class_name))
-            elif module == 'FilterFrame':
-                ff_items.append((slot, gold))
-            else:
-                raise NotImplementedError('intermediate loss for %s' % module)
+    _, slot_t, aux_t, _, rel_t = res.node_table()
+    base = np.asarray(res._prog_off, dtype=np.int64)
+    packs = [compile_gold(q, pretrain_modules, no_intermediate) for q in questions]
 
     losses, touched = {}, set()
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     vec, gvec = res._arena(res.info.vec_off, res.info.n_vec, H), res.grad_arena('vec')
     att, gatt = res._arena(res.info.att_off, res.info.n_att, T), res.grad_arena('att')
-    i32 = lambda a: torch.tensor(a, dtype=torch.int32, device=dev)
+    i32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32)).to(dev, non_blocking=True)
 
-    if att_items:
-        slot = i32([a[0] for a in att_items]); K = i32([a[1] for a in att_items])
-        off = i32(np.concatenate([[0], np.cumsum([a[1] for a in att_items])]).tolist())
-        iv = torch.tensor([p for a in att_items for p in a[2]], dtype=torch.float64, device=dev)
-        out = torch.empty(len(att_items), device=dev)
-        check(lib.stair_loss_attention(C.c_void_p(att.data_ptr()), C.c_void_p(gatt.data_ptr()), C.c_void_p(slot.data_ptr()),
-                                       C.c_void_p(K.data_ptr()), C.c_void_p(off.data_ptr()), C.c_void_p(iv.data_ptr()),
-                                       len(att_items), T, C.c_float(scale), C.c_void_p(out.data_ptr()), stream))
+    # ---- attention criteria (Localize / Temporal / ExistsFrame) ----
+    sel = [qi for qi, p in enumerate(packs) if p.att_pos.size]
+    if sel:
+        tok = np.concatenate([packs[qi].att_pos + base[qi] for qi in sel])
+        kind = np.concatenate([packs[qi].att_kind for qi in sel])
+        iv = np.concatenate([packs[qi].att_iv for qi in sel])                    # [n, 2, 2]
+        slot = np.where(kind == 1, rel_t[tok], slot_t[tok])
+        K = np.where(kind == 0, aux_t[tok], 1).astype(np.int64)
+        off = np.concatenate([[0], np.cumsum(K)])
+        rows = np.concatenate([iv[:, 0][:, None, :], iv[:, 1][:, None, :]], axis=1)   # [n, 2, 2]
+        keep = np.arange(2)[None, :] < K[:, None]
+        ivf = torch.as_tensor(np.ascontiguousarray(rows[keep])).to(dev)             # [sum K, 2] float64
+        slot_d, K_d, off_d = i32(slot), i32(K), i32(off)
+        out = torch.empty(len(tok), device=dev)
+        check(lib.stair_loss_attention(C.c_void_p(att.data_ptr()), C.c_void_p(gatt.data_ptr()), C.c_void_p(slot_d.data_ptr()),
+                                       C.c_void_p(K_d.data_ptr()), C.c_void_p(off_d.data_ptr()), C.c_void_p(ivf.data_ptr()),
+                                       len(tok), T, C.c_float(scale), C.c_void_p(out.data_ptr()), stream))
         losses['attention'] = out
-    for module, items in head_items.items():
-        if not items:
+    # ---- linear heads (Exists / Xor / Equals) ----
+    for module in ('Exists', 'Xor', 'Equals'):
+        sel = [qi for qi, p in enumerate(packs) if module in p.head]
+        if not sel:
             continue
         if not model.config['have_pretrain_head']:
             raise RuntimeError('%s loss needs have_pretrain_head (modules.py)' % module)
         head = model.submodules[module].pretrain_head
         if head.weight.grad is None:
             raise RuntimeError('pretrain head of %s has no .grad buffer (use stair_amd.train.Trainer)' % module)
-        slot = i32([a[0] for a in items]); lab = i32([a[1] for a in items])
-        out = torch.empty(len(items), device=dev)
+        tok = np.concatenate([packs[qi].head[module][0] + base[qi] for qi in sel])
+        slot_d, lab_d = i32(slot_t[tok]), i32(np.concatenate([packs[qi].head[module][1] for qi in sel]))
+        out = torch.empty(len(tok), device=dev)
         check(lib.stair_loss_head(head.weight.shape[0], C.c_void_p(vec.data_ptr()), C.c_void_p(gvec.data_ptr()),
-                                  C.c_void_p(slot.data_ptr()), C.c_void_p(lab.data_ptr()), C.c_void_p(head.weight.data_ptr()),
+                                  C.c_void_p(slot_d.data_ptr()), C.c_void_p(lab_d.data_ptr()), C.c_void_p(head.weight.data_ptr()),
                                   C.c_void_p(head.bias.data_ptr()), C.c_void_p(head.weight.grad.data_ptr()),
-                                  C.c_void_p(head.bias.grad.data_ptr()), len(items), H, C.c_float(scale),
+                                  C.c_void_p(head.bias.grad.data_ptr()), len(tok), H, C.c_float(scale),
                                   C.c_void_p(out.data_ptr()), stream))
         losses[module] = out
         touched.update({'submodules.%s.pretrain_head.weight' % module, 'submodules.%s.pretrain_head.bias' % module})
+    # ---- FilterFrame ----
+    ff_items = [(int(slot_t[base[qi] + pos]), gold) for qi, p in enumerate(packs) for pos, gold in p.ff]
     if ff_items:
         losses['FilterFrame'] = _filterframe_launch(model, res, ff_items, scale, True)
         touched.update({'submodules.FilterFrame.pretrain_head.weight', 'submodules.FilterFrame.pretrain_head.bias'})
+    # ---- contrastive (Filter / ToAction / Superlative): class representations of every global window ----
+    cont_items, entries = [], []
+    for qi, p in enumerate(packs):
+        if not p.cont:
+            continue
+        gpos = window_base + rank + qi * world
+        for pos, module, gold in p.cont:
+            for class_name, emb in gold:
+                cont_items.append((int(slot_t[base[qi] + pos]), gpos // window if window else 0, class_name))
+                entries.append((gpos, class_name, emb))
+    if cont_items or world > 1:
+        table, embs, win_range = contrastive_windows(entries, window, world)
     if cont_items:
-        # class representations of every window: text encoder without gradient + L2Normalize (module_net.py:78-89)
-        table, embs, win_range = {}, [], {}
-        for wid in sorted(windows):
-            start = len(embs)
-            for name, emb in windows[wid].items():
-                table[(wid, name)] = len(embs)
-                embs.append(torch.as_tensor(emb, dtype=torch.float32))
-            win_range[wid] = (start, len(embs) - start)
         lens = [e.shape[0] for e in embs]
         x = torch.cat(embs).to(dev).contiguous()
-        seq_off = i32(np.concatenate([[0], np.cumsum(lens)]).tolist())
+        seq_off = i32(np.concatenate([[0], np.cumsum(lens)]))
         _, h_n = ops.lstm_bidir(x, seq_off, max(lens), [w.detach() for w in model._lstm_weights('text_encoder')])
         G = ops.l2normalize(h_n)
-        slot = i32([c[0] for c in cont_items]); pos = i32([table[(c[1], c[2])] for c in cont_items])
+        slot_d = i32([c[0] for c in cont_items]); pos_d = i32([table[c[1]][c[2]] for c in cont_items])
         ws_ = i32([win_range[c[1]][0] for c in cont_items]); wc = i32([win_range[c[1]][1] for c in cont_items])
         out = torch.empty(len(cont_items), device=dev)
-        check(lib.stair_loss_contrastive(C.c_void_p(vec.data_ptr()), C.c_void_p(gvec.data_ptr()), C.c_void_p(slot.data_ptr()),
-                                         C.c_void_p(pos.data_ptr()), C.c_void_p(ws_.data_ptr()), C.c_void_p(wc.data_ptr()),
+        check(lib.stair_loss_contrastive(C.c_void_p(vec.data_ptr()), C.c_void_p(gvec.data_ptr()), C.c_void_p(slot_d.data_ptr()),
+                                         C.c_void_p(pos_d.data_ptr()), C.c_void_p(ws_.data_ptr()), C.c_void_p(wc.data_ptr()),
                                          C.c_void_p(G.data_ptr()), len(cont_items), H, max(r[1] for r in win_range.values()),
                                          C.c_float(scale), C.c_void_p(out.data_ptr()), stream))
         losses['contrastive'] = out
@@ -206,6 +279,7 @@ def evaluate_module_losses(model, res, questions, pretrain_modules=CRITERION_MOD
     H, T = model.config['hidden_size'], res.info.T
     att_items, head_items, cont_items, embs, ff_items = [], {'Exists': [], 'Xor': [], 'Equals': []}, [], [], []
     out = {m: [] for m in sorted(pretrain_modules)}
+    _, slot_t, aux_t, _, rel_t = res.node_table()
     for qi, q in enumerate(questions):
         sg = q.get('sg_res_by_step') or {}
         prog = q['nmn_program_list']
@@ -214,7 +288,8 @@ def evaluate_module_losses(model, res, questions, pretrain_modules=CRITERION_MOD
             if step not in sg or sg[step] is None or module == 'decoder':
                 continue
             gold = sg[step]
-            kind, slot, aux, _, rel = res.node_info(qi, i)
+            tok_ = int(res._prog_off[qi]) + i
+            slot, aux, rel = int(slot_t[tok_]), int(aux_t[tok_]), int(rel_t[tok_])
             if module == 'Localize':
                 att_items.append((slot, aux, [tuple(map(float, gold[r])) for r in range(aux)], module))
             elif module == 'Temporal':

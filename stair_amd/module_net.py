@@ -146,6 +146,18 @@ class BatchResult:
     def _arena(self, off, rows, cols):
         return self._ws[off: off + rows * cols].view(rows, cols)
 
+    def node_table(self):
+        """(kind, slot, aux, level, rel_slot) of EVERY program token of the batch as int32 numpy arrays indexed by
+        prog_off[q] + i -- one library call (stair_plan_nodes) instead of one per node."""
+        tab = getattr(self, '_node_table', None)
+        if tab is None:
+            n = self.info.n_nodes
+            tab = tuple(np.empty(n, dtype=np.int32) for _ in range(5))
+            ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+            check(lib.stair_plan_nodes(self._plan, ip(tab[0]), ip(tab[1]), ip(tab[2]), ip(tab[3]), ip(tab[4]), n))
+            self._node_table = tab
+        return tab
+
     def node_info(self, q, i):
         k, s, a, l, r = (C.c_int32() for _ in range(5))
         check(lib.stair_plan_node(self._plan, int(self._prog_off[q] + i), C.byref(k), C.byref(s), C.byref(a),

@@ -6,10 +6,11 @@
         loss.backward(); Adam.step(); zero_grad(); LambdaLR.step()                     (:408-412)
 
 One window = one batched forward + one HIP backward pass per rank (questions sharded across ranks);
-gradients live in ONE flat fp32 buffer that is sum-all-reduced over RCCL once per step, together with the
-per-parameter "touched" mask (max-reduce), so that parameters of modules no rank used are skipped by Adam
-exactly as torch skips grad == None.  Parameters, gradients and Adam moments are flat buffers whose
-per-tensor segments start on multiples of 256 floats; the model's Parameters are views into them.
+gradients live in ONE flat fp32 buffer that is sum-all-reduced over RCCL once per step; the per-parameter
+"touched" mask rides in the tail of the same buffer (a parameter is touched if ANY rank's shard used its
+module), so that parameters of modules no rank used are skipped by Adam exactly as torch skips grad == None
+-- one collective per step.  Parameters, gradients and Adam moments are flat buffers whose per-tensor
+segments start on multiples of 256 floats; the model's Parameters are views into them.
 """
 from __future__ import annotations
 
@@ -22,14 +23,22 @@ from ._lib import check, lib
 SEG = 256
 
 
-def reduce_gradients(flat_g, touched, world):
+def reduce_gradients(flat_g, touched, world, bucket=None):
     """The one exchange step of data-parallel training: sum the flat fp32 gradient bucket over all ranks and
-    max-reduce the per-parameter touched mask (a parameter is "touched" if ANY rank's shard used its module).
+    OR the per-parameter touched mask (a parameter is "touched" if ANY rank's shard used its module).
+    With `bucket` (a buffer whose head is flat_g and whose tail has room for the mask, as Trainer lays it out) the mask
+    travels as floats behind the gradients and ONE all-reduce does both; without it, two collectives.
     Backend-agnostic (RCCL on GPUs, gloo in the CPU test); in place."""
     if world > 1:
         import torch.distributed as dist
-        dist.all_reduce(flat_g, op=dist.ReduceOp.SUM)
-        dist.all_reduce(touched, op=dist.ReduceOp.MAX)
+        if bucket is not None:
+            tail = bucket[flat_g.numel(): flat_g.numel() + touched.numel()]
+            tail.copy_(touched.to(bucket.dtype))
+            dist.all_reduce(bucket, op=dist.ReduceOp.SUM)
+            touched.copy_((tail > 0).to(touched.dtype))
+        else:
+            dist.all_reduce(flat_g, op=dist.ReduceOp.SUM)
+            dist.all_reduce(touched, op=dist.ReduceOp.MAX)
     return flat_g, touched
 
 
@@ -38,7 +47,7 @@ class Trainer:
                  module_loss_weight=1.0, contrastive_window=32, no_intermediate=('FilterFrame',),
                  scheduler_start_factor=1.0, scheduler_end_factor=0.1, scheduler_total_iters=200000, world=1,
                  skip_untouched='ever', train_module_before_iters=1e10, train_decoder_after_iters=0, rank=0,
-                 dropout=0.0, dropout_seed=0):
+                 dropout=None, dropout_seed=0):
         """skip_untouched: 'ever'   -- a parameter is skipped by Adam until the first window that sends it a gradient
                                       (torch 1.13, which the reference pins: zero_grad() keeps zero tensors afterwards);
                            'window' -- skipped in every window that does not touch it (torch >= 2.0, set_to_none=True)."""
@@ -47,10 +56,12 @@ class Trainer:
         # train_decoder_after_iters.  Question i of a rank's shard has global step seen + 1 + rank + i * world.
         self.before_iters, self.after_iters, self.rank = train_module_before_iters, train_decoder_after_iters, rank
         self.questions_seen = 0
-        # nn.Dropout(config['dropout']) of the reference's model.train() (modules.py `D` positions).  Off by default: the
-        # parity pins are defined at dropout = 0; pass dropout=model.config['dropout'] to train the way the reference does.
+        # nn.Dropout(config['dropout']) of the reference's model.train() (modules.py `D` positions, args.py:31).  Default:
+        # the model's own config['dropout'], i.e. the reference's training recipe; the parity pins are defined at dropout = 0
+        # (torch's Philox masks cannot be reproduced) and the tests / bench pass dropout=0.0 explicitly.
         # Every step and rank draws fresh masks: seed = dropout_seed + step * world + rank.
-        self.dropout, self.dropout_seed = float(dropout), int(dropout_seed)
+        self.dropout = float(model.config.get('dropout', 0.0) if dropout is None else dropout)
+        self.dropout_seed = int(dropout_seed)
         assert skip_untouched in ('ever', 'window')
         self.skip_untouched = skip_untouched
         self.model, self.world = model, world
@@ -69,7 +80,9 @@ class Trainer:
             total += (params[nme].numel() + SEG - 1) // SEG * SEG
         self.n = total
         self.flat_p = torch.zeros(total, device=dev)
-        self.flat_g = torch.zeros(total, device=dev)
+        mask_room = (len(names) + SEG - 1) // SEG * SEG
+        self.bucket = torch.zeros(total + mask_room, device=dev)       # [gradients | touched mask as floats]: ONE all-reduce
+        self.flat_g = self.bucket[:total]
         self.exp_avg = torch.zeros(total, device=dev)
         self.exp_avg_sq = torch.zeros(total, device=dev)
         seg_of_block = torch.empty(total // SEG, dtype=torch.int32)
@@ -98,7 +111,12 @@ class Trainer:
         Returns (per-question decoder CE of the local shard, BatchResult)."""
         from . import losses as L
         n = len(programs)
-        G = global_batch or n * self.world
+        if global_batch is None and self.world > 1:           # ragged shards: the window is the SUM of the shard sizes
+            import torch.distributed as dist
+            cnt = torch.tensor([n], dtype=torch.int64, device=self.flat_g.device if dist.get_backend() == 'nccl' else 'cpu')
+            dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+            global_batch = int(cnt.item())
+        G = global_batch or n
         self.flat_g.zero_()                                   # optimizer.zero_grad()
         gstep = [self.questions_seen + 1 + self.rank + i * self.world for i in range(n)]
         self.questions_seen += G
@@ -113,7 +131,8 @@ class Trainer:
         if questions is not None and self.module_loss_weight != 0:
             res.zero_grad_arenas()
             self.module_losses, extra = L.apply_module_losses(self.model, res, questions, self.module_loss_weight / G,
-                                                              no_intermediate=self.no_intermediate, window=self.contrastive_window)
+                                                              no_intermediate=self.no_intermediate, window=self.contrastive_window,
+                                                              world=self.world, rank=self.rank)
             loss = res.backward(answers, self.decoder_loss_weight / G, keep_arenas=True)
         else:
             loss = res.backward(answers, self.decoder_loss_weight / G)
@@ -121,7 +140,7 @@ class Trainer:
         if extra:
             tl = [t_ or (nme in extra) for t_, nme in zip(tl, self.model._weight_names)]
         t = torch.tensor(tl, dtype=torch.int32).to(self.touched.device, non_blocking=True)
-        reduce_gradients(self.flat_g, t, self.world)                    # ONE flat bucket over RCCL / xGMI
+        reduce_gradients(self.flat_g, t, self.world, self.bucket)       # ONE flat bucket over RCCL / xGMI
         if self.skip_untouched == 'ever':
             self.touched = torch.maximum(self.touched, t)
         else:

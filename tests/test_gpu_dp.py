@@ -1,0 +1,113 @@
+"""Data-parallel training on ONE card: two processes, each a rank of a gloo group, each running Trainer.step(world=2)
+on its round-robin shard of the window -- the path bench.py --gpus N takes with nccl (= RCCL), rehearsed here with
+gloo so that a single-GPU box can run it.  The post-step state must equal the single-process step over the whole
+window (/root/reference/train_module.py:386-412: ONE accumulation window, one Adam step), including
+  * a ragged split (13 questions -> 7 + 6): the loss normalisation is the GLOBAL window, found by an all-reduce;
+  * the touched mask riding in the gradient bucket (one collective), union over ranks;
+  * intermediate supervision with contrastive gold: the class pools are those of the global window on every rank.
+Only sums of fp32 partial gradients are re-ordered between the two runs, hence the tight tolerances."""
+import os
+import socket
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+from stair_amd import spec, synth
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+CONFIG = dict(spec.DEFAULT_CONFIG, hidden_size=64, video_size=128, answer_vocab_length=16, max_video_length=40,
+              object_types=10, dropout=0.25)          # dropout in the config: the Trainer gets dropout=0.0 explicitly
+N_Q, WINDOW = 13, 5
+
+
+def _questions(supervised):
+    qs = [synth.make_question(CONFIG, 5, i, form=synth.ALL_FORMS[i % len(synth.ALL_FORMS)]) for i in range(N_Q)]
+    for q in qs:
+        if supervised:
+            sg = synth.make_gold(CONFIG, 3, q, keep=1.0)
+            q['sg_res_by_step'] = {k: ([(n, torch.from_numpy(np.asarray(e))) for n, e in v] if isinstance(v, list) else v)
+                                   for k, v in sg.items()}
+    return qs
+
+
+def _model(dev):
+    from stair_amd import losses as L
+    from stair_amd.module_net import VideoNMN
+    m = VideoNMN(CONFIG, pretrain_modules=set(L.CRITERION_MODULES))
+    w = synth.make_weights(CONFIG, 2)
+    m.load_state_dict({k: torch.from_numpy(w[k].copy()) for k in spec.state_dict_keys(CONFIG)})
+    return m.to(dev)
+
+
+def _pack(qs, dev, bf16):
+    video = torch.stack([torch.as_tensor(q['video_features']) for q in qs]).to(dev)
+    video = video.to(torch.bfloat16).contiguous() if bf16 else video.float().contiguous()
+    question = torch.cat([torch.as_tensor(q['question']) for q in qs]).to(dev, torch.float32).contiguous()
+    answers = torch.tensor([q['answer'] for q in qs], dtype=torch.int32, device=dev)
+    return ([q['nmn_program_list'] for q in qs], [q['prog_str_to_question_tokens'] for q in qs], video, question,
+            [q['question'].shape[0] for q in qs], answers)
+
+
+def _run(rank, world, supervised, bf16, out):
+    from stair_amd.train import Trainer
+    dev = torch.device('cuda', 0)
+    qs = _questions(supervised)
+    mine = qs[rank::world]                                    # local i <-> global position rank + i * world
+    model = _model(dev)
+    tr = Trainer(model, world=world, rank=rank, dropout=0.0, contrastive_window=WINDOW, lr=1e-3)
+    state = {}
+    for it in range(2):                                        # the second step exercises 'ever'-touched bookkeeping
+        progs, spans, video, question, q_lens, answers = _pack(mine, dev, bf16)
+        loss, _ = tr.step(progs, spans, video, question, q_lens, answers, questions=mine if supervised else None)
+        torch.cuda.synchronize()
+        state['grad%d' % it] = tr.flat_g.cpu().clone()
+        state['loss%d' % it] = loss.cpu().clone()
+    state.update(params=tr.flat_p.cpu().clone(), touched=tr.touched.cpu().clone(), steps=tr.steps.cpu().clone(),
+                 seen=tr.questions_seen)
+    torch.save(state, out)
+
+
+def _worker(rank, world, port, supervised, bf16, out_dir):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        _run(rank, world, supervised, bf16, os.path.join(out_dir, 'rank%d.pt' % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize('supervised,bf16', [(False, False), (True, False), (True, True)])
+def test_two_rank_trainer_step_equals_single_process_step(supervised, bf16):
+    import torch.multiprocessing as mp
+    with tempfile.TemporaryDirectory() as d:
+        _run(0, 1, supervised, bf16, os.path.join(d, 'solo.pt'))
+        mp.spawn(_worker, args=(2, _free_port(), supervised, bf16, d), nprocs=2, join=True)
+        solo = torch.load(os.path.join(d, 'solo.pt'))
+        ranks = [torch.load(os.path.join(d, 'rank%d.pt' % r)) for r in range(2)]
+    assert solo['seen'] == ranks[0]['seen'] == ranks[1]['seen'] == 2 * N_Q
+    for key in ('params', 'touched', 'steps', 'grad0', 'grad1'):
+        assert torch.equal(ranks[0][key], ranks[1][key]), key                   # both ranks hold the same state
+    assert torch.equal(solo['touched'], ranks[0]['touched']) and torch.equal(solo['steps'], ranks[0]['steps'])
+    for it in range(2):
+        g, r = solo['grad%d' % it], ranks[0]['grad%d' % it]
+        assert float((g - r).abs().max()) <= 2e-5 * float(g.abs().max()), it     # same terms, summed in another order
+        # the decoder losses of the shards are those of the solo run, question by question
+        both = torch.empty(N_Q)
+        both[0::2], both[1::2] = ranks[0]['loss%d' % it], ranks[1]['loss%d' % it]
+        assert torch.allclose(both, solo['loss%d' % it], rtol=1e-5, atol=1e-6), it
+    dp = (solo['params'] - ranks[0]['params']).abs()
+    # Adam divides by sqrt(v): where a gradient is ~0 the step direction is ill-conditioned; lr = 1e-3, two steps
+    assert float((dp > 2e-5).float().mean()) < 2e-3 and float(dp.max()) <= 2.1e-3

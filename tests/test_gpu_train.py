@@ -157,7 +157,7 @@ def test_trainer_steps_match_torch_adam(matmul):
     opt = torch.optim.Adam([w[n] for n in names], lr=2e-4)
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda it: 1.0 + (0.1 - 1.0) / 10 * it if it <= 10 else 0.1)
     model = _model(config, 0)
-    tr = Trainer(model, lr=2e-4, scheduler_total_iters=10, skip_untouched='ever')
+    tr = Trainer(model, lr=2e-4, scheduler_total_iters=10, skip_untouched='ever', dropout=0.0)
     qid = 100
     for forms in windows:
         qs = []
@@ -324,7 +324,7 @@ def test_trainer_loss_gates_follow_the_global_step():
     qs = _with_gold(config, 3, [question_for(meta, q) for q in meta['questions']], T)
     model = _model(config, meta['seed'])
     model.pretrain_modules = set(L.CRITERION_MODULES)
-    tr = Trainer(model, train_module_before_iters=9, train_decoder_after_iters=4)
+    tr = Trainer(model, train_module_before_iters=9, train_decoder_after_iters=4, dropout=0.0)
     progs, spans, video, question, q_lens, answers = _pack(model, qs)
     dec, res = tr.step(progs, spans, video, question, q_lens, answers, questions=qs)
     dec = dec.cpu()
@@ -334,7 +334,7 @@ def test_trainer_loss_gates_follow_the_global_step():
     n_items = sum(int(v.numel()) for v in tr.module_losses.values())
     model2 = _model(config, meta['seed'])
     model2.pretrain_modules = set(L.CRITERION_MODULES)
-    tr2 = Trainer(model2)
+    tr2 = Trainer(model2, dropout=0.0)
     tr2.step(progs, spans, video, question, q_lens, answers, questions=qs)
     n_all = sum(int(v.numel()) for v in tr2.module_losses.values())
     assert 0 < n_items < n_all
