@@ -1,26 +1,31 @@
 #!/usr/bin/env python3
 """Benchmark of the NMN hot path (BASELINE.json metric: questions/sec on AGQA2-shaped inputs).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--mode train|infer] [--features bf16|f32]
+                    [--supervision] [--dropout P]
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--mode train|infer]
+Default = BASELINE.json configs[1] ("AGQA2 full train, I3D rgb+flow [T=64,2048] feats, bf16, 1 MI355X"): one step = one
+optimizer step over a window of B synthetic questions per GPU -- program packing, plan build, encode_video,
+encode_question, every program level, decoder, cross-entropy loss, the full backward pass (BPTT through both bi-LSTMs
+included), one flat-bucket RCCL all-reduce when N > 1, Adam + LambdaLR.  Clip features are STORED in bf16 (the input
+format configs[1] names; the oracle that checks the answers is fed the same rounded values, which fp32 holds exactly);
+everything downstream is fp32 storage with split-bf16 (hi/lo) MFMA products.  `--features f32` keeps fp32 clips,
+`--supervision` adds the per-module intermediate losses of configs[4] to the timed step, `--mode infer` times the
+forward path + argmax only.  Shapes: T=64 frames x V=2048, H=512, A=172, programs from the 8-form corpus of SURVEY.md
+Appendix B, inputs resident in HBM before the timed region.  For N > 1 the driver launches this file under
+torch.distributed.run; questions shard across ranks, timing is barrier-bracketed, the max over ranks is reported.
+Rank 0 prints ONE JSON line.
 
-Default mode `train` = BASELINE.json configs[1] ("AGQA2 full train ... 1 MI355X"): one step = one optimizer
-step over a window of B synthetic questions per GPU -- program encoding, plan build, encode_video,
-encode_question, every program level, decoder, cross-entropy loss, the full backward pass (BPTT through both
-bi-LSTMs included), one flat-bucket RCCL gradient all-reduce when N>1, Adam + LambdaLR.  `--mode infer` times
-the forward path + argmax only (configs[3] without hipGraph).  Shapes: T=64 frames x V=2048 features, H=512,
-A=172, programs drawn from the 8-form corpus of SURVEY.md Appendix B, inputs resident in HBM before the timed
-region.  For N>1 the driver launches this file under torch.distributed.run; questions shard across ranks,
-timing is barrier-bracketed and the max over ranks is reported.  Rank 0 prints ONE JSON line.
-
-Extra objects on the line:
-  roofline      the dominant kernel (fp32 MFMA GEMM of the LSTM input projection), timed live with
-                events on the launch stream: achieved TFLOP/s vs the 157.3 TFLOP/s fp32 matrix peak.
-  roofline_hbm  whole-path algorithmic bytes (1.93 MB/question incl. weights/128) x q/s
-                vs 8 TB/s -- reported separately, never blended.
-  cpu_baseline  the oracle (CPU restatement, kind "port") timed on this box's host cores on a bounded
-                sample of the same questions; also the checker for top-1 agreement.
+Objects on the line besides the contract's fields:
+  roofline      the dominant kernel -- the video bi-LSTM input projection, a plane GEMM (csrc/gemm_planes.hip) on the
+                stored bf16 features with M = B*T, N = 8*Hh (both directions in one launch), K = V -- timed live with
+                events on its launch stream: algorithmic 2MNK / launch time against the 2.5 PFLOP/s dense bf16 MFMA
+                peak; `traffic` = HBM bytes per launch from the PMC passes under profiles/ (read from that file).
+  roofline_hbm  whole-path algorithmic bytes x q/s vs 8 TB/s -- reported separately, never blended.
+  cpu_baseline  the oracle (CPU restatement, kind "port") timed on this box's host cores on a bounded sample of the
+                same questions, at one thread and at all cores of the GPU's CPU share; also the top-1 / logit checker.
+  batch_sweep   train and inference rates at 32 / 128 / 512 / 2048 questions per GPU per step (configs[2] is 128).
+  supervised_step  the configs[4] step (gold intermediates, all module losses) next to the decoder-only step.
 """
 import argparse
 import json
@@ -41,36 +46,62 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA" 
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md, "HBM3E peak BW" (spec)
 ALGO_BYTES_PER_QUESTION = 1.93e6   # SURVEY.md section 8(d), mean over the 8 forms, fp32, weights/128
 ALGO_FLOP_PER_QUESTION = 0.86e9
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r02_pmc_dominant.json')     # written by tools/summarize_prof.py from the PMC passes
 
 
-def make_batch(config, B, T, seed, device):
+def make_batch(config, B, T, seed, device, features):
     """B synthetic questions; programs/spans from the deterministic generator, tensors drawn on the GPU."""
     qs = [synth.make_question(config, seed, i, T=T, with_video=False) for i in range(B)]
     g = torch.Generator(device=device).manual_seed(1234 + seed)
     video = torch.randn(B, T, config['video_size'], device=device, generator=g)
+    if features == 'bf16':
+        video = video.to(torch.bfloat16)                     # the STORED format; every consumer sees exactly these values
     q_lens = [q['question'].shape[0] for q in qs]
     question = torch.randn(sum(q_lens), config['text_size'], device=device, generator=g)
     return qs, video, question, q_lens
 
 
-# Memory-side bytes per launch of the dominant kernel from the PMC passes of tools/pmc_dominant.py
-# (profiles/r01_g_pmc_dominant_t256.json): 2 x FETCH_SIZE (the gfx950 correction for 16-B-per-lane reads) + WRITE_SIZE, KiB.
-PMC_TRAFFIC_BYTES = {(131072, 1024, 2048): int((2 * 787070.0 + 524288.0) * 1024)}
-PMC_TRAFFIC_NOTE = ('bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH doubled per the gfx950 '
-                    'correction; Infinity-Cache hits are counted, so the excess over the 1.62 GB algorithmic A+W+C is W tiles '
-                    're-read through L2 (8 MB of W per XCD > 4 MB L2; 3.73 GB with the 128 x 128 tile); null for shapes that were not profiled')
+def pmc_traffic(M, N, K):
+    """HBM bytes per launch of the dominant kernel, read from the committed PMC summary of tools/pmc_planes.py."""
+    try:
+        rows = json.load(open(PMC_FILE))
+    except Exception:
+        return None, 'profiles/r02_pmc_dominant.json missing'
+    vals = {}
+    for r in rows:
+        if 'gemm_planes' in r['kernel'] and r.get('shape') == [M, N, K]:
+            vals[r['counter']] = r['mean_per_dispatch']
+    if 'FETCH_SIZE' not in vals or 'WRITE_SIZE' not in vals:
+        return None, 'shape not profiled'
+    # rocprofv3 reports KiB.  The LDS-DMA reads of this kernel are 64-byte half lines (16 rows x 64 B per instruction), which the
+    # memory-side counter tallies at their true size: FETCH is NOT doubled here (the 2x correction of MI355X_MICROARCH.md applies
+    # to 128-byte requests); calibration: FETCH_SIZE = 1.00x the bf16 A panel + W planes of the launch.
+    return int((vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024), \
+        'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (profiles/r02_pmc_dominant.json); 64-byte requests, no 2x correction'
 
 
-def time_dominant_kernel(model, B, T, device, iters=10):
-    """HIP-event timing of the input-projection GEMM launch (M=B*T, N=4*Hh, K=V), same stream."""
+def time_dominant_kernel(model, B, T, device, features, iters=10):
+    """HIP-event timing of the input-projection launch on its own stream.  bf16 features: ONE plane GEMM for both
+    directions (M = B*T, N = 8*Hh, K = V).  fp32 features: the register-staged split kernel, one direction (N = 4*Hh)."""
     from stair_amd import ops
     H, V = model.config['hidden_size'], model.config['video_size']
-    M, N, K = B * T, 2 * H, V
-    x = torch.randn(M, K, device=device)
-    w = model.submodules['video_encoder'].weight_ih_l0
-    b = model.submodules['video_encoder'].bias_ih_l0
-    out = torch.empty(M, 4 * H, device=device)
-    run = lambda: ops.gemm_grouped(x, K, None, w, b, out, 4 * H, None, M, 1, N, K, lda=K, ldc=4 * H)
+    enc = model.submodules['video_encoder']
+    M, K = B * T, V
+    if features == 'bf16':
+        N = 4 * H
+        x = torch.randn(M, K, device=device).to(torch.bfloat16)
+        w = torch.cat([enc.weight_ih_l0, enc.weight_ih_l0_reverse]).contiguous()
+        wh, wl = ops.split_planes_tiled(w)
+        b = torch.cat([enc.bias_ih_l0, enc.bias_ih_l0_reverse]).contiguous()
+        out = torch.empty(M, N, device=device)
+        run = lambda: ops.gemm_planes(x, None, wh, wl, b, out=out)
+        name = 'gemm_planes_kernel<1,0,tiled> (video bi-LSTM input projection on stored bf16 features, both directions)'
+    else:
+        N = 2 * H
+        x = torch.randn(M, K, device=device)
+        out = torch.empty(M, 4 * H, device=device)
+        run = lambda: ops.gemm_grouped(x, K, None, enc.weight_ih_l0, enc.bias_ih_l0, out, 4 * H, None, M, 1, N, K, lda=K, ldc=4 * H)
+        name = 'gemm_bf16x3_t256_kernel<0> (video bi-LSTM input projection on fp32 features, one direction)'
     for _ in range(3):
         run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -79,20 +110,23 @@ def time_dominant_kernel(model, B, T, device, iters=10):
         run()
     e1.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
-    return ms, 2.0 * M * N * K
+    return e0.elapsed_time(e1) / iters, (M, N, K), name
 
 
-def cpu_baseline_train(config, weights, qs, video, question, q_lens, budget_s=15.0, max_q=256):
+def _oracle_inputs(qs, video, question, q_lens, n):
+    off = np.concatenate([[0], np.cumsum(q_lens)])
+    return video[:n].float().cpu(), question[:off[n]].cpu(), off        # bf16 clips widen exactly
+
+
+def cpu_baseline_train(config, weights, qs, video, question, q_lens, budget_s=12.0, max_q=256):
     """The reference's training loop shape on the CPU: batch-1 forward + CE + backward per question through the
     oracle (torch autograd), one Adam step per 32 questions (train_module.py:341-412)."""
     from oracle import nmn_oracle as O
     names = [n for n, _ in spec.weight_table(config)]
     w = {k: torch.from_numpy(weights[k].copy()).requires_grad_(True) for k in names}
     opt = torch.optim.Adam([w[n] for n in names], lr=2e-4)
-    off = np.concatenate([[0], np.cumsum(q_lens)])
     n = min(max_q, len(qs))
-    vid, qst = video[:n].cpu(), question[:off[n]].cpu()
+    vid, qst, off = _oracle_inputs(qs, video, question, q_lens, n)
     t0 = time.perf_counter()
     done = 0
     for i in range(n):
@@ -108,13 +142,11 @@ def cpu_baseline_train(config, weights, qs, video, question, q_lens, budget_s=15
     return done / (time.perf_counter() - t0), done
 
 
-def cpu_baseline(config, weights, qs, video, question, q_lens, budget_s=15.0, max_q=512):
+def cpu_baseline(config, weights, qs, video, question, q_lens, budget_s=8.0, max_q=512):
     from oracle import nmn_oracle as O
     w = O.to_torch(weights)
-    off = np.concatenate([[0], np.cumsum(q_lens)])
     n = min(max_q, len(qs))
-    vid = video[:n].cpu()
-    qst = question[:off[n]].cpu()
+    vid, qst, off = _oracle_inputs(qs, video, question, q_lens, n)
     preds, logits = [], []
     t0 = time.perf_counter()
     done = 0
@@ -131,6 +163,16 @@ def cpu_baseline(config, weights, qs, video, question, q_lens, budget_s=15.0, ma
     return done / dt, done, preds, torch.stack(logits)
 
 
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -138,9 +180,12 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=2048, help='questions per GPU per step (window size per rank)')
     ap.add_argument('--frames', type=int, default=64)
-    ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--mode', choices=['train', 'infer'], default='train')
-    ap.add_argument('--no-extras', action='store_true', help='skip the supplementary inference figures (clean kernel profiles)')
+    ap.add_argument('--features', choices=['bf16', 'f32'], default='bf16', help='storage format of the clip features (configs[1]: bf16)')
+    ap.add_argument('--supervision', action='store_true', help='configs[4]: gold intermediates + every per-module loss inside the timed step')
+    ap.add_argument('--dropout', type=float, default=0.0, help='nn.Dropout p of the training step (the reference trains with 0.25; parity is defined at 0)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the supplementary figures (clean kernel profiles)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -159,115 +204,82 @@ def main():
             dist.init_process_group(backend)
     device = torch.device('cuda', dev_index)
 
+    from stair_amd import losses as L, ops
     from stair_amd.module_net import VideoNMN      # raises if libstair_hip.so is missing
     config = dict(spec.DEFAULT_CONFIG)
     weights = synth.make_weights(config, 0)
-    model = VideoNMN(config)
+    model = VideoNMN(config, pretrain_modules=set(L.CRITERION_MODULES))
     model.load_state_dict({k: torch.from_numpy(weights[k].copy()) for k in spec.state_dict_keys(config)})
     model = model.to(device)
 
     B, T = args.batch, args.frames
-    qs, video, question, q_lens = make_batch(config, B, T, seed=rank, device=device)
+    qs, video, question, q_lens = make_batch(config, B, T, seed=rank, device=device, features=args.features)
     programs = [q['nmn_program_list'] for q in qs]
     spans = [q['prog_str_to_question_tokens'] for q in qs]
-
     answers = torch.tensor([q['answer'] for q in qs], dtype=torch.int32, device=device)
+    off = np.concatenate([[0], np.cumsum(q_lens)])
+
+    def gold_questions(sel):
+        """the same questions with synthetic gold intermediates (sg_res_by_step in the layout of dataset.py:200-221) and
+        their gold packs, i.e. what a data-loader worker prepares per question (losses.compile_gold)"""
+        out = []
+        for q in sel:
+            q = dict(q)
+            sg = synth.make_gold(config, 0, q, T=T)
+            q['sg_res_by_step'] = {k: ([(n, torch.from_numpy(np.asarray(e))) for n, e in v] if isinstance(v, list) else v) for k, v in sg.items()}
+            L.compile_gold(q)
+            out.append(q)
+        return out
+
     trainer = None
     if args.mode == 'train':
         from stair_amd.train import Trainer
         trainer = Trainer(model, world=world, rank=rank, dropout=args.dropout)
+    gold_qs = gold_questions(qs) if (args.supervision or not args.no_extras) and args.mode == 'train' else None
 
-    def step():
+    def run_step(nq=B, supervised=False):
+        """one pass over the first nq questions of the rank's batch"""
         if trainer is not None:
-            return trainer.step(programs, spans, video, question, q_lens, answers)[1]
-        return model.run_programs(programs, spans, video, question, q_lens)
-
-    res = None
-    for _ in range(args.warmup):
-        res = step()
+            return trainer.step(programs[:nq], spans[:nq], video[:nq], question[:off[nq]], q_lens[:nq], answers[:nq],
+                                questions=gold_qs[:nq] if supervised else None)[1]
+        return model.run_programs(programs[:nq], spans[:nq], video[:nq], question[:off[nq]], q_lens[:nq])
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = fn()
+        barrier()
+        return time.perf_counter() - t0, r
+
+    elapsed, res = timed(lambda: run_step(B, args.supervision), args.steps, args.warmup)
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    qps = B * args.steps * world / elapsed
 
-    total_q = B * args.steps * world
-    qps = total_q / elapsed
-
-    infer_qps = None
-    if args.mode == 'train' and not args.no_extras:          # the forward-only rate in the same process, for reference
-        torch.cuda.synchronize()
-        ti = time.perf_counter()
-        for _ in range(3):
-            r_inf = model.run_programs(programs, spans, video, question, q_lens)
-        torch.cuda.synchronize()
-        infer_qps = 3 * B / (time.perf_counter() - ti)
-        res = r_inf
-    # questions that share a clip encode it once.  Same B questions, 8 per clip (AGQA asks tens per video).
-    shared_qps = None
-    if B % 8 == 0 and not args.no_extras:
-        vidx = [i // 8 for i in range(B)]
-        vshared = video[:B // 8].contiguous()
-        model.run_programs(programs, spans, vshared, question, q_lens, video_index=vidx)
-        torch.cuda.synchronize()
-        ti = time.perf_counter()
-        for _ in range(3):
-            model.run_programs(programs, spans, vshared, question, q_lens, video_index=vidx)
-        torch.cuda.synchronize()
-        shared_qps = 3 * B / (time.perf_counter() - ti)
-
-    # BASELINE configs[1] names bf16: the single-product mode (top-1 identity only, never the headline) measured in the same
-    # process -- inference first (same weights as r_inf, so the answers can be compared), then optimizer steps.
-    bf16_mode = None
-    if args.mode == 'train' and not args.no_extras:
-        from stair_amd import ops as _ops2
-        default_mode = _ops2.get_matmul_mode()
-        if default_mode != 'bf16':
-            _ops2.set_matmul_mode('bf16')
-            rb = model.run_programs(programs, spans, video, question, q_lens)
-            torch.cuda.synchronize()
-            ti = time.perf_counter()
-            for _ in range(3):
-                rb = model.run_programs(programs, spans, video, question, q_lens)
-            torch.cuda.synchronize()
-            b_inf = 3 * B / (time.perf_counter() - ti)
-            agree_b = float((rb.pred == r_inf.pred).float().mean())
-            dlogit_b = float((rb.logits - r_inf.logits).abs().max())
-            step()
-            barrier()
-            ti = time.perf_counter()
-            for _ in range(3):
-                step()
-            barrier()
-            b_train = 3 * B * world / (time.perf_counter() - ti)
-            _ops2.set_matmul_mode(default_mode)
-            bf16_mode = {'train_questions_per_s': round(b_train, 1), 'inference_questions_per_s_per_gpu': round(b_inf, 1),
-                         'top1_agreement_vs_default_mode': round(agree_b, 4), 'max_abs_logit_diff_vs_default_mode': dlogit_b,
-                         'note': 'STAIR_MATMUL=bf16: one bf16 MFMA product per operand pair, fp32 accumulate; outside the 1e-4 '
-                                 'logit budget by design, so it is reported beside `value`, never as it'}
-
-    # Host-fed pipeline (SURVEY 8d "a second figure including H2D"): the batch's features start in pinned host memory;
-    # a copy stream stages batch i+1 into the other of two device buffers while batch i is computed.  Never `value`.
-    h2d_qps = None
-    if world == 1 and not args.no_extras:
-        host_v = video.cpu().pin_memory()
-        host_q = question.cpu().pin_memory()
-        dv = [torch.empty_like(video), torch.empty_like(video)]
-        dq = [torch.empty_like(question), torch.empty_like(question)]
+    extras = {}
+    if not args.no_extras and world == 1:
+        # ---- forward-only rate, shared clips (SURVEY 8f-1), host-fed pipeline (SURVEY 8d "a second figure including H2D") ----
+        dt, r_inf = timed(lambda: model.run_programs(programs, spans, video, question, q_lens), 3, 1)
+        extras['inference_questions_per_s_per_gpu'] = round(3 * B / dt, 1)
+        if B % 8 == 0:
+            vidx = [i // 8 for i in range(B)]
+            vshared = video[:B // 8].contiguous()
+            dt, _ = timed(lambda: model.run_programs(programs, spans, vshared, question, q_lens, video_index=vidx), 3, 1)
+            extras['inference_8_questions_per_clip_questions_per_s_per_gpu'] = round(3 * B / dt, 1)
+        host_v, host_q = video.cpu().pin_memory(), question.cpu().pin_memory()
+        dv, dq = [torch.empty_like(video), torch.empty_like(video)], [torch.empty_like(question), torch.empty_like(question)]
         copy_stream = torch.cuda.Stream(device=device)
-        ready = [torch.cuda.Event(), torch.cuda.Event()]
-        done = [torch.cuda.Event(), torch.cuda.Event()]
+        ready, done = [torch.cuda.Event(), torch.cuda.Event()], [torch.cuda.Event(), torch.cuda.Event()]
         main_stream = torch.cuda.current_stream(device)
 
         def stage(i):
@@ -276,10 +288,10 @@ def main():
                 dv[i % 2].copy_(host_v, non_blocking=True)
                 dq[i % 2].copy_(host_q, non_blocking=True)
                 ready[i % 2].record(copy_stream)
-        n_it = 4
         for e in done:
             e.record(main_stream)
         torch.cuda.synchronize()
+        n_it = 4
         ti = time.perf_counter()
         stage(0)
         for i in range(n_it):
@@ -289,79 +301,116 @@ def main():
             model.run_programs(programs, spans, dv[i % 2], dq[i % 2], q_lens)
             done[i % 2].record(main_stream)
         torch.cuda.synchronize()
-        h2d_qps = n_it * B / (time.perf_counter() - ti)
+        extras['inference_h2d_inclusive_questions_per_s_per_gpu'] = round(n_it * B / (time.perf_counter() - ti), 1)
+        extras['inference_h2d_bytes_per_question'] = int(video[0].numel() * video.element_size())
         del host_v, host_q, dv, dq
 
+        if args.mode == 'train':
+            # ---- batch sweep: the regime BASELINE.json's other configs name (configs[2]: 128 questions per GPU per step) ----
+            sweep = []
+            for nq in (32, 128, 512, 2048):
+                if nq > B:
+                    continue
+                k = 12 if nq <= 512 else 4
+                dt_t, _ = timed(lambda: run_step(nq), k, 2)
+                dt_i, _ = timed(lambda: model.run_programs(programs[:nq], spans[:nq], video[:nq], question[:off[nq]], q_lens[:nq]), k, 2)
+                sweep.append({'questions_per_step': nq, 'train_ms_per_step': round(dt_t / k * 1e3, 3), 'train_questions_per_s': round(nq * k / dt_t, 1),
+                              'infer_ms_per_batch': round(dt_i / k * 1e3, 3), 'infer_questions_per_s': round(nq * k / dt_i, 1)})
+            extras['batch_sweep'] = sweep
+            # ---- configs[4]: the step with per-module intermediate supervision, next to the decoder-only step ----
+            if not args.supervision:
+                dt_s, _ = timed(lambda: run_step(B, True), 6, 3)
+                dt_p, _ = timed(lambda: run_step(B, False), 6, 3)
+                n_gold = sum(len(q['sg_res_by_step']) for q in gold_qs)
+                extras['supervised_step'] = {'train_questions_per_s': round(6 * B / dt_s, 1), 'ms_per_step': round(dt_s / 6 * 1e3, 3),
+                                             'decoder_only_ms_per_step': round(dt_p / 6 * 1e3, 3), 'supervised_nodes_per_step': n_gold,
+                                             'note': 'BASELINE configs[4] on one GPU: gold intermediates on ~85 % of the supervisable nodes, attention / head / '
+                                                     'contrastive (32-question windows) criteria + decoder CE in one step; gold packs prepared per question outside '
+                                                     'the loop, as a data-loader worker would (losses.compile_gold)'}
+            # ---- the other storage / arithmetic modes, a few steps each ----
+            other = 'f32' if args.features == 'bf16' else 'bf16'
+            v2 = video.float() if other == 'f32' else video.to(torch.bfloat16)
+            step2 = lambda: trainer.step(programs, spans, v2, question, q_lens, answers)
+            dt2, _ = timed(step2, 3, 1)
+            extras['%s_feature_storage' % other] = {'train_questions_per_s': round(3 * B / dt2, 1), 'ms_per_step': round(dt2 / 3 * 1e3, 3)}
+            vf = video.float() if args.features == 'bf16' else video
+            ops.set_matmul_mode('f32')                                   # exact fp32 MFMA everywhere (fp32 features: the plane GEMMs are split kernels)
+            dtf, _ = timed(lambda: trainer.step(programs, spans, vf, question, q_lens, answers), 2, 1)
+            ops.set_matmul_mode('bf16')                                  # one bf16 product per operand pair: top-1 identity only, never the headline
+            dtb, _ = timed(lambda: trainer.step(programs, spans, vf, question, q_lens, answers), 3, 1)
+            ops.set_matmul_mode('bf16x3')
+            extras['exact_f32_mfma_mode'] = {'train_questions_per_s': round(2 * B / dtf, 1), 'ms_per_step': round(dtf / 2 * 1e3, 3),
+                                             'note': 'STAIR_MATMUL=f32: v_mfma_f32_32x32x2_f32 everywhere, fp32 features'}
+            extras['bf16_single_product_mode'] = {'train_questions_per_s': round(3 * B / dtb, 1), 'ms_per_step': round(dtb / 3 * 1e3, 3),
+                                                  'note': 'STAIR_MATMUL=bf16: one bf16 MFMA product per operand pair, fp32 accumulate, fp32 features; outside the '
+                                                          '1e-4 logit budget by design, so it is reported beside `value`, never as it'}
+            del v2, vf
+
     if rank == 0:
-        from stair_amd import ops as _ops
-        mm = _ops.get_matmul_mode()
-        split = mm != 'f32'
-        nprod = 3 if mm == 'bf16x3' else 1
-        gemm_ms, gemm_flop = time_dominant_kernel(model, B, T, device)
+        gemm_ms, (Mg, Ng, Kg), kname = time_dominant_kernel(model, B, T, device, args.features)
+        gemm_flop = 2.0 * Mg * Ng * Kg
         achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12            # ALGORITHMIC flops (2MNK) per second
-        peak = BF16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
+        nprod = 2 if args.features == 'bf16' else 3
+        traffic, tnote = pmc_traffic(Mg, Ng, Kg) if args.features == 'bf16' else (None, 'fp32-feature kernel: see profiles/r01_g_pmc_dominant_t256.json')
+        mode_txt = ('AGQA2 full train (BASELINE.json configs[%s]): I3D-like [T=%d,V=%d] features stored in %s, H=512, A=172, 8 program forms, %s, '
+                    'one Adam step per window' % ('4' if args.supervision else '1', T, config['video_size'], args.features,
+                                                  'decoder CE + per-module intermediate losses' if args.supervision else 'decoder CE loss')
+                    if args.mode == 'train' else
+                    'AGQA2-shaped inference, I3D-like [T=%d,V=%d] features stored in %s, H=512, A=172, 8 program forms' % (T, config['video_size'], args.features))
         line = {
-            'metric': ('questions/sec on AGQA2-shaped synthetic features, training step (forward + CE + backward + Adam)'
+            'metric': ('questions/sec on AGQA2-shaped synthetic features, training step (forward + losses + backward + Adam)'
                        if args.mode == 'train' else
                        'questions/sec on AGQA2-shaped synthetic features (NMN forward: encode -> program -> decoder -> argmax)'),
             'value': round(qps, 1), 'unit': 'questions/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'data': 'synthetic',
-            'dtype': ('f32 storage/accumulate; products as bf16x3 split (hi*hi+hi*lo+lo*hi on bf16 MFMA, ~4e-6 rel. error)' if mm == 'bf16x3'
-                      else 'f32 storage/accumulate; single bf16 MFMA product per operand pair (~2e-3 rel. error, top-1 identity only)' if mm == 'bf16' else 'f32'),
-            'config': {'workload': ('AGQA2 full train (BASELINE.json configs[1]): I3D-like [T=%d,V=%d] features, H=512, A=172, 8 program '
-                                    'forms, decoder CE loss, fp32, one Adam step per window' if args.mode == 'train' else
-                                    'AGQA2-shaped inference, I3D-like [T=%d,V=%d] features, H=512, A=172, 8 program forms, fp32')
-                                   % (T, config['video_size']),
-                       'questions_per_gpu_per_step': B, 'mode': args.mode,
-                       'parallelism': ('dp%d (questions sharded, one flat fp32 gradient all-reduce per step)' if args.mode == 'train'
-                                       else 'dp%d (questions sharded, no collective)') % world},
-            'roofline': {'bound': 'mfma', 'kernel': '%s (LSTM input projection, M=%d N=%d K=%d)' % (
-                             'gemm_bf16x3_t256_kernel<0>' if split else 'gemm_f32_kernel', B * T, 2 * config['hidden_size'], config['video_size']),
-                         'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / peak, 4), 'traffic': PMC_TRAFFIC_BYTES.get((B * T, 2 * config['hidden_size'], config['video_size'])),
-                         'traffic_note': PMC_TRAFFIC_NOTE, 'launch_ms': round(gemm_ms, 4),
-                         'note': ('achieved = algorithmic 2MNK / launch time against the dense bf16 MFMA peak; the kernel executes 3 bf16 '
-                                  'MFMAs per algorithmic product by design: executed %.0f TFLOP/s = %.3f of peak; the exact fp32-MFMA kernel '
-                                  'peaks at 157.3' % (3 * achieved, 3 * achieved / peak)) if mm == 'bf16x3' else
-                                 ('single bf16 product per pair' if mm == 'bf16' else 'exact fp32 MFMA')},
+            'dtype': ('%s clip features; f32 storage/accumulate elsewhere; products on bf16 MFMA as split hi/lo pairs (~4e-6 rel. error): '
+                      '2 per operand pair where an operand is the stored bf16 clip, else 3' % args.features),
+            'config': {'workload': mode_txt, 'questions_per_gpu_per_step': B, 'mode': args.mode, 'dropout': args.dropout,
+                       'parallelism': ('dp%d (questions sharded round-robin, one flat fp32 gradient all-reduce per step, touched mask in the same bucket)'
+                                       if args.mode == 'train' else 'dp%d (questions sharded, no collective)') % world},
+            'roofline': {'bound': 'mfma', 'kernel': '%s, M=%d N=%d K=%d' % (kname, Mg, Ng, Kg),
+                         'achieved': round(achieved, 2), 'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic, 'traffic_note': tnote,
+                         'launch_ms': round(gemm_ms, 4),
+                         'note': 'achieved = algorithmic 2MNK / launch time against the dense bf16 MFMA peak; the kernel executes %d bf16 MFMAs per '
+                                 'algorithmic product by design (executed %.0f TFLOP/s = %.3f of peak)' % (nprod, nprod * achieved, nprod * achieved / BF16_MFMA_PEAK_TFLOPS)},
             'roofline_hbm': {'bound': 'hbm', 'scope': 'whole path, algorithmic bytes x q/s (per GPU)',
                              'achieved': round(ALGO_BYTES_PER_QUESTION * qps / world / 1e9, 2), 'peak': HBM_PEAK_GBS,
                              'unit': 'GB/s', 'frac': round(ALGO_BYTES_PER_QUESTION * qps / world / 1e9 / HBM_PEAK_GBS, 5)},
             'path_tflops': round(ALGO_FLOP_PER_QUESTION * (3.0 if args.mode == 'train' else 1.0) * qps / world / 1e12, 2),
         }
-        if infer_qps is not None:
-            line['inference_questions_per_s_per_gpu'] = round(infer_qps, 1)
-        if h2d_qps is not None:
-            line['inference_h2d_inclusive_questions_per_s_per_gpu'] = round(h2d_qps, 1)
-        if shared_qps is not None:
-            line['inference_8_questions_per_clip_questions_per_s_per_gpu'] = round(shared_qps, 1)
-        if bf16_mode is not None:
-            line['bf16_single_product_mode'] = bf16_mode
+        line.update(extras)
         if not args.no_cpu_baseline and world == 1:        # the CPU leg runs on rank 0 at N=1 only
             # the box gives one GPU a 16-core CPU share; more ATen threads than that only thrash
             ncores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
-            torch.set_num_threads(ncores)
+            model.load_state_dict({k: torch.from_numpy(weights[k].copy()) for k in spec.state_dict_keys(config)})
+            res = model.run_programs(programs, spans, video, question, q_lens)     # parity check below on the initial weights
+            per_threads = {}
+            for nt in (1, ncores):
+                torch.set_num_threads(nt)
+                if args.mode == 'train':
+                    tq, tn = cpu_baseline_train(config, weights, qs, video, question, q_lens, budget_s=8.0 if nt == 1 else 12.0)
+                    per_threads[nt] = (tq, tn)
+                iq, n_done, preds, cpu_logits = cpu_baseline(config, weights, qs, video, question, q_lens, budget_s=5.0 if nt == 1 else 8.0)
+                per_threads[('inf', nt)] = (iq, n_done)
+            sample_t = ('first %d questions: batch-1 oracle forward + CE + autograd backward, Adam every 32 (the reference loop shape, '
+                        'train_module.py:341-412), ATen CPU, clips = the same bf16-rounded values')
+            sample_i = 'first %d questions of the rank-0 batch through oracle/nmn_oracle.py (batch-1 forward, ATen CPU)'
             if args.mode == 'train':
-                tq, tn = cpu_baseline_train(config, weights, qs, video, question, q_lens)
-                line['cpu_baseline'] = {'value': round(tq, 1), 'unit': 'questions/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-                                        'sample': 'first %d questions: batch-1 oracle forward + CE + autograd backward, Adam every 32 '
-                                                  '(the reference loop shape, train_module.py:341-412), ATen CPU' % tn}
-                model.load_state_dict({k: torch.from_numpy(weights[k].copy()) for k in spec.state_dict_keys(config)})
-                res = model.run_programs(programs, spans, video, question, q_lens)     # parity check below on the initial weights
-            cpu_qps, n_done, preds, cpu_logits = cpu_baseline(config, weights, qs, video, question, q_lens,
-                                                              budget_s=8.0 if args.mode == 'train' else 15.0)
-            gpu_pred = res.pred[:n_done].cpu().tolist()
-            agree = sum(int(a == b) for a, b in zip(gpu_pred, preds)) / max(1, n_done)
-            maxdiff = float((res.logits[:n_done].cpu() - cpu_logits).abs().max())
-            inf = {'value': round(cpu_qps, 1), 'unit': 'questions/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-                   'sample': 'first %d questions of the rank-0 batch through oracle/nmn_oracle.py (batch-1 forward, ATen CPU)' % n_done}
-            if args.mode == 'train':
-                line['cpu_baseline_inference'] = inf
+                line['cpu_baseline'] = {'value': round(per_threads[ncores][0], 1), 'unit': 'questions/s', 'cores': ncores, 'kind': 'port',
+                                        'sample': sample_t % per_threads[ncores][1], 'cpu_model': cpu_model(),
+                                        'one_thread': {'value': round(per_threads[1][0], 1), 'cores': 1, 'sample': sample_t % per_threads[1][1]}}
+                line['cpu_baseline_inference'] = {'value': round(per_threads[('inf', ncores)][0], 1), 'unit': 'questions/s', 'cores': ncores, 'kind': 'port',
+                                                  'sample': sample_i % per_threads[('inf', ncores)][1],
+                                                  'one_thread': {'value': round(per_threads[('inf', 1)][0], 1), 'cores': 1}}
             else:
-                line['cpu_baseline'] = inf
-            line['top1_agreement_vs_oracle'] = round(agree, 4)
-            line['max_abs_logit_diff_vs_oracle'] = maxdiff
+                line['cpu_baseline'] = {'value': round(per_threads[('inf', ncores)][0], 1), 'unit': 'questions/s', 'cores': ncores, 'kind': 'port',
+                                        'sample': sample_i % per_threads[('inf', ncores)][1], 'cpu_model': cpu_model(),
+                                        'one_thread': {'value': round(per_threads[('inf', 1)][0], 1), 'cores': 1}}
+            gpu_pred = res.pred[:n_done].cpu().tolist()
+            line['top1_agreement_vs_oracle'] = round(sum(int(a == b) for a, b in zip(gpu_pred, preds)) / max(1, n_done), 4)
+            line['max_abs_logit_diff_vs_oracle'] = float((res.logits[:n_done].cpu() - cpu_logits).abs().max())
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -156,26 +156,63 @@ def compile_gold(question, pretrain_modules=CRITERION_MODULES, no_intermediate=(
 def contrastive_windows(entries, window, world=1):
     """The class pools of train_module.py:386-402 over the GLOBAL accumulation window.
     entries: [(global question position, class_name, embedding)] of this rank's contrastive golds; with world > 1 every
-    rank contributes its entries (all_gather_object: a few KB of host data) and builds the same table, so that a
+    rank contributes its entries (all_gather_object: a few KB of host data) and builds the same tables, so that a
     data-parallel step pools exactly the classes the single-process window of the reference pools.
-    Returns ({window id: {class_name: row}}, [embedding per row], {window id: (first row, count)})."""
+    A class representation depends on the class name only (text encoder without gradient + L2Normalize,
+    module_net.py:78-89), so each DISTINCT class is encoded once per step and the windows index into that table.
+    Returns (names: distinct class names, sorted; embs: their embeddings; rows: int32 row of `names` for every window
+    entry, window after window; win_range: {window id: (first entry, count)}; slot_of: {(window id, class_name): entry})."""
     if world > 1:
         import torch.distributed as dist
         gathered = [None] * world
         dist.all_gather_object(gathered, [(g, n, np.asarray(e, dtype=np.float32)) for g, n, e in entries])
         entries = [t for part in gathered for t in part]
-    pools = {}
-    for gpos, name, emb in sorted(entries, key=lambda t: (t[0], t[1])):
-        pools.setdefault(gpos // window if window else 0, {}).setdefault(name, emb)
-    table, embs, rng = {}, [], {}
+    first, pools = {}, {}
+    for gpos, name, emb in entries:
+        first.setdefault(name, emb)
+        pools.setdefault(gpos // window if window else 0, set()).add(name)
+    names = sorted(first)
+    row_of = {n: i for i, n in enumerate(names)}
+    rows, win_range, slot_of = [], {}, {}
     for wid in sorted(pools):
-        start = len(embs)
-        table[wid] = {}
-        for name, emb in pools[wid].items():
-            table[wid][name] = len(embs)
-            embs.append(torch.as_tensor(np.asarray(emb), dtype=torch.float32))
-        rng[wid] = (start, len(embs) - start)
-    return table, embs, rng
+        start = len(rows)
+        for name in sorted(pools[wid]):
+            slot_of[(wid, name)] = len(rows)
+            rows.append(row_of[name])
+        win_range[wid] = (start, len(rows) - start)
+    return names, [first[n] for n in names], np.asarray(rows, dtype=np.int32), win_range, slot_of
+
+
+class _Staging:
+    """One pinned host buffer + one device buffer per model: every index / label / interval array of a step's loss launches
+    goes to the GPU in ONE asynchronous copy (a pageable `.to(device)` per array blocks the host on the stream each time)."""
+
+    def __init__(self):
+        self.host = self.dev = None
+
+    def upload(self, arrays, device):
+        """arrays: list of contiguous numpy arrays (int32 / float64).  Returns device views in the same order."""
+        offs, total = [], 0
+        for a in arrays:
+            total = (total + 15) // 16 * 16               # kernels want 16-byte aligned operands
+            offs.append(total)
+            total += a.nbytes
+        total = max(16, (total + 15) // 16 * 16)
+        if self.host is None or self.host.numel() < total or self.dev.device != device:
+            cap = max(total * 2, 1 << 16)
+            self.host = torch.empty(cap, dtype=torch.uint8).pin_memory()
+            self.dev = torch.empty(cap, dtype=torch.uint8, device=device)
+            self.event = None
+        if self.event is not None:
+            self.event.synchronize()                      # the previous step's copy has left the pinned buffer
+        hv = self.host.numpy()
+        for a, o in zip(arrays, offs):
+            hv[o: o + a.nbytes] = a.view(np.uint8).reshape(-1)
+        self.dev[:total].copy_(self.host[:total], non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+        tdt = {np.dtype(np.float64): torch.float64, np.dtype(np.float32): torch.float32, np.dtype(np.int32): torch.int32}
+        return [self.dev[o: o + a.nbytes].view(tdt[a.dtype]) for a, o in zip(arrays, offs)]
 
 
 def apply_module_losses(model, res, questions, scale, pretrain_modules=CRITERION_MODULES,
@@ -184,87 +221,102 @@ def apply_module_losses(model, res, questions, scale, pretrain_modules=CRITERION
     (call res.zero_grad_arenas() first and res.backward(..., keep_arenas=True) afterwards).
     Local question i sits at global position window_base + rank + i * world of the accumulation window (the round-robin
     sharding of Trainer.step); contrastive classes are pooled per `window` GLOBAL questions (contrastive_windows).
+    Host work per step: concatenating the questions' gold packs (losses.compile_gold, prepared once per question),
+    one gather through the plan's node table and ONE upload; no per-node library call.
     Returns ({loss_kind: per-item losses tensor}, set of extra parameter names that received a gradient)."""
     dev = res.logits.device
     H, T = model.config['hidden_size'], res.info.T
     _, slot_t, aux_t, _, rel_t = res.node_table()
     base = np.asarray(res._prog_off, dtype=np.int64)
     packs = [compile_gold(q, pretrain_modules, no_intermediate) for q in questions]
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    up, plan = [], {}                                    # arrays to upload, and where each launch finds its own
 
-    losses, touched = {}, set()
-    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    vec, gvec = res._arena(res.info.vec_off, res.info.n_vec, H), res.grad_arena('vec')
-    att, gatt = res._arena(res.info.att_off, res.info.n_att, T), res.grad_arena('att')
-    i32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32)).to(dev, non_blocking=True)
+    def stage(key, *arrays):
+        plan[key] = (len(up), len(arrays))
+        up.extend(arrays)
 
     # ---- attention criteria (Localize / Temporal / ExistsFrame) ----
     sel = [qi for qi, p in enumerate(packs) if p.att_pos.size]
+    n_att = 0
     if sel:
         tok = np.concatenate([packs[qi].att_pos + base[qi] for qi in sel])
         kind = np.concatenate([packs[qi].att_kind for qi in sel])
         iv = np.concatenate([packs[qi].att_iv for qi in sel])                    # [n, 2, 2]
         slot = np.where(kind == 1, rel_t[tok], slot_t[tok])
         K = np.where(kind == 0, aux_t[tok], 1).astype(np.int64)
-        off = np.concatenate([[0], np.cumsum(K)])
-        rows = np.concatenate([iv[:, 0][:, None, :], iv[:, 1][:, None, :]], axis=1)   # [n, 2, 2]
         keep = np.arange(2)[None, :] < K[:, None]
-        ivf = torch.as_tensor(np.ascontiguousarray(rows[keep])).to(dev)             # [sum K, 2] float64
-        slot_d, K_d, off_d = i32(slot), i32(K), i32(off)
-        out = torch.empty(len(tok), device=dev)
-        check(lib.stair_loss_attention(C.c_void_p(att.data_ptr()), C.c_void_p(gatt.data_ptr()), C.c_void_p(slot_d.data_ptr()),
-                                       C.c_void_p(K_d.data_ptr()), C.c_void_p(off_d.data_ptr()), C.c_void_p(ivf.data_ptr()),
-                                       len(tok), T, C.c_float(scale), C.c_void_p(out.data_ptr()), stream))
-        losses['attention'] = out
+        n_att = len(tok)
+        stage('att', i32(slot), i32(K), i32(np.concatenate([[0], np.cumsum(K)])), np.ascontiguousarray(iv[keep], dtype=np.float64))
     # ---- linear heads (Exists / Xor / Equals) ----
+    n_head = {}
     for module in ('Exists', 'Xor', 'Equals'):
         sel = [qi for qi, p in enumerate(packs) if module in p.head]
         if not sel:
             continue
         if not model.config['have_pretrain_head']:
             raise RuntimeError('%s loss needs have_pretrain_head (modules.py)' % module)
-        head = model.submodules[module].pretrain_head
-        if head.weight.grad is None:
+        if model.submodules[module].pretrain_head.weight.grad is None:
             raise RuntimeError('pretrain head of %s has no .grad buffer (use stair_amd.train.Trainer)' % module)
         tok = np.concatenate([packs[qi].head[module][0] + base[qi] for qi in sel])
-        slot_d, lab_d = i32(slot_t[tok]), i32(np.concatenate([packs[qi].head[module][1] for qi in sel]))
-        out = torch.empty(len(tok), device=dev)
-        check(lib.stair_loss_head(head.weight.shape[0], C.c_void_p(vec.data_ptr()), C.c_void_p(gvec.data_ptr()),
-                                  C.c_void_p(slot_d.data_ptr()), C.c_void_p(lab_d.data_ptr()), C.c_void_p(head.weight.data_ptr()),
-                                  C.c_void_p(head.bias.data_ptr()), C.c_void_p(head.weight.grad.data_ptr()),
-                                  C.c_void_p(head.bias.grad.data_ptr()), len(tok), H, C.c_float(scale),
-                                  C.c_void_p(out.data_ptr()), stream))
-        losses[module] = out
-        touched.update({'submodules.%s.pretrain_head.weight' % module, 'submodules.%s.pretrain_head.bias' % module})
-    # ---- FilterFrame ----
-    ff_items = [(int(slot_t[base[qi] + pos]), gold) for qi, p in enumerate(packs) for pos, gold in p.ff]
-    if ff_items:
-        losses['FilterFrame'] = _filterframe_launch(model, res, ff_items, scale, True)
-        touched.update({'submodules.FilterFrame.pretrain_head.weight', 'submodules.FilterFrame.pretrain_head.bias'})
-    # ---- contrastive (Filter / ToAction / Superlative): class representations of every global window ----
-    cont_items, entries = [], []
+        n_head[module] = len(tok)
+        stage(module, i32(slot_t[tok]), i32(np.concatenate([packs[qi].head[module][1] for qi in sel])))
+    # ---- contrastive (Filter / ToAction / Superlative) ----
+    c_slot, c_wid, c_name, entries = [], [], [], []
     for qi, p in enumerate(packs):
         if not p.cont:
             continue
         gpos = window_base + rank + qi * world
+        wid = gpos // window if window else 0
         for pos, module, gold in p.cont:
+            s_ = int(slot_t[base[qi] + pos])
             for class_name, emb in gold:
-                cont_items.append((int(slot_t[base[qi] + pos]), gpos // window if window else 0, class_name))
+                c_slot.append(s_); c_wid.append(wid); c_name.append(class_name)
                 entries.append((gpos, class_name, emb))
-    if cont_items or world > 1:
-        table, embs, win_range = contrastive_windows(entries, window, world)
-    if cont_items:
-        lens = [e.shape[0] for e in embs]
-        x = torch.cat(embs).to(dev).contiguous()
-        seq_off = i32(np.concatenate([[0], np.cumsum(lens)]))
+    cw = contrastive_windows(entries, window, world) if (c_slot or world > 1) else None
+    if c_slot:
+        names, embs, rows, win_range, slot_of = cw
+        embs = [np.asarray(e, dtype=np.float32).reshape(-1, model.config['text_size']) for e in embs]
+        lens = [int(e.shape[0]) for e in embs]
+        stage('cont', i32(c_slot), i32([slot_of[(w, n)] for w, n in zip(c_wid, c_name)]),
+              i32([win_range[w][0] for w in c_wid]), i32([win_range[w][1] for w in c_wid]), rows,
+              i32(np.concatenate([[0], np.cumsum(lens)])), np.ascontiguousarray(np.concatenate(embs)))
+    # ---- ONE upload ----
+    staging = model.__dict__.setdefault('_loss_staging', _Staging())
+    d = staging.upload(up, dev) if up else []
+    got = lambda key: d[plan[key][0]: plan[key][0] + plan[key][1]]
+
+    losses, touched = {}, set()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    vec, gvec = res._arena(res.info.vec_off, res.info.n_vec, H), res.grad_arena('vec')
+    att, gatt = res._arena(res.info.att_off, res.info.n_att, T), res.grad_arena('att')
+    P = lambda t: C.c_void_p(t.data_ptr())
+    if n_att:
+        slot_d, K_d, off_d, iv_d = got('att')
+        out = torch.empty(n_att, device=dev)
+        check(lib.stair_loss_attention(P(att), P(gatt), P(slot_d), P(K_d), P(off_d), P(iv_d), n_att, T, C.c_float(scale), P(out), stream))
+        losses['attention'] = out
+    for module, n_items in n_head.items():
+        head = model.submodules[module].pretrain_head
+        slot_d, lab_d = got(module)
+        out = torch.empty(n_items, device=dev)
+        check(lib.stair_loss_head(head.weight.shape[0], P(vec), P(gvec), P(slot_d), P(lab_d), P(head.weight), P(head.bias),
+                                  P(head.weight.grad), P(head.bias.grad), n_items, H, C.c_float(scale), P(out), stream))
+        losses[module] = out
+        touched.update({'submodules.%s.pretrain_head.weight' % module, 'submodules.%s.pretrain_head.bias' % module})
+    # ---- FilterFrame (off by default, args.py:62) ----
+    ff_items = [(int(slot_t[base[qi] + pos]), gold) for qi, p in enumerate(packs) for pos, gold in p.ff]
+    if ff_items:
+        losses['FilterFrame'] = _filterframe_launch(model, res, ff_items, scale, True)
+        touched.update({'submodules.FilterFrame.pretrain_head.weight', 'submodules.FilterFrame.pretrain_head.bias'})
+    if c_slot:
+        slot_d, pos_d, ws_d, wc_d, rows_d, seq_off, x = got('cont')
+        x = x.view(-1, model.config['text_size'])
         _, h_n = ops.lstm_bidir(x, seq_off, max(lens), [w.detach() for w in model._lstm_weights('text_encoder')])
-        G = ops.l2normalize(h_n)
-        slot_d = i32([c[0] for c in cont_items]); pos_d = i32([table[c[1]][c[2]] for c in cont_items])
-        ws_ = i32([win_range[c[1]][0] for c in cont_items]); wc = i32([win_range[c[1]][1] for c in cont_items])
-        out = torch.empty(len(cont_items), device=dev)
-        check(lib.stair_loss_contrastive(C.c_void_p(vec.data_ptr()), C.c_void_p(gvec.data_ptr()), C.c_void_p(slot_d.data_ptr()),
-                                         C.c_void_p(pos_d.data_ptr()), C.c_void_p(ws_.data_ptr()), C.c_void_p(wc.data_ptr()),
-                                         C.c_void_p(G.data_ptr()), len(cont_items), H, max(r[1] for r in win_range.values()),
-                                         C.c_float(scale), C.c_void_p(out.data_ptr()), stream))
+        G = ops.l2normalize(h_n).index_select(0, rows_d.long())          # every window's classes, window after window
+        out = torch.empty(len(c_slot), device=dev)
+        check(lib.stair_loss_contrastive(P(vec), P(gvec), P(slot_d), P(pos_d), P(ws_d), P(wc_d), P(G), len(c_slot), H,
+                                         max(r[1] for r in win_range.values()), C.c_float(scale), P(out), stream))
         losses['contrastive'] = out
     return losses, touched
 

@@ -7,15 +7,16 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stair_amd import ops
 
-B, T, V, N = 2048, 64, 2048, 1024
+B, T, V, N = 2048, 64, 2048, 2048          # N = 8 * Hh: both directions of the bi-LSTM in one launch
 M = B * T
 dev = 'cuda:0'
 x = torch.randn(M, V, device=dev).to(torch.bfloat16)
 w = torch.randn(N, V, device=dev) * 0.02
-wh, wl = ops.split_planes(w)
+wh, wl = ops.split_planes_tiled(w)
 b = torch.zeros(N, device=dev)
-out = torch.empty(M, 2 * N, device=dev)
+out = torch.empty(M, N, device=dev)
 for _ in range(6):
-    ops.gemm_planes(x, None, wh, wl, b, out=out[:, :N])
+    ops.gemm_planes(x, None, wh, wl, b, out=out)
 torch.cuda.synchronize()
+print('shape M N K = %d %d %d' % (M, N, V))
 print('algorithmic bytes per launch: A %d + W %d + C %d = %d' % (M * V * 2, N * V * 4, M * N * 4, M * V * 2 + N * V * 4 + M * N * 4))

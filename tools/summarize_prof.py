@@ -2,7 +2,7 @@
 """Turn rocprofv3 outputs under gpurun_out/ into the small summaries kept in profiles/.
   summarize_prof.py stats <results.db> <out.csv>            per-kernel calls / total / average / share
   summarize_prof.py pmc <counter_collection.csv>... <out.json>   mean counter value per kernel"""
-import sys, csv, json, sqlite3, collections
+import os, sys, csv, json, sqlite3, collections
 
 
 def stats(db, out):
@@ -33,9 +33,13 @@ def pmc(files, out):
             k = (r['Kernel_Name'].split('(')[0], r['Counter_Name'])
             agg[k].append(float(r['Counter_Value']))
             grid[k] = int(r['Grid_Size'])
+        shape = [int(x) for x in os.environ['STAIR_PMC_SHAPE'].split(',')] if os.environ.get('STAIR_PMC_SHAPE') else None
         for (kern, ctr), v in agg.items():
-            res.append({'file': fn.split('/')[-2], 'kernel': kern, 'counter': ctr, 'dispatches': len(v), 'grid_threads': grid[(kern, ctr)],
-                        'mean_per_dispatch': sum(v) / len(v), 'min': min(v), 'max': max(v)})
+            row = {'file': fn.split('/')[-3] if fn.split('/')[-2].startswith('run') else fn.split('/')[-2], 'kernel': kern, 'counter': ctr,
+                   'dispatches': len(v), 'grid_threads': grid[(kern, ctr)], 'mean_per_dispatch': sum(v) / len(v), 'min': min(v), 'max': max(v)}
+            if shape and ('gemm' in kern):
+                row['shape'] = shape            # M, N, K of the launches in this run (tools/pmc_*.py print it)
+            res.append(row)
     json.dump(res, open(out, 'w'), indent=1)
 
 
