@@ -127,3 +127,17 @@ def test_compiled_program_cache_and_batch_packing():
     assert prog_off.tolist() == [0, 5, 7, 12] and q_off.tolist() == [0, 9, 13, 20]
     assert tokens.dtype == np.int32 and tokens.tolist() == c1.codes.tolist() + c2.codes.tolist() + c1.codes.tolist()
     assert lo.tolist()[5:7] == [0, 0] and hi.tolist()[8 - 2 + 0] == 0 and hi[1] == 4 and hi[8] == 4
+
+
+SPANS = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'spans.json')))
+
+
+@pytest.mark.parametrize('key', sorted(SPANS))
+def test_match_spans_equals_reference_matcher_under_the_injected_normaliser(key):
+    """tests/golden/spans.json holds the outputs of the REFERENCE's get_program_list_string_index (utils/agqa_lite.py:62-119)
+    driven with frontend.Normaliser as its three nltk tools (make_spans_golden.py): rewrite tables, 'ing' override, the scan
+    that stops one position early (X0), repeated words (X1), unmatched phrases (C3, X2), word and character spans."""
+    case = SPANS[key]
+    by_word, by_char = F.match_spans(case['nmn'], case['question'], F.Normaliser())
+    assert {str(k): list(v) for k, v in by_word.items()} == case['by_word']
+    assert {str(k): list(v) for k, v in by_char.items()} == case['by_char']

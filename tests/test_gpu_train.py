@@ -210,6 +210,11 @@ def test_backward_matches_reference_backward(fixture, matmul):
     print('worst gradient error / tolerance vs reference:', worst)
 
 
+# measured: 2.1 % (f32, LSTM biases: every flip of a module mask reaches the encoder through dX) and 20 % (bf16x3, a 512-entry
+# bias) with six questions in the window; a real window of thousands averages the flips out (rel. L2 above)
+FRAC_OUTSIDE_STRICT = {'f32': 5e-2, 'bf16x3': 0.3}
+
+
 def test_full_size_backward_sample(matmul):
     """Full-size shapes (H=512, V=2048, T=64): 6 questions against autograd of the oracle."""
     config = dict(spec.DEFAULT_CONFIG)
@@ -230,6 +235,7 @@ def test_full_size_backward_sample(matmul):
     # weight gradient can differ by O(1/rows) while everything else agrees to 1e-6 (verified by dumping the saved
     # activations: 1 mask flip in 65536 elements, no other difference).  The criterion is therefore the relative
     # L2 error per tensor plus a loose max-abs bound; the tiny-config tests above use the strict elementwise bound.
+    worst_frac = (0.0, '')
     for n in names:
         ref = w[n].grad
         if ref is None:
@@ -239,6 +245,13 @@ def test_full_size_backward_sample(matmul):
         lim = 3e-3 if matmul == 'f32' else 1e-2      # split kernels: ~100x more inputs fall inside the rounding band of a kink
         assert rel_l2 < (lim if ref.numel() >= 64 else 2e-2), (n, rel_l2)     # scalars cannot average a flip out
         assert float((g - ref).abs().max()) < 0.05 * float(ref.abs().max()) + 3e-6, n
+        # ... and ELEMENTWISE at the strict bound of the tiny-config tests (2e-4 max|g|) for all but the few rows a flipped
+        # mask touches: the fraction of entries outside the strict bound is itself bounded
+        frac = float(((g - ref).abs() > 2e-4 * float(ref.abs().max()) + 1e-9).float().mean())
+        if ref.numel() >= 512:
+            worst_frac = max(worst_frac, (frac, n))
+    print('largest fraction of gradient entries outside 2e-4 max|g| (%s): %.3g in %s' % (matmul, worst_frac[0], worst_frac[1]))
+    assert worst_frac[0] < FRAC_OUTSIDE_STRICT[matmul], worst_frac
 
 
 def _with_gold(config, seed, qs, T):
