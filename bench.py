@@ -327,6 +327,18 @@ def main():
                                              'note': 'BASELINE configs[4] on one GPU: gold intermediates on ~85 % of the supervisable nodes, attention / head / '
                                                      'contrastive (32-question windows) criteria + decoder CE in one step; gold packs prepared per question outside '
                                                      'the loop, as a data-loader worker would (losses.compile_gold)'}
+            # ---- clips of their own lengths in one launch batch (dataset.py:137-143 keeps every clip's frame count): T uniform
+            # in 16..64 (mean 40), padded to 64; the same questions, the frames past a clip's length are padding ----
+            rng = np.random.RandomState(0)
+            vlen = rng.randint(16, T + 1, size=B).astype(np.int32)
+            vmask = (torch.arange(T, device=device)[None, :] < torch.as_tensor(vlen, device=device)[:, None]).unsqueeze(-1)
+            vr = (video * vmask).contiguous()
+            dt_rt, _ = timed(lambda: trainer.step(programs, spans, vr, question, q_lens, answers, video_len=vlen), 4, 2)
+            dt_ri, _ = timed(lambda: model.run_programs(programs, spans, vr, question, q_lens, video_len=vlen), 4, 2)
+            extras['ragged_clip_lengths'] = {'frames': 'uniform 16..%d (mean %.1f), one launch batch, padded to %d' % (T, float(vlen.mean()), T),
+                                             'train_questions_per_s': round(4 * B / dt_rt, 1), 'train_ms_per_step': round(dt_rt / 4 * 1e3, 3),
+                                             'infer_questions_per_s': round(4 * B / dt_ri, 1)}
+            del vr
             # ---- the other storage / arithmetic modes, a few steps each ----
             other = 'f32' if args.features == 'bf16' else 'bf16'
             v2 = video.float() if other == 'f32' else video.to(torch.bfloat16)

@@ -195,6 +195,10 @@ typedef struct stair_lstm_args {
                     of 4 co-resident workgroups that exchange h every step, W_hh resident in registers.  NULL = the
                     one-workgroup-per-16-sequences kernel.  The launch occupies up to one workgroup on every CU and its
                     workgroups wait for each other: do not run two of them concurrently on different streams. */
+    const int32_t *seq_len; /* optional device [n]: PADDED storage -- sequence s occupies rows seq_off[s] .. seq_off[s+1]-1 but
+                    only its first seq_len[s] rows are data (clips of different frame counts stored at one stride,
+                    /root/reference/video_nmn/dataset.py:137-143); out rows past the length are written as zero.  NULL: every
+                    row of the span is data. */
 } stair_lstm_args;
 int64_t stair_lstm_coop_ws_bytes(int32_t n);
 int stair_lstm_bidir_fwd(const stair_lstm_args *args, stair_stream stream);
@@ -214,6 +218,7 @@ typedef struct stair_lstm_bwd_args {
     float *whh_pack_ws, *hprev_ws;
     float *dw_ih[2], *dw_hh[2], *db_ih[2], *db_hh[2];
     const void *x_bf16; /* optional, as in stair_lstm_args: dW_ih = dG^T X then reads X as exact bf16 (two products per pair) */
+    const int32_t *seq_len; /* optional, as in stair_lstm_args (the gate-gradient rows past a sequence's length are cleared) */
 } stair_lstm_bwd_args;
 int stair_lstm_bidir_bwd(const stair_lstm_bwd_args *args, stair_stream stream);
 
@@ -269,6 +274,18 @@ int stair_plan_build(stair_ctx *ctx, int32_t n, const int32_t *prog_off, const i
 int stair_plan_build_shared(stair_ctx *ctx, int32_t n, const int32_t *prog_off, const int32_t *tokens,
                             const int32_t *span_lo, const int32_t *span_hi, const int32_t *q_off,
                             int32_t n_videos, const int32_t *video_of_question, int32_t T,
+                            int32_t flags, stair_plan **out);
+/* Same, for batches whose clips differ in FRAME COUNT (real I3D .npy clips keep their own length and are only truncated
+ * above max_video_length, dataset.py:137-143): `video` is [n_videos, T, V] with clip v's video_len[v] <= T frames first and
+ * padding behind; every [T,H] map and [T] attention row keeps the stride T.  Each question is computed as the reference
+ * computes a clip of ITS length: the LSTM runs video_len steps, Filter sums, Relate's softmax, Superlative's pooling (and
+ * its action count when the actions are a map), the Conv1d Temporal nets ('same' zero padding at the clip's own end) and
+ * the attention criterion see exactly video_len frames; padded frames of map outputs hold finite don't-care values and
+ * padded attention frames of Temporal / Relate outputs are zero.  Needs the Conv1d Temporal configuration
+ * (max_video_length > 32).  video_len == NULL: every clip has T frames (== stair_plan_build_shared). */
+int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t *prog_off, const int32_t *tokens,
+                            const int32_t *span_lo, const int32_t *span_hi, const int32_t *q_off,
+                            int32_t n_videos, const int32_t *video_of_question, const int32_t *video_len, int32_t T,
                             int32_t flags, stair_plan **out);
 void stair_plan_destroy(stair_plan *plan);
 
@@ -356,6 +373,11 @@ int stair_plan_zero_grads(stair_plan *plan, void *workspace, stair_stream stream
 int stair_loss_attention(const float *att, float *d_att, const int32_t *slot, const int32_t *K,
                          const int32_t *iv_off, const double *intervals, int32_t n, int32_t T, float scale,
                          float *loss, stair_stream stream);
+/* The same with per-item clip lengths (plans built by stair_plan_build_ragged): len[i] frames of the rows of item i count,
+ * the interval masks are drawn for len[i] frames.  len == NULL: T. */
+int stair_loss_attention_len(const float *att, float *d_att, const int32_t *slot, const int32_t *K,
+                             const int32_t *iv_off, const double *intervals, const int32_t *len, int32_t n, int32_t T,
+                             float scale, float *loss, stair_stream stream);
 /* Linear pretrain head W [nout,H] on vec[slot[i]] + loss: nout = 2 CrossEntropy vs bool label (Exists, Xor :92-99),
  * nout = 1 squared error vs 0/1 (Equals :101-107). */
 int stair_loss_head(int32_t nout, const float *vec, float *d_vec, const int32_t *slot, const int32_t *label,

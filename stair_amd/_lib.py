@@ -58,7 +58,8 @@ class LstmArgs(C.Structure):
                 ('w_ih', C.c_void_p * 2), ('w_hh', C.c_void_p * 2), ('b_ih', C.c_void_p * 2), ('b_hh', C.c_void_p * 2),
                 ('xproj_ws', C.c_void_p), ('bias_ws', C.c_void_p), ('whh_pack_ws', C.c_void_p),
                 ('out', C.c_void_p), ('ldo', C.c_int64), ('h_n', C.c_void_p), ('cbuf', C.c_void_p),
-                ('x_bf16', C.c_void_p), ('wih_planes_ws', C.c_void_p), ('coop_ws', C.c_void_p), ('coop_ws_bytes', C.c_int64)]
+                ('x_bf16', C.c_void_p), ('wih_planes_ws', C.c_void_p), ('coop_ws', C.c_void_p), ('coop_ws_bytes', C.c_int64),
+                ('seq_len', C.c_void_p)]
 
 
 class LstmBwdArgs(C.Structure):
@@ -69,7 +70,7 @@ class LstmBwdArgs(C.Structure):
                 ('d_out', C.c_void_p), ('ldd', C.c_int64), ('d_hn', C.c_void_p),
                 ('whh_pack_ws', C.c_void_p), ('hprev_ws', C.c_void_p),
                 ('dw_ih', C.c_void_p * 2), ('dw_hh', C.c_void_p * 2), ('db_ih', C.c_void_p * 2), ('db_hh', C.c_void_p * 2),
-                ('x_bf16', C.c_void_p)]
+                ('x_bf16', C.c_void_p), ('seq_len', C.c_void_p)]
 
 
 class PlanInfo(C.Structure):
@@ -115,6 +116,10 @@ SIGNATURES = [
                                    C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     ('stair_plan_build_shared', C.c_int, [C.c_void_p, C.c_int32, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p,
                                           C.c_int32, c_int32_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    ('stair_plan_build_ragged', C.c_int, [C.c_void_p, C.c_int32, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p,
+                                          C.c_int32, c_int32_p, c_int32_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    ('stair_loss_attention_len', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                           C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     ('stair_plan_backward', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                       C.c_float, C.c_void_p, C.c_int32, C.c_void_p]),
     ('stair_loss_filterframe', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -27,16 +27,19 @@ __device__ __forceinline__ float span_gold(double g0, double g1, int L, int t) {
 }  // namespace
 
 // attention_score_criterion (:83-90) for Localize [K,T] (:173-182), Temporal / ExistsFrame [T] (:157-164,184-191)
+// `len` (optional): frames of item i's clip; the attention rows keep the stride T, criterion and gold mask see L frames
 __global__ void loss_attention_kernel(const float *att, float *d_att, const int32_t *slot, const int32_t *K,
-                                      const int32_t *iv_off, const double *intervals, int n, int T, float scale, float *loss) {
+                                      const int32_t *iv_off, const double *intervals, int n, int T, float scale, float *loss,
+                                      const int32_t *len) {
     const int i = blockIdx.x;
     const int k = K[i];
-    const float inv = 1.0f / (float)(k * T);
+    const int L = len ? len[i] : T;
+    const float inv = 1.0f / (float)(k * L);
     float acc = 0.f;
-    for (int e = threadIdx.x; e < k * T; e += blockDim.x) {
-        const int r = e / T, t = e - r * T;
+    for (int e = threadIdx.x; e < k * L; e += blockDim.x) {
+        const int r = e / L, t = e - r * L;
         const double *iv = intervals + 2 * (int64_t)(iv_off[i] + r);
-        const float g = span_gold(iv[0], iv[1], T, t);
+        const float g = span_gold(iv[0], iv[1], L, t);
         const int64_t o = ((int64_t)slot[i] + r) * T + t;
         const float p = att[o];
         acc += -(g * logf(p) + (1.f - g) * logf(1.f - p));
@@ -46,9 +49,9 @@ __global__ void loss_attention_kernel(const float *att, float *d_att, const int3
     if (threadIdx.x == 0) loss[i] = acc * inv;       // blockDim == 64: one wave
 }
 int launch_loss_attention(const float *att, float *d_att, const int32_t *slot, const int32_t *K, const int32_t *iv_off,
-                          const double *intervals, int n, int T, float scale, float *loss, hipStream_t s) {
+                          const double *intervals, int n, int T, float scale, float *loss, hipStream_t s, const int32_t *len = nullptr) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(loss_attention_kernel, dim3(n), dim3(64), 0, s, att, d_att, slot, K, iv_off, intervals, n, T, scale, loss);
+    hipLaunchKernelGGL(loss_attention_kernel, dim3(n), dim3(64), 0, s, att, d_att, slot, K, iv_off, intervals, n, T, scale, loss, len);
     STAIR_LAUNCH_CHECK();
     return 0;
 }
@@ -283,6 +286,11 @@ extern "C" int stair_loss_attention(const float *att, float *d_att, const int32_
                                     const int32_t *iv_off, const double *intervals, int32_t n, int32_t T, float scale,
                                     float *loss, stair_stream stream) {
     return stair::launch_loss_attention(att, d_att, slot, K, iv_off, intervals, n, T, scale, loss, static_cast<hipStream_t>(stream));
+}
+extern "C" int stair_loss_attention_len(const float *att, float *d_att, const int32_t *slot, const int32_t *K,
+                                        const int32_t *iv_off, const double *intervals, const int32_t *len, int32_t n, int32_t T,
+                                        float scale, float *loss, stair_stream stream) {
+    return stair::launch_loss_attention(att, d_att, slot, K, iv_off, intervals, n, T, scale, loss, static_cast<hipStream_t>(stream), len);
 }
 extern "C" int stair_loss_head(int32_t nout, const float *vec, float *d_vec, const int32_t *slot, const int32_t *label,
                                const float *W, const float *b, float *dW, float *db, int32_t n, int32_t H, float scale,

@@ -23,6 +23,7 @@ struct LstmRecParams {
     const float *xproj;      // [rows, 8Hh]
     const float *w_pack;     // [2][Hh/32][4*Hh/16][2][64][4] W_hh in MFMA-fragment order (see whh_pack_kernel)
     const int32_t *seq_off;  // [n+1]
+    const int32_t *seq_len;  // optional [n]: sequence s holds seq_len[s] rows from seq_off[s] (padded storage); null: off[s+1] - off[s]
     float *out;              // [rows, ldo]
     int64_t ldo;
     float *h_n;              // [n, 2Hh]
@@ -95,10 +96,10 @@ __global__ __launch_bounds__(NWAVES * 64) void lstm_rec_kernel(LstmRecParams p) 
         len4[e] = 0;
         if (s < p.n) {
             off4[e] = p.seq_off[s];
-            len4[e] = p.seq_off[s + 1] - off4[e];
+            len4[e] = p.seq_len ? p.seq_len[s] : p.seq_off[s + 1] - off4[e];
         }
     }
-    for (int s = s0; s < min(s0 + 16, p.n); ++s) lmax = max(lmax, p.seq_off[s + 1] - p.seq_off[s]);
+    for (int s = s0; s < min(s0 + 16, p.n); ++s) lmax = max(lmax, p.seq_len ? p.seq_len[s] : p.seq_off[s + 1] - p.seq_off[s]);
 
     for (int i = tid; i < 2 * 16 * ldh; i += NWAVES * 64) hbuf[i] = 0.0f;
     float creg[NCT][4], hreg[NCT][4];
@@ -288,9 +289,9 @@ __global__ __launch_bounds__(NWAVES * 64) void lstm_rec_x3_kernel(LstmRecParams 
     for (int e = 0; e < 4; ++e) {
         const int s = s0 + g4 * 4 + e;
         off4[e] = 0; len4[e] = 0;
-        if (s < p.n) { off4[e] = p.seq_off[s]; len4[e] = p.seq_off[s + 1] - off4[e]; }
+        if (s < p.n) { off4[e] = p.seq_off[s]; len4[e] = p.seq_len ? p.seq_len[s] : p.seq_off[s + 1] - off4[e]; }
     }
-    for (int s = s0; s < min(s0 + 16, p.n); ++s) lmax = max(lmax, p.seq_off[s + 1] - p.seq_off[s]);
+    for (int s = s0; s < min(s0 + 16, p.n); ++s) lmax = max(lmax, p.seq_len ? p.seq_len[s] : p.seq_off[s + 1] - p.seq_off[s]);
     for (int i = tid; i < 2 * 16 * ldh; i += NWAVES * 64) hbuf[i] = 0.0f;
     float creg[NCT][4];          // h of a finished (inactive) sequence is carried in LDS, not in registers
 #pragma unroll
@@ -437,14 +438,29 @@ __global__ void whh_packT_kernel(const float *w0, const float *w1, float *pack, 
 }
 
 // hprev[row][dir*Hh + u] = h of the previous step of that direction (0 at the sequence start)
-__global__ void lstm_hprev_kernel(const float *out, int64_t ldo, const int32_t *seq_off, int n, int Hh, float *hprev) {
+// (padded storage: the rows past a sequence's length get h_prev = 0 and their gate-gradient rows are cleared, so that the
+// weight-gradient GEMMs, which run over ALL rows, add nothing for them)
+__global__ void lstm_hprev_kernel(const float *out, int64_t ldo, const int32_t *seq_off, const int32_t *seq_len, int n, int Hh,
+                                  float *hprev, float *G) {
     const int s = blockIdx.x;
-    const int beg = seq_off[s], len = seq_off[s + 1] - beg;
-    for (int i = threadIdx.x; i < len * 2 * Hh; i += blockDim.x) {
+    const int beg = seq_off[s], span = seq_off[s + 1] - beg, len = seq_len ? seq_len[s] : span;
+    for (int i = threadIdx.x; i < span * 2 * Hh; i += blockDim.x) {
         const int t = i / (2 * Hh), c = i - t * 2 * Hh;
         const int dir = c >= Hh;
         const int tp = dir == 0 ? t - 1 : t + 1;
-        hprev[(int64_t)(beg + t) * 2 * Hh + c] = (tp >= 0 && tp < len) ? out[(int64_t)(beg + tp) * ldo + c] : 0.0f;
+        hprev[(int64_t)(beg + t) * 2 * Hh + c] = (t < len && tp >= 0 && tp < len) ? out[(int64_t)(beg + tp) * ldo + c] : 0.0f;
+    }
+    if (seq_len && len < span)
+        for (int i = threadIdx.x; i < (span - len) * 8 * Hh; i += blockDim.x) G[(int64_t)(beg + len) * 8 * Hh + i] = 0.0f;
+}
+
+// out rows past a sequence's length (padded storage) are defined: zero
+__global__ void lstm_zero_tail_kernel(float *out, int64_t ldo, const int32_t *seq_off, const int32_t *seq_len, int Hh) {
+    const int s = blockIdx.x;
+    const int beg = seq_off[s], span = seq_off[s + 1] - beg, len = seq_len[s];
+    for (int i = threadIdx.x; i < (span - len) * 2 * Hh; i += blockDim.x) {
+        const int t = len + i / (2 * Hh), c = i % (2 * Hh);
+        out[(int64_t)(beg + t) * ldo + c] = 0.0f;
     }
 }
 
@@ -456,6 +472,7 @@ struct LstmBwdParams {
     const float *d_hn;       // [n, 2Hh] or null
     const float *w_packT;
     const int32_t *seq_off;
+    const int32_t *seq_len;  // optional, as in LstmRecParams
     int n, Hh;
 };
 
@@ -481,9 +498,9 @@ __global__ __launch_bounds__(NWAVES * 64) void lstm_bwd_kernel(LstmBwdParams p) 
     for (int e = 0; e < 4; ++e) {
         const int s = s0 + g4 * 4 + e;
         off4[e] = 0; len4[e] = 0;
-        if (s < p.n) { off4[e] = p.seq_off[s]; len4[e] = p.seq_off[s + 1] - off4[e]; }
+        if (s < p.n) { off4[e] = p.seq_off[s]; len4[e] = p.seq_len ? p.seq_len[s] : p.seq_off[s + 1] - off4[e]; }
     }
-    for (int s = s0; s < min(s0 + 16, p.n); ++s) lmax = max(lmax, p.seq_off[s + 1] - p.seq_off[s]);
+    for (int s = s0; s < min(s0 + 16, p.n); ++s) lmax = max(lmax, p.seq_len ? p.seq_len[s] : p.seq_off[s + 1] - p.seq_off[s]);
 
     bool own[NCT];
     int unit[NCT];
@@ -617,9 +634,9 @@ __global__ __launch_bounds__(NWAVES * 64) void lstm_bwd_x3_kernel(LstmBwdParams 
     for (int e = 0; e < 4; ++e) {
         const int s = s0 + g4 * 4 + e;
         off4[e] = 0; len4[e] = 0;
-        if (s < p.n) { off4[e] = p.seq_off[s]; len4[e] = p.seq_off[s + 1] - off4[e]; }
+        if (s < p.n) { off4[e] = p.seq_off[s]; len4[e] = p.seq_len ? p.seq_len[s] : p.seq_off[s + 1] - off4[e]; }
     }
-    for (int s = s0; s < min(s0 + 16, p.n); ++s) lmax = max(lmax, p.seq_off[s + 1] - p.seq_off[s]);
+    for (int s = s0; s < min(s0 + 16, p.n); ++s) lmax = max(lmax, p.seq_len ? p.seq_len[s] : p.seq_off[s + 1] - p.seq_off[s]);
     bool own[NCT];
     int unit[NCT], cb[NCT];
 #pragma unroll
@@ -744,7 +761,7 @@ int launch_lstm_bwd(const stair_lstm_bwd_args &a, hipStream_t s) {
     }
     LstmBwdParams p;
     p.G = a.gates; p.cbuf = a.cbuf; p.d_out = a.d_out; p.ldd = a.ldd; p.d_hn = a.d_hn; p.w_packT = a.whh_pack_ws;
-    p.seq_off = a.seq_off; p.n = a.n; p.Hh = Hh;
+    p.seq_off = a.seq_off; p.seq_len = a.seq_len; p.n = a.n; p.Hh = Hh;
     const dim3 grid((a.n + 15) / 16, 2);
     const size_t shmem = split ? 2 * 16 * (4 * Hh + 8) * sizeof(__bf16) : 16 * (4 * Hh + 4) * sizeof(float);
     const int tiles = Hh / 16;
@@ -763,7 +780,7 @@ int launch_lstm_bwd(const stair_lstm_bwd_args &a, hipStream_t s) {
     else if (tiles > 2) hipLaunchKernelGGL((lstm_bwd_kernel<1, 4>), grid, dim3(256), shmem, s, p);
     else hipLaunchKernelGGL((lstm_bwd_kernel<1, 2>), grid, dim3(128), shmem, s, p);
     STAIR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(lstm_hprev_kernel, dim3(a.n), dim3(256), 0, s, a.out, a.ldo, a.seq_off, a.n, Hh, a.hprev_ws);
+    hipLaunchKernelGGL(lstm_hprev_kernel, dim3(a.n), dim3(256), 0, s, a.out, a.ldo, a.seq_off, a.seq_len, a.n, Hh, a.hprev_ws, a.gates);
     STAIR_LAUNCH_CHECK();
     // weight gradients: dW_ih = dG^T X, dW_hh = dG^T Hprev, db_ih = db_hh = colsum(dG)
     for (int dir = 0; dir < 2; ++dir) {
@@ -817,6 +834,10 @@ int launch_lstm(const stair_lstm_args &a, hipStream_t s) {
         if (int rc = launch_gemm(g, s)) return rc;
     }
     STAIR_CHECK(a.whh_pack_ws != nullptr, "whh_pack_ws missing");
+    if (a.seq_len) {                  // padded storage: rows past each sequence's length read as zero downstream
+        hipLaunchKernelGGL(lstm_zero_tail_kernel, dim3(a.n), dim3(256), 0, s, a.out, a.ldo, a.seq_off, a.seq_len, Hh);
+        STAIR_LAUNCH_CHECK();
+    }
     if (a.coop_ws && lstm_coop_usable(Hh)) return launch_lstm_rec_coop(a, s);   // hidden units split over co-resident workgroups
     const bool split = matmul_mode() != STAIR_MATMUL_F32 && Hh % 64 == 0;     // the split kernel walks k blocks in pairs
     if (split) {
@@ -832,7 +853,7 @@ int launch_lstm(const stair_lstm_args &a, hipStream_t s) {
     }
     LstmRecParams p;
     p.xproj = a.xproj_ws; p.w_pack = a.whh_pack_ws;
-    p.seq_off = a.seq_off; p.out = a.out; p.ldo = a.ldo; p.h_n = a.h_n; p.cbuf = a.cbuf; p.n = a.n; p.Hh = Hh;
+    p.seq_off = a.seq_off; p.seq_len = a.seq_len; p.out = a.out; p.ldo = a.ldo; p.h_n = a.h_n; p.cbuf = a.cbuf; p.n = a.n; p.Hh = Hh;
     const dim3 grid((a.n + 15) / 16, 2);
     const size_t shmem = 2 * 16 * (Hh + 4) * sizeof(float);
     const int tiles = Hh / 16;

@@ -46,6 +46,7 @@ struct CoopParams {
     float *xproj;             // [rows, 8 Hh]: gate pre-activations from the input projection; training: overwritten with activated gates
     const float *w_hh[2];     // [4 Hh, Hh] per direction
     const int32_t *seq_off;   // [n + 1]
+    const int32_t *seq_len;   // optional [n]: rows of sequence s when the storage is padded (else off[s+1] - off[s])
     float *out; int64_t ldo;  // [rows, ldo]
     float *h_n;               // [n, 2 Hh]
     float *cbuf;              // [rows, 2 Hh] or null
@@ -121,9 +122,9 @@ __global__ __launch_bounds__(512, 1) void lstm_rec_coop_kernel(CoopParams p) {
         for (int x = 0; x < NT; ++x) {
             const int s = s_base + 32 * x + r;
             off[x] = 0; len[x] = 0;
-            if (s < p.n) { off[x] = p.seq_off[s]; len[x] = p.seq_off[s + 1] - off[x]; }
+            if (s < p.n) { off[x] = p.seq_off[s]; len[x] = p.seq_len ? p.seq_len[s] : p.seq_off[s + 1] - off[x]; }
         }
-        for (int s = s_base; s < min(s_base + SPG, p.n); ++s) lmax = max(lmax, p.seq_off[s + 1] - p.seq_off[s]);
+        for (int s = s_base; s < min(s_base + SPG, p.n); ++s) lmax = max(lmax, p.seq_len ? p.seq_len[s] : p.seq_off[s + 1] - p.seq_off[s]);
         for (int i = tid; i < NT * TILE_BYTES / 16 + 1; i += 512) reinterpret_cast<v4u *>(hl)[i] = v4u{0, 0, 0, 0};     // h(-1) = 0, arrival counters = 0
         float creg[NT][4];
 #pragma unroll
@@ -334,7 +335,7 @@ int launch_lstm_rec_coop(const stair_lstm_args &a, hipStream_t s) {
     STAIR_CHECK(a.ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.h_n) & 15) == 0,
                 "out / h_n must be 16-byte aligned with ldo % 4 == 0");
     CoopParams p;
-    p.xproj = a.xproj_ws; p.w_hh[0] = a.w_hh[0]; p.w_hh[1] = a.w_hh[1]; p.seq_off = a.seq_off;
+    p.xproj = a.xproj_ws; p.w_hh[0] = a.w_hh[0]; p.w_hh[1] = a.w_hh[1]; p.seq_off = a.seq_off; p.seq_len = a.seq_len;
     p.out = a.out; p.ldo = a.ldo; p.h_n = a.h_n; p.cbuf = a.cbuf; p.n = a.n;
     int nt = 1;
     coop_geometry(a.n, nt, p.gpd);

@@ -20,14 +20,15 @@ int launch_cosine_attn(const float *F, int64_t f_gstride, const int32_t *f_idx, 
 
 int launch_temporal_relate(const float *att, const int32_t *att_idx, const int32_t *att_k, float *out,
                            const int32_t *out_idx, int n, int T, int mode, int conv, int ksize,
-                           const float *const w[6], hipStream_t s);
+                           const float *const w[6], hipStream_t s, const int32_t *len = nullptr);
 
 // LayerNorm over H: rows of Y [n*T, H] (contiguous) -> tiles X + gidx[g]*gstride, [T,H]      modules.py:283,327
 int launch_layernorm(const float *Y, float *X, int64_t gstride, const int32_t *gidx, int n, int T, int H, const float *gamma,
                      const float *beta, float eps, hipStream_t s);
 
 // out[g][:] = sum_t X[g][t][:]                                                 modules.py:374,376
-int launch_sum_rows(const float *X, float *out, int n, int T, int H, hipStream_t s);
+// `len` (optional, here and below): frames per instance when a batch mixes clip lengths; rows keep the stride T
+int launch_sum_rows(const float *X, float *out, int n, int T, int H, hipStream_t s, const int32_t *len = nullptr);
 
 // out[out_idx[g]*out_gstride + t] = sigmoid(X[g][t] . w + b[0] + (extra ? extra[g] : 0))
 int launch_rowdot_sigmoid(const float *X, int n, int T, int H, const float *w, const float *b, const float *extra,
@@ -37,7 +38,7 @@ int launch_vecdot(const float *V, const int32_t *idx, const float *w, float *out
 
 // att[out[i]] = softmax_T(att[in[i]] + sign * beta[:T])                         modules.py:417-435
 int launch_relate_softmax(float *att, const int32_t *in_idx, const int32_t *out_idx, const float *beta, float sign,
-                          int n, int T, hipStream_t s);
+                          int n, int T, hipStream_t s, const int32_t *len = nullptr);
 
 // mode 0: min(a,b) (AndModule :7-12); mode 1: |a-b| (XorFrameModule :75-80); rows of `len` floats
 int launch_eltwise(int mode, float *base, const int32_t *ia, const int32_t *ib, const int32_t *io, int n, int len,
@@ -53,7 +54,8 @@ int launch_choose(float *vec, const int32_t *k1, const int32_t *k2, const int32_
 
 // Superlative pooling: w = softmax_a(sum_t S[a][t]) (1-w for min); out[i] = sum_a w_a * rows[row_id[a]]
 int launch_superlative_pool(const float *S, const float *rowbase, const int32_t *row_id, const int32_t *row_start,
-                            const int32_t *row_cnt, int is_min, float *out, int n, int T, int H, hipStream_t s);
+                            const int32_t *row_cnt, int is_min, float *out, int n, int T, int H, hipStream_t s,
+                            const int32_t *len = nullptr);
 
 int launch_l2norm(const float *x, float *out, int n, int H, hipStream_t s);
 
@@ -61,7 +63,7 @@ int launch_l2norm(const float *x, float *out, int n, int H, hipStream_t s);
 int launch_mask_relu(float *dst, const float *G, int64_t g_gs, const int32_t *g_idx, const float *Y, int64_t y_gs,
                      const int32_t *y_idx, int groups, int rowlen, hipStream_t s, float scale = 1.0f);
 int launch_bcast_mask_relu(float *dst, const float *dsum, const float *Y, int groups, int T, int H, hipStream_t s,
-                           float scale = 1.0f);
+                           float scale = 1.0f, const int32_t *len = nullptr);
 int launch_scatter_add_rows(float *dst, const int32_t *dst_idx, const float *src, int n, int len, float scale, hipStream_t s);
 int launch_pack_bwd(int mode, const float *A, const int32_t *ia, const float *B, const int32_t *ib, const float *g,
                     float *dA, float *dB, int n, int H, hipStream_t s);
@@ -76,7 +78,7 @@ int launch_cosine_attn_bwd_grouped(const float *F, const float *Kmat, const floa
                                    int T, int H, int ka_max, hipStream_t s);
 int launch_temporal_relate_bwd(const float *att, const int32_t *att_idx, const int32_t *att_k, const float *drel,
                                const int32_t *rel_idx, float *datt, int n, int T, int mode, int conv, int ksize,
-                               const float *const w[6], float *const dw[6], hipStream_t s);
+                               const float *const w[6], float *const dw[6], hipStream_t s, const int32_t *len = nullptr);
 int launch_layernorm_bwd(const float *dOut, int64_t g_gs, const int32_t *g_idx, const float *Y, int n, int T, int H,
                          const float *gamma, float eps, float *dZ, float *stats, float *dgamma, float *dbeta, hipStream_t s,
                          float scale = 1.0f);
@@ -94,7 +96,7 @@ int launch_weighted_colsum(const float *X, int64_t ld, const int32_t *x_idx, con
 int launch_axpy_rows(float *dV, const int32_t *idx, const float *scale, const float *w, int n, int H, hipStream_t s);
 int launch_sum_all(const float *x, float *out, int n, hipStream_t s);
 int launch_relate_softmax_bwd(const float *att, float *datt, const int32_t *in_idx, const int32_t *out_idx, float *dbeta,
-                              float sign, int n, int T, hipStream_t s);
+                              float sign, int n, int T, hipStream_t s, const int32_t *len = nullptr);
 int launch_eltwise_bwd(int mode, const float *base, float *dbase, const int32_t *ia, const int32_t *ib, const int32_t *io,
                        int n, int len, hipStream_t s);
 int launch_attnvideo_bwd(const float *map, float *dmap, const float *att, float *datt, const int32_t *in_idx,
@@ -103,7 +105,7 @@ int launch_choose_bwd(const float *vec, float *dvec, const int32_t *k1, const in
                       const int32_t *out, int n, int H, hipStream_t s);
 int launch_superlative_pool_bwd(const float *S, const float *rowbase, float *drowbase, const int32_t *row_id,
                                 const int32_t *row_start, const int32_t *row_cnt, int is_min, const float *dpre, float *dS,
-                                int n, int T, int H, hipStream_t s);
+                                int n, int T, int H, hipStream_t s, const int32_t *len = nullptr);
 int launch_scale_rows(float *G, const float *rs, int64_t rows, int H, hipStream_t s);
 int launch_ce_loss(const float *logits, const int32_t *answers, float scale, float *loss, float *dlogits, int n, int A,
                    hipStream_t s);

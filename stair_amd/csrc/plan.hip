@@ -12,6 +12,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <tuple>
 #include <unordered_map>
 #include <vector>
@@ -211,14 +212,53 @@ struct Bucket {
 
 }  // namespace
 
+// Pinned staging of a plan's index image.  The image used to be copied from the plan's pageable std::vector: a pageable
+// hipMemcpyAsync stalls the host on the stream and leaves the source's lifetime to the runtime's own staging.  Now the
+// copy reads page-locked memory and an event marks its completion; stair_plan_destroy waits for that event before the
+// buffer goes back to a small process-wide pool (so a step does not pay a hipHostMalloc).
+namespace {
+struct PinnedBuf { int32_t *p = nullptr; size_t cap = 0; };
+std::mutex g_pin_mu;
+std::vector<PinnedBuf> g_pin_pool;
+PinnedBuf pinned_take(size_t ints) {
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        for (size_t i = 0; i < g_pin_pool.size(); ++i)
+            if (g_pin_pool[i].cap >= ints) {
+                PinnedBuf b = g_pin_pool[i];
+                g_pin_pool.erase(g_pin_pool.begin() + i);
+                return b;
+            }
+    }
+    PinnedBuf b;
+    b.cap = std::max<size_t>(ints * 5 / 4, 1 << 14);
+    if (hipHostMalloc(reinterpret_cast<void **>(&b.p), b.cap * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) b.p = nullptr;
+    return b;
+}
+void pinned_give(PinnedBuf b) {
+    if (!b.p) return;
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    if (g_pin_pool.size() < 8) g_pin_pool.push_back(b);
+    else (void)hipHostFree(b.p);
+}
+}  // namespace
+
 struct stair_plan {
     stair_config cfg;
+    PinnedBuf pin;                  // page-locked copy of idx, made at the first upload
+    hipEvent_t pin_ev = nullptr;    // recorded after every upload from `pin`
+    ~stair_plan() {
+        if (pin_ev) { (void)hipEventSynchronize(pin_ev); (void)hipEventDestroy(pin_ev); }
+        pinned_give(pin);
+    }
     int n = 0, n_vid = 0, T = 0, rows_q = 0, max_q = 0;   // n_vid distinct videos (== n unless questions share them)
     std::vector<Node> nodes;
     std::vector<Bucket> buckets;
     std::vector<int32_t> roots;
     std::vector<int32_t> idx;       // host image of the device index buffer
-    int64_t off_seqv = 0, off_seqt = 0, off_roots = 0;
+    int64_t off_seqv = 0, off_seqt = 0, off_roots = 0, off_lenv = 0;
+    bool ragged = false;            // clips of different frame counts in this batch (padded to T; per-instance lengths in col[6])
+    std::vector<int32_t> vlen;      // frames per clip [n_vid]
     int n_vec = 0, n_map = 0, n_att = 0;
     int maxI = 0, maxV = 0, maxK = 0, maxSupRows = 0, n_levels = 0;
     int64_t coop_bytes = 0;
@@ -278,6 +318,13 @@ extern "C" int stair_plan_build_shared(stair_ctx *ctx, int32_t n, const int32_t 
                                        const int32_t *span_lo, const int32_t *span_hi, const int32_t *q_off,
                                        int32_t n_videos, const int32_t *video_of_question, int32_t T,
                                        int32_t flags, stair_plan **out) {
+    return stair_plan_build_ragged(ctx, n, prog_off, tokens, span_lo, span_hi, q_off, n_videos, video_of_question, nullptr, T, flags, out);
+}
+
+extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t *prog_off, const int32_t *tokens,
+                                       const int32_t *span_lo, const int32_t *span_hi, const int32_t *q_off,
+                                       int32_t n_videos, const int32_t *video_of_question, const int32_t *video_len, int32_t T,
+                                       int32_t flags, stair_plan **out) {
     STAIR_CHECK(ctx && prog_off && tokens && span_lo && span_hi && q_off && out, "null argument");
     STAIR_CHECK(n > 0 && T > 0, "n and T must be positive");
     STAIR_CHECK(n_videos > 0 && (video_of_question || n_videos == n), "video_of_question is required when n_videos != n");
@@ -298,6 +345,14 @@ extern "C" int stair_plan_build_shared(stair_ctx *ctx, int32_t n, const int32_t 
     pl->roots.assign(n, -1);
     pl->n_vid = n_videos;
     pl->n_map = n_videos;   // map slot v = encoded video v
+    pl->vlen.assign(n_videos, T);
+    if (video_len)
+        for (int v = 0; v < n_videos; ++v) {
+            STAIR_CHECK(video_len[v] >= 1 && video_len[v] <= T, "video_len[" + std::to_string(v) + "] must be in 1..T");
+            pl->vlen[v] = video_len[v];
+            if (video_len[v] != T) pl->ragged = true;
+        }
+    STAIR_CHECK(!pl->ragged || ctx->conv, "clips of different lengths need the Conv1d Temporal nets (Linear(T,T) fixes T, modules.py:266-277)");
     Builder B{pl};
     std::vector<int> stack;
 
@@ -306,6 +361,7 @@ extern "C" int stair_plan_build_shared(stair_ctx *ctx, int32_t n, const int32_t 
         STAIR_CHECK(Q > 0, "empty question " + std::to_string(q));
         pl->max_q = std::max(pl->max_q, Q);
         stack.clear();
+        const int Lq = pl->vlen[video_of_question ? video_of_question[q] : q];      // frames of this question's clip
         STAIR_CHECK(prog_off[q + 1] > prog_off[q], "empty program, question " + std::to_string(q));
         for (int i = prog_off[q + 1] - 1; i >= prog_off[q]; --i) {
             const int tok = tokens[i];
@@ -388,7 +444,7 @@ extern "C" int stair_plan_build_shared(stair_ctx *ctx, int32_t n, const int32_t 
                         else return bad("Filter keyword must be a [H] vector or actions/objects/relations (modules.py:346-351)");
                         nd.kind = STAIR_VAL_VEC; nd.slot = pl->n_vec++;
                         Bucket &b = B.bucket(nd.level, tok, variant, 0);
-                        b.col[0].push_back(c0.slot); b.col[1].push_back(nd.slot);
+                        b.col[0].push_back(c0.slot); b.col[1].push_back(nd.slot); b.col[6].push_back(Lq);
                         b.cnt++;
                         break;
                     }
@@ -436,7 +492,7 @@ extern "C" int stair_plan_build_shared(stair_ctx *ctx, int32_t n, const int32_t 
                         if (c0.kind != STAIR_VAL_STR || c1.kind != STAIR_VAL_FRAME) return bad("Relate(mode, attn [T])");
                         nd.kind = STAIR_VAL_FRAME; nd.slot = pl->n_att++;
                         Bucket &b = B.bucket(nd.level, tok, c0.aux == STAIR_KW_FORWARD ? 0 : 1, 0);   // modules.py:429
-                        b.col[0].push_back(c1.slot); b.col[1].push_back(nd.slot);
+                        b.col[0].push_back(c1.slot); b.col[1].push_back(nd.slot); b.col[6].push_back(Lq);
                         b.cnt++;
                         break;
                     }
@@ -448,9 +504,9 @@ extern "C" int stair_plan_build_shared(stair_ctx *ctx, int32_t n, const int32_t 
                         Bucket &b = B.bucket(nd.level, tok, c0.aux == STAIR_KW_MIN ? 1 : 0, 0);       // modules.py:245
                         b.col[0].push_back(c2.slot);          // feat map
                         b.col[1].push_back(b.nrows);          // first action row of this instance
-                        const int Ka = c1.kind == STAIR_VAL_MAP ? T : (c1.kind == STAIR_VAL_PAIR ? 2 : 1);
+                        const int Ka = c1.kind == STAIR_VAL_MAP ? Lq : (c1.kind == STAIR_VAL_PAIR ? 2 : 1);   // a [T,H] map = one action per frame of the clip
                         b.col[2].push_back(Ka);
-                        b.col[3].push_back(nd.slot);
+                        b.col[3].push_back(nd.slot); b.col[6].push_back(Lq);
                         for (int a = 0; a < Ka; ++a) {
                             // action row id: >= 0 -> vec arena row; < 0 -> -(map row + 1) (resolved at finalise)
                             int rid;
@@ -475,7 +531,7 @@ extern "C" int stair_plan_build_shared(stair_ctx *ctx, int32_t n, const int32_t 
                         nd.kind = STAIR_VAL_MAP; nd.slot = pl->n_map++; nd.rel = pl->n_att++;
                         Bucket &b = B.bucket(nd.level, tok, mode, 0);
                         b.col[0].push_back(c1.slot); b.col[1].push_back(c2.slot); b.col[2].push_back(c2.aux);
-                        b.col[3].push_back(nd.rel); b.col[4].push_back(nd.slot);
+                        b.col[3].push_back(nd.rel); b.col[4].push_back(nd.slot); b.col[6].push_back(Lq);
                         b.cnt++;
                         break;
                     }
@@ -548,6 +604,7 @@ extern "C" int stair_plan_build_shared(stair_ctx *ctx, int32_t n, const int32_t 
         pl->off_seqv = push(sv);
         pl->off_seqt = push(st);
         pl->off_roots = push(pl->roots);
+        pl->off_lenv = push(pl->vlen);
     }
     // layout (float offsets; vec and map arenas start on multiples of H so that any [H] row of
     // either arena has a global row id relative to the workspace base)
@@ -825,14 +882,24 @@ extern "C" int stair_plan_set_dropout(stair_plan *pl, float p, uint64_t seed) {
     return 0;
 }
 
+static int upload_index_image(stair_plan *pl, int32_t *didx, hipStream_t s) {
+    if (!pl->pin.p) {
+        pl->pin = pinned_take(pl->idx.size());
+        STAIR_CHECK(pl->pin.p != nullptr, "hipHostMalloc of the index staging buffer failed");
+        memcpy(pl->pin.p, pl->idx.data(), pl->idx.size() * sizeof(int32_t));
+        STAIR_HIP(hipEventCreateWithFlags(&pl->pin_ev, hipEventDisableTiming));
+    }
+    STAIR_HIP(hipMemcpyAsync(didx, pl->pin.p, pl->idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    STAIR_HIP(hipEventRecord(pl->pin_ev, s));
+    return 0;
+}
+
 extern "C" int stair_plan_upload(stair_plan *pl, void *workspace, int64_t workspace_bytes, stair_stream stream) {
     STAIR_CHECK(pl && workspace, "null argument");
     STAIR_CHECK(workspace_bytes >= pl->total * (int64_t)sizeof(float), "workspace too small");
     STAIR_CHECK((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "workspace must be 256-byte aligned");
     int32_t *didx = reinterpret_cast<int32_t *>(static_cast<float *>(workspace) + pl->o_idx);
-    STAIR_HIP(hipMemcpyAsync(didx, pl->idx.data(), pl->idx.size() * sizeof(int32_t), hipMemcpyHostToDevice,
-                             static_cast<hipStream_t>(stream)));
-    return 0;
+    return upload_index_image(pl, didx, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int stair_plan_run(stair_ctx *ctx, stair_plan *pl, const float *video, const float *question,
@@ -864,7 +931,7 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
     else if (!logits) logits = ws + pl->o_logits;
 
     if (!(flags & STAIR_RUN_INDEX_RESIDENT))
-        STAIR_HIP(hipMemcpyAsync(didx, pl->idx.data(), pl->idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        if (int rc_ = upload_index_image(pl, didx, s)) return rc_;
 
     struct SplitKScope {            // forward products of this call may stage split-K partials in the workspace
         explicit SplitKScope(float *p) { g_splitk_ws = p; }
@@ -888,6 +955,7 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
             a.x = nullptr; a.x_bf16 = video; a.wih_planes_ws = ws + pl->o_wplanes;
         }
         a.seq_off = didx + pl->off_seqv;
+        if (pl->ragged) a.seq_len = didx + pl->off_lenv;
         for (int d = 0; d < 2; ++d) {
             a.w_ih[d] = W.enc[0][4 * d]; a.w_hh[d] = W.enc[0][4 * d + 1];
             a.b_ih[d] = W.enc[0][4 * d + 2]; a.b_hh[d] = W.enc[0][4 * d + 3];
@@ -920,6 +988,7 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
         const int c = b.cnt;
         const int32_t *I0 = didx + b.off[0], *I1 = didx + b.off[1], *I2 = didx + b.off[2], *I3 = didx + b.off[3],
                       *I4 = didx + b.off[4], *I5 = didx + b.off[5];
+        const int32_t *LEN = pl->ragged ? didx + b.off[6] : nullptr;       // frames of each instance's clip (T-mixing operators)
         float *tmpA = ws + b.svA, *tmpB = ws + b.svB, *kbuf = ws + b.svK, *cat = ws + b.svCat, *hid = ws + b.svHid;
         float *rsb = ws + b.svRs, *sup = ws + b.svSup, *extra = ws + b.svExtra;
         switch (b.op) {
@@ -971,7 +1040,7 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
                 RUN(drop(tmpA, TH, nullptr, c, TH, 0));
                 RUN(dense(s, tmpA, H, TH, nullptr, W.f3[v], H, tmpB, H, TH, nullptr, c, T, H, H, 1));
                 RUN(drop(tmpB, TH, nullptr, c, TH, 1));
-                RUN(launch_sum_rows(tmpB, cat, c, T, H, s));
+                RUN(launch_sum_rows(tmpB, cat, c, T, H, s, LEN));
                 RUN(dense(s, cat, H, H, nullptr, W.fdense, H, vec, H, H, I1, c, 1, H, H, 1));
                 break;
             }
@@ -1006,7 +1075,7 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
                 RUN(launch_cosine_attn(tmpB, TH, I1, kbuf, nullptr, att, I3, b.nrows, T, H, s));
                 break;
             case STAIR_OP_RELATE:       // modules.py:417-435
-                RUN(launch_relate_softmax(att, I0, I1, W.beta, b.variant == 0 ? 1.0f : -1.0f, c, T, s));
+                RUN(launch_relate_softmax(att, I0, I1, W.beta, b.variant == 0 ? 1.0f : -1.0f, c, T, s, LEN));
                 break;
             case STAIR_OP_SUPERLATIVE:  // modules.py:220-248 (shares Localize's weights, module_net.py:31-32)
                 RUN(dense(s, map, H, TH, I0, W.lv0, H, tmpA, H, TH, nullptr, c, T, H, H, 1));
@@ -1014,13 +1083,13 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
                 RUN(dense(s, tmpA, H, TH, nullptr, W.lv3, H, tmpB, H, TH, nullptr, c, T, H, H, 0));
                 RUN(dense(s, ws, H, H, I4, W.lk, H, kbuf, H, H, nullptr, b.nrows, 1, H, H, 0));
                 RUN(launch_cosine_attn(tmpB, TH, I5, kbuf, nullptr, sup, nullptr, b.nrows, T, H, s));
-                RUN(launch_superlative_pool(sup, ws, I4, I1, I2, b.variant, cat, c, T, H, s));
+                RUN(launch_superlative_pool(sup, ws, I4, I1, I2, b.variant, cat, c, T, H, s, LEN));
                 RUN(dense(s, cat, H, H, nullptr, W.supdense, H, vec, H, H, I3, c, 1, H, H, 1));
                 break;
             case STAIR_OP_TEMPORAL: {   // modules.py:310-327
                 const int mode = b.variant;
                 RUN(launch_temporal_relate(att, I1, I2, att, I3, c, T, mode, ctx->conv ? 1 : 0, ctx->ksize,
-                                           mode ? W.relate[mode - 1] : nullptr, s));
+                                           mode ? W.relate[mode - 1] : nullptr, s, LEN));
                 RUN(dense(s, map, H, TH, I0, W.tdense, H, tmpA, H, TH, nullptr, c, T, H, H, 1, att, T, I3));
                 RUN(drop(tmpA, TH, nullptr, c, TH, 0));
                 RUN(launch_layernorm(tmpA, map, TH, I4, c, T, H, W.ln_w, W.ln_b, 1e-5f, s));
@@ -1145,6 +1214,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
         const int c = b.cnt;
         const int32_t *I0 = didx + b.off[0], *I1 = didx + b.off[1], *I2 = didx + b.off[2], *I3 = didx + b.off[3],
                       *I4 = didx + b.off[4], *I5 = didx + b.off[5];
+        const int32_t *LEN = pl->ragged ? didx + b.off[6] : nullptr;
         const float *svA = ws + b.svA, *svB = ws + b.svB, *svK = ws + b.svK, *svCat = ws + b.svCat, *svHid = ws + b.svHid;
         const float *svRs = ws + b.svRs, *svSup = ws + b.svSup;
         // tail shared by Filter / FilterFrame / Localize / Superlative: gB = d(second linear output)
@@ -1202,7 +1272,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
                 const int v = b.variant;
                 RUN(launch_mask_relu(gV0, g_vec, H, I1, vec, H, I1, c, H, s));
                 RUN(dense_bwd(B, gV0, c, 1, H, H, svCat, H, H, nullptr, W.fdense, gV1, H, H, nullptr, 0));
-                RUN(launch_bcast_mask_relu(gB, gV1, svB, c, T, H, s, inv_keep));
+                RUN(launch_bcast_mask_relu(gB, gV1, svB, c, T, H, s, inv_keep, LEN));
                 RUN(mlp_tail(W.f3[v], W.f0[v], false));
                 break;
             }
@@ -1240,12 +1310,12 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
                 RUN(mlp_tail(W.lv3, W.lv0, false));
                 break;
             case STAIR_OP_RELATE:
-                RUN(launch_relate_softmax_bwd(att, g_att, I0, I1, W.dbeta, b.variant == 0 ? 1.0f : -1.0f, c, T, s));
+                RUN(launch_relate_softmax_bwd(att, g_att, I0, I1, W.dbeta, b.variant == 0 ? 1.0f : -1.0f, c, T, s, LEN));
                 break;
             case STAIR_OP_SUPERLATIVE:
                 RUN(launch_mask_relu(gV0, g_vec, H, I3, vec, H, I3, c, H, s));
                 RUN(dense_bwd(B, gV0, c, 1, H, H, svCat, H, H, nullptr, W.supdense, gV1, H, H, nullptr, 0));
-                RUN(launch_superlative_pool_bwd(svSup, ws, gws, I4, I1, I2, b.variant, gV1, gS, c, T, H, s));
+                RUN(launch_superlative_pool_bwd(svSup, ws, gws, I4, I1, I2, b.variant, gV1, gS, c, T, H, s, LEN));
                 RUN(launch_cosine_attn_bwd_grouped(svB, svK, svSup, nullptr, gS, nullptr, I1, I2, gB, gK, gRs2, gStats, c, b.nrows, T, H, T, s));
                 RUN(dense_bwd(B, gK, b.nrows, 1, H, H, ws, H, H, I4, W.lk, gws, H, H, I4, 1));
                 RUN(mlp_tail(W.lv3, W.lv0, false));
@@ -1256,7 +1326,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
                 RUN(dense_bwd(B, gA, c, T, H, H, map, H, TH, I0, W.tdense, gB, H, TH, nullptr, 0, att, T, I3));
                 RUN(launch_rowscale_bwd(gB, map, TH, I0, att, T, I3, g_map, g_att, c, T, H, s));
                 RUN(launch_temporal_relate_bwd(att, I1, I2, g_att, I3, g_att, c, T, mode, ctx->conv ? 1 : 0, ctx->ksize,
-                                               mode ? W.relate[mode - 1] : nullptr, mode ? W.drelate[mode - 1] : nullptr, s));
+                                               mode ? W.relate[mode - 1] : nullptr, mode ? W.drelate[mode - 1] : nullptr, s, LEN));
                 break;
             }
             default:
@@ -1269,6 +1339,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
         stair_lstm_bwd_args a = {};
         if (e == 0) {
             a.x = video; a.ldx = V; a.rows = pl->n_vid * T; a.max_len = T; a.I = V; a.seq_off = didx + pl->off_seqv;
+            if (pl->ragged) a.seq_len = didx + pl->off_lenv;
             if (flags & STAIR_RUN_VIDEO_BF16) { a.x = nullptr; a.x_bf16 = video; }
             a.gates = ws + pl->o_xpv; a.cbuf = ws + pl->o_cv; a.out = map; a.d_out = g_map; a.d_hn = nullptr;
             a.whh_pack_ws = ws + pl->o_wpack;

@@ -102,18 +102,23 @@ int launch_cosine_attn(const float *F, int64_t f_gstride, const int32_t *f_idx, 
 // ---------------------------------------------------------------------------------------------
 // TemporalModule relate nets, modules.py:255-277 (definition) and :317-323 (use).
 struct RelateW { const float *w[6]; };
+// `len` (optional): frames of instance i's clip when the batch mixes clip lengths; rows keep the stride T, the nets see
+// a sequence of L = len[i] frames (Conv1d 'same' pads with zeros beyond L, as it does for a clip of that length) and
+// frames >= L of the output are zero.
 __global__ void temporal_relate_kernel(const float *att, const int32_t *att_idx, const int32_t *att_k, float *out,
                                        const int32_t *out_idx, int n, int T, int mode, int conv, int ksize,
-                                       RelateW W) {
+                                       RelateW W, const int32_t *len) {
     extern __shared__ float sm[];   // two ping-pong rows [T]
     float *x = sm, *y = sm + T;
     const int i = blockIdx.x;
     const int K = att_k[i];
+    const int L = len ? len[i] : T;
     const float *a = att + (int64_t)att_idx[i] * T;
     for (int t = threadIdx.x; t < T; t += blockDim.x) {
         float acc = 0.0f;
         for (int k = 0; k < K; ++k) acc += a[(int64_t)k * T + t];
-        x[t] = acc / (float)K;          // torch.mean(attention_scores, dim=0)
+        x[t] = t < L ? acc / (float)K : 0.0f;          // torch.mean(attention_scores, dim=0)
+        y[t] = 0.0f;
     }
     __syncthreads();
     if (mode != 0) {
@@ -123,11 +128,11 @@ __global__ void temporal_relate_kernel(const float *att, const int32_t *att_idx,
                 // Conv1d(1,1,k,padding='same'): left pad (k-1)/2, the odd element goes right
                 const int k = layer < 2 ? ksize : 2 * ksize + 1;
                 const int left = (k - 1) / 2;
-                for (int t = threadIdx.x; t < T; t += blockDim.x) {
+                for (int t = threadIdx.x; t < L; t += blockDim.x) {
                     float acc = b[0];
                     for (int j = 0; j < k; ++j) {
                         const int u = t + j - left;
-                        if (u >= 0 && u < T) acc += w[j] * x[u];
+                        if (u >= 0 && u < L) acc += w[j] * x[u];
                     }
                     y[t] = layer < 2 ? fmaxf(acc, 0.0f) : sigmoid_acc(acc);
                 }
@@ -147,14 +152,15 @@ __global__ void temporal_relate_kernel(const float *att, const int32_t *att_idx,
 }
 int launch_temporal_relate(const float *att, const int32_t *att_idx, const int32_t *att_k, float *out,
                            const int32_t *out_idx, int n, int T, int mode, int conv, int ksize,
-                           const float *const w[6], hipStream_t s) {
+                           const float *const w[6], hipStream_t s, const int32_t *len) {
     if (n == 0) return 0;
     STAIR_CHECK(mode >= 0 && mode <= 3, "mode must be 0..3");
     RelateW W;
     for (int i = 0; i < 6; ++i) W.w[i] = (mode != 0 && w) ? w[i] : nullptr;
     if (mode != 0) for (int i = 0; i < 6; ++i) STAIR_CHECK(W.w[i] != nullptr, "relate weights missing");
+    STAIR_CHECK(!len || conv || mode == 0, "Linear(T,T) relate nets take one clip length (modules.py:266-277)");
     hipLaunchKernelGGL(temporal_relate_kernel, dim3(n), dim3(64), 2 * T * sizeof(float), s, att, att_idx, att_k, out,
-                       out_idx, n, T, mode, conv, ksize, W);
+                       out_idx, n, T, mode, conv, ksize, W, len);
     STAIR_LAUNCH_CHECK();
     return 0;
 }
@@ -199,18 +205,19 @@ int launch_layernorm(const float *Y, float *X, int64_t gstride, const int32_t *g
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ void sum_rows_kernel(const float *X, float *out, int n, int T, int H) {
+__global__ void sum_rows_kernel(const float *X, float *out, int n, int T, int H, const int32_t *len) {
     const int g = blockIdx.x;
     const float *x = X + (int64_t)g * T * H;
+    const int L = len ? len[g] : T;                 // frames of this instance's clip (rows L..T-1 are padding)
     for (int c = threadIdx.x; c < H; c += blockDim.x) {
         float acc = 0.f;
-        for (int t = 0; t < T; ++t) acc += x[(int64_t)t * H + c];
+        for (int t = 0; t < L; ++t) acc += x[(int64_t)t * H + c];
         out[(int64_t)g * H + c] = acc;
     }
 }
-int launch_sum_rows(const float *X, float *out, int n, int T, int H, hipStream_t s) {
+int launch_sum_rows(const float *X, float *out, int n, int T, int H, hipStream_t s, const int32_t *len) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(sum_rows_kernel, dim3(n), dim3(kBlock), 0, s, X, out, n, T, H);
+    hipLaunchKernelGGL(sum_rows_kernel, dim3(n), dim3(kBlock), 0, s, X, out, n, T, H, len);
     STAIR_LAUNCH_CHECK();
     return 0;
 }
@@ -260,25 +267,26 @@ int launch_vecdot(const float *V, const int32_t *idx, const float *w, float *out
 
 // ---------------------------------------------------------------------------------------------
 __global__ void relate_softmax_kernel(float *att, const int32_t *in_idx, const int32_t *out_idx, const float *beta,
-                                      float sign, int n, int T) {
+                                      float sign, int n, int T, const int32_t *len) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (i >= n) return;
     const float *x = att + (int64_t)in_idx[i] * T;
     float *o = att + (int64_t)out_idx[i] * T;
+    const int L = len ? len[i] : T;                 // softmax over the clip's own frames (beta[:T] of modules.py:431 with T = L)
     float m = -INFINITY;
-    for (int t = lane; t < T; t += 64) m = fmaxf(m, x[t] + sign * beta[t]);
+    for (int t = lane; t < L; t += 64) m = fmaxf(m, x[t] + sign * beta[t]);
     m = wave_max(m);
     float sum = 0.f;
-    for (int t = lane; t < T; t += 64) sum += expf(x[t] + sign * beta[t] - m);
+    for (int t = lane; t < L; t += 64) sum += expf(x[t] + sign * beta[t] - m);
     sum = wave_sum(sum);
-    for (int t = lane; t < T; t += 64) o[t] = expf(x[t] + sign * beta[t] - m) / sum;
+    for (int t = lane; t < T; t += 64) o[t] = t < L ? expf(x[t] + sign * beta[t] - m) / sum : 0.f;
 }
 int launch_relate_softmax(float *att, const int32_t *in_idx, const int32_t *out_idx, const float *beta, float sign,
-                          int n, int T, hipStream_t s) {
+                          int n, int T, hipStream_t s, const int32_t *len) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(relate_softmax_kernel, dim3((n + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlock), 0, s, att,
-                       in_idx, out_idx, beta, sign, n, T);
+                       in_idx, out_idx, beta, sign, n, T, len);
     STAIR_LAUNCH_CHECK();
     return 0;
 }
@@ -360,15 +368,16 @@ int launch_choose(float *vec, const int32_t *k1, const int32_t *k2, const int32_
 // SuperlativeModule pooling, modules.py:244-247.
 __global__ void superlative_pool_kernel(const float *S, const float *rowbase, const int32_t *row_id,
                                         const int32_t *row_start, const int32_t *row_cnt, int is_min, float *out,
-                                        int n, int T, int H) {
+                                        int n, int T, int H, const int32_t *len) {
     extern __shared__ float wsm[];   // [Ka]
     const int i = blockIdx.x;
     const int r0 = row_start[i], Ka = row_cnt[i];
+    const int L = len ? len[i] : T;                 // frames of the clip: the score rows are summed over them only
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int a = wave; a < Ka; a += kWavesPerBlock) {
         const float *s = S + (int64_t)(r0 + a) * T;
         float acc = 0.f;
-        for (int t = lane; t < T; t += 64) acc += s[t];
+        for (int t = lane; t < L; t += 64) acc += s[t];
         acc = wave_sum(acc);
         if (lane == 0) wsm[a] = acc;
     }
@@ -393,10 +402,10 @@ __global__ void superlative_pool_kernel(const float *S, const float *rowbase, co
     }
 }
 int launch_superlative_pool(const float *S, const float *rowbase, const int32_t *row_id, const int32_t *row_start,
-                            const int32_t *row_cnt, int is_min, float *out, int n, int T, int H, hipStream_t s) {
+                            const int32_t *row_cnt, int is_min, float *out, int n, int T, int H, hipStream_t s, const int32_t *len) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(superlative_pool_kernel, dim3(n), dim3(kBlock), (size_t)std::max(T, 2) * sizeof(float), s, S,
-                       rowbase, row_id, row_start, row_cnt, is_min, out, n, T, H);
+                       rowbase, row_id, row_start, row_cnt, is_min, out, n, T, H, len);
     STAIR_LAUNCH_CHECK();
     return 0;
 }

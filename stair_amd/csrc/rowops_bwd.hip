@@ -38,19 +38,23 @@ int launch_mask_relu(float *dst, const float *G, int64_t g_gs, const int32_t *g_
 }
 
 // Filter's sum over frames, backward + ReLU mask: dst[g][t][:] = dsum[g][:] * (Y[g][t][:] > 0)
-__global__ void bcast_mask_relu_kernel(float *dst, const float *dsum, const float *Y, int groups, int T, int H, float scale) {
+__global__ void bcast_mask_relu_kernel(float *dst, const float *dsum, const float *Y, int groups, int T, int H, float scale,
+                                       const int32_t *len) {
     const int64_t total = (int64_t)groups * T * H;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int g = (int)(e / ((int64_t)T * H));
         const int c = (int)(e % H);
-        dst[e] = Y[e] > 0.f ? dsum[(int64_t)g * H + c] * scale : 0.f;
+        const int t = (int)((e / H) % T);
+        const bool in = !len || t < len[g];            // frames past the clip's length never entered the sum
+        dst[e] = (in && Y[e] > 0.f) ? dsum[(int64_t)g * H + c] * scale : 0.f;
     }
 }
-int launch_bcast_mask_relu(float *dst, const float *dsum, const float *Y, int groups, int T, int H, hipStream_t s, float scale) {
+int launch_bcast_mask_relu(float *dst, const float *dsum, const float *Y, int groups, int T, int H, hipStream_t s, float scale,
+                           const int32_t *len) {
     if (groups == 0) return 0;
     const int64_t total = (int64_t)groups * T * H;
     hipLaunchKernelGGL(bcast_mask_relu_kernel, dim3((unsigned)std::min<int64_t>((total + kBlock - 1) / kBlock, 4096)), dim3(kBlock),
-                       0, s, dst, dsum, Y, groups, T, H, scale);
+                       0, s, dst, dsum, Y, groups, T, H, scale, len);
     STAIR_LAUNCH_CHECK();
     return 0;
 }
@@ -259,18 +263,20 @@ int launch_cosine_attn_bwd_grouped(const float *F, const float *Kmat, const floa
 struct RelateWB { const float *w[6]; float *dw[6]; };
 __global__ void temporal_relate_bwd_kernel(const float *att, const int32_t *att_idx, const int32_t *att_k,
                                            const float *drel, const int32_t *rel_idx, float *datt, int n, int T, int mode,
-                                           int conv, int ksize, RelateWB W) {
+                                           int conv, int ksize, RelateWB W, const int32_t *len) {
     extern __shared__ float sm[];   // x0, y1, y2, y3 (post-activation), g (ping), g2 (pong): 6 rows of T
     float *x0 = sm, *y1 = sm + T, *y2 = sm + 2 * T, *y3 = sm + 3 * T, *ga = sm + 4 * T, *gb = sm + 5 * T;
     const int i = blockIdx.x;
     const int K = att_k[i];
+    const int L = len ? len[i] : T;                 // the clip's own frame count (see temporal_relate_kernel); Linear nets: L == T
     const float *a = att + (int64_t)att_idx[i] * T;
     const float *dr = drel + (int64_t)rel_idx[i] * T;
     for (int t = threadIdx.x; t < T; t += blockDim.x) {
         float acc = 0.f;
         for (int k = 0; k < K; ++k) acc += a[(int64_t)k * T + t];
-        x0[t] = acc / (float)K;
-        ga[t] = dr[t];
+        x0[t] = t < L ? acc / (float)K : 0.f;
+        ga[t] = t < L ? dr[t] : 0.f;
+        y1[t] = y2[t] = y3[t] = gb[t] = 0.f;
     }
     __syncthreads();
     if (mode != 0) {
@@ -281,11 +287,11 @@ __global__ void temporal_relate_bwd_kernel(const float *att, const int32_t *att_
             const float *x = xin[layer];
             float *y = yout[layer];
             const int k = layer < 2 ? ksize : 2 * ksize + 1, left = (k - 1) / 2;
-            for (int t = threadIdx.x; t < T; t += blockDim.x) {
+            for (int t = threadIdx.x; t < L; t += blockDim.x) {
                 float acc;
                 if (conv) {
                     acc = b[0];
-                    for (int j = 0; j < k; ++j) { const int u = t + j - left; if (u >= 0 && u < T) acc += w[j] * x[u]; }
+                    for (int j = 0; j < k; ++j) { const int u = t + j - left; if (u >= 0 && u < L) acc += w[j] * x[u]; }
                 } else {
                     acc = b[t];
                     for (int u = 0; u < T; ++u) acc += w[(int64_t)t * T + u] * x[u];
@@ -299,23 +305,23 @@ __global__ void temporal_relate_bwd_kernel(const float *att, const int32_t *att_
             const float *w = W.w[2 * layer];
             const float *x = xin[layer], *y = yout[layer];
             const int k = layer < 2 ? ksize : 2 * ksize + 1, left = (k - 1) / 2;
-            for (int t = threadIdx.x; t < T; t += blockDim.x)      // through the activation
+            for (int t = threadIdx.x; t < L; t += blockDim.x)      // through the activation
                 gin[t] = layer < 2 ? (y[t] > 0.f ? gin[t] : 0.f) : gin[t] * y[t] * (1.f - y[t]);
             __syncthreads();
             if (conv) {
                 for (int j = threadIdx.x; j < k; j += blockDim.x) {        // dw[j] = sum_t dz[t] x[t+j-left]
                     float acc = 0.f;
-                    for (int t = 0; t < T; ++t) { const int u = t + j - left; if (u >= 0 && u < T) acc += gin[t] * x[u]; }
+                    for (int t = 0; t < L; ++t) { const int u = t + j - left; if (u >= 0 && u < L) acc += gin[t] * x[u]; }
                     unsafeAtomicAdd(W.dw[2 * layer] + j, acc);
                 }
                 if (threadIdx.x == 0) {
                     float acc = 0.f;
-                    for (int t = 0; t < T; ++t) acc += gin[t];
+                    for (int t = 0; t < L; ++t) acc += gin[t];
                     unsafeAtomicAdd(W.dw[2 * layer + 1], acc);
                 }
-                for (int u = threadIdx.x; u < T; u += blockDim.x) {       // dx[u] = sum_j w[j] dz[u-j+left]
+                for (int u = threadIdx.x; u < L; u += blockDim.x) {       // dx[u] = sum_j w[j] dz[u-j+left]
                     float acc = 0.f;
-                    for (int j = 0; j < k; ++j) { const int t = u - j + left; if (t >= 0 && t < T) acc += w[j] * gin[t]; }
+                    for (int j = 0; j < k; ++j) { const int t = u - j + left; if (t >= 0 && t < L) acc += w[j] * gin[t]; }
                     gout[u] = acc;
                 }
             } else {
@@ -336,19 +342,19 @@ __global__ void temporal_relate_bwd_kernel(const float *att, const int32_t *att_
         ga = gin;
     }
     // mean over K rows backward
-    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    for (int t = threadIdx.x; t < L; t += blockDim.x) {
         const float v = ga[t] / (float)K;
         for (int k = 0; k < K; ++k) unsafeAtomicAdd(datt + ((int64_t)att_idx[i] + k) * T + t, v);
     }
 }
 int launch_temporal_relate_bwd(const float *att, const int32_t *att_idx, const int32_t *att_k, const float *drel,
                                const int32_t *rel_idx, float *datt, int n, int T, int mode, int conv, int ksize,
-                               const float *const w[6], float *const dw[6], hipStream_t s) {
+                               const float *const w[6], float *const dw[6], hipStream_t s, const int32_t *len) {
     if (n == 0) return 0;
     RelateWB W;
     for (int i = 0; i < 6; ++i) { W.w[i] = (mode && w) ? w[i] : nullptr; W.dw[i] = (mode && dw) ? dw[i] : nullptr; }
     hipLaunchKernelGGL(temporal_relate_bwd_kernel, dim3(n), dim3(64), 6 * T * sizeof(float), s, att, att_idx, att_k, drel,
-                       rel_idx, datt, n, T, mode, conv, ksize, W);
+                       rel_idx, datt, n, T, mode, conv, ksize, W, len);
     STAIR_LAUNCH_CHECK();
     return 0;
 }
@@ -530,26 +536,27 @@ int launch_sum_all(const float *x, float *out, int n, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 // Relate backward: y = softmax(x + sign*beta): dx = y * (dy - sum(dy*y)); datt[in] += dx; dbeta += sign*dx
 __global__ void relate_softmax_bwd_kernel(const float *att, float *datt, const int32_t *in_idx, const int32_t *out_idx,
-                                          float *dbeta, float sign, int n, int T) {
+                                          float *dbeta, float sign, int n, int T, const int32_t *len) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (i >= n) return;
     const float *y = att + (int64_t)out_idx[i] * T;
     const float *dy = datt + (int64_t)out_idx[i] * T;
+    const int L = len ? len[i] : T;
     float dot = 0.f;
-    for (int t = lane; t < T; t += 64) dot += dy[t] * y[t];
+    for (int t = lane; t < L; t += 64) dot += dy[t] * y[t];
     dot = wave_sum(dot);
-    for (int t = lane; t < T; t += 64) {
+    for (int t = lane; t < L; t += 64) {
         const float dx = y[t] * (dy[t] - dot);
         unsafeAtomicAdd(datt + (int64_t)in_idx[i] * T + t, dx);
         unsafeAtomicAdd(dbeta + t, sign * dx);
     }
 }
 int launch_relate_softmax_bwd(const float *att, float *datt, const int32_t *in_idx, const int32_t *out_idx, float *dbeta,
-                              float sign, int n, int T, hipStream_t s) {
+                              float sign, int n, int T, hipStream_t s, const int32_t *len) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(relate_softmax_bwd_kernel, dim3((n + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlock), 0, s, att, datt,
-                       in_idx, out_idx, dbeta, sign, n, T);
+                       in_idx, out_idx, dbeta, sign, n, T, len);
     STAIR_LAUNCH_CHECK();
     return 0;
 }
@@ -638,17 +645,18 @@ int launch_choose_bwd(const float *vec, float *dvec, const int32_t *k1, const in
 //   drows[row_id[a]] += w'_a dpre;   dS[a][t] = w_a (dw_a - sum_b dw_b w_b),  dw_a = +-(dpre . rows[a])
 __global__ void superlative_pool_bwd_kernel(const float *S, const float *rowbase, float *drowbase, const int32_t *row_id,
                                             const int32_t *row_start, const int32_t *row_cnt, int is_min, const float *dpre,
-                                            float *dS, int n, int T, int H) {
+                                            float *dS, int n, int T, int H, const int32_t *len) {
     extern __shared__ float sm[];    // w[Ka], dw[Ka]
     const int i = blockIdx.x;
     const int r0 = row_start[i], Ka = row_cnt[i];
+    const int L = len ? len[i] : T;
     float *w = sm, *dw = sm + Ka;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float *dp = dpre + (int64_t)i * H;
     for (int a = wave; a < Ka; a += kWavesPerBlock) {
         const float *sr = S + (int64_t)(r0 + a) * T;
         float acc = 0.f;
-        for (int t = lane; t < T; t += 64) acc += sr[t];
+        for (int t = lane; t < L; t += 64) acc += sr[t];
         acc = wave_sum(acc);
         const float *row = rowbase + (int64_t)row_id[r0 + a] * H;
         float d = 0.f;
@@ -673,7 +681,7 @@ __global__ void superlative_pool_bwd_kernel(const float *S, const float *rowbase
     __syncthreads();
     for (int e = threadIdx.x; e < Ka * T; e += blockDim.x) {
         const int a = e / T;
-        dS[(int64_t)(r0 + a) * T + (e - a * T)] = w[a] * (dw[a] - s_dot);
+        dS[(int64_t)(r0 + a) * T + (e - a * T)] = (e - a * T) < L ? w[a] * (dw[a] - s_dot) : 0.f;
     }
     for (int c = threadIdx.x; c < H; c += blockDim.x) {
         const float g = dp[c];
@@ -683,10 +691,10 @@ __global__ void superlative_pool_bwd_kernel(const float *S, const float *rowbase
 }
 int launch_superlative_pool_bwd(const float *S, const float *rowbase, float *drowbase, const int32_t *row_id,
                                 const int32_t *row_start, const int32_t *row_cnt, int is_min, const float *dpre, float *dS,
-                                int n, int T, int H, hipStream_t s) {
+                                int n, int T, int H, hipStream_t s, const int32_t *len) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(superlative_pool_bwd_kernel, dim3(n), dim3(kBlock), (size_t)2 * std::max(T, 2) * sizeof(float), s, S, rowbase,
-                       drowbase, row_id, row_start, row_cnt, is_min, dpre, dS, n, T, H);
+                       drowbase, row_id, row_start, row_cnt, is_min, dpre, dS, n, T, H, len);
     STAIR_LAUNCH_CHECK();
     return 0;
 }
@@ -709,6 +717,12 @@ __global__ void ce_loss_kernel(const float *logits, const int32_t *answers, floa
     const int ans = answers[i];
     if (ans < 0) {                 // question without a decoder loss (train_module.py:376: global_steps <= train_decoder_after_iters)
         if (lane == 0 && loss) loss[i] = 0.f;
+        if (dlogits)
+            for (int c = lane; c < A; c += 64) dlogits[(int64_t)i * A + c] = 0.f;
+        return;
+    }
+    if (ans >= A) {                // not a class of this vocabulary: never read out of bounds; the NaN loss flags the caller's bug
+        if (lane == 0 && loss) loss[i] = __builtin_nanf("");
         if (dlogits)
             for (int c = lane; c < A; c += 64) dlogits[(int64_t)i * A + c] = 0.f;
         return;

@@ -272,13 +272,14 @@ class AGQAQuestions:
 # items -> executor tensors
 # ----------------------------------------------------------------------------------------------
 class PackedBatch:
-    __slots__ = ('programs', 'spans', 'video', 'video_index', 'question', 'q_lens', 'answers', 'n_clips', 'h2d_bytes')
+    __slots__ = ('programs', 'spans', 'video', 'video_index', 'question', 'q_lens', 'answers', 'n_clips', 'h2d_bytes', 'video_len')
 
 
 def pack_questions(items, device, share_clips=True, pin=True):
-    """Question dicts with one frame count -> the arguments of VideoNMN.run_programs.  Clips are staged once each
-    (items of one clip carry the same feature tensor), every tensor goes through one pinned host buffer and one
-    asynchronous H2D copy on the current stream."""
+    """Question dicts -> the arguments of VideoNMN.run_programs.  Clips are staged once each (items of one clip carry
+    the same feature tensor); clips of different frame counts are padded to the longest and their lengths kept in
+    `video_len` (None when all agree); every tensor goes through one pinned host buffer and one asynchronous H2D copy on
+    the current stream."""
     from .evaluate import clip_key
     n = len(items)
     keys, order, index = {}, [], []
@@ -288,10 +289,9 @@ def pack_questions(items, device, share_clips=True, pin=True):
             keys[k] = len(order)
             order.append(d['video_features'])
         index.append(keys[k])
-    T = {int(c.shape[0]) for c in order}
-    if len(T) != 1:
-        raise ValueError('one frame count per batch (got %s); bucket with evaluate.group_by_frames first' % sorted(T))
-    video = torch.stack([torch.as_tensor(c, dtype=torch.float32) for c in order])
+    frames = [int(c.shape[0]) for c in order]
+    Tm = max(frames)
+    video = torch.stack([torch.nn.functional.pad(torch.as_tensor(c, dtype=torch.float32), (0, 0, 0, Tm - int(c.shape[0]))) for c in order])
     qs = [torch.as_tensor(d['question'], dtype=torch.float32) for d in items]
     question = torch.cat(qs)
     answers = torch.tensor([int(d['answer']) for d in items], dtype=torch.int32) if 'answer' in items[0] else None
@@ -312,6 +312,7 @@ def pack_questions(items, device, share_clips=True, pin=True):
     b.video_index = index if len(order) < n else None
     b.q_lens = [int(q.shape[0]) for q in qs]
     b.n_clips = len(order)
+    b.video_len = frames if len(set(frames)) > 1 else None
     return b
 
 

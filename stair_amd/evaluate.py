@@ -51,8 +51,12 @@ def shard_by_clip(questions, rank, world):
     return [i for g in sorted(mine, key=lambda g: g[0]) for i in g]
 
 
-def group_by_frames(batch):
-    """The executor wants one frame count per launch batch; bucket a list of question dicts by T."""
+def group_by_frames(batch, ragged=True):
+    """Launch groups of a question list.  Clips of different frame counts run in ONE batch (stair_plan_build_ragged), so
+    with ragged=True (Conv1d-Temporal configurations) there is a single group; ragged=False buckets by frame count, which
+    the Linear(T,T) Temporal configurations still need (they fix T = max_video_length like the reference)."""
+    if ragged:
+        return {0: list(range(len(batch)))} if len(batch) else {}
     groups = {}
     for i, d in enumerate(batch):
         groups.setdefault(int(d['video_features'].shape[0]), []).append(i)
@@ -62,7 +66,7 @@ def group_by_frames(batch):
 def predict(model, questions, batch_size=1024):
     """Top-1 answer ids (python ints) for a list of question dicts, in order."""
     preds = [None] * len(questions)
-    for T, idxs in sorted(group_by_frames(questions).items()):
+    for T, idxs in sorted(group_by_frames(questions, ragged=model.config['max_video_length'] > 32).items()):
         # questions of one clip next to each other, so a launch batch encodes each of its clips once
         first = {}
         for i in idxs:
@@ -128,7 +132,7 @@ def filter_text_results(model, questions, filter_vocab, phrase_embeddings, batch
     reps = model.encode_phrases(phrase_embeddings)                      # [C, H]
     H = model.config['hidden_size']
     out = {}
-    for T, idxs in sorted(group_by_frames(questions).items()):
+    for T, idxs in sorted(group_by_frames(questions, ragged=model.config['max_video_length'] > 32).items()):
         for s in range(0, len(idxs), batch_size):
             chunk = [questions[i] for i in idxs[s:s + batch_size]]
             res = model.forward_batch(chunk)
@@ -165,7 +169,7 @@ def evaluate_by_module(model, questions, unk_token_id, batch_size=1024, module_l
     modules = set(model.pretrain_modules) | {'decoder'}
     losses = {m: [] for m in L.CRITERION_MODULES}
     preds = [None] * len(questions)
-    for T, idxs in sorted(group_by_frames(questions).items()):
+    for T, idxs in sorted(group_by_frames(questions, ragged=model.config['max_video_length'] > 32).items()):
         for s in range(0, len(idxs), batch_size):
             chunk_idx = idxs[s:s + batch_size]
             chunk = [questions[i] for i in chunk_idx]

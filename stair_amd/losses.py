@@ -247,7 +247,9 @@ def apply_module_losses(model, res, questions, scale, pretrain_modules=CRITERION
         K = np.where(kind == 0, aux_t[tok], 1).astype(np.int64)
         keep = np.arange(2)[None, :] < K[:, None]
         n_att = len(tok)
-        stage('att', i32(slot), i32(K), i32(np.concatenate([[0], np.cumsum(K)])), np.ascontiguousarray(iv[keep], dtype=np.float64))
+        qf = res.question_frames
+        att_len = i32(np.concatenate([np.full(packs[qi].att_pos.size, qf[qi]) for qi in sel])) if qf is not None else np.zeros(0, np.int32)
+        stage('att', i32(slot), i32(K), i32(np.concatenate([[0], np.cumsum(K)])), np.ascontiguousarray(iv[keep], dtype=np.float64), att_len)
     # ---- linear heads (Exists / Xor / Equals) ----
     n_head = {}
     for module in ('Exists', 'Xor', 'Equals'):
@@ -292,9 +294,10 @@ def apply_module_losses(model, res, questions, scale, pretrain_modules=CRITERION
     att, gatt = res._arena(res.info.att_off, res.info.n_att, T), res.grad_arena('att')
     P = lambda t: C.c_void_p(t.data_ptr())
     if n_att:
-        slot_d, K_d, off_d, iv_d = got('att')
+        slot_d, K_d, off_d, iv_d, len_d = got('att')
         out = torch.empty(n_att, device=dev)
-        check(lib.stair_loss_attention(P(att), P(gatt), P(slot_d), P(K_d), P(off_d), P(iv_d), n_att, T, C.c_float(scale), P(out), stream))
+        check(lib.stair_loss_attention_len(P(att), P(gatt), P(slot_d), P(K_d), P(off_d), P(iv_d), P(len_d) if len_d.numel() else None,
+                                           n_att, T, C.c_float(scale), P(out), stream))
         losses['attention'] = out
     for module, n_items in n_head.items():
         head = model.submodules[module].pretrain_head
@@ -307,6 +310,8 @@ def apply_module_losses(model, res, questions, scale, pretrain_modules=CRITERION
     # ---- FilterFrame (off by default, args.py:62) ----
     ff_items = [(int(slot_t[base[qi] + pos]), gold) for qi, p in enumerate(packs) for pos, gold in p.ff]
     if ff_items:
+        if res.question_frames is not None:
+            raise NotImplementedError('the FilterFrame criterion (off by default, args.py:62) takes batches of one clip length')
         losses['FilterFrame'] = _filterframe_launch(model, res, ff_items, scale, True)
         touched.update({'submodules.FilterFrame.pretrain_head.weight', 'submodules.FilterFrame.pretrain_head.bias'})
     if c_slot:
@@ -343,11 +348,11 @@ def evaluate_module_losses(model, res, questions, pretrain_modules=CRITERION_MOD
             tok_ = int(res._prog_off[qi]) + i
             slot, aux, rel = int(slot_t[tok_]), int(aux_t[tok_]), int(rel_t[tok_])
             if module == 'Localize':
-                att_items.append((slot, aux, [tuple(map(float, gold[r])) for r in range(aux)], module))
+                att_items.append((slot, aux, [tuple(map(float, gold[r])) for r in range(aux)], module, qi))
             elif module == 'Temporal':
-                att_items.append((rel, 1, [tuple(map(float, gold))], module))
+                att_items.append((rel, 1, [tuple(map(float, gold))], module, qi))
             elif module == 'ExistsFrame':
-                att_items.append((slot, 1, [tuple(map(float, gold))], module))
+                att_items.append((slot, 1, [tuple(map(float, gold))], module, qi))
             elif module in head_items:
                 head_items[module].append((slot, int(bool(gold))))
             elif module in CONTRASTIVE:
@@ -370,9 +375,12 @@ def evaluate_module_losses(model, res, questions, pretrain_modules=CRITERION_MOD
         off = i32(np.concatenate([[0], np.cumsum([a[1] for a in att_items])]).tolist())
         iv = torch.tensor([p for a in att_items for p in a[2]], dtype=torch.float64, device=dev)
         val = torch.empty(len(att_items), device=dev)
-        check(lib.stair_loss_attention(C.c_void_p(att.data_ptr()), None, C.c_void_p(slot.data_ptr()), C.c_void_p(K.data_ptr()),
-                                       C.c_void_p(off.data_ptr()), C.c_void_p(iv.data_ptr()), len(att_items), T,
-                                       C.c_float(0.0), C.c_void_p(val.data_ptr()), stream))
+        qf = res.question_frames
+        lens = i32([int(qf[a[4]]) for a in att_items]) if qf is not None else None
+        check(lib.stair_loss_attention_len(C.c_void_p(att.data_ptr()), None, C.c_void_p(slot.data_ptr()), C.c_void_p(K.data_ptr()),
+                                           C.c_void_p(off.data_ptr()), C.c_void_p(iv.data_ptr()),
+                                           C.c_void_p(lens.data_ptr()) if lens is not None else None, len(att_items), T,
+                                           C.c_float(0.0), C.c_void_p(val.data_ptr()), stream))
         for a, v in zip(att_items, val.cpu().tolist()):
             out[a[3]].append(v)
     for module, items in head_items.items():
@@ -388,6 +396,8 @@ def evaluate_module_losses(model, res, questions, pretrain_modules=CRITERION_MOD
                                   None, None, len(items), H, C.c_float(0.0), C.c_void_p(val.data_ptr()), stream))
         out[module].extend(val.cpu().tolist())
     if ff_items:
+        if res.question_frames is not None:
+            raise NotImplementedError('the FilterFrame criterion takes batches of one clip length')
         out['FilterFrame'].extend(_filterframe_launch(model, res, ff_items, 0.0, False).cpu().tolist())
     if cont_items:
         reps = model.encode_phrases(embs)                                  # [sum of gold sizes, H], L2-normalised

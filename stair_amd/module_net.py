@@ -84,13 +84,18 @@ def _clip_key(x):
 
 
 class BatchResult:
-    """Outputs of one batched pass plus read access to every intermediate program value."""
+    """Outputs of one batched pass plus read access to every intermediate program value.
+
+    `logits` and `pred` are tensors of their own.  Everything else -- node(), related_attn(), token_feature,
+    question_feature, grad_arena() -- is a VIEW into the model's shared workspace and is overwritten by the next
+    run_programs / forward_batch / Trainer.step on the same model: clone what must outlive it (VideoNMN.forward does)."""
 
     def __init__(self, model, plan, info, ws, logits, pred, prog_off, programs, video=None, question=None):
         self._model, self._plan, self.info, self._ws = model, plan, info, ws
         self.logits, self.pred = logits, pred
         self._prog_off, self._programs = prog_off, programs
         self._video, self._question = video, question
+        self.question_frames = None          # [n] frames per question when the batch mixes clip lengths, else None (all info.T)
 
     def zero_grad_arenas(self):
         check(lib.stair_plan_zero_grads(self._plan, C.c_void_p(self._ws.data_ptr()),
@@ -318,7 +323,7 @@ class VideoNMN(nn.Module):
         return self._ws
 
     # ---------------------------------------------------------------------------------------
-    def run_programs(self, programs, spans, video, question, q_lens, train=False, video_index=None, dropout=None):
+    def run_programs(self, programs, spans, video, question, q_lens, train=False, video_index=None, dropout=None, video_len=None):
         """Batched pass.  programs: list of token lists; spans: list of {pos: (lo, hi)}; video
         [n,T,V] and question [sum(q_lens), E] float32 on the GPU.  Returns a BatchResult.
 
@@ -327,7 +332,10 @@ class VideoNMN(nn.Module):
         parity test pins.
         video_index (optional, [n] ints): question q asks about clip video[video_index[q]]; video is then
         [n_videos,T,V] and each clip is encoded once instead of once per question (module_net.py:74 encodes per
-        question; the results are identical)."""
+        question; the results are identical).
+        video_len (optional, [n_videos] ints): clips of different frame counts in one batch -- clip v holds video_len[v]
+        <= T frames at the front of video[v], padding behind (dataset.py:137-143 keeps every clip's own length); each
+        question is computed as the reference computes a clip of its own length (stair_plan_build_ragged)."""
         n = len(programs)
         if video_index is not None:
             video_index = np.ascontiguousarray(np.asarray(video_index, dtype=np.int32))
@@ -354,8 +362,15 @@ class VideoNMN(nn.Module):
         def ip(a):
             return a.ctypes.data_as(C.POINTER(C.c_int32))
         plan = C.c_void_p()
-        check(lib.stair_plan_build_shared(self._ctx, n, ip(prog_off), ip(tokens), ip(lo), ip(hi), ip(q_off), video.shape[0],
-                                          ip(video_index) if video_index is not None else None, T, 1 if train else 0,
+        if video_len is not None:
+            video_len = np.ascontiguousarray(np.asarray(video_len, dtype=np.int32))
+            if video_len.shape != (video.shape[0],):
+                raise ValueError('video_len must have one entry per clip')
+            if bool((video_len == T).all()):
+                video_len = None
+        check(lib.stair_plan_build_ragged(self._ctx, n, ip(prog_off), ip(tokens), ip(lo), ip(hi), ip(q_off), video.shape[0],
+                                          ip(video_index) if video_index is not None else None,
+                                          ip(video_len) if video_len is not None else None, T, 1 if train else 0,
                                           C.byref(plan)))
         try:
             info = PlanInfo()
@@ -372,16 +387,21 @@ class VideoNMN(nn.Module):
                                            C.c_void_p(ws.data_ptr()), ws.numel() * 4, C.c_void_p(logits.data_ptr()),
                                            C.c_void_p(pred.data_ptr()), RUN_VIDEO_BF16 if video.dtype == torch.bfloat16 else 0,
                                            C.c_void_p(torch.cuda.current_stream().cuda_stream)))
-            if train:       # a training plan keeps its logits inside the workspace for the backward pass
-                logits = ws[info.logits_off: info.logits_off + n * A].view(n, A)
+            if train:       # a training plan keeps its logits inside the workspace for the backward pass; hand the caller a copy
+                logits = ws[info.logits_off: info.logits_off + n * A].view(n, A).clone()    # (n x A floats) that survives the next step
         except Exception:
             lib.stair_plan_destroy(plan)
             raise
-        return BatchResult(self, plan, info, ws, logits, pred, prog_off, programs, video, question)
+        res = BatchResult(self, plan, info, ws, logits, pred, prog_off, programs, video, question)
+        if video_len is not None:       # frames of every question's clip (the loss driver masks its criteria with them)
+            res.question_frames = video_len[video_index] if video_index is not None else video_len
+        return res
 
     def forward_batch(self, batch, train=False, share_videos=True, dropout=None):
-        """batch: list of question dicts in the reference layout (dataset.py:191-233), all with the
-        same number of frames.  Tensors may live on the host; they are moved once, packed.
+        """batch: list of question dicts in the reference layout (dataset.py:191-233).  Clips may differ in their
+        number of frames (they are padded to the longest of the batch and run with their own lengths, see run_programs);
+        Linear-Temporal configurations (max_video_length <= 32) need every clip at max_video_length, like the reference.
+        Tensors may live on the host; they are moved once, packed.
 
         Questions about the same clip share one encoder pass.  AGQADataset hands every question of a video the
         same `self.video_feats[video_id]` tensor (dataset.py:183), so clips are told apart by the memory their
@@ -404,12 +424,17 @@ class VideoNMN(nn.Module):
         clips = [torch.as_tensor(c) for c in clips]
         # clips stored as bf16 (data.load_clip_features(..., dtype='bf16')) stay bf16 on the device
         vdtype = torch.bfloat16 if all(c.dtype == torch.bfloat16 for c in clips) else torch.float32
+        frames = [int(c.shape[0]) for c in clips]
+        video_len = None
+        if len(set(frames)) > 1:                   # mixed clip lengths: pad to the longest, keep every clip's own length
+            video_len, Tm = frames, max(frames)
+            clips = [torch.nn.functional.pad(c.to(vdtype), (0, 0, 0, Tm - c.shape[0])) for c in clips]
         video = torch.stack(clips).to(dev, vdtype).contiguous()
         qs = [torch.as_tensor(d['question']) for d in batch]
         question = torch.cat(qs).to(dev, torch.float32).contiguous()
         return self.run_programs([d['nmn_program_list'] for d in batch],
                                  [d['prog_str_to_question_tokens'] for d in batch], video, question,
-                                 [q.shape[0] for q in qs], train=train, video_index=index, dropout=dropout)
+                                 [q.shape[0] for q in qs], train=train, video_index=index, dropout=dropout, video_len=video_len)
 
     # ---------------------------------------------------------------------------------------
     @torch.no_grad()

@@ -104,7 +104,8 @@ class Trainer:
         start, end, total = self.sched
         return end if self.iters > total else start + (end - start) / total * self.iters
 
-    def step(self, programs, spans, video, question, q_lens, answers, global_batch=None, questions=None, video_index=None):
+    def step(self, programs, spans, video, question, q_lens, answers, global_batch=None, questions=None, video_index=None,
+             video_len=None):
         """One optimizer step over this rank's shard of a window.  `questions` (the dicts, with
         'sg_res_by_step') switches the per-module intermediate losses on (train_module.py:351-373, 388-406).
         video_index: questions that share a clip (see VideoNMN.run_programs).
@@ -126,7 +127,8 @@ class Trainer:
         if questions is not None and gstep[-1] >= self.before_iters:
             questions = [q if g < self.before_iters else dict(q, sg_res_by_step={}) for q, g in zip(questions, gstep)]
         drop = (self.dropout, self.dropout_seed + self.iters * self.world + self.rank) if self.dropout > 0 else None
-        res = self.model.run_programs(programs, spans, video, question, q_lens, train=True, video_index=video_index, dropout=drop)
+        res = self.model.run_programs(programs, spans, video, question, q_lens, train=True, video_index=video_index, dropout=drop,
+                                      video_len=video_len)
         extra = set()
         if questions is not None and self.module_loss_weight != 0:
             res.zero_grad_arenas()

@@ -462,7 +462,12 @@ def test_on_disk_dataset_to_logits():
     w = oracle_weights(config, 5)
     items = [ds[i] for i in range(len(ds))]
     preds = E.predict(model, items, batch_size=4)
-    for T, idxs in E.group_by_frames(items).items():
+    ball = D.pack_questions(items, DEV)            # every clip length in ONE launch batch
+    rall = model.run_programs(ball.programs, ball.spans, ball.video, ball.question, ball.q_lens, video_index=ball.video_index,
+                              video_len=ball.video_len)
+    for i in range(len(items)):
+        assert _maxerr(rall.logits[i], O.forward(w, config, items[i])['logits']) < 1e-4
+    for T, idxs in E.group_by_frames(items, ragged=False).items():
         group = [items[i] for i in idxs]
         b = D.pack_questions(group, DEV)
         res = model.run_programs(b.programs, b.spans, b.video, b.question, b.q_lens, video_index=b.video_index)
