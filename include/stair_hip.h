@@ -76,6 +76,12 @@ enum stair_value_kind {
 int stair_abi_version(void);
 const char *stair_last_error(void);
 
+/* Measurement aid: while enabled, every launch of an HBM-bound row kernel adds the bytes it must move (inputs once +
+ * outputs once) to a per-kernel table; stair_acct_dump writes "kernel launches bytes" lines.  tools/row_kernels.py pairs the
+ * table with rocprofv3 kernel durations (GB/s per kernel against the 8 TB/s HBM peak).  Off by default, process-wide. */
+void stair_acct_enable(int32_t on);
+int stair_acct_dump(char *buf, int32_t cap);
+
 /* ---- context: configuration + borrowed weight pointers ------------------------------------ */
 int stair_ctx_create(const stair_config *cfg, stair_ctx **out);
 void stair_ctx_destroy(stair_ctx *ctx);

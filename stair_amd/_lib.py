@@ -86,6 +86,8 @@ class PlanInfo(C.Structure):
 SIGNATURES = [
     ('stair_abi_version', C.c_int, []),
     ('stair_last_error', C.c_char_p, []),
+    ('stair_acct_enable', None, [C.c_int32]),
+    ('stair_acct_dump', C.c_int, [C.c_char_p, C.c_int32]),
     ('stair_ctx_create', C.c_int, [C.POINTER(StairConfig), C.POINTER(C.c_void_p)]),
     ('stair_ctx_destroy', None, [C.c_void_p]),
     ('stair_weight_count', C.c_int, [C.c_void_p]),

@@ -24,6 +24,14 @@ namespace stair {
 static thread_local std::string g_err;
 void set_error(const std::string &msg) { g_err = msg; }
 
+bool g_acct_on = false;
+static std::map<std::string, std::pair<int64_t, int64_t>> g_acct;       // kernel -> (launches, algorithmic bytes)
+void acct_add(const char *kernel, int64_t bytes) {
+    auto &e = g_acct[kernel];
+    e.first += 1;
+    e.second += bytes;
+}
+
 }  // namespace stair
 
 using namespace stair;
@@ -138,6 +146,13 @@ static void build_weight_table(stair_ctx *c) {
 }
 
 extern "C" int stair_abi_version(void) { return STAIR_ABI_VERSION; }
+extern "C" void stair_acct_enable(int32_t on) { g_acct_on = on != 0; if (on) g_acct.clear(); }
+extern "C" int stair_acct_dump(char *buf, int32_t cap) {        // "kernel launches bytes\n" lines; returns the length needed
+    std::string out;
+    for (auto &kv : g_acct) out += kv.first + " " + std::to_string(kv.second.first) + " " + std::to_string(kv.second.second) + "\n";
+    if (buf && cap > 0) { const size_t n = std::min<size_t>(out.size(), (size_t)cap - 1); memcpy(buf, out.data(), n); buf[n] = 0; }
+    return (int)out.size() + 1;
+}
 extern "C" const char *stair_last_error(void) { return g_err.c_str(); }
 
 extern "C" int stair_ctx_create(const stair_config *cfg, stair_ctx **out) {

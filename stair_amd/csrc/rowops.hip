@@ -91,6 +91,7 @@ int launch_cosine_attn(const float *F, int64_t f_gstride, const int32_t *f_idx, 
                        const int32_t *k_idx, float *att, const int32_t *out_idx, int npairs, int T, int H,
                        hipStream_t s) {
     if (npairs == 0) return 0;
+    STAIR_ACCT("cosine_attn_kernel", ((int64_t)npairs * T * H + (int64_t)npairs * H + (int64_t)npairs * T) * 4);
     STAIR_CHECK(H % 4 == 0 && f_gstride % 4 == 0, "H and f_gstride must be multiples of 4");
     const int64_t rows = (int64_t)npairs * T;
     hipLaunchKernelGGL(cosine_attn_kernel, dim3((unsigned)((rows + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock),
@@ -197,6 +198,7 @@ __global__ void layernorm_kernel(const float *Y, float *X, int64_t gstride, cons
 int launch_layernorm(const float *Y, float *X, int64_t gstride, const int32_t *gidx, int n, int T, int H, const float *gamma,
                      const float *beta, float eps, hipStream_t s) {
     if (n == 0) return 0;
+    STAIR_ACCT("layernorm_kernel", 2ll * n * T * H * 4);
     const int64_t rows = (int64_t)n * T;
     hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0,
                        s, Y, X, gstride, gidx, n, T, H, gamma, beta, eps);
@@ -215,8 +217,34 @@ __global__ void sum_rows_kernel(const float *X, float *out, int n, int T, int H,
         out[(int64_t)g * H + c] = acc;
     }
 }
+// float4 form: thread = (16-byte column piece, row phase); the phases' partial sums meet in LDS
+__global__ void sum_rows_v4_kernel(const float *X, float *out, int T, int H4, const int32_t *len) {
+    extern __shared__ __attribute__((aligned(16))) float part[];          // [phases][H]
+    using v4 = __attribute__((ext_vector_type(4))) float;
+    const int g = blockIdx.x;
+    const int L = len ? len[g] : T;
+    const int phases = blockDim.x / H4, c = threadIdx.x % H4, ph = threadIdx.x / H4;
+    const v4 *x = reinterpret_cast<const v4 *>(X) + (int64_t)g * T * H4 + c;
+    v4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (ph < phases)
+        for (int t = ph; t < L; t += phases) acc += x[(int64_t)t * H4];
+    if (ph < phases) reinterpret_cast<v4 *>(part)[ph * H4 + c] = acc;
+    __syncthreads();
+    if (ph == 0) {
+        for (int q = 1; q < phases; ++q) acc += reinterpret_cast<v4 *>(part)[q * H4 + c];
+        reinterpret_cast<v4 *>(out)[(int64_t)g * H4 + c] = acc;
+    }
+}
 int launch_sum_rows(const float *X, float *out, int n, int T, int H, hipStream_t s, const int32_t *len) {
     if (n == 0) return 0;
+    if (H % 4 == 0 && H / 4 <= 256 && ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+        STAIR_ACCT("sum_rows_kernel", ((int64_t)n * T * H + (int64_t)n * H) * 4);
+        const int H4 = H / 4, phases = std::max(1, 512 / H4), threads = phases * H4;
+        hipLaunchKernelGGL(sum_rows_v4_kernel, dim3(n), dim3(threads), (size_t)phases * H * sizeof(float), s, X, out, T, H4, len);
+        STAIR_LAUNCH_CHECK();
+        return 0;
+    }
+    STAIR_ACCT("sum_rows_kernel", ((int64_t)n * T * H + (int64_t)n * H) * 4);
     hipLaunchKernelGGL(sum_rows_kernel, dim3(n), dim3(kBlock), 0, s, X, out, n, T, H, len);
     STAIR_LAUNCH_CHECK();
     return 0;
@@ -239,6 +267,7 @@ __global__ void rowdot_sigmoid_kernel(const float *X, int n, int T, int H, const
 int launch_rowdot_sigmoid(const float *X, int n, int T, int H, const float *w, const float *b, const float *extra,
                           float *out, const int32_t *out_idx, int64_t out_gstride, hipStream_t s) {
     if (n == 0) return 0;
+    STAIR_ACCT("rowdot_sigmoid_kernel", ((int64_t)n * T * H + (int64_t)n * T) * 4);
     const int64_t rows = (int64_t)n * T;
     hipLaunchKernelGGL(rowdot_sigmoid_kernel, dim3((unsigned)((rows + kWavesPerBlock - 1) / kWavesPerBlock)),
                        dim3(kBlock), 0, s, X, n, T, H, w, b, extra, out, out_idx, out_gstride);
@@ -325,6 +354,7 @@ __global__ void attnvideo_kernel(float *map, const int32_t *in_idx, const float 
 int launch_attnvideo(float *map, const int32_t *in_idx, const float *att, const int32_t *att_idx,
                      const int32_t *out_idx, int n, int T, int H, hipStream_t s) {
     if (n == 0) return 0;
+    STAIR_ACCT("attnvideo_kernel", (2ll * n * T * H + (int64_t)n * T) * 4);
     const int64_t total = (int64_t)n * T * H / 4;
     const int blocks = (int)std::min<int64_t>((total + kBlock - 1) / kBlock, 256 * 8);
     hipLaunchKernelGGL(attnvideo_kernel, dim3(blocks), dim3(kBlock), 0, s, map, in_idx, att, att_idx, out_idx, n, T, H);

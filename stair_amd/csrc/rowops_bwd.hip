@@ -8,6 +8,8 @@
 
 namespace stair {
 
+using v4f = __attribute__((ext_vector_type(4))) float;
+
 namespace {
 constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = kBlock / 64;
@@ -27,9 +29,33 @@ __global__ void mask_relu_kernel(float *dst, const float *G, int64_t g_gs, const
         dst[e] = yv > 0.f ? gv * scale : 0.f;      // scale = 1/(1-p) where a dropout follows the ReLU (Y is the dropped tensor)
     }
 }
+// float4 form: blockIdx.y = group, threads walk the row in 16-byte pieces (no per-element division, 16-byte accesses)
+__global__ void mask_relu_v4_kernel(float *dst, const float *G, int64_t g_gs, const int32_t *g_idx, const float *Y,
+                                    int64_t y_gs, const int32_t *y_idx, int rowlen4, float scale) {
+    const int g = blockIdx.y;
+    const v4f *gp = reinterpret_cast<const v4f *>(G + (int64_t)idx_or_id(g_idx, g) * g_gs);
+    const v4f *yp = reinterpret_cast<const v4f *>(Y + (int64_t)idx_or_id(y_idx, g) * y_gs);
+    v4f *dp = reinterpret_cast<v4f *>(dst + (int64_t)g * rowlen4 * 4);
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < rowlen4; e += gridDim.x * blockDim.x) {
+        const v4f gv = gp[e], yv = yp[e];
+        v4f o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = yv[j] > 0.f ? gv[j] * scale : 0.f;
+        dp[e] = o;
+    }
+}
 int launch_mask_relu(float *dst, const float *G, int64_t g_gs, const int32_t *g_idx, const float *Y, int64_t y_gs,
                      const int32_t *y_idx, int groups, int rowlen, hipStream_t s, float scale) {
     if (groups == 0) return 0;
+    STAIR_ACCT("mask_relu_kernel", 3ll * groups * rowlen * 4);
+    const bool al = ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(Y)) & 15) == 0;
+    if (al && rowlen % 4 == 0 && g_gs % 4 == 0 && y_gs % 4 == 0 && groups <= 65535) {
+        const int r4 = rowlen / 4;
+        const int bx = std::max(1, std::min((r4 + kBlock - 1) / kBlock, std::max(1, 4096 / groups)));
+        hipLaunchKernelGGL(mask_relu_v4_kernel, dim3(bx, groups), dim3(kBlock), 0, s, dst, G, g_gs, g_idx, Y, y_gs, y_idx, r4, scale);
+        STAIR_LAUNCH_CHECK();
+        return 0;
+    }
     const int64_t total = (int64_t)groups * rowlen;
     hipLaunchKernelGGL(mask_relu_kernel, dim3((unsigned)std::min<int64_t>((total + kBlock - 1) / kBlock, 4096)), dim3(kBlock), 0,
                        s, dst, G, g_gs, g_idx, Y, y_gs, y_idx, groups, rowlen, scale);
@@ -49,9 +75,33 @@ __global__ void bcast_mask_relu_kernel(float *dst, const float *dsum, const floa
         dst[e] = (in && Y[e] > 0.f) ? dsum[(int64_t)g * H + c] * scale : 0.f;
     }
 }
+__global__ void bcast_mask_relu_v4_kernel(float *dst, const float *dsum, const float *Y, int T, int H4, float scale, const int32_t *len) {
+    const int g = blockIdx.y;
+    const int L = len ? len[g] : T;
+    const v4f *yp = reinterpret_cast<const v4f *>(Y) + (int64_t)g * T * H4;
+    const v4f *sp = reinterpret_cast<const v4f *>(dsum) + (int64_t)g * H4;
+    v4f *dp = reinterpret_cast<v4f *>(dst) + (int64_t)g * T * H4;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < T * H4; e += gridDim.x * blockDim.x) {
+        const int t = e / H4, c = e - t * H4;
+        const v4f yv = yp[e], sv = sp[c];
+        v4f o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (t < L && yv[j] > 0.f) ? sv[j] * scale : 0.f;
+        dp[e] = o;
+    }
+}
 int launch_bcast_mask_relu(float *dst, const float *dsum, const float *Y, int groups, int T, int H, hipStream_t s, float scale,
                            const int32_t *len) {
     if (groups == 0) return 0;
+    if (H % 4 == 0 && groups <= 65535 && ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(dsum) | reinterpret_cast<uintptr_t>(Y)) & 15) == 0) {
+        STAIR_ACCT("bcast_mask_relu_kernel", (2ll * groups * T * H + (int64_t)groups * H) * 4);
+        const int e4 = T * (H / 4);
+        const int bx = std::max(1, std::min((e4 + kBlock - 1) / kBlock, std::max(1, 4096 / groups)));
+        hipLaunchKernelGGL(bcast_mask_relu_v4_kernel, dim3(bx, groups), dim3(kBlock), 0, s, dst, dsum, Y, T, H / 4, scale, len);
+        STAIR_LAUNCH_CHECK();
+        return 0;
+    }
+    STAIR_ACCT("bcast_mask_relu_kernel", (2ll * groups * T * H + (int64_t)groups * H) * 4);
     const int64_t total = (int64_t)groups * T * H;
     hipLaunchKernelGGL(bcast_mask_relu_kernel, dim3((unsigned)std::min<int64_t>((total + kBlock - 1) / kBlock, 4096)), dim3(kBlock),
                        0, s, dst, dsum, Y, groups, T, H, scale, len);
@@ -242,6 +292,7 @@ int launch_cosine_attn_bwd_grouped(const float *F, const float *Kmat, const floa
                                    const int32_t *pair_cnt, float *dF, float *dK, float *nf_ws, float *nk_ws, int n, int npairs,
                                    int T, int H, int ka_max, hipStream_t s) {
     if (n == 0) return 0;
+    STAIR_ACCT("cosine_attn_bwd_grouped_kernel", (2ll * n * T * H + 2ll * npairs * H + 2ll * npairs * T) * 4);
     STAIR_CHECK(H % 64 == 0, "H must be a multiple of 64");
     const int64_t frows = (int64_t)n * T;
     hipLaunchKernelGGL(rownorm_kernel, dim3((unsigned)((frows + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, s, F, frows, H, nf_ws);
@@ -351,6 +402,7 @@ int launch_temporal_relate_bwd(const float *att, const int32_t *att_idx, const i
                                const int32_t *rel_idx, float *datt, int n, int T, int mode, int conv, int ksize,
                                const float *const w[6], float *const dw[6], hipStream_t s, const int32_t *len) {
     if (n == 0) return 0;
+    STAIR_ACCT("temporal_relate_bwd_kernel", 0);
     RelateWB W;
     for (int i = 0; i < 6; ++i) { W.w[i] = (mode && w) ? w[i] : nullptr; W.dw[i] = (mode && dw) ? dw[i] : nullptr; }
     hipLaunchKernelGGL(temporal_relate_bwd_kernel, dim3(n), dim3(64), 6 * T * sizeof(float), s, att, att_idx, att_k, drel,
@@ -405,11 +457,93 @@ __global__ void layernorm_param_grad_kernel(const float *dOut, int64_t g_gs, con
     unsafeAtomicAdd(dgamma + c, ag);
     unsafeAtomicAdd(dbeta + c, ab);
 }
+// One pass for H a multiple of 256: a wave owns a row at a time (16-byte pieces in registers: y and dOut are read ONCE),
+// walks rows grid-stride and keeps the dgamma / dbeta sums of its columns in registers until the end (the two-kernel form
+// above reads Y four times and dOut three times and runs at 1.4 TB/s: profiles/r02_row_kernels.json).
+template <int NV>
+__global__ void layernorm_bwd_fused_kernel(const float *dOut, int64_t g_gs, const int32_t *g_idx, const float *Y, int n, int T,
+                                           const float *gamma, float eps, float *dZ, float *dgamma, float *dbeta, float scale) {
+    constexpr int H = NV * 256;
+    const int lane = threadIdx.x & 63;
+    const int64_t rows = (int64_t)n * T, stride = (int64_t)gridDim.x * kWavesPerBlock;
+    v4f gm[NV], ag[NV], ab[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        gm[j] = *reinterpret_cast<const v4f *>(gamma + 256 * j + 4 * lane);
+        ag[j] = v4f{0.f, 0.f, 0.f, 0.f}; ab[j] = v4f{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); row < rows; row += stride) {
+        const int g = (int)(row / T), t = (int)(row - (int64_t)g * T);
+        const float *yr = Y + row * H;
+        const float *gr = dOut + (int64_t)idx_or_id(g_idx, g) * g_gs + (int64_t)t * H;
+        v4f y[NV], go[NV];
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            y[j] = *reinterpret_cast<const v4f *>(yr + 256 * j + 4 * lane);
+            go[j] = *reinterpret_cast<const v4f *>(gr + 256 * j + 4 * lane);
+            sum += y[j][0] + y[j][1] + y[j][2] + y[j][3];
+        }
+        const float mean = wave_sum(sum) / (float)H;
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = y[j][e] - mean; sq += d * d; }
+        const float rstd = rsqrtf(wave_sum(sq) / (float)H + eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float dxh = go[j][e] * gm[j][e], xh = (y[j][e] - mean) * rstd;
+                s1 += dxh; s2 += dxh * xh;
+                ag[j][e] += go[j][e] * xh; ab[j][e] += go[j][e];
+            }
+        s1 = wave_sum(s1) / (float)H; s2 = wave_sum(s2) / (float)H;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            v4f o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float dxh = go[j][e] * gm[j][e], xh = (y[j][e] - mean) * rstd;
+                o[e] = y[j][e] > 0.f ? rstd * (dxh - s1 - xh * s2) * scale : 0.f;
+            }
+            *reinterpret_cast<v4f *>(dZ + row * H + 256 * j + 4 * lane) = o;
+        }
+    }
+    // the four waves of the workgroup add up through LDS, then ONE set of atomics per workgroup (at most 256 workgroups:
+    // every workgroup adds into the same 2 x H addresses, where atomics run an order of magnitude below their streaming rate)
+    __shared__ float red[2][kWavesPerBlock][H];
+    const int wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        *reinterpret_cast<v4f *>(&red[0][wv][256 * j + 4 * lane]) = ag[j];
+        *reinterpret_cast<v4f *>(&red[1][wv][256 * j + 4 * lane]) = ab[j];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * H; c += kBlock) {
+        const int which = c / H, col = c - which * H;
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < kWavesPerBlock; ++q) v += red[which][q][col];
+        unsafeAtomicAdd((which ? dbeta : dgamma) + col, v);
+    }
+}
 int launch_layernorm_bwd(const float *dOut, int64_t g_gs, const int32_t *g_idx, const float *Y, int n, int T, int H,
                          const float *gamma, float eps, float *dZ, float *stats, float *dgamma, float *dbeta, hipStream_t s,
                          float scale) {
     if (n == 0) return 0;
+    STAIR_ACCT("layernorm_bwd_kernel+param_grad", (3ll * n * T * H + 2ll * n * T) * 4);
     const int64_t rows = (int64_t)n * T;
+    const bool al = ((reinterpret_cast<uintptr_t>(dOut) | reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(dZ) | reinterpret_cast<uintptr_t>(gamma)) & 15) == 0;
+    if (al && (H == 256 || H == 512) && g_gs % 4 == 0) {
+        const unsigned blocks = (unsigned)std::min<int64_t>((rows + kWavesPerBlock - 1) / kWavesPerBlock, 256 * 4);
+        if (H == 512) hipLaunchKernelGGL(layernorm_bwd_fused_kernel<2>, dim3(blocks), dim3(kBlock), 0, s, dOut, g_gs, g_idx, Y, n, T, gamma, eps, dZ, dgamma, dbeta, scale);
+        else hipLaunchKernelGGL(layernorm_bwd_fused_kernel<1>, dim3(blocks), dim3(kBlock), 0, s, dOut, g_gs, g_idx, Y, n, T, gamma, eps, dZ, dgamma, dbeta, scale);
+        STAIR_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)((rows + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0,
                        s, dOut, g_gs, g_idx, Y, n, T, H, gamma, eps, dZ, stats, scale);
     STAIR_LAUNCH_CHECK();
@@ -445,6 +579,7 @@ __global__ void rowscale_bwd_kernel(const float *G, const float *X, int64_t x_gs
 int launch_rowscale_bwd(const float *G, const float *X, int64_t x_gs, const int32_t *x_idx, const float *rs, int64_t rs_gs,
                         const int32_t *rs_idx, float *dX, float *drs, int n, int T, int H, hipStream_t s) {
     if (n == 0) return 0;
+    STAIR_ACCT("rowscale_bwd_kernel", (2ll * n * T * H + (dX ? (int64_t)n * T * H : 0) + (int64_t)n * T) * 4);
     const int64_t rows = (int64_t)n * T;
     hipLaunchKernelGGL(rowscale_bwd_kernel, dim3((unsigned)((rows + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, s,
                        G, X, x_gs, x_idx, rs, rs_gs, rs_idx, dX, drs, n, T, H);
@@ -478,6 +613,7 @@ int launch_rowdot_sigmoid_bwd(const float *dOut, int64_t o_gs, const int32_t *o_
                               const int32_t *a_idx, const float *w, float *dXdst, int add_mode, float *dpre_out,
                               float *dextra, int n, int T, int H, hipStream_t s, float keep) {
     if (n == 0) return 0;
+    STAIR_ACCT("rowdot_sigmoid_bwd_kernel", (2ll * n * T * H + 2ll * n * T) * 4);
     const int64_t rows = (int64_t)n * T;
     hipLaunchKernelGGL(rowdot_sigmoid_bwd_kernel, dim3((unsigned)((rows + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock),
                        0, s, dOut, o_gs, o_idx, A, a_gs, a_idx, w, dXdst, add_mode, dpre_out, dextra, n, T, H, keep);
@@ -498,6 +634,7 @@ __global__ void weighted_colsum_kernel(const float *X, int64_t ld, const int32_t
 int launch_weighted_colsum(const float *X, int64_t ld, const int32_t *x_idx, const float *scale, float *out, int rows, int H,
                            hipStream_t s) {
     if (rows == 0) return 0;
+    STAIR_ACCT("weighted_colsum_kernel", ((int64_t)rows * H + rows + H) * 4);
     const int slab = std::max(64, (rows + 255) / 256);
     hipLaunchKernelGGL(weighted_colsum_kernel, dim3((H + 255) / 256, (rows + slab - 1) / slab), dim3(256), 0, s, X, ld, x_idx,
                        scale, out, rows, H, slab);
@@ -609,6 +746,7 @@ __global__ void attnvideo_bwd_kernel(const float *map, float *dmap, const float 
 int launch_attnvideo_bwd(const float *map, float *dmap, const float *att, float *datt, const int32_t *in_idx,
                          const int32_t *att_idx, const int32_t *out_idx, int n, int T, int H, hipStream_t s) {
     if (n == 0) return 0;
+    STAIR_ACCT("attnvideo_bwd_kernel", (4ll * n * T * H + 2ll * n * T) * 4);
     const int64_t rows = (int64_t)n * T;
     hipLaunchKernelGGL(attnvideo_bwd_kernel, dim3((unsigned)((rows + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, s,
                        map, dmap, att, datt, in_idx, att_idx, out_idx, n, T, H);
@@ -693,6 +831,7 @@ int launch_superlative_pool_bwd(const float *S, const float *rowbase, float *dro
                                 const int32_t *row_start, const int32_t *row_cnt, int is_min, const float *dpre, float *dS,
                                 int n, int T, int H, hipStream_t s, const int32_t *len) {
     if (n == 0) return 0;
+    STAIR_ACCT("superlative_pool_bwd_kernel", 0);
     hipLaunchKernelGGL(superlative_pool_bwd_kernel, dim3(n), dim3(kBlock), (size_t)2 * std::max(T, 2) * sizeof(float), s, S, rowbase,
                        drowbase, row_id, row_start, row_cnt, is_min, dpre, dS, n, T, H, len);
     STAIR_LAUNCH_CHECK();
@@ -745,25 +884,34 @@ int launch_ce_loss(const float *logits, const int32_t *answers, float scale, flo
 // over a flat parameter buffer.  `touched[seg]` != 0 marks parameter tensors that received a gradient in
 // this window; untouched tensors are skipped entirely, which is what torch does for grad == None
 // (modules that no program of the window used) -- their moments and step count do not advance.
+// one workgroup of 64 threads per 256-float block (= one segment granule), 16 bytes per thread
 __global__ void adam_kernel(float *p, const float *g, float *m, float *v, const int32_t *seg_of_block, const int32_t *touched,
                             const float *step_of_seg, float lr, float b1, float b2, float eps, float wd, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= n) return;
     const int seg = seg_of_block[blockIdx.x];
     if (!touched[seg]) return;
     const float t = step_of_seg[seg];                 // already incremented for this step
-    float grad = g[i];
-    if (wd != 0.f) grad += wd * p[i];
-    const float mi = b1 * m[i] + (1.f - b1) * grad;
-    const float vi = b2 * v[i] + (1.f - b2) * grad * grad;
-    m[i] = mi; v[i] = vi;
     const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
-    p[i] -= lr / bc1 * mi / (sqrtf(vi) / sqrtf(bc2) + eps);
+    const float a = lr / bc1, rb2 = 1.0f / sqrtf(bc2);
+    const v4f gv = *reinterpret_cast<const v4f *>(g + i);
+    v4f pv = *reinterpret_cast<v4f *>(p + i), mv = *reinterpret_cast<v4f *>(m + i), vv = *reinterpret_cast<v4f *>(v + i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float grad = gv[j];
+        if (wd != 0.f) grad += wd * pv[j];
+        mv[j] = b1 * mv[j] + (1.f - b1) * grad;
+        vv[j] = b2 * vv[j] + (1.f - b2) * grad * grad;
+        pv[j] -= a * mv[j] / (sqrtf(vv[j]) * rb2 + eps);
+    }
+    *reinterpret_cast<v4f *>(p + i) = pv; *reinterpret_cast<v4f *>(m + i) = mv; *reinterpret_cast<v4f *>(v + i) = vv;
 }
 int launch_adam(float *p, const float *g, float *m, float *v, const int32_t *seg_of_block, const int32_t *touched,
                 const float *step_of_seg, float lr, float b1, float b2, float eps, float wd, int64_t n, hipStream_t s) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, m, v, seg_of_block, touched,
+    STAIR_ACCT("adam_kernel", 7ll * n * 4);
+    STAIR_CHECK(n % 256 == 0, "the flat parameter buffer is made of whole 256-float blocks");
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)(n / 256)), dim3(64), 0, s, p, g, m, v, seg_of_block, touched,
                        step_of_seg, lr, b1, b2, eps, wd, n);
     STAIR_LAUNCH_CHECK();
     return 0;
@@ -780,6 +928,7 @@ __global__ void scale_rows_kernel(float *G, const float *rs, int64_t rows, int H
 }
 int launch_scale_rows(float *G, const float *rs, int64_t rows, int H, hipStream_t s) {
     if (rows == 0) return 0;
+    STAIR_ACCT("scale_rows_kernel", (2ll * rows * H + rows) * 4);
     const int64_t total = rows * H;
     hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, s, G, rs, rows, H);
     STAIR_LAUNCH_CHECK();
