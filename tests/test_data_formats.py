@@ -115,8 +115,10 @@ def test_pack_questions_stages_each_clip_once():
     assert b.h2d_bytes == 4 * (5 * 16 + sum(b.q_lens) * 8 + 3)
     flat = D.pack_questions(items, 'cpu', share_clips=False)
     assert flat.n_clips == 3 and flat.video_index is None and torch.equal(flat.video[2], b.video[0])
-    with pytest.raises(ValueError, match='one frame count'):
-        D.pack_questions([ds[0], ds[4]], 'cpu')                         # 8 vs 5 frames
+    mixed = D.pack_questions([ds[0], ds[4]], 'cpu')                     # 8 vs 5 frames: padded to 8, lengths kept
+    assert mixed.video_len == [8, 5] and tuple(mixed.video.shape) == (2, 8, 16)
+    assert torch.equal(mixed.video[1, :5], b.video[0]) and float(mixed.video[1, 5:].abs().max()) == 0.0
+    assert b.video_len is None
 
 
 def test_checkpoint_round_trip_and_refusal_of_pickled_modules(tmp_path):
