@@ -147,3 +147,50 @@ def test_two_rank_gradient_reduction_equals_single_process(tmp_path):
     assert torch.equal(g0['touched'], touched)
     # Equals is only used by P4 (rank 1's shard): rank 0 alone would have left it untouched
     assert int(touched[names.index('submodules.Equals.param.0.weight')]) == 1
+
+
+def _worker_exchange(rank, world, port, out_dir):
+    """The host side of the one exchange step of a DP training step, on CPU tensors: the bucket all-reduce with the touched
+    mask in its tail, and the global contrastive class pools."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import numpy as np
+    import torch.distributed as dist
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    # losses.contrastive_windows / train.reduce_gradients are pure host logic; import them without the HIP library's GPU calls
+    from stair_amd import losses as L
+    from stair_amd.train import reduce_gradients
+    total, ntensor = 512, 5
+    bucket = torch.zeros(total + 256)
+    flat_g = bucket[:total]
+    flat_g.copy_(torch.arange(total, dtype=torch.float32) * (rank + 1))
+    touched = torch.tensor([1, 0, 0, 1, 0] if rank == 0 else [0, 0, 1, 1, 0], dtype=torch.int32)
+    reduce_gradients(flat_g, touched, world, bucket)
+    # rank r holds the contrastive golds of global positions r, r + 2, ...: classes chosen so that windows overlap
+    entries = [(g, 'class_%d' % (g % 5), np.full((1 + g % 3, 4), float(g % 5), dtype=np.float32)) for g in range(rank, 21, world)]
+    names, embs, rows, win_range, slot_of = L.contrastive_windows(entries, 8, world)
+    torch.save({'g': flat_g.clone(), 'touched': touched, 'names': names, 'rows': rows.tolist(), 'win_range': win_range,
+                'slot_of': {'%d/%s' % k: v for k, v in slot_of.items()}, 'emb0': [e.tolist() for e in embs]}, os.path.join(out_dir, 'x%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_bucket_and_global_contrastive_windows(tmp_path):
+    import numpy as np
+    world = 2
+    mp.spawn(_worker_exchange, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(os.path.join(tmp_path, 'x0.pt'))
+    r1 = torch.load(os.path.join(tmp_path, 'x1.pt'))
+    # ONE all-reduce: gradients summed, touched mask = union over ranks
+    assert torch.equal(r0['g'], torch.arange(512, dtype=torch.float32) * 3) and torch.equal(r0['g'], r1['g'])
+    assert r0['touched'].tolist() == r1['touched'].tolist() == [1, 0, 1, 1, 0]
+    # every rank built the tables of the whole window, i.e. the single-process tables
+    sys.path.insert(0, ROOT)
+    from stair_amd import losses as L
+    entries = [(g, 'class_%d' % (g % 5), np.full((1 + g % 3, 4), float(g % 5), dtype=np.float32)) for g in range(21)]
+    names, embs, rows, win_range, slot_of = L.contrastive_windows(entries, 8, 1)
+    for r in (r0, r1):
+        assert r['names'] == names and r['rows'] == rows.tolist() and r['win_range'] == win_range
+        assert r['slot_of'] == {'%d/%s' % k: v for k, v in slot_of.items()}
+    assert sorted(win_range) == [0, 1, 2] and win_range[0][1] == 5 and win_range[2][1] == 5

@@ -14,7 +14,7 @@ model = model.to('cuda:0')
 for B in (8, 32, 128, 512, 2048):
     qs = synth.make_questions(config, 0, B)
     progs = [q['nmn_program_list'] for q in qs]; spans = [q['prog_str_to_question_tokens'] for q in qs]
-    video = torch.randn(B, 64, config['video_size'], device='cuda:0')
+    video = torch.randn(B, 64, config['video_size'], device='cuda:0').to(torch.bfloat16)        # stored bf16 clips (BASELINE configs[1])
     question = torch.cat([torch.as_tensor(q['question']) for q in qs]).to('cuda:0')
     q_lens = [q['question'].shape[0] for q in qs]
     run = lambda: model.run_programs(progs, spans, video, question, q_lens)
