@@ -225,7 +225,9 @@ typedef struct stair_lstm_bwd_args {
     float *dw_ih[2], *dw_hh[2], *db_ih[2], *db_hh[2];
     const void *x_bf16; /* optional, as in stair_lstm_args: dW_ih = dG^T X then reads X as exact bf16 (two products per pair) */
     const int32_t *seq_len; /* optional, as in stair_lstm_args (the gate-gradient rows past a sequence's length are cleared) */
+    void *coop_ws; int64_t coop_ws_bytes; /* optional: >= stair_lstm_coop_bwd_ws_bytes(n), 256-byte aligned -> cooperative BPTT (Hh = 256, split mode) */
 } stair_lstm_bwd_args;
+int64_t stair_lstm_coop_bwd_ws_bytes(int32_t n);
 int stair_lstm_bidir_bwd(const stair_lstm_bwd_args *args, stair_stream stream);
 
 /* att[p][t] = (cos(F[f_idx[p]][t][:], Kmat[k_idx[p]][:]) + 1) * 0.49 -- nn.CosineSimilarity(dim=-1,

@@ -70,7 +70,7 @@ class LstmBwdArgs(C.Structure):
                 ('d_out', C.c_void_p), ('ldd', C.c_int64), ('d_hn', C.c_void_p),
                 ('whh_pack_ws', C.c_void_p), ('hprev_ws', C.c_void_p),
                 ('dw_ih', C.c_void_p * 2), ('dw_hh', C.c_void_p * 2), ('db_ih', C.c_void_p * 2), ('db_hh', C.c_void_p * 2),
-                ('x_bf16', C.c_void_p), ('seq_len', C.c_void_p)]
+                ('x_bf16', C.c_void_p), ('seq_len', C.c_void_p), ('coop_ws', C.c_void_p), ('coop_ws_bytes', C.c_int64)]
 
 
 class PlanInfo(C.Structure):
@@ -104,6 +104,7 @@ SIGNATURES = [
     ('stair_split_planes_tiled', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     ('stair_gemm_planes', C.c_int, [C.POINTER(GemmPlanesArgs), C.c_void_p]),
     ('stair_lstm_coop_ws_bytes', C.c_int64, [C.c_int32]),
+    ('stair_lstm_coop_bwd_ws_bytes', C.c_int64, [C.c_int32]),
     ('stair_lstm_bidir_fwd', C.c_int, [C.POINTER(LstmArgs), C.c_void_p]),
     ('stair_lstm_bidir_bwd', C.c_int, [C.POINTER(LstmBwdArgs), C.c_void_p]),
     ('stair_cosine_attn_fwd', C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

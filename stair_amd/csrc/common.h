@@ -67,6 +67,8 @@ int launch_lstm_bwd(const stair_lstm_bwd_args &a, hipStream_t s);
 int launch_lstm_rec_coop(const stair_lstm_args &a, hipStream_t s);
 bool lstm_coop_usable(int Hh);
 int64_t lstm_coop_ws_bytes(int n);
+int launch_lstm_bwd_coop(const stair_lstm_bwd_args &a, hipStream_t s);
+int64_t lstm_coop_bwd_ws_bytes(int n);
 int launch_gemm_bf16x3(const stair_gemm_args &a, hipStream_t s);
 int launch_gemm_tn_bf16x3(const stair_gemm_tn_args &a, hipStream_t s);
 int matmul_mode();

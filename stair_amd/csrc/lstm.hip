@@ -14,6 +14,8 @@
 //      a 16-wide block is permuted identically for h and W_hh (lane group g owns k = 16b+4g..+3).
 //      The xproj reads of a step are issued before its MFMA chain and consumed after it, which
 //      hides their HBM latency behind the matrix work.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace stair {
@@ -747,39 +749,47 @@ int launch_lstm_bwd(const stair_lstm_bwd_args &a, hipStream_t s) {
     STAIR_CHECK(a.gates && a.cbuf && a.out && a.d_out && a.whh_pack_ws && a.hprev_ws, "null buffer");
     if (a.n == 0 || a.rows == 0) return 0;
     const int Hh = a.Hh;
-    const bool split = matmul_mode() != STAIR_MATMUL_F32 && Hh % 64 == 0;
-    if (split) {
-        const int64_t n8 = 2 * 8 * (int64_t)Hh * Hh / 8;
-        hipLaunchKernelGGL(whh_packT_bf16_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, a.w_hh[0], a.w_hh[1],
-                           reinterpret_cast<__bf16 *>(a.whh_pack_ws), Hh);
-        STAIR_LAUNCH_CHECK();
+    // Cooperative BPTT (csrc/lstm_coop.hip) while every 32-sequence tile gets a group of its own: 338 us at n = 8 and 819 us at
+    // n = 1024 against 727 / 920 us of the one-workgroup kernel; beyond that both are bound by the saved-state traffic
+    // (2.8 GB per launch at n = 2048) and the one-workgroup kernel's 1.1 ms beats two tiles per group (1.6 ms).
+    const char *cmax = getenv("STAIR_LSTM_COOP_BWD_MAX_N");
+    if (a.coop_ws && lstm_coop_usable(Hh) && a.n <= (cmax ? atoi(cmax) : 1024)) {
+        if (int rc = launch_lstm_bwd_coop(a, s)) return rc;
     } else {
-        const int64_t ne = 2 * 4 * (int64_t)Hh * Hh;
-        hipLaunchKernelGGL(whh_packT_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, a.w_hh[0], a.w_hh[1],
-                           a.whh_pack_ws, Hh);
+        const bool split = matmul_mode() != STAIR_MATMUL_F32 && Hh % 64 == 0;
+        if (split) {
+            const int64_t n8 = 2 * 8 * (int64_t)Hh * Hh / 8;
+            hipLaunchKernelGGL(whh_packT_bf16_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, a.w_hh[0], a.w_hh[1],
+                               reinterpret_cast<__bf16 *>(a.whh_pack_ws), Hh);
+            STAIR_LAUNCH_CHECK();
+        } else {
+            const int64_t ne = 2 * 4 * (int64_t)Hh * Hh;
+            hipLaunchKernelGGL(whh_packT_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, a.w_hh[0], a.w_hh[1],
+                               a.whh_pack_ws, Hh);
+            STAIR_LAUNCH_CHECK();
+        }
+        LstmBwdParams p;
+        p.G = a.gates; p.cbuf = a.cbuf; p.d_out = a.d_out; p.ldd = a.ldd; p.d_hn = a.d_hn; p.w_packT = a.whh_pack_ws;
+        p.seq_off = a.seq_off; p.seq_len = a.seq_len; p.n = a.n; p.Hh = Hh;
+        const dim3 grid((a.n + 15) / 16, 2);
+        const size_t shmem = split ? 2 * 16 * (4 * Hh + 8) * sizeof(__bf16) : 16 * (4 * Hh + 4) * sizeof(float);
+        const int tiles = Hh / 16;
+        if (shmem > 48 * 1024) {   // 16 x (4*256+4) floats = 65.8 KB: above the default dynamic-LDS limit
+            STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_bwd_kernel<2, 8>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+            STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_bwd_x3_kernel<2, 8>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        }
+        if (split) {
+            if (tiles > 8) hipLaunchKernelGGL((lstm_bwd_x3_kernel<2, 8>), grid, dim3(512), shmem, s, p);
+            else if (tiles > 4) hipLaunchKernelGGL((lstm_bwd_x3_kernel<1, 8>), grid, dim3(512), shmem, s, p);
+            else hipLaunchKernelGGL((lstm_bwd_x3_kernel<1, 4>), grid, dim3(256), shmem, s, p);
+        } else if (tiles > 8) hipLaunchKernelGGL((lstm_bwd_kernel<2, 8>), grid, dim3(512), shmem, s, p);
+        else if (tiles > 4) hipLaunchKernelGGL((lstm_bwd_kernel<1, 8>), grid, dim3(512), shmem, s, p);
+        else if (tiles > 2) hipLaunchKernelGGL((lstm_bwd_kernel<1, 4>), grid, dim3(256), shmem, s, p);
+        else hipLaunchKernelGGL((lstm_bwd_kernel<1, 2>), grid, dim3(128), shmem, s, p);
         STAIR_LAUNCH_CHECK();
     }
-    LstmBwdParams p;
-    p.G = a.gates; p.cbuf = a.cbuf; p.d_out = a.d_out; p.ldd = a.ldd; p.d_hn = a.d_hn; p.w_packT = a.whh_pack_ws;
-    p.seq_off = a.seq_off; p.seq_len = a.seq_len; p.n = a.n; p.Hh = Hh;
-    const dim3 grid((a.n + 15) / 16, 2);
-    const size_t shmem = split ? 2 * 16 * (4 * Hh + 8) * sizeof(__bf16) : 16 * (4 * Hh + 4) * sizeof(float);
-    const int tiles = Hh / 16;
-    if (shmem > 48 * 1024) {   // 16 x (4*256+4) floats = 65.8 KB: above the default dynamic-LDS limit
-        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_bwd_kernel<2, 8>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_bwd_x3_kernel<2, 8>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    }
-    if (split) {
-        if (tiles > 8) hipLaunchKernelGGL((lstm_bwd_x3_kernel<2, 8>), grid, dim3(512), shmem, s, p);
-        else if (tiles > 4) hipLaunchKernelGGL((lstm_bwd_x3_kernel<1, 8>), grid, dim3(512), shmem, s, p);
-        else hipLaunchKernelGGL((lstm_bwd_x3_kernel<1, 4>), grid, dim3(256), shmem, s, p);
-    } else if (tiles > 8) hipLaunchKernelGGL((lstm_bwd_kernel<2, 8>), grid, dim3(512), shmem, s, p);
-    else if (tiles > 4) hipLaunchKernelGGL((lstm_bwd_kernel<1, 8>), grid, dim3(512), shmem, s, p);
-    else if (tiles > 2) hipLaunchKernelGGL((lstm_bwd_kernel<1, 4>), grid, dim3(256), shmem, s, p);
-    else hipLaunchKernelGGL((lstm_bwd_kernel<1, 2>), grid, dim3(128), shmem, s, p);
-    STAIR_LAUNCH_CHECK();
     hipLaunchKernelGGL(lstm_hprev_kernel, dim3(a.n), dim3(256), 0, s, a.out, a.ldo, a.seq_off, a.seq_len, a.n, Hh, a.hprev_ws, a.gates);
     STAIR_LAUNCH_CHECK();
     // weight gradients: dW_ih = dG^T X, dW_hh = dG^T Hprev, db_ih = db_hh = colsum(dG)

@@ -153,6 +153,7 @@ __global__ __launch_bounds__(512, 1) void lstm_rec_coop_kernel(CoopParams p) {
                     seen = __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");              // no instruction: keeps the loads below the poll
             const int so = slab_off(ep, x);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -300,7 +301,9 @@ __global__ __launch_bounds__(512, 1) void lstm_rec_coop_kernel(CoopParams p) {
             if (tid == 0 && total > 0)
                 __hip_atomic_store(flag_of((total - 1) % NT, j), ebase + (total - 1) / NT + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        ebase += lmax;
+        // a further chunk's first publish (epoch ebase' + 1) must not land in the slab a slower workgroup of the group is still
+        // reading -- that of the last epoch consumed, ebase + lmax - 1 -- so one epoch is skipped: the parities then differ
+        ebase += lmax + 1;
         __syncthreads();                                           // LDS is re-zeroed for the next chunk
     }
     if (PROF && blockIdx.x == 0 && tid == 0)
@@ -378,6 +381,273 @@ int launch_lstm_rec_coop(const stair_lstm_args &a, hipStream_t s) {
     return 0;
 }
 
+
+// =============================================================================================
+// Cooperative BPTT: the reverse-time recurrence with the same ownership as the forward kernel above.
+//
+// Workgroup j of a group owns hidden units [64 j, 64 j + 64) of up to 32 NT sequences of one direction: the cell
+// backward of those units is lane-local (the lane that holds (sequence r, units U0..U0+3) reads their four saved gates,
+// c(t), c(t-1) and d_out(t), and keeps dh / dc in registers).  What crosses units is
+//     dh(t-1)[k] = sum over the 4 Hh gate rows rho of dgates(t)[rho] * W_hh[rho][k]:
+// each workgroup multiplies ITS 256 gate rows (gate q, unit 64 j + 8 w' + u' <-> local row 32 w' + 8 q + u') into ALL 256
+// hidden columns -- the transposed quarter of W_hh lives in 128 VGPRs as bf16 hi + lo fragments for the whole launch, the
+// gate gradients are the B operand out of LDS (bf16 hi + lo, written by the cell lanes) -- and publishes the fp32 partial
+// sums, each 64-column block to the workgroup that owns those units: slab [dst][src][32 seq][64 units], write-through
+// 16-byte stores, epoch flags and sc1 loads exactly as in the forward kernel (Guideline 16 R1, "Valid forms" row 1).
+// The consumer lane loads the four partials of its own 4 units (4 x 16 B) straight into registers and adds them in source
+// order, so the result does not depend on timing.  (lstm_bwd_x3_kernel, which this replaces for Hh = 256, re-streams the
+// 1 MB image of W_hh^T from L2 on each of the serial steps: 12 us per step whatever the batch.)
+// =============================================================================================
+namespace {
+
+constexpr int BSLAB_BYTES = CP * CP * 32 * 64 * 4;      // one tile and parity of partial sums: 128 KB
+
+struct CoopBwdParams {
+    float *G;                 // [rows, 8 Hh]: activated gates in, gate pre-activation gradients out (in place)
+    const float *cbuf;        // [rows, 2 Hh]
+    const float *d_out;       // [rows, ldd]
+    int64_t ldd;
+    const float *d_hn;        // [n, 2 Hh] or null
+    const float *w_hh[2];
+    const int32_t *seq_off, *seq_len;
+    char *xh;                 // partial-sum slabs [2 parity][groups][NT][BSLAB_BYTES]
+    unsigned *flags, *err;
+    int n, gpd;
+};
+
+}  // namespace
+
+template <int NT>
+__global__ __launch_bounds__(512, 1) void lstm_bwd_coop_kernel(CoopBwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) char hl[];      // [NT tiles][2 planes][32 seq][256 local gate rows] bf16, swizzled; counters
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.x, q8 = b >> 3;
+    const int j = q8 & 3, g = (b & 7) + 8 * (q8 >> 2);
+    const int G = 2 * p.gpd;
+    if (g >= G) return;
+    const int dir = g / p.gpd, gl = g - dir * p.gpd;
+    constexpr int Hh = CH;
+    constexpr int SPG = 32 * NT;
+    const int U0 = 64 * j + 8 * wave + 4 * hh;                     // this lane's 4 hidden units in the cell backward
+    const int64_t ldx = 8 * (int64_t)Hh;
+    const int xcol = dir * 4 * Hh + U0;
+
+    // ---- W_hh^T fragments: A[m][rho] = W_hh[row(rho)][32 wave + m], rho = 16 s + 8 hh + e <-> gate 2 (s & 1) + hh, unit 64 j + 8 (s >> 1) + e ----
+    bf16x8 whi[16], wlo[16];
+    {
+        const float *wcol = p.w_hh[dir] + 32 * wave + r;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float *w0 = wcol + (int64_t)((2 * (s & 1) + hh) * Hh + 64 * j + 8 * (s >> 1)) * Hh;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = w0[(int64_t)e * Hh];
+                whi[s][e] = (__bf16)v; wlo[s][e] = (__bf16)(v - (float)whi[s][e]);
+            }
+        }
+    }
+    __amdgpu_buffer_rsrc_t xh_rs = __builtin_amdgcn_make_buffer_rsrc(p.xh, 0, 0x7fffffff, 0x00020000);
+    auto slab_off = [&](unsigned ep, int x) { return (int)(((int64_t)((ep & 1) * G + g) * NT + x) * BSLAB_BYTES); };
+    auto flag_of = [&](int x, int wg) { return (gu32 *)(p.flags + ((g * NT + x) * CP + wg) * FLAG_STRIDE); };
+    unsigned *counters = reinterpret_cast<unsigned *>(hl + NT * TILE_BYTES);
+
+    unsigned ebase = 0;
+    bool dead = false;
+    for (int chunk = gl; chunk * SPG < p.n; chunk += p.gpd) {
+        const int s_base = chunk * SPG;
+        int off[NT], len[NT], lmax = 0;
+        float dh[NT][4], dc[NT][4];
+#pragma unroll
+        for (int x = 0; x < NT; ++x) {
+            const int s = s_base + 32 * x + r;
+            off[x] = 0; len[x] = 0;
+            if (s < p.n) { off[x] = p.seq_off[s]; len[x] = p.seq_len ? p.seq_len[s] : p.seq_off[s + 1] - off[x]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                dc[x][i] = 0.0f;
+                dh[x][i] = (p.d_hn && s < p.n) ? p.d_hn[(int64_t)s * 2 * Hh + dir * Hh + U0 + i] : 0.0f;
+            }
+        }
+        for (int s = s_base; s < min(s_base + SPG, p.n); ++s) lmax = max(lmax, p.seq_len ? p.seq_len[s] : p.seq_off[s + 1] - p.seq_off[s]);
+        for (int i = tid; i < NT * TILE_BYTES / 16 + 1; i += 512) reinterpret_cast<v4u *>(hl)[i] = v4u{0, 0, 0, 0};
+        __syncthreads();
+
+        int pend_x = -1; unsigned pend_ep = 0;                     // a published tile whose flag is still to be stored
+        auto flush_pending = [&]() {
+            if (pend_x < 0) return;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains its write-through stores ...
+            if (lane == 0) {                                       // ... then the wave whose add comes last stores the flag
+                const unsigned old = __hip_atomic_fetch_add(counters + pend_x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (old == 7u) {
+                    __hip_atomic_store(counters + pend_x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_store(flag_of(pend_x, j), pend_ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            pend_x = -1;
+        };
+
+        for (int k = 0; k < lmax; ++k) {
+            const int tau = lmax - 1 - k;
+#pragma unroll
+            for (int x = 0; x < NT; ++x) {
+                char *hx = hl + x * TILE_BYTES;
+                const bool active = tau < len[x];
+                const int tt = dir == 0 ? tau : len[x] - 1 - tau;
+                const int64_t row = off[x] + (active ? tt : 0);
+                const int64_t rowp = row + (dir == 0 ? -1 : 1);
+                // ---- the saved forward state of this step: independent of the recurrence, in flight during the poll ----
+                v4f gi, gf, gg, go, cc, cp, dy;
+                gi = gf = gg = go = cc = cp = dy = v4f{0.f, 0.f, 0.f, 0.f};
+                if (active) {
+                    const float *gs = p.G + row * ldx + xcol;
+                    gi = *(const __attribute__((address_space(1))) v4f *)(gs);
+                    gf = *(const __attribute__((address_space(1))) v4f *)(gs + Hh);
+                    gg = *(const __attribute__((address_space(1))) v4f *)(gs + 2 * Hh);
+                    go = *(const __attribute__((address_space(1))) v4f *)(gs + 3 * Hh);
+                    cc = *(const __attribute__((address_space(1))) v4f *)(p.cbuf + row * 2 * Hh + dir * Hh + U0);
+                    if (tau > 0) cp = *(const __attribute__((address_space(1))) v4f *)(p.cbuf + rowp * 2 * Hh + dir * Hh + U0);
+                    dy = *(const __attribute__((address_space(1))) v4f *)(p.d_out + row * p.ldd + dir * Hh + U0);
+                }
+                // ---- dh(t) of my units: the four workgroups' partial sums of the previous step ----
+                if (k > 0) {
+                    const unsigned ep = ebase + k;
+                    if (!dead) {
+                        const gu32 *fl = flag_of(x, lane & 3);
+                        unsigned spins = 0, seen = __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        while (!__all((int)(seen - ep) >= 0)) {
+                            if (++spins > SPIN_LIMIT) {
+                                if (lane == 0) __hip_atomic_store((gu32 *)p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                dead = true;
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(1);
+                            seen = __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // no instruction: keeps the loads below the poll
+                    const int so = slab_off(ep, x) + ((j * CP * 32 + r) * 64 + 8 * wave + 4 * hh) * 4;
+                    v4u part[CP];
+#pragma unroll
+                    for (int src = 0; src < CP; ++src)
+                        part[src] = __builtin_amdgcn_raw_buffer_load_b128(xh_rs, so + src * (32 * 64 * 4), 0, 16);     // aux 16 = sc1
+                    if (tau + 1 < len[x]) {                        // the sequence took part in the previous step
+                        v4f sum = __builtin_bit_cast(v4f, part[0]);
+#pragma unroll
+                        for (int src = 1; src < CP; ++src) sum += __builtin_bit_cast(v4f, part[src]);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) dh[x][i] = sum[i];
+                    }
+                }
+                // ---- cell backward (lstm_bwd_x3_kernel's arithmetic, lane-local) ----
+                v4f di = v4f{0.f, 0.f, 0.f, 0.f}, df = di, dg = di, dob = di;
+                if (active) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float dht = dh[x][i] + dy[i];
+                        const float tc = tanh_fast(cc[i]);
+                        dob[i] = dht * tc * go[i] * (1.0f - go[i]);
+                        const float dct = dc[x][i] + dht * go[i] * (1.0f - tc * tc);
+                        di[i] = dct * gg[i] * gi[i] * (1.0f - gi[i]);
+                        df[i] = dct * cp[i] * gf[i] * (1.0f - gf[i]);
+                        dg[i] = dct * gi[i] * (1.0f - gg[i] * gg[i]);
+                        dc[x][i] = dct * gf[i];
+                    }
+                    float *gs = p.G + row * ldx + xcol;
+                    *(__attribute__((address_space(1))) v4f *)(gs) = di;
+                    *(__attribute__((address_space(1))) v4f *)(gs + Hh) = df;
+                    *(__attribute__((address_space(1))) v4f *)(gs + 2 * Hh) = dg;
+                    *(__attribute__((address_space(1))) v4f *)(gs + 3 * Hh) = dob;
+                }
+                {
+                    const v4f vq[4] = {di, df, dg, dob};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        bf16x4 ph, pl;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { ph[i] = (__bf16)vq[q][i]; pl[i] = (__bf16)(vq[q][i] - (float)ph[i]); }
+                        const int o = lds_unit(r, 4 * wave + q) + 8 * hh;
+                        *reinterpret_cast<v2u *>(hx + o) = __builtin_bit_cast(v2u, ph);
+                        *reinterpret_cast<v2u *>(hx + 32 * CH * 2 + o) = __builtin_bit_cast(v2u, pl);
+                    }
+                }
+                __syncthreads();
+                if (k + 1 < lmax) {                                // the last step's dh(t-1) has no consumer
+                    f32x16 acc;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) {
+                        const bf16x8 bh = *reinterpret_cast<const bf16x8 *>(hx + lds_unit(r, 2 * s + hh));
+                        const bf16x8 bl = *reinterpret_cast<const bf16x8 *>(hx + 32 * CH * 2 + lds_unit(r, 2 * s + hh));
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo[s], bh, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[s], bl, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[s], bh, acc, 0, 0, 0);
+                    }
+                    if (NT > 1) flush_pending();                   // the other tile's stores were issued one chain ago
+                    // publish: rows 32 wave + 8 q + 4 hh + i of dh(t-1) go to workgroup wave >> 1, 16 bytes per gate block
+                    const int so = slab_off(ebase + k + 1, x) + ((((wave >> 1) * CP + j) * 32 + r) * 64 + 32 * (wave & 1) + 4 * hh) * 4;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const v4f v = v4f{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), xh_rs, so + 8 * q * 4, 0, 16);   // aux 16 = sc1: write-through
+                    }
+                    pend_x = x; pend_ep = ebase + k + 1;
+                    if (NT == 1) flush_pending();
+                } else if (NT > 1) {
+                    flush_pending();
+                }
+            }
+        }
+        flush_pending();
+        // the next chunk's first publish must not land in the slab a slower workgroup is still reading (parity of the
+        // last epoch consumed): skip one epoch
+        ebase += lmax + 1;
+        __syncthreads();
+    }
+}
+
+int64_t lstm_coop_bwd_ws_bytes(int n) {
+    (void)n;
+    const int G = 64;
+    return (int64_t)2 * G * 2 * BSLAB_BYTES + (int64_t)(G * 2 * CP * FLAG_STRIDE + 64) * 4;
+}
+
+int launch_lstm_bwd_coop(const stair_lstm_bwd_args &a, hipStream_t s) {
+    STAIR_CHECK(a.Hh == CH, "cooperative BPTT is built for Hh = 256");
+    STAIR_CHECK(a.coop_ws && a.coop_ws_bytes >= lstm_coop_bwd_ws_bytes(a.n), "coop_ws missing or too small");
+    STAIR_CHECK((reinterpret_cast<uintptr_t>(a.coop_ws) & 255) == 0, "coop_ws must be 256-byte aligned");
+    STAIR_CHECK(a.ldd % 4 == 0 && (reinterpret_cast<uintptr_t>(a.d_out) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.gates) & 15) == 0 &&
+                (reinterpret_cast<uintptr_t>(a.cbuf) & 15) == 0, "gates / cbuf / d_out must be 16-byte aligned with ldd % 4 == 0");
+    CoopBwdParams p;
+    p.G = a.gates; p.cbuf = a.cbuf; p.d_out = a.d_out; p.ldd = a.ldd; p.d_hn = a.d_hn;
+    p.w_hh[0] = a.w_hh[0]; p.w_hh[1] = a.w_hh[1]; p.seq_off = a.seq_off; p.seq_len = a.seq_len; p.n = a.n;
+    int nt = 1;
+    coop_geometry(a.n, nt, p.gpd);
+    if (nt > 2) nt = 2;
+    p.gpd = std::max(1, std::min((a.n + 32 * nt - 1) / (32 * nt), 32));
+    const int G = 2 * p.gpd;
+    char *base = static_cast<char *>(a.coop_ws);
+    const int64_t slab_bytes = (int64_t)2 * G * nt * BSLAB_BYTES;
+    const int flag_words = G * nt * CP * FLAG_STRIDE + 64;
+    p.xh = base;
+    p.flags = reinterpret_cast<unsigned *>(base + slab_bytes);
+    p.err = p.flags + G * nt * CP * FLAG_STRIDE;
+    STAIR_HIP(hipMemsetAsync(p.flags, 0, (size_t)flag_words * 4, s));
+    const int blocks = 32 * ((G + 7) / 8);
+    static bool attr_set = false;
+    if (!attr_set) {
+        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_bwd_coop_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 1 * TILE_BYTES + 64));
+        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_bwd_coop_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE_BYTES + 64));
+        attr_set = true;
+    }
+    if (nt == 1) hipLaunchKernelGGL((lstm_bwd_coop_kernel<1>), dim3(blocks), dim3(512), 1 * TILE_BYTES + 64, s, p);
+    else hipLaunchKernelGGL((lstm_bwd_coop_kernel<2>), dim3(blocks), dim3(512), 2 * TILE_BYTES + 64, s, p);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace stair
 
 extern "C" int64_t stair_lstm_coop_ws_bytes(int32_t n) { return stair::lstm_coop_ws_bytes(n); }
+extern "C" int64_t stair_lstm_coop_bwd_ws_bytes(int32_t n) { return stair::lstm_coop_bwd_ws_bytes(n); }

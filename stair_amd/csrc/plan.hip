@@ -654,7 +654,8 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
     pl->o_bias = take(2 * 4 * H, 64);
     pl->o_wpack = take(2 * 2 * H * H, 64);       // 8*Hh*Hh floats per encoder
     pl->o_wplanes = ctx->cfg.video_size % 32 == 0 ? take(4 * H * ctx->cfg.video_size, 64) : 0;   // video W_ih hi/lo planes (bf16 features): 2 x [4H, V] bf16
-    pl->coop_bytes = lstm_coop_usable((int)(H / 2)) || true ? std::max(lstm_coop_ws_bytes(pl->n_vid), lstm_coop_ws_bytes(n)) : 0;
+    pl->coop_bytes = std::max(lstm_coop_ws_bytes(pl->n_vid), lstm_coop_ws_bytes(n));
+    if (pl->train) pl->coop_bytes = std::max(pl->coop_bytes, std::max(lstm_coop_bwd_ws_bytes(pl->n_vid), lstm_coop_bwd_ws_bytes(n)));
     pl->o_coop = take((pl->coop_bytes + 3) / 4, 64);   // h exchange slabs + flags of the cooperative recurrence (both encoders, in turn)
     pl->o_splitk = take(kSplitKFloats, 64);      // partial sums of split-K launches (<= 64 output tiles x 16 pieces)
     pl->o_tmpA = take((int64_t)std::max(pl->maxI, 1) * T * H, 64);
@@ -1134,6 +1135,7 @@ namespace {
 struct BwdCtx {
     hipStream_t s;
     float *wt;                       // transposed weight images
+    float *splitk = nullptr;         // split-K scratch (plan workspace): dX products that overwrite their target stage partials there
     std::vector<int64_t> wt_off;     // per weight id
 };
 
@@ -1156,6 +1158,7 @@ int dense_bwd(const BwdCtx &B, const float *dZ, int groups, int R, int N, int K,
         g.W = B.wt + B.wt_off[l.id]; g.ldw = N;                 // W^T [K][N]
         g.C = dX; g.ldc = ldd; g.c_gstride = d_gs; g.c_gidx = d_gidx;
         g.groups = groups; g.rows_per_group = R; g.N = K; g.K = N; g.act = 0; g.accumulate = accumulate;
+        g.splitk_ws = B.splitk; g.splitk_ws_floats = B.splitk ? kSplitKFloats : 0;
         if (int rc = launch_gemm(g, B.s)) return rc;
     }
     return 0;
@@ -1196,7 +1199,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
 
     // transposed images of every 2-D weight that needs a dX product
     BwdCtx B;
-    B.s = s; B.wt = ws + pl->o_wt;
+    B.s = s; B.wt = ws + pl->o_wt; B.splitk = ws + pl->o_splitk;
     B.wt_off.assign(ctx->names.size(), 0);
     {
         int64_t o = 0;
@@ -1364,6 +1367,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
             a.whh_pack_ws = ws + pl->o_wpack + 2 * (int64_t)H * H;
         }
         a.n = e == 0 ? pl->n_vid : n; a.Hh = Hh; a.ldo = H; a.ldd = H; a.hprev_ws = ws + pl->o_hprev;
+        a.coop_ws = ws + pl->o_coop; a.coop_ws_bytes = pl->coop_bytes;
         for (int d = 0; d < 2; ++d) {
             a.w_hh[d] = W.enc[e][4 * d + 1];
             a.dw_ih[d] = W.denc[e][4 * d]; a.dw_hh[d] = W.denc[e][4 * d + 1];

@@ -149,11 +149,12 @@ def gemm_tn(A, B, Cmat, M, N, K, rows_per_group=1, b_gstride=None, b_gidx=None, 
     check(lib.stair_gemm_tn_f32(C.byref(a), _stream()))
 
 
-def lstm_bidir(x, seq_off, max_len, weights, save=False, coop=True):
+def lstm_bidir(x, seq_off, max_len, weights, save=False, coop=True, seq_len=None):
     """Bidirectional LSTM over packed ragged sequences.
 
     x [rows, I]; seq_off int32 [n+1] (device); weights = (w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r).
     Returns (out [rows, 2*Hh], h_n [n, 2*Hh]); with save=True also (gates, cbuf) for lstm_bidir_bwd.
+    seq_len: int32 [n] (device) when the storage is padded -- sequence s holds seq_len[s] data rows of its span.
     """
     bf = x.dtype == torch.bfloat16           # stored bf16 input rows (clip features): plane GEMM input projection
     _req(x, 'x', torch.bfloat16 if bf else torch.float32); _req(seq_off, 'seq_off', torch.int32)
@@ -173,6 +174,8 @@ def lstm_bidir(x, seq_off, max_len, weights, save=False, coop=True):
         planes = torch.empty(2 * 8 * Hh * I, device=x.device, dtype=torch.bfloat16)
         a.x_bf16, a.wih_planes_ws = x.data_ptr(), planes.data_ptr()
     a.seq_off = seq_off.data_ptr()
+    if seq_len is not None:
+        a.seq_len = seq_len.data_ptr()
     if coop and Hh == 256:       # scratch for the cooperative recurrence (hidden units split over co-resident workgroups)
         coop_ws = torch.empty(int(lib.stair_lstm_coop_ws_bytes(n)), device=x.device, dtype=torch.uint8)
         a.coop_ws, a.coop_ws_bytes = coop_ws.data_ptr(), coop_ws.numel()
@@ -187,9 +190,10 @@ def lstm_bidir(x, seq_off, max_len, weights, save=False, coop=True):
     return (out, h_n, xproj, cbuf) if save else (out, h_n)
 
 
-def lstm_bidir_bwd(x, seq_off, max_len, weights, out, gates, cbuf, d_out, d_hn=None):
+def lstm_bidir_bwd(x, seq_off, max_len, weights, out, gates, cbuf, d_out, d_hn=None, coop=True, seq_len=None):
     """Gradients of (w_ih, w_hh, b_ih, b_hh) x 2 directions given d_out [rows, 2Hh] and d_hn [n, 2Hh].
-    `gates` (from lstm_bidir(save=True)) is overwritten."""
+    `gates` (from lstm_bidir(save=True)) is overwritten.  coop: use the cooperative BPTT kernel where it applies
+    (Hh = 256, split matmul modes); seq_len: per-sequence lengths of padded storage (int32 [n])."""
     rows, I = x.shape
     n = seq_off.numel() - 1
     Hh = weights[1].shape[1]
@@ -210,6 +214,11 @@ def lstm_bidir_bwd(x, seq_off, max_len, weights, out, gates, cbuf, d_out, d_hn=N
     a.d_out, a.ldd = d_out.data_ptr(), 2 * Hh
     a.d_hn = d_hn.data_ptr() if d_hn is not None else None
     a.whh_pack_ws, a.hprev_ws = pack_ws.data_ptr(), hprev.data_ptr()
+    if seq_len is not None:
+        a.seq_len = seq_len.data_ptr()
+    if coop and Hh == 256:
+        coop_ws = torch.empty(int(lib.stair_lstm_coop_bwd_ws_bytes(n)), device=x.device, dtype=torch.uint8)
+        a.coop_ws, a.coop_ws_bytes = coop_ws.data_ptr(), coop_ws.numel()
     check(lib.stair_lstm_bidir_bwd(C.byref(a), _stream()))
     return grads
 

@@ -31,6 +31,22 @@ for _ in range(a.iters):
 e1.record(); torch.cuda.synchronize()
 print('lstm_bidir n=%d T=%d V=%d Hh=%d: %.3f ms per call (input proj + recurrence)' % (a.n, a.T, a.V, a.Hh, e0.elapsed_time(e1) / a.iters))
 
+# BPTT (recurrence + hprev + the four weight-gradient GEMMs), cooperative vs one-workgroup reverse recurrence
+out, h_n, gates, cbuf = ops.lstm_bidir(x, off, a.T, ws, save=True)
+d_out = torch.randn(a.n * a.T, 2 * a.Hh, device=dev, generator=g)
+saved = gates.clone()
+for coop in (True, False):
+    for it in range(2 + a.iters):
+        if it == 2:
+            torch.cuda.synchronize(); tot = 0.0
+        gates.copy_(saved)
+        e0.record()
+        ops.lstm_bidir_bwd(x, off, a.T, ws, out, gates, cbuf, d_out, None, coop=coop)
+        e1.record(); torch.cuda.synchronize()
+        if it >= 2:
+            tot += e0.elapsed_time(e1)
+    print('lstm_bidir_bwd coop=%d: %.3f ms per call (BPTT + dW GEMMs)' % (coop, tot / a.iters))
+
 if os.environ.get('STAIR_LSTM_COOP_PROF') == '1':
     # diagnostic build: re-run once with our own scratch so the phase sums (cycles of wave 0, workgroup 0) can be read back
     from stair_amd._lib import LstmArgs, lib, check

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Turn rocprofv3 outputs under gpurun_out/ into the small summaries kept in profiles/.
   summarize_prof.py stats <results.db> <out.csv>            per-kernel calls / total / average / share
-  summarize_prof.py pmc <counter_collection.csv>... <out.json>   mean counter value per kernel"""
+  summarize_prof.py pmc <counter_collection.csv>... <out.json>   mean counter value per kernel
+  summarize_prof.py bygrid <kernel_trace.csv> <out.csv>      per (kernel, launch grid): calls, total, average, min"""
 import os, sys, csv, json, sqlite3, collections
 
 
@@ -20,6 +21,19 @@ def stats(db, out):
                 "select name, grid_x / workgroup_x, count(*), sum(end - start) / 1e3 from kernels where name like '%gemm%' "
                 "group by name, grid_x / workgroup_x order by 4 desc limit 24"):
             w.writerow([name.split('(')[0][:80], wg, calls, round(tot, 3), round(tot / calls, 3)])
+
+
+def bygrid(trace, out):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(trace)):
+        wg = [max(1, int(r['Workgroup_Size_' + a])) for a in 'XYZ']
+        grid = tuple(int(r['Grid_Size_' + a]) // w for a, w in zip('XYZ', wg))
+        agg[(r['Kernel_Name'].split('(')[0][:90], grid)].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+    with open(out, 'w', newline='') as f:
+        w = csv.writer(f)
+        w.writerow(['Name', 'GridWorkgroups', 'Calls', 'TotalUs', 'AverageUs', 'MinUs'])
+        for (name, grid), v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+            w.writerow([name, 'x'.join(map(str, grid)), len(v), round(sum(v), 1), round(sum(v) / len(v), 2), round(min(v), 2)])
 
 
 def pmc(files, out):
@@ -44,6 +58,8 @@ def pmc(files, out):
 
 
 if __name__ == '__main__':
+    if sys.argv[1] == 'bygrid':
+        bygrid(sys.argv[2], sys.argv[3]); sys.exit(0)
     if sys.argv[1] == 'stats':
         stats(sys.argv[2], sys.argv[3])
     else:
