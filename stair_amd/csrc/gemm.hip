@@ -217,6 +217,9 @@ int launch_gemm(const stair_gemm_args &a, hipStream_t s) {
     const int64_t M = (int64_t)a.groups * a.rows_per_group;
     if (M == 0) return 0;
     STAIR_CHECK(M < (1ll << 31), "M too large");
+    if (gemm_trace_on())
+        fprintf(stderr, "STAIR_GEMM nt M=%lld N=%d K=%d act=%d acc=%d gather=%d scale=%d\n", (long long)M, a.N, a.K, a.act, a.accumulate,
+                a.a_gidx || a.c_gidx ? 1 : 0, a.row_scale ? 1 : 0);
     if (matmul_mode() != STAIR_MATMUL_F32 && M >= kSplitMinRows) return launch_gemm_bf16x3(a, s);
     p.M = (int)M;
     p.tilesM = (p.M + BM - 1) / BM;
@@ -325,6 +328,8 @@ int launch_gemm_tn(const stair_gemm_tn_args &a, hipStream_t s) {
     STAIR_CHECK(a.N % 4 == 0 && a.K % 4 == 0 && a.lda % 4 == 0 && a.ldb % 4 == 0 && a.b_gstride % 4 == 0,
                 "N, K, lda, ldb, b_gstride must be multiples of 4 floats");
     if (a.M == 0) return 0;
+    if (gemm_trace_on())
+        fprintf(stderr, "STAIR_GEMM tn M=%d N=%d K=%d act=0 acc=1 gather=%d scale=%d\n", a.M, a.N, a.K, a.b_gidx ? 1 : 0, a.row_scale ? 1 : 0);
     STAIR_CHECK(!a.b_is_bf16 || matmul_mode() == STAIR_MATMUL_BF16X3, "bf16 B rows (stored clip features) need the bf16x3 matmul mode");
     if (a.b_is_bf16) return launch_gemm_tn_bf16x3(a, s);
     if (matmul_mode() != STAIR_MATMUL_F32 && a.M >= kSplitMinRows) return launch_gemm_tn_bf16x3(a, s);

@@ -404,6 +404,8 @@ int launch_gemm_planes(const stair_gemm_planes_args &a, hipStream_t s) {
     STAIR_CHECK(a.lda % 8 == 0 && (a.w_tiled || a.ldw % 8 == 0), "lda / ldw must be multiples of 8 bf16 (16-byte rows)");
     STAIR_CHECK(((reinterpret_cast<uintptr_t>(a.A_hi) | reinterpret_cast<uintptr_t>(a.A_lo) | reinterpret_cast<uintptr_t>(a.W_hi) |
                   reinterpret_cast<uintptr_t>(a.W_lo)) & 15) == 0, "plane pointers must be 16-byte aligned");
+    if (gemm_trace_on())
+        fprintf(stderr, "STAIR_GEMM planes M=%d N=%d K=%d act=%d acc=0 gather=0 scale=0\n", a.M, a.N, a.K, a.act);
     PlParams p;
     p.A[0] = static_cast<const __bf16 *>(a.A_hi); p.A[1] = static_cast<const __bf16 *>(a.A_lo);
     p.W[0] = static_cast<const __bf16 *>(a.W_hi); p.W[1] = static_cast<const __bf16 *>(a.W_lo);

@@ -18,6 +18,8 @@ dev = 'cuda:0'
 shapes = [(131072, 1024, 2048), (131072, 1024, 256), (131072, 512, 512), (65536, 512, 512), (32768, 512, 512), (8192, 512, 512), (2048, 512, 1536), (2048, 1024, 1024), (34000, 1024, 300)]
 if len(sys.argv) > 1 and sys.argv[1] == 'tn':
     MODES = ('bf16x3',)
+    if len(sys.argv) > 2:       # tn M,N,K M,N,K ...
+        shapes = [tuple(int(v) for v in a.split(',')) for a in sys.argv[2:]]
 else:
     MODES = ('f32', 'bf16x3')
 for (M, N, K) in shapes:
