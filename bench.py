@@ -28,6 +28,7 @@ Objects on the line besides the contract's fields:
   supervised_step  the configs[4] step (gold intermediates, all module losses) next to the decoder-only step.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -236,6 +237,11 @@ def main():
         from stair_amd.train import Trainer
         trainer = Trainer(model, world=world, rank=rank, dropout=args.dropout)
     gold_qs = gold_questions(qs) if (args.supervision or not args.no_extras) and args.mode == 'train' else None
+    # The batch is a few hundred thousand long-lived Python objects (question dicts, gold packs).  A generation-2 pass of the
+    # cyclic collector walks all of them -- 30-50 ms, i.e. two whole steps -- every few supervised steps; a training job's
+    # data loader hands batches over from worker processes and never holds this many objects in the stepping process.
+    gc.collect()
+    gc.freeze()
 
     def run_step(nq=B, supervised=False):
         """one pass over the first nq questions of the rank's batch"""

@@ -397,6 +397,14 @@ int stair_loss_head(int32_t nout, const float *vec, float *d_vec, const int32_t 
 int stair_loss_contrastive(const float *vec, float *d_vec, const int32_t *slot, const int32_t *pos,
                            const int32_t *win_start, const int32_t *win_cnt, const float *G, int32_t n, int32_t H,
                            int32_t max_classes, float scale, float *loss, stair_stream stream);
+/* Decoder cross entropy without gradients -- the validation loop's loss (train_module.py:193-194, 246-248):
+ * loss[i] = logsumexp(logits[i]) - logits[i][answers[i]]; answers[i] < 0: 0, answers[i] >= A: NaN. */
+int stair_loss_decoder_ce(const float *logits, const int32_t *answers, float *loss, int32_t n, int32_t A, stair_stream stream);
+/* 'cont-valid' score of Filter / ToAction / Superlative in validation (train_module.py:127-132): cosine between
+ * vec[slot[i]] and the mean of reps[seg_off[i] .. seg_off[i+1]) (the question's own gold class representations, [rows,H]);
+ * 0 for an empty list. */
+int stair_score_cosine_to_mean(const float *vec, const int32_t *slot, const float *reps, const int32_t *seg_off, float *out,
+                               int32_t n, int32_t H, stair_stream stream);
 
 /* FilterFrame (:141-155): pretrain head W [O,H], b [O] on the T frames of map tile slot[i] (rows (slot*T + t) of the map
  * arena), softmax over the O object classes, BCELoss against gold [n,T,O] = the row-normalised interval masks the host

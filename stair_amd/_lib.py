@@ -121,6 +121,8 @@ SIGNATURES = [
                                           C.c_int32, c_int32_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     ('stair_plan_build_ragged', C.c_int, [C.c_void_p, C.c_int32, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p,
                                           C.c_int32, c_int32_p, c_int32_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    ('stair_loss_decoder_ce', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    ('stair_score_cosine_to_mean', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     ('stair_loss_attention_len', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                            C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     ('stair_plan_backward', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,

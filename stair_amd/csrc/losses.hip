@@ -280,6 +280,42 @@ int launch_loss_filterframe(const float *map, float *d_map, const int32_t *slot,
     return 0;
 }
 
+// 'cont-valid' score of the validation loop (train_module.py:127-132): cosine between a contrastive module's output
+// vec[slot[i]] and the MEAN of the question's own gold class representations reps[seg_off[i] .. seg_off[i+1]) (L2-normalised
+// rows), nn.CosineSimilarity(dim=0, eps=1e-8); an empty gold list scores 0.  One wave per item.
+__global__ void cosine_to_mean_kernel(const float *vec, const int32_t *slot, const float *reps, const int32_t *seg_off, float *out,
+                                      int n, int H) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int r0 = seg_off[i], r1 = seg_off[i + 1];
+    if (r1 <= r0) {
+        if (lane == 0) out[i] = 0.0f;
+        return;
+    }
+    const float *x = vec + (int64_t)slot[i] * H;
+    const float inv = 1.0f / (float)(r1 - r0);
+    float dot = 0.f, nx = 0.f, nm = 0.f;
+    for (int c = lane; c < H; c += 64) {
+        float m = 0.f;
+        for (int r = r0; r < r1; ++r) m += reps[(int64_t)r * H + c];
+        m *= inv;
+        const float v = x[c];
+        dot += v * m; nx += v * v; nm += m * m;
+    }
+    dot = wave_sum(dot); nx = wave_sum(nx); nm = wave_sum(nm);
+    if (lane == 0) out[i] = dot / (fmaxf(sqrtf(nx), 1e-8f) * fmaxf(sqrtf(nm), 1e-8f));
+}
+
+int launch_cosine_to_mean(const float *vec, const int32_t *slot, const float *reps, const int32_t *seg_off, float *out, int n, int H,
+                          hipStream_t s) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(cosine_to_mean_kernel, dim3((n + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlock), 0, s, vec, slot, reps, seg_off,
+                       out, n, H);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace stair
 
 extern "C" int stair_loss_attention(const float *att, float *d_att, const int32_t *slot, const int32_t *K,
@@ -308,4 +344,13 @@ extern "C" int stair_loss_filterframe(const float *map, float *d_map, const int3
                                       float scale, float *loss, stair_stream stream) {
     return stair::launch_loss_filterframe(map, d_map, slot, gold, W, b, dW, db, n, T, H, O, scale, loss,
                                           static_cast<hipStream_t>(stream));
+}
+extern "C" int stair_loss_decoder_ce(const float *logits, const int32_t *answers, float *loss, int32_t n, int32_t A, stair_stream stream) {
+    STAIR_CHECK(logits && answers && loss && n >= 0 && A > 0, "bad argument");
+    return stair::launch_ce_loss(logits, answers, 0.0f, loss, nullptr, n, A, static_cast<hipStream_t>(stream));
+}
+extern "C" int stair_score_cosine_to_mean(const float *vec, const int32_t *slot, const float *reps, const int32_t *seg_off, float *out,
+                                          int32_t n, int32_t H, stair_stream stream) {
+    STAIR_CHECK(vec && slot && seg_off && out && n >= 0 && H > 0, "bad argument");
+    return stair::launch_cosine_to_mean(vec, slot, reps, seg_off, out, n, H, static_cast<hipStream_t>(stream));
 }

@@ -229,8 +229,8 @@ struct Bucket {
 
 // Pinned staging of a plan's index image.  The image used to be copied from the plan's pageable std::vector: a pageable
 // hipMemcpyAsync stalls the host on the stream and leaves the source's lifetime to the runtime's own staging.  Now the
-// copy reads page-locked memory and an event marks its completion; stair_plan_destroy waits for that event before the
-// buffer goes back to a small process-wide pool (so a step does not pay a hipHostMalloc).
+// copy reads page-locked memory and an event marks its completion; stair_plan_destroy parks the buffer until that event has
+// completed, then it goes back to a small process-wide pool (so a step does not pay a hipHostMalloc).
 namespace {
 struct PinnedBuf { int32_t *p = nullptr; size_t cap = 0; };
 std::mutex g_pin_mu;
@@ -256,16 +256,39 @@ void pinned_give(PinnedBuf b) {
     if (g_pin_pool.size() < 8) g_pin_pool.push_back(b);
     else (void)hipHostFree(b.p);
 }
+// A destroyed plan's buffer may still be the source of an upload the GPU has not reached (the host runs ahead of the
+// stream): it is parked with its event and goes back to the pool once the event has completed -- checked, never waited for,
+// so that destroying a plan does not tie the host to the GPU's progress.
+struct ParkedBuf { PinnedBuf b; hipEvent_t ev; };
+std::vector<ParkedBuf> g_parked;
+void pinned_reclaim() {                 // g_pin_mu NOT held
+    std::vector<ParkedBuf> done;
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        for (size_t i = 0; i < g_parked.size();)
+            if (hipEventQuery(g_parked[i].ev) != hipErrorNotReady) { done.push_back(g_parked[i]); g_parked.erase(g_parked.begin() + i); }
+            else ++i;
+    }
+    for (const ParkedBuf &d : done) { (void)hipEventDestroy(d.ev); pinned_give(d.b); }
+}
+void pinned_park(PinnedBuf b, hipEvent_t ev) {
+    if (!ev) { pinned_give(b); return; }
+    if (hipEventQuery(ev) != hipErrorNotReady) { (void)hipEventDestroy(ev); pinned_give(b); return; }
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        if (g_parked.size() < 64) { g_parked.push_back({b, ev}); return; }
+    }
+    (void)hipEventSynchronize(ev);      // 64 plans in flight: wait for this one after all
+    (void)hipEventDestroy(ev);
+    pinned_give(b);
+}
 }  // namespace
 
 struct stair_plan {
     stair_config cfg;
     PinnedBuf pin;                  // page-locked copy of idx, made at the first upload
     hipEvent_t pin_ev = nullptr;    // recorded after every upload from `pin`
-    ~stair_plan() {
-        if (pin_ev) { (void)hipEventSynchronize(pin_ev); (void)hipEventDestroy(pin_ev); }
-        pinned_give(pin);
-    }
+    ~stair_plan() { pinned_park(pin, pin_ev); }
     int n = 0, n_vid = 0, T = 0, rows_q = 0, max_q = 0;   // n_vid distinct videos (== n unless questions share them)
     std::vector<Node> nodes;
     std::vector<Bucket> buckets;
@@ -900,6 +923,7 @@ extern "C" int stair_plan_set_dropout(stair_plan *pl, float p, uint64_t seed) {
 
 static int upload_index_image(stair_plan *pl, int32_t *didx, hipStream_t s) {
     if (!pl->pin.p) {
+        pinned_reclaim();
         pl->pin = pinned_take(pl->idx.size());
         STAIR_CHECK(pl->pin.p != nullptr, "hipHostMalloc of the index staging buffer failed");
         memcpy(pl->pin.p, pl->idx.data(), pl->idx.size() * sizeof(int32_t));

@@ -10,9 +10,12 @@ test uses gloo).
 """
 from __future__ import annotations
 
+import ctypes as C
 import json
 
 import torch
+
+from ._lib import check, lib
 
 
 def shard_indices(n, rank, world):
@@ -177,8 +180,11 @@ def evaluate_by_module(model, questions, unk_token_id, batch_size=1024, module_l
             if module_loss_weight != 0:
                 for m, vals in L.evaluate_module_losses(model, res, chunk, modules & L.CRITERION_MODULES).items():
                     losses[m].extend(vals)
-            answers = torch.tensor([int(q['answer']) for q in chunk], dtype=torch.long, device=res.logits.device)
-            losses['decoder'].extend(torch.nn.functional.cross_entropy(res.logits, answers, reduction='none').cpu().tolist())
+            answers = torch.tensor([int(q['answer']) for q in chunk], dtype=torch.int32).to(res.logits.device)
+            ce = torch.empty(len(chunk), dtype=torch.float32, device=res.logits.device)
+            check(lib.stair_loss_decoder_ce(C.c_void_p(res.logits.data_ptr()), C.c_void_p(answers.data_ptr()), C.c_void_p(ce.data_ptr()),
+                                            len(chunk), res.logits.shape[1], C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            losses['decoder'].extend(ce.cpu().tolist())
             for i, p in zip(chunk_idx, res.pred.cpu().tolist()):
                 preds[i] = int(p)
     golds = [int(q['answer']) for q in questions]

@@ -215,16 +215,14 @@ class _Staging:
         return [self.dev[o: o + a.nbytes].view(tdt[a.dtype]) for a, o in zip(arrays, offs)]
 
 
-def apply_module_losses(model, res, questions, scale, pretrain_modules=CRITERION_MODULES,
-                        no_intermediate=('FilterFrame',), window=32, world=1, rank=0, window_base=0):
-    """Evaluate every intermediate loss of the batch and add scale * gradient into res's gradient arenas
-    (call res.zero_grad_arenas() first and res.backward(..., keep_arenas=True) afterwards).
-    Local question i sits at global position window_base + rank + i * world of the accumulation window (the round-robin
-    sharding of Trainer.step); contrastive classes are pooled per `window` GLOBAL questions (contrastive_windows).
-    Host work per step: concatenating the questions' gold packs (losses.compile_gold, prepared once per question),
-    one gather through the plan's node table and ONE upload; no per-node library call.
-    Returns ({loss_kind: per-item losses tensor}, set of extra parameter names that received a gradient)."""
-    dev = res.logits.device
+def prepare_module_losses(model, res, questions, pretrain_modules=CRITERION_MODULES, no_intermediate=('FilterFrame',), window=32,
+                          world=1, rank=0, window_base=0):
+    """Everything of apply_module_losses that needs the PLAN but not the forward results: the index / target arrays of every
+    criterion (one upload), the contrastive class tables and the encoding of the distinct classes.  Call it from
+    VideoNMN.run_programs(before_run=...) so that this host work (a few ms per 2048 questions) is done before the forward
+    pass is enqueued and the stream goes from the forward straight into the loss kernels and the backward pass.
+    Returns an opaque dict for launch_module_losses."""
+    dev = res.pred.device
     H, T = model.config['hidden_size'], res.info.T
     _, slot_t, aux_t, _, rel_t = res.node_table()
     base = np.asarray(res._prog_off, dtype=np.int64)
@@ -276,54 +274,83 @@ def apply_module_losses(model, res, questions, scale, pretrain_modules=CRITERION
                 c_slot.append(s_); c_wid.append(wid); c_name.append(class_name)
                 entries.append((gpos, class_name, emb))
     cw = contrastive_windows(entries, window, world) if (c_slot or world > 1) else None
+    lens, max_classes = [], 0
     if c_slot:
         names, embs, rows, win_range, slot_of = cw
         embs = [np.asarray(e, dtype=np.float32).reshape(-1, model.config['text_size']) for e in embs]
         lens = [int(e.shape[0]) for e in embs]
+        max_classes = max(r[1] for r in win_range.values())
         stage('cont', i32(c_slot), i32([slot_of[(w, n)] for w, n in zip(c_wid, c_name)]),
               i32([win_range[w][0] for w in c_wid]), i32([win_range[w][1] for w in c_wid]), rows,
               i32(np.concatenate([[0], np.cumsum(lens)])), np.ascontiguousarray(np.concatenate(embs)))
+    ff_items = [(int(slot_t[base[qi] + pos]), gold) for qi, p in enumerate(packs) for pos, gold in p.ff]
+    if ff_items and res.question_frames is not None:
+        raise NotImplementedError('the FilterFrame criterion (off by default, args.py:62) takes batches of one clip length')
     # ---- ONE upload ----
     staging = model.__dict__.setdefault('_loss_staging', _Staging())
     d = staging.upload(up, dev) if up else []
     got = lambda key: d[plan[key][0]: plan[key][0] + plan[key][1]]
+    prep = {'n_att': n_att, 'n_head': n_head, 'n_cont': len(c_slot), 'ff_items': ff_items, 'max_classes': max_classes,
+            'att': got('att') if n_att else None, 'head': {m: got(m) for m in n_head}}
+    if c_slot:
+        # class representations: text encoder without gradient + L2Normalize (module_net.py:78-89); they depend on the weights
+        # only, so they are encoded here, ahead of the forward pass, on the same stream
+        slot_d, pos_d, ws_d, wc_d, rows_d, seq_off, x = got('cont')
+        x = x.view(-1, model.config['text_size'])
+        _, h_n = ops.lstm_bidir(x, seq_off, max(lens), [w.detach() for w in model._lstm_weights('text_encoder')])
+        prep['cont'] = (slot_d, pos_d, ws_d, wc_d, ops.l2normalize(h_n).index_select(0, rows_d.long()))    # every window's classes, window after window
+    return prep
 
+
+def launch_module_losses(model, res, prep, scale):
+    """The loss kernels of a prepared batch (prepare_module_losses): values + scale * gradient into res's gradient arenas.
+    Returns ({loss_kind: per-item losses tensor}, set of extra parameter names that received a gradient)."""
+    dev = res.pred.device
+    H, T = model.config['hidden_size'], res.info.T
     losses, touched = {}, set()
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     vec, gvec = res._arena(res.info.vec_off, res.info.n_vec, H), res.grad_arena('vec')
     att, gatt = res._arena(res.info.att_off, res.info.n_att, T), res.grad_arena('att')
     P = lambda t: C.c_void_p(t.data_ptr())
-    if n_att:
-        slot_d, K_d, off_d, iv_d, len_d = got('att')
-        out = torch.empty(n_att, device=dev)
+    if prep['n_att']:
+        slot_d, K_d, off_d, iv_d, len_d = prep['att']
+        out = torch.empty(prep['n_att'], device=dev)
         check(lib.stair_loss_attention_len(P(att), P(gatt), P(slot_d), P(K_d), P(off_d), P(iv_d), P(len_d) if len_d.numel() else None,
-                                           n_att, T, C.c_float(scale), P(out), stream))
+                                           prep['n_att'], T, C.c_float(scale), P(out), stream))
         losses['attention'] = out
-    for module, n_items in n_head.items():
+    for module, n_items in prep['n_head'].items():
         head = model.submodules[module].pretrain_head
-        slot_d, lab_d = got(module)
+        slot_d, lab_d = prep['head'][module]
         out = torch.empty(n_items, device=dev)
         check(lib.stair_loss_head(head.weight.shape[0], P(vec), P(gvec), P(slot_d), P(lab_d), P(head.weight), P(head.bias),
                                   P(head.weight.grad), P(head.bias.grad), n_items, H, C.c_float(scale), P(out), stream))
         losses[module] = out
         touched.update({'submodules.%s.pretrain_head.weight' % module, 'submodules.%s.pretrain_head.bias' % module})
     # ---- FilterFrame (off by default, args.py:62) ----
-    ff_items = [(int(slot_t[base[qi] + pos]), gold) for qi, p in enumerate(packs) for pos, gold in p.ff]
-    if ff_items:
-        if res.question_frames is not None:
-            raise NotImplementedError('the FilterFrame criterion (off by default, args.py:62) takes batches of one clip length')
-        losses['FilterFrame'] = _filterframe_launch(model, res, ff_items, scale, True)
+    if prep['ff_items']:
+        losses['FilterFrame'] = _filterframe_launch(model, res, prep['ff_items'], scale, True)
         touched.update({'submodules.FilterFrame.pretrain_head.weight', 'submodules.FilterFrame.pretrain_head.bias'})
-    if c_slot:
-        slot_d, pos_d, ws_d, wc_d, rows_d, seq_off, x = got('cont')
-        x = x.view(-1, model.config['text_size'])
-        _, h_n = ops.lstm_bidir(x, seq_off, max(lens), [w.detach() for w in model._lstm_weights('text_encoder')])
-        G = ops.l2normalize(h_n).index_select(0, rows_d.long())          # every window's classes, window after window
-        out = torch.empty(len(c_slot), device=dev)
-        check(lib.stair_loss_contrastive(P(vec), P(gvec), P(slot_d), P(pos_d), P(ws_d), P(wc_d), P(G), len(c_slot), H,
-                                         max(r[1] for r in win_range.values()), C.c_float(scale), P(out), stream))
+    if prep['n_cont']:
+        slot_d, pos_d, ws_d, wc_d, G = prep['cont']
+        out = torch.empty(prep['n_cont'], device=dev)
+        check(lib.stair_loss_contrastive(P(vec), P(gvec), P(slot_d), P(pos_d), P(ws_d), P(wc_d), P(G), prep['n_cont'], H,
+                                         prep['max_classes'], C.c_float(scale), P(out), stream))
         losses['contrastive'] = out
     return losses, touched
+
+
+def apply_module_losses(model, res, questions, scale, pretrain_modules=CRITERION_MODULES,
+                        no_intermediate=('FilterFrame',), window=32, world=1, rank=0, window_base=0):
+    """Evaluate every intermediate loss of the batch and add scale * gradient into res's gradient arenas
+    (call res.zero_grad_arenas() first and res.backward(..., keep_arenas=True) afterwards).
+    Local question i sits at global position window_base + rank + i * world of the accumulation window (the round-robin
+    sharding of Trainer.step); contrastive classes are pooled per `window` GLOBAL questions (contrastive_windows).
+    Host work per step: concatenating the questions' gold packs (losses.compile_gold, prepared once per question),
+    one gather through the plan's node table and ONE upload; no per-node library call.  = prepare_module_losses +
+    launch_module_losses; Trainer.step calls the two halves either side of the forward pass.
+    Returns ({loss_kind: per-item losses tensor}, set of extra parameter names that received a gradient)."""
+    prep = prepare_module_losses(model, res, questions, pretrain_modules, no_intermediate, window, world, rank, window_base)
+    return launch_module_losses(model, res, prep, scale)
 
 
 def evaluate_module_losses(model, res, questions, pretrain_modules=CRITERION_MODULES):
@@ -401,11 +428,13 @@ def evaluate_module_losses(model, res, questions, pretrain_modules=CRITERION_MOD
         out['FilterFrame'].extend(_filterframe_launch(model, res, ff_items, 0.0, False).cpu().tolist())
     if cont_items:
         reps = model.encode_phrases(embs)                                  # [sum of gold sizes, H], L2-normalised
-        seg = torch.repeat_interleave(torch.arange(len(cont_items), device=dev), i32([c[3] for c in cont_items]).long())
-        mean = torch.zeros(len(cont_items), H, device=dev).index_add_(0, seg, reps)
-        mean /= torch.tensor([c[3] for c in cont_items], dtype=torch.float32, device=dev).unsqueeze(1)
-        pred = vec[i32([c[1] for c in cont_items]).long()]
-        cos = torch.nn.functional.cosine_similarity(pred, mean, dim=1).cpu().tolist()
+        cnt = np.asarray([c[3] for c in cont_items], dtype=np.int64)
+        seg_off = i32(np.concatenate([[0], np.cumsum(cnt)]).tolist())
+        slot_d = i32([c[1] for c in cont_items])
+        score = torch.empty(len(cont_items), device=dev)
+        check(lib.stair_score_cosine_to_mean(C.c_void_p(vec.data_ptr()), C.c_void_p(slot_d.data_ptr()), C.c_void_p(reps.data_ptr()),
+                                             C.c_void_p(seg_off.data_ptr()), C.c_void_p(score.data_ptr()), len(cont_items), H, stream))
+        cos = score.cpu().tolist()
         for c, v in zip(cont_items, cos):
             out[c[0]][c[4]] = v
     return out

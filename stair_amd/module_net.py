@@ -323,7 +323,8 @@ class VideoNMN(nn.Module):
         return self._ws
 
     # ---------------------------------------------------------------------------------------
-    def run_programs(self, programs, spans, video, question, q_lens, train=False, video_index=None, dropout=None, video_len=None):
+    def run_programs(self, programs, spans, video, question, q_lens, train=False, video_index=None, dropout=None, video_len=None,
+                     before_run=None):
         """Batched pass.  programs: list of token lists; spans: list of {pos: (lo, hi)}; video
         [n,T,V] and question [sum(q_lens), E] float32 on the GPU.  Returns a BatchResult.
 
@@ -335,7 +336,10 @@ class VideoNMN(nn.Module):
         question; the results are identical).
         video_len (optional, [n_videos] ints): clips of different frame counts in one batch -- clip v holds video_len[v]
         <= T frames at the front of video[v], padding behind (dataset.py:137-143 keeps every clip's own length); each
-        question is computed as the reference computes a clip of its own length (stair_plan_build_ragged)."""
+        question is computed as the reference computes a clip of its own length (stair_plan_build_ragged).
+        before_run (optional): called with the BatchResult after the plan is built (node table, slots and offsets are
+        known) and BEFORE the pass is enqueued -- host work that only needs the plan (the loss driver's index arrays)
+        then overlaps the previous step's GPU work instead of sitting between this step's forward and backward."""
         n = len(programs)
         if video_index is not None:
             video_index = np.ascontiguousarray(np.asarray(video_index, dtype=np.int32))
@@ -383,18 +387,20 @@ class VideoNMN(nn.Module):
             A = self.config['answer_vocab_length']
             logits = torch.empty(n, A, dtype=torch.float32, device=video.device)
             pred = torch.empty(n, dtype=torch.int32, device=video.device)
-            check(lib.stair_plan_run_flags(self._ctx, plan, C.c_void_p(video.data_ptr()), C.c_void_p(question.data_ptr()),
-                                           C.c_void_p(ws.data_ptr()), ws.numel() * 4, C.c_void_p(logits.data_ptr()),
-                                           C.c_void_p(pred.data_ptr()), RUN_VIDEO_BF16 if video.dtype == torch.bfloat16 else 0,
-                                           C.c_void_p(torch.cuda.current_stream().cuda_stream)))
-            if train:       # a training plan keeps its logits inside the workspace for the backward pass; hand the caller a copy
-                logits = ws[info.logits_off: info.logits_off + n * A].view(n, A).clone()    # (n x A floats) that survives the next step
         except Exception:
             lib.stair_plan_destroy(plan)
             raise
-        res = BatchResult(self, plan, info, ws, logits, pred, prog_off, programs, video, question)
+        res = BatchResult(self, plan, info, ws, logits, pred, prog_off, programs, video, question)     # owns the plan from here on
         if video_len is not None:       # frames of every question's clip (the loss driver masks its criteria with them)
             res.question_frames = video_len[video_index] if video_index is not None else video_len
+        if before_run is not None:
+            before_run(res)
+        check(lib.stair_plan_run_flags(self._ctx, plan, C.c_void_p(video.data_ptr()), C.c_void_p(question.data_ptr()),
+                                       C.c_void_p(ws.data_ptr()), ws.numel() * 4, C.c_void_p(logits.data_ptr()),
+                                       C.c_void_p(pred.data_ptr()), RUN_VIDEO_BF16 if video.dtype == torch.bfloat16 else 0,
+                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        if train:       # a training plan keeps its logits inside the workspace for the backward pass; hand the caller a copy
+            res.logits = ws[info.logits_off: info.logits_off + n * A].view(n, A).clone()    # (n x A floats) that survives the next step
         return res
 
     def forward_batch(self, batch, train=False, share_videos=True, dropout=None):

@@ -42,6 +42,29 @@ def reduce_gradients(flat_g, touched, world, bucket=None):
     return flat_g, touched
 
 
+class _PinnedRing:
+    """Small host -> device uploads (the per-step touched mask) without tying the host to the stream: a pageable
+    `.to(device)` makes the host wait until the stream has reached the copy -- the end of the backward pass -- and a single
+    page-locked buffer has to wait for its previous copy, which is the same thing one step later.  A ring of `depth`
+    page-locked buffers waits only for the copy issued `depth` steps ago, so the host may run that far ahead."""
+
+    def __init__(self, numel, depth=8):
+        self.bufs = [torch.empty(numel, dtype=torch.int32).pin_memory() for _ in range(depth)]
+        self.events = [None] * depth
+        self.i = 0
+
+    def upload(self, values, device):
+        k = self.i
+        self.i = (k + 1) % len(self.bufs)
+        if self.events[k] is not None:
+            self.events[k].synchronize()
+        self.bufs[k].copy_(torch.tensor(values, dtype=torch.int32))
+        t = self.bufs[k].to(device, non_blocking=True)
+        self.events[k] = torch.cuda.Event()
+        self.events[k].record()
+        return t
+
+
 class Trainer:
     def __init__(self, model, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decoder_loss_weight=1.0,
                  module_loss_weight=1.0, contrastive_window=32, no_intermediate=('FilterFrame',),
@@ -97,6 +120,7 @@ class Trainer:
         self.seg_of_block = seg_of_block.to(dev)
         self.steps = torch.zeros(len(names), device=dev)     # per-tensor Adam step counts
         self.touched = torch.zeros(len(names), dtype=torch.int32, device=dev)
+        self._mask_ring = _PinnedRing(len(names))
         self.offsets = offs
 
     def lr_factor(self):
@@ -127,21 +151,25 @@ class Trainer:
         if questions is not None and gstep[-1] >= self.before_iters:
             questions = [q if g < self.before_iters else dict(q, sg_res_by_step={}) for q, g in zip(questions, gstep)]
         drop = (self.dropout, self.dropout_seed + self.iters * self.world + self.rank) if self.dropout > 0 else None
+        supervised = questions is not None and self.module_loss_weight != 0
+        prep = {}
+
+        def prepare(res_):        # host side of the intermediate losses: needs the plan only, runs before the pass is enqueued
+            prep['p'] = L.prepare_module_losses(self.model, res_, questions, no_intermediate=self.no_intermediate,
+                                                window=self.contrastive_window, world=self.world, rank=self.rank)
         res = self.model.run_programs(programs, spans, video, question, q_lens, train=True, video_index=video_index, dropout=drop,
-                                      video_len=video_len)
+                                      video_len=video_len, before_run=prepare if supervised else None)
         extra = set()
-        if questions is not None and self.module_loss_weight != 0:
+        if supervised:
             res.zero_grad_arenas()
-            self.module_losses, extra = L.apply_module_losses(self.model, res, questions, self.module_loss_weight / G,
-                                                              no_intermediate=self.no_intermediate, window=self.contrastive_window,
-                                                              world=self.world, rank=self.rank)
+            self.module_losses, extra = L.launch_module_losses(self.model, res, prep['p'], self.module_loss_weight / G)
             loss = res.backward(answers, self.decoder_loss_weight / G, keep_arenas=True)
         else:
             loss = res.backward(answers, self.decoder_loss_weight / G)
         tl = res.touched()
         if extra:
             tl = [t_ or (nme in extra) for t_, nme in zip(tl, self.model._weight_names)]
-        t = torch.tensor(tl, dtype=torch.int32).to(self.touched.device, non_blocking=True)
+        t = self._mask_ring.upload(tl, self.touched.device)
         reduce_gradients(self.flat_g, t, self.world, self.bucket)       # ONE flat bucket over RCCL / xGMI
         if self.skip_untouched == 'ever':
             self.touched = torch.maximum(self.touched, t)
