@@ -1005,6 +1005,10 @@ int launch_gemm_tn_bf16x3(const stair_gemm_tn_args &a, hipStream_t s) {
     } else if (plain_matrix) {
         p.fast8 = 2;                  // ragged row count (e.g. the text encoder's sum of question lengths)
     }
+    if (bx) {                     // the long dW_ih shapes: row-major LDS tiles read transposed (csrc/gemm_tn_tr.hip)
+        const int rc = launch_gemm_tn_tr(a, s);
+        if (rc >= 0) return rc;
+    }
     {   // 256 x 256 tiles where the output is large enough (>= 16 of them) and the staging is the simple case
         static const int tn256 = [] { const char *e = getenv("STAIR_GEMM_TN256"); return e ? atoi(e) : 16; }();   // 0 = off
         const int t2n = (a.N + 255) / 256, t2k = (a.K + 255) / 256, t2 = t2n * t2k;

@@ -132,11 +132,11 @@ def gemm_planes(a_hi, a_lo, w_hi, w_lo, bias=None, act=None, out=None):
 
 
 def gemm_tn(A, B, Cmat, M, N, K, rows_per_group=1, b_gstride=None, b_gidx=None, row_scale=None, rs_gstride=0,
-            rs_gidx=None, colsum=None, colsum2=None):
+            rs_gidx=None, colsum=None, colsum2=None, lda=None):
     """Cmat[N,K] += A[M,N]^T @ (rs * B[M,K]) -- weight gradients (see stair_gemm_tn_args); colsum[N] (and
     colsum2) += column sums of A, the bias gradient of the same layer."""
     a = GemmTnArgs()
-    a.A, a.lda = A.data_ptr(), N
+    a.A, a.lda = A.data_ptr(), (lda if lda is not None else N)      # lda > N: A is a column block of a wider matrix
     a.b_is_bf16 = 1 if B.dtype == torch.bfloat16 else 0        # stored clip features: exact bf16 rows, two products per pair
     a.B, a.ldb, a.b_gstride = B.data_ptr(), K, (b_gstride if b_gstride is not None else K * rows_per_group)
     a.b_gidx = b_gidx.data_ptr() if b_gidx is not None else None

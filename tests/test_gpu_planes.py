@@ -123,6 +123,26 @@ def test_gemm_tn_with_exact_bf16_rows(M, N, K):
     assert _maxerr(b1, dZ.double().sum(0)) < 4e-5 * max(1.0, (M / 100) ** 0.5)
 
 
+@pytest.mark.parametrize('M,N,K,wide', [(16384, 256, 256, False), (16384, 1024, 2048, True), (32768, 512, 256, True), (17408, 256, 512, False)])
+def test_gemm_tn_transposed_read_kernel(M, N, K, wide):
+    """The long dW_ih shapes (M a multiple of 512 and >= 16384, N and K multiples of 256, no bias sum riding along) go to
+    csrc/gemm_tn_tr.hip: row-major LDS tiles, fragments by ds_read_b64_tr_b16, X by LDS-DMA.  `wide`: dZ is a column block
+    of a wider matrix, as the gate gradients of one direction are."""
+    from stair_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    X = torch.randn(M, K, generator=g).to(DEV).to(torch.bfloat16)
+    lda = 2 * N if wide else N
+    full = torch.randn(M, lda, generator=g).to(DEV)
+    dZ = full[:, lda - N:]
+    C0 = torch.randn(N, K, generator=g).to(DEV)
+    Cm = C0.clone()
+    ops.gemm_tn(dZ, X, Cm, M, N, K, rows_per_group=1, lda=lda)
+    ref = C0.double() + dZ.double().t() @ X.double()
+    assert _maxerr(Cm, ref) < 4e-4 * max(1.0, (M / 1000) ** 0.5 * 3)
+    rel = float((Cm.double() - ref).norm() / ref.norm())
+    assert rel < 2e-5, rel          # split arithmetic: ~4e-6 per product, averaged over the long reduction
+
+
 @pytest.mark.parametrize('Hh,I,lens', [(32, 128, [5, 1, 9, 9, 3]), (256, 2048, [64] * 5), (64, 64, [4, 6]), (128, 96, [10, 3, 7]),
                                        (256, 512, [64] * 40)])
 def test_lstm_on_bf16_rows_matches_oracle_fed_the_rounded_rows(Hh, I, lens):
