@@ -253,8 +253,14 @@ PinnedBuf pinned_take(size_t ints) {
 void pinned_give(PinnedBuf b) {
     if (!b.p) return;
     std::lock_guard<std::mutex> lk(g_pin_mu);
-    if (g_pin_pool.size() < 8) g_pin_pool.push_back(b);
-    else (void)hipHostFree(b.p);
+    if (g_pin_pool.size() < 8) { g_pin_pool.push_back(b); return; }
+    // full: keep the larger buffers (a process that moves on to bigger batches would otherwise free and re-pin a buffer of the
+    // new size on every step, milliseconds each, while the pool holds eight that are too small)
+    size_t k = 0;
+    for (size_t i = 1; i < g_pin_pool.size(); ++i)
+        if (g_pin_pool[i].cap < g_pin_pool[k].cap) k = i;
+    if (g_pin_pool[k].cap < b.cap) std::swap(g_pin_pool[k], b);
+    (void)hipHostFree(b.p);
 }
 // A destroyed plan's buffer may still be the source of an upload the GPU has not reached (the host runs ahead of the
 // stream): it is parked with its event and goes back to the pool once the event has completed -- checked, never waited for,
@@ -274,13 +280,22 @@ void pinned_reclaim() {                 // g_pin_mu NOT held
 void pinned_park(PinnedBuf b, hipEvent_t ev) {
     if (!ev) { pinned_give(b); return; }
     if (hipEventQuery(ev) != hipErrorNotReady) { (void)hipEventDestroy(ev); pinned_give(b); return; }
+    ParkedBuf oldest{};
+    bool wait_oldest = false;
     {
         std::lock_guard<std::mutex> lk(g_pin_mu);
-        if (g_parked.size() < 64) { g_parked.push_back({b, ev}); return; }
+        g_parked.push_back({b, ev});
+        if (g_parked.size() > 4) {          // the host is more than 4 plans ahead of the stream: let it wait for the oldest one
+            oldest = g_parked.front();      // (bounds the page-locked memory in flight; no allocation churn in a long run)
+            g_parked.erase(g_parked.begin());
+            wait_oldest = true;
+        }
     }
-    (void)hipEventSynchronize(ev);      // 64 plans in flight: wait for this one after all
-    (void)hipEventDestroy(ev);
-    pinned_give(b);
+    if (wait_oldest) {
+        (void)hipEventSynchronize(oldest.ev);
+        (void)hipEventDestroy(oldest.ev);
+        pinned_give(oldest.b);
+    }
 }
 }  // namespace
 
