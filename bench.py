@@ -186,6 +186,7 @@ def main():
     ap.add_argument('--supervision', action='store_true', help='configs[4]: gold intermediates + every per-module loss inside the timed step')
     ap.add_argument('--dropout', type=float, default=0.0, help='nn.Dropout p of the training step (the reference trains with 0.25; parity is defined at 0)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--native-allreduce', action='store_true', help='N > 1: the gradient all-reduce through the C ABI (stair_allreduce_grads, RCCL from libstair_hip.so) instead of torch.distributed')
     ap.add_argument('--no-extras', action='store_true', help='skip the supplementary figures (clean kernel profiles)')
     args = ap.parse_args()
 
@@ -235,7 +236,7 @@ def main():
     trainer = None
     if args.mode == 'train':
         from stair_amd.train import Trainer
-        trainer = Trainer(model, world=world, rank=rank, dropout=args.dropout)
+        trainer = Trainer(model, world=world, rank=rank, dropout=args.dropout, native_allreduce=args.native_allreduce)
     gold_qs = gold_questions(qs) if (args.supervision or not args.no_extras) and args.mode == 'train' else None
     # The batch is a few hundred thousand long-lived Python objects (question dicts, gold packs).  A generation-2 pass of the
     # cyclic collector walks all of them -- 30-50 ms, i.e. two whole steps -- every few supervised steps; a training job's

@@ -248,6 +248,19 @@ int stair_temporal_relate_fwd(const float *att, const int32_t *att_idx, const in
  * Superlative and ToAction (module_net.py:21, 211-216).  x, out [n,H]. */
 int stair_l2normalize_fwd(const float *x, float *out, int32_t n, int32_t H, stair_stream stream);
 
+/* ---- data-parallel exchange: the one collective of a training step ---------------------
+ * RCCL, resolved at run time (the copy torch already loaded is reused).  One communicator per process / GPU.
+ * stair_comm_unique_id: rank 0 fills 128 bytes (ncclUniqueId) and hands them to the other ranks by any side channel
+ * (Python: torch.distributed.broadcast_object_list over gloo, a file, ...); every rank then calls stair_comm_create.
+ * stair_allreduce_grads: in-place SUM over ranks of the flat fp32 bucket [gradients | touched mask as floats]
+ * (stair_amd/train.py lays it out) on `stream`; replaces the accumulation of /root/reference/train_module.py:386-412
+ * across a sharded window.  Asynchronous like every other entry point. */
+typedef struct stair_comm stair_comm;
+int stair_comm_unique_id(void *id128);
+int stair_comm_create(const void *id128, int32_t rank, int32_t world, stair_comm **out);
+void stair_comm_destroy(stair_comm *comm);
+int stair_allreduce_grads(stair_comm *comm, float *bucket, int64_t n, stair_stream stream);
+
 /* ---- program plans: the batched stack interpreter (module_net.py:94-138) -------------------- */
 
 /* Rank C candidate representations by cosine similarity to each query row and keep the k best

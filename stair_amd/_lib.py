@@ -121,6 +121,10 @@ SIGNATURES = [
                                           C.c_int32, c_int32_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     ('stair_plan_build_ragged', C.c_int, [C.c_void_p, C.c_int32, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p,
                                           C.c_int32, c_int32_p, c_int32_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    ('stair_comm_unique_id', C.c_int, [C.c_void_p]),
+    ('stair_comm_create', C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    ('stair_comm_destroy', None, [C.c_void_p]),
+    ('stair_allreduce_grads', C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     ('stair_loss_decoder_ce', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     ('stair_score_cosine_to_mean', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     ('stair_loss_attention_len', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,

@@ -23,18 +23,22 @@ from ._lib import check, lib
 SEG = 256
 
 
-def reduce_gradients(flat_g, touched, world, bucket=None):
+def reduce_gradients(flat_g, touched, world, bucket=None, comm=None):
     """The one exchange step of data-parallel training: sum the flat fp32 gradient bucket over all ranks and
     OR the per-parameter touched mask (a parameter is "touched" if ANY rank's shard used its module).
     With `bucket` (a buffer whose head is flat_g and whose tail has room for the mask, as Trainer lays it out) the mask
     travels as floats behind the gradients and ONE all-reduce does both; without it, two collectives.
-    Backend-agnostic (RCCL on GPUs, gloo in the CPU test); in place."""
+    Backend-agnostic (RCCL on GPUs, gloo in the CPU test); in place.  comm: a stair_amd.comm.NativeComm -- the bucket then
+    goes through the C ABI's stair_allreduce_grads (RCCL from libstair_hip.so, same stream, no torch collective)."""
     if world > 1:
         import torch.distributed as dist
         if bucket is not None:
             tail = bucket[flat_g.numel(): flat_g.numel() + touched.numel()]
             tail.copy_(touched.to(bucket.dtype))
-            dist.all_reduce(bucket, op=dist.ReduceOp.SUM)
+            if comm is not None:
+                comm.allreduce_(bucket)
+            else:
+                dist.all_reduce(bucket, op=dist.ReduceOp.SUM)
             touched.copy_((tail > 0).to(touched.dtype))
         else:
             dist.all_reduce(flat_g, op=dist.ReduceOp.SUM)
@@ -70,7 +74,7 @@ class Trainer:
                  module_loss_weight=1.0, contrastive_window=32, no_intermediate=('FilterFrame',),
                  scheduler_start_factor=1.0, scheduler_end_factor=0.1, scheduler_total_iters=200000, world=1,
                  skip_untouched='ever', train_module_before_iters=1e10, train_decoder_after_iters=0, rank=0,
-                 dropout=None, dropout_seed=0):
+                 dropout=None, dropout_seed=0, native_allreduce=False):
         """skip_untouched: 'ever'   -- a parameter is skipped by Adam until the first window that sends it a gradient
                                       (torch 1.13, which the reference pins: zero_grad() keeps zero tensors afterwards);
                            'window' -- skipped in every window that does not touch it (torch >= 2.0, set_to_none=True)."""
@@ -121,6 +125,10 @@ class Trainer:
         self.steps = torch.zeros(len(names), device=dev)     # per-tensor Adam step counts
         self.touched = torch.zeros(len(names), dtype=torch.int32, device=dev)
         self._mask_ring = _PinnedRing(len(names))
+        self.comm = None
+        if native_allreduce and world > 1:          # the step's one collective through the C ABI (stair_allreduce_grads)
+            from .comm import NativeComm
+            self.comm = NativeComm(rank, world)
         self.offsets = offs
 
     def lr_factor(self):
@@ -170,7 +178,7 @@ class Trainer:
         if extra:
             tl = [t_ or (nme in extra) for t_, nme in zip(tl, self.model._weight_names)]
         t = self._mask_ring.upload(tl, self.touched.device)
-        reduce_gradients(self.flat_g, t, self.world, self.bucket)       # ONE flat bucket over RCCL / xGMI
+        reduce_gradients(self.flat_g, t, self.world, self.bucket, self.comm)       # ONE flat bucket over RCCL / xGMI
         if self.skip_untouched == 'ever':
             self.touched = torch.maximum(self.touched, t)
         else:

@@ -111,3 +111,23 @@ def test_two_rank_trainer_step_equals_single_process_step(supervised, bf16):
     dp = (solo['params'] - ranks[0]['params']).abs()
     # Adam divides by sqrt(v): where a gradient is ~0 the step direction is ill-conditioned; lr = 1e-3, two steps
     assert float((dp > 2e-5).float().mean()) < 2e-3 and float(dp.max()) <= 2.1e-3
+
+
+def test_native_allreduce_entry_point_single_rank():
+    """stair_comm_* / stair_allreduce_grads (RCCL resolved at run time from libstair_hip.so) on a one-rank communicator:
+    the sum over one rank is the identity, on the caller's stream; a two-rank RCCL communicator needs two GPUs and is
+    left to the driver's multi-GPU run (Trainer(native_allreduce=True))."""
+    import torch
+    from stair_amd.comm import NativeComm
+    from stair_amd._lib import StairError
+    comm = NativeComm(0, 1)
+    x = torch.randn(1 << 20, device='cuda:0')
+    ref = x.clone()
+    comm.allreduce_(x)
+    torch.cuda.synchronize()
+    assert torch.equal(x, ref)
+    with pytest.raises(TypeError):
+        comm.allreduce_(x.double())
+    comm.close()
+    with pytest.raises(StairError):
+        NativeComm(1, 1)            # rank outside the world
