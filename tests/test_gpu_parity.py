@@ -347,6 +347,26 @@ def test_appearance_feature_config_against_oracle(matmul):
         assert int(res.pred[qi]) == int(torch.argmax(r['logits']))
 
 
+def test_configs0_thousand_questions_against_oracle():
+    """BASELINE configs[0] at the survey's size (Config 1): 1 000 questions, 8 frames of 2048 appearance
+    features (the h5 path averages the clip-frames axis, dataset.py:145-154), max_video_length 8 -> Linear(T,T) Temporal nets.
+    One batched pass on the GPU; every question's logits against the CPU oracle (batch-1, as the reference runs) at 1e-4
+    with identical top-1."""
+    config = dict(spec.DEFAULT_CONFIG, video_size=2048, max_video_length=8)
+    model = _model(config, 8)
+    w = oracle_weights(config, 8)
+    qs = synth.make_questions(config, 21, 1000, T=8)
+    assert qs[0]['video_features'].shape == (8, 2048)
+    res = model.forward_batch(qs)
+    logits, pred = res.logits.cpu(), res.pred.cpu()
+    worst = 0.0
+    for qi, q in enumerate(qs):
+        r = O.forward(w, config, q)
+        worst = max(worst, float((logits[qi] - r['logits']).abs().max()))
+        assert int(pred[qi]) == int(torch.argmax(r['logits'])), qi
+    assert worst < 1e-4, worst
+
+
 @pytest.mark.parametrize('H,V,L,T', [(64, 128, 40, 2), (64, 260, 40, 33), (128, 128, 2, 2), (128, 260, 64, 63), (256, 128, 100, 100),
                                      (256, 260, 40, 7), (512, 128, 8, 8), (512, 260, 40, 33), (512, 128, 100, 100)])
 def test_odd_shapes_against_oracle(H, V, L, T):
