@@ -726,8 +726,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16x3_kernel(XTnParams p) {
     const int cc = min(col0 + 4 * cq, ncols - 4);
     const float cmask = col0 + 4 * cq < ncols ? 1.0f : 0.0f;
 
-    v4f v[2][8];
-    float sc[2][8];
+    v4f v[3][8];              // three register sets: the loads of chunks c+1, c+2, c+3 are in flight while chunk c multiplies
+    float sc[3][8];
     // bias gradient riding along: the workgroups of the first K tile already stage every dZ element of their (slab, N tile)
     // once, so waves 0,1 add them up per column while splitting (colsum_kernel re-read all of dZ for this)
     const bool do_colsum = p.colsum != nullptr && !isB && k0 == 0;
@@ -797,24 +797,33 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16x3_kernel(XTnParams p) {
 
     const int nchunks = (mend - mbeg + XBK - 1) / XBK;
     if (nchunks > 0) {      // block-uniform; rows past mend are zeroed by sc, so every load below is unconditional
+        // Chunk c multiplies out of LDS buffer c % 2 while register set (c+1) % 3 (loaded two steps ago) is split into the other
+        // buffer and set c % 3 takes the loads of chunk c + 3: at M ~ 17 k rows a workgroup has 17 chunks of ~1 us and a load
+        // takes 2-3 us, so with two sets (one step of slack less) every chunk waited for memory -- these launches move
+        // 1.3 TB/s, nowhere near a bandwidth limit.
         T_GLOAD(0, mbeg);
         T_GLOAD(1, mbeg + XBK);
+        T_GLOAD(2, mbeg + 2 * XBK);
         T_LSTORE(0, 0, 0);
         __syncthreads();
-        for (int c = 0; c < nchunks; c += 2) {
-            T_GLOAD(0, mbeg + (c + 2) * XBK);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_chunk<(BX && NP == 3) ? 2 : NP>(xlds, 0, wm, wn, r, h, acc00, acc01, acc10, acc11);
-            __builtin_amdgcn_sched_barrier(0);
-            T_LSTORE(1, 1, c + 1);
-            __syncthreads();
-            T_GLOAD(1, mbeg + (c + 3) * XBK);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_chunk<(BX && NP == 3) ? 2 : NP>(xlds, 1, wm, wn, r, h, acc00, acc01, acc10, acc11);
-            __builtin_amdgcn_sched_barrier(0);
-            T_LSTORE(0, 0, c + 2);
-            __syncthreads();
+#define T_STEP(cur_, nxt_, buf_, c_)                                                                        \
+        if ((c_) < nchunks) {                                                                               \
+            T_GLOAD(cur_, mbeg + ((c_) + 3) * XBK);                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                              \
+            mfma_chunk<(BX && NP == 3) ? 2 : NP>(xlds, buf_, wm, wn, r, h, acc00, acc01, acc10, acc11);     \
+            __builtin_amdgcn_sched_barrier(0);                                                              \
+            T_LSTORE(nxt_, 1 - (buf_), (c_) + 1);                                                           \
+            __syncthreads();                                                                                \
         }
+        for (int c = 0; c < nchunks; c += 6) {
+            T_STEP(0, 1, 0, c)
+            T_STEP(1, 2, 1, c + 1)
+            T_STEP(2, 0, 0, c + 2)
+            T_STEP(0, 1, 1, c + 3)
+            T_STEP(1, 2, 0, c + 4)
+            T_STEP(2, 0, 1, c + 5)
+        }
+#undef T_STEP
     }
 #undef T_GLOAD
 #undef T_LSTORE
