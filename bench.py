@@ -247,8 +247,9 @@ def main():
     def run_step(nq=B, supervised=False):
         """one pass over the first nq questions of the rank's batch"""
         if trainer is not None:
+            # every rank holds nq questions: the window size is known, so the step needs no size exchange (and no host sync)
             return trainer.step(programs[:nq], spans[:nq], video[:nq], question[:off[nq]], q_lens[:nq], answers[:nq],
-                                questions=gold_qs[:nq] if supervised else None)[1]
+                                global_batch=nq * world, questions=gold_qs[:nq] if supervised else None)[1]
         return model.run_programs(programs[:nq], spans[:nq], video[:nq], question[:off[nq]], q_lens[:nq])
 
     def barrier():
