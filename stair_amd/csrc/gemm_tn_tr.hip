@@ -283,7 +283,7 @@ int launch_gemm_tn_tr(const stair_gemm_tn_args &a, hipStream_t s) {
     static const bool on = [] { const char *e = getenv("STAIR_GEMM_TN_TR"); return !(e && e[0] == '0'); }();
     if (!on || !a.b_is_bf16 || a.row_scale || a.b_gidx || a.colsum || a.colsum2) return -1;
     if (a.rows_per_group != 1 && a.b_gstride != (int64_t)a.rows_per_group * a.ldb) return -1;
-    if (a.N % 256 || a.K % 256 || a.M % (8 * 64) || a.M < 16384) return -1;
+    if (a.N % 256 || a.K % 256 || a.M % (8 * 64) || a.M < 2048) return -1;        // >= 4 stages per slab; measured down to M = 2048 (32 questions)
     if (32 * a.lda + 256 >= (1ll << 31) || 32 * a.ldb + 256 >= (1ll << 31)) return -1;
     if (a.lda % 4 || a.ldb % 8 || (reinterpret_cast<uintptr_t>(a.A) & 15) || (reinterpret_cast<uintptr_t>(a.B) & 15)) return -1;
     if (matmul_mode() != STAIR_MATMUL_BF16X3) return -1;

@@ -123,10 +123,10 @@ def test_gemm_tn_with_exact_bf16_rows(M, N, K):
     assert _maxerr(b1, dZ.double().sum(0)) < 4e-5 * max(1.0, (M / 100) ** 0.5)
 
 
-@pytest.mark.parametrize('M,N,K,wide', [(16384, 256, 256, False), (16384, 1024, 2048, True), (32768, 512, 256, True), (17408, 256, 512, False),
+@pytest.mark.parametrize('M,N,K,wide', [(2048, 256, 256, False), (8192, 1024, 2048, True), (16384, 256, 256, False), (16384, 1024, 2048, True), (32768, 512, 256, True), (17408, 256, 512, False),
                                         (131072, 1024, 2048, True)])       # the last one is the bench shape: 512 stages per slab
 def test_gemm_tn_transposed_read_kernel(M, N, K, wide):
-    """The long dW_ih shapes (M a multiple of 512 and >= 16384, N and K multiples of 256, no bias sum riding along) go to
+    """The dW_ih shapes (M a multiple of 512 and >= 2048, N and K multiples of 256, no bias sum riding along) go to
     csrc/gemm_tn_tr.hip: row-major LDS tiles, fragments by ds_read_b64_tr_b16, X by LDS-DMA.  `wide`: dZ is a column block
     of a wider matrix, as the gate gradients of one direction are."""
     from stair_amd import ops
