@@ -248,34 +248,125 @@ __global__ void rownorm_kernel(const float *X, int64_t rows, int H, float *out) 
     if (lane == 0) out[row] = fmaxf(sqrtf(ss), 1e-8f);
 }
 
-// grid (instance, 64-column chunk); the chunk's K [Ka][64] and F [T][64] slices and the pair scalars live in LDS
-__global__ void cosine_attn_bwd_grouped_kernel(const float *F, const float *Kmat, const float *nf_all, const float *nk_all,
+// grid (instance, 64-column chunk); the chunk's K [Ka][64] and F [T][64] slices and the pair scalars live in LDS.
+// MF: the two products of a block -- dF[T x 64] = sa^T k and dK[Ka x 64] = sa f -- on v_mfma_f32_32x32x2_f32 (exact fp32
+// products, fp32 accumulate) over LDS images zero-padded to multiples of 32 (sa rows TP + 1 floats apart: conflict-free for both
+// operand orders).  The scalar loops did two LDS reads per FMA and were bound by LDS bandwidth (Superlative, Ka = T = 64:
+// 247 us for 254 instances).
+using f32x16_rb = __attribute__((ext_vector_type(16))) float;
+template <bool MF>
+__global__ __launch_bounds__(256) void cosine_attn_bwd_grouped_kernel(const float *F, const float *Kmat, const float *nf_all, const float *nk_all,
                                                const float *score, int64_t s_stride, const int32_t *score_idx,
                                                const float *dscore, const int32_t *dscore_idx, const int32_t *pair_start,
                                                const int32_t *pair_cnt, float *dF, float *dK, int n, int T, int H, int ka_max) {
-    extern __shared__ float sm[];          // sa [Ka][T] | kt [Ka][64] | ft [T][64] | sbsum [T] | scsum [Ka]
+    extern __shared__ float sm[];          // sa [KP][TS] | kt [KP][64] | ft [TP][64] | sbsum [TP] | scsum [KP]
     const int i = blockIdx.x, c0 = blockIdx.y * 64;
     const int p0 = pair_start[i], Ka = pair_cnt[i];
-    float *sa = sm, *kt = sa + ka_max * T, *ft = kt + ka_max * 64, *sbsum = ft + T * 64, *scsum = sbsum + T;
+    const int TP = MF ? (T + 31) / 32 * 32 : T, KP = MF ? (ka_max + 31) / 32 * 32 : ka_max, TS = MF ? TP + 1 : T;
+    float *sa = sm, *kt = sa + KP * TS, *ft = kt + KP * 64, *sbsum = ft + TP * 64, *scsum = sbsum + TP;
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;      // 4 waves: lane = column, part = row quarter
     const float *f = F + (int64_t)i * T * H;
     const float *nf = nf_all + (int64_t)i * T, *nk = nk_all + p0;
-    for (int t = threadIdx.x; t < T; t += blockDim.x) sbsum[t] = 0.f;
-    for (int a = threadIdx.x; a < Ka; a += blockDim.x) scsum[a] = 0.f;
-    for (int t = part; t < T; t += 4) ft[t * 64 + lane] = f[(int64_t)t * H + c0 + lane];
-    for (int a = part; a < Ka; a += 4) kt[a * 64 + lane] = Kmat[(int64_t)(p0 + a) * H + c0 + lane];
-    __syncthreads();
-    for (int e = threadIdx.x; e < Ka * T; e += blockDim.x) {
-        const int a = e / T, t = e - a * T;
-        const int64_t so = (int64_t)(score_idx ? score_idx[p0 + a] : p0 + a) * s_stride + t;
-        const int64_t go = (int64_t)(dscore_idx ? dscore_idx[p0 + a] : p0 + a) * s_stride + t;
-        const float cosv = score[so] / 0.49f - 1.0f;
-        const float dcos = 0.49f * dscore[go];
-        sa[e] = dcos / (nf[t] * nk[a]);
-        atomicAdd(&sbsum[t], dcos * cosv / (nf[t] * nf[t]));
-        atomicAdd(&scsum[a], dcos * cosv);
+    for (int t = threadIdx.x; t < TP; t += blockDim.x) sbsum[t] = 0.f;
+    for (int a = threadIdx.x; a < KP; a += blockDim.x) scsum[a] = 0.f;
+    if (MF) for (int e = threadIdx.x; e < KP * TS; e += blockDim.x) sa[e] = 0.f;
+    // Loads first, in batches of 8 independent ones per thread, then the LDS stores: written as `load; store` per iteration
+    // every global load waited for the previous store (a block took ~40 us whatever it computed: 16 dependent round trips)
+    for (int t0 = part; t0 < TP; t0 += 32) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int t = t0 + 4 * j; v[j] = t < T ? f[(int64_t)t * H + c0 + lane] : 0.f; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int t = t0 + 4 * j; if (t < TP) ft[t * 64 + lane] = v[j]; }
+    }
+    for (int a0 = part; a0 < KP; a0 += 32) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int a = a0 + 4 * j; v[j] = a < Ka ? Kmat[(int64_t)(p0 + a) * H + c0 + lane] : 0.f; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int a = a0 + 4 * j; if (a < KP) kt[a * 64 + lane] = v[j]; }
+    }
+    float *su = scsum + KP;                 // MF only: u[a][t] = dcos * cos, same [KP][TS] layout as sa
+    int *rowi = reinterpret_cast<int *>(su + (MF ? KP * TS : 0));       // [2][ka_max]: score / dscore row of pair a
+    for (int a = threadIdx.x; a < Ka; a += blockDim.x) {
+        rowi[a] = score_idx ? score_idx[p0 + a] : p0 + a;
+        rowi[ka_max + a] = dscore_idx ? dscore_idx[p0 + a] : p0 + a;
     }
     __syncthreads();
+    for (int e0 = threadIdx.x; e0 < Ka * T; e0 += 8 * blockDim.x) {
+        float sv[8], dv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int e = e0 + j * blockDim.x;
+            sv[j] = dv[j] = 0.f;
+            if (e < Ka * T) {
+                const int a = e / T, t = e - a * T;
+                sv[j] = score[(int64_t)rowi[a] * s_stride + t];
+                dv[j] = dscore[(int64_t)rowi[ka_max + a] * s_stride + t];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int e = e0 + j * blockDim.x;
+            if (e >= Ka * T) continue;
+            const int a = e / T, t = e - a * T;
+            const float cosv = sv[j] / 0.49f - 1.0f;
+            const float dcos = 0.49f * dv[j];
+            sa[a * TS + t] = dcos / (nf[t] * nk[a]);
+            if (MF) su[a * TS + t] = dcos * cosv;
+            else {
+                atomicAdd(&sbsum[t], dcos * cosv / (nf[t] * nf[t]));
+                atomicAdd(&scsum[a], dcos * cosv);
+            }
+        }
+    }
+    __syncthreads();
+    if (MF) {       // the two marginal sums without LDS atomics (Ka * T adds onto T + Ka addresses serialised): column / row walks
+        for (int t = threadIdx.x; t < T; t += blockDim.x) {
+            float acc = 0.f;
+            for (int a = 0; a < Ka; ++a) acc += su[a * TS + t];
+            sbsum[t] = acc / (nf[t] * nf[t]);
+        }
+        for (int a = threadIdx.x; a < Ka; a += blockDim.x) {
+            float acc = 0.f;
+            for (int t = 0; t < T; ++t) acc += su[a * TS + t];
+            scsum[a] = acc;
+        }
+        __syncthreads();
+    }
+    if (MF) {
+        const int r = lane & 31, kk = lane >> 5;
+        const int tilesT = TP / 32, tilesK = (Ka + 31) / 32;
+        // dF tiles: (row tile of t) x (2 column tiles); contraction over a
+        for (int tile = part; tile < tilesT * 2; tile += 4) {
+            const int tt = tile >> 1, cc = tile & 1;
+            f32x16_rb acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            for (int a = 0; a < tilesK * 32; a += 2)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sa[(a + kk) * TS + 32 * tt + r], kt[(a + kk) * 64 + 32 * cc + r], acc, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int t = 32 * tt + 8 * (e >> 2) + 4 * kk + (e & 3), col = 32 * cc + r;
+                if (t < T) dF[((int64_t)i * T + t) * H + c0 + col] = acc[e] - sbsum[t] * ft[t * 64 + col];
+            }
+        }
+        // dK tiles: (row tile of a) x (2 column tiles); contraction over t
+        for (int tile = part; tile < tilesK * 2; tile += 4) {
+            const int at = tile >> 1, cc = tile & 1;
+            f32x16_rb acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            for (int t = 0; t < TP; t += 2)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sa[(32 * at + r) * TS + t + kk], ft[(t + kk) * 64 + 32 * cc + r], acc, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int a = 32 * at + 8 * (e >> 2) + 4 * kk + (e & 3), col = 32 * cc + r;
+                if (a < Ka) dK[(int64_t)(p0 + a) * H + c0 + col] = acc[e] - scsum[a] * kt[a * 64 + col] / (nk[a] * nk[a]);
+            }
+        }
+        return;
+    }
     for (int t = part; t < T; t += 4) {
         float acc = 0.f;
         for (int a = 0; a < Ka; ++a) acc += sa[a * T + t] * kt[a * 64 + lane];
@@ -298,13 +389,22 @@ int launch_cosine_attn_bwd_grouped(const float *F, const float *Kmat, const floa
     hipLaunchKernelGGL(rownorm_kernel, dim3((unsigned)((frows + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, s, F, frows, H, nf_ws);
     hipLaunchKernelGGL(rownorm_kernel, dim3((npairs + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlock), 0, s, Kmat, (int64_t)npairs, H, nk_ws);
     STAIR_LAUNCH_CHECK();
-    const size_t shmem = ((size_t)ka_max * T + (size_t)ka_max * 64 + (size_t)T * 64 + T + ka_max) * sizeof(float);
+    const int TP = (T + 31) / 32 * 32, KP = (ka_max + 31) / 32 * 32;
+    const size_t shmem_mf = (2 * (size_t)KP * (TP + 1) + (size_t)KP * 64 + (size_t)TP * 64 + TP + KP + 2 * ka_max) * sizeof(float);
+    const size_t shmem_sc = ((size_t)ka_max * T + (size_t)ka_max * 64 + (size_t)T * 64 + T + ka_max + 2 * ka_max) * sizeof(float);
+    const bool mf = ka_max > 8 && shmem_mf <= 80 * 1024;     // many pairs per instance (Superlative); Localize (1-2 pairs) is bound by its F and dF rows, not by the products; at least two blocks per CU
+    const size_t shmem = mf ? shmem_mf : shmem_sc;
     STAIR_CHECK(shmem <= 160 * 1024, "cosine backward: Ka*T too large for LDS");
-    if (shmem > 48 * 1024)     // e.g. Superlative at T = 64: 16 + 16 + 16 KB; at max_video_length = 150 (args.py:29): 165 KB
-        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cosine_attn_bwd_grouped_kernel),
+    if (shmem > 48 * 1024) {   // e.g. Superlative at T = 64: 16 + 16 + 16 KB; at max_video_length = 150 (args.py:29): 165 KB
+        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cosine_attn_bwd_grouped_kernel<true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL(cosine_attn_bwd_grouped_kernel, dim3(n, H / 64), dim3(256), shmem, s, F, Kmat, nf_ws, nk_ws, score, (int64_t)T,
-                       score_idx, dscore, dscore_idx, pair_start, pair_cnt, dF, dK, n, T, H, ka_max);
+        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cosine_attn_bwd_grouped_kernel<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    }
+    if (mf) hipLaunchKernelGGL(cosine_attn_bwd_grouped_kernel<true>, dim3(n, H / 64), dim3(256), shmem, s, F, Kmat, nf_ws, nk_ws, score, (int64_t)T,
+                               score_idx, dscore, dscore_idx, pair_start, pair_cnt, dF, dK, n, T, H, ka_max);
+    else hipLaunchKernelGGL(cosine_attn_bwd_grouped_kernel<false>, dim3(n, H / 64), dim3(256), shmem, s, F, Kmat, nf_ws, nk_ws, score, (int64_t)T,
+                            score_idx, dscore, dscore_idx, pair_start, pair_cnt, dF, dK, n, T, H, ka_max);
     STAIR_LAUNCH_CHECK();
     return 0;
 }
@@ -603,7 +703,17 @@ __global__ void rowdot_sigmoid_bwd_kernel(const float *dOut, int64_t o_gs, const
     const float a = A[(int64_t)idx_or_id(a_idx, g) * a_gs + t] * keep;
     const float dpre = dOut[(int64_t)idx_or_id(o_idx, g) * o_gs + t] / keep * a * (1.f - a);
     float *dx = dXdst + row * H;
-    for (int c = lane; c < H; c += 64) dx[c] = (add_mode ? dx[c] : 0.f) + dpre * w[c];
+    if ((H & 3) == 0) {                     // 16-byte accesses (rows start on multiples of H floats of a 256-byte aligned workspace)
+        float4 *dx4 = reinterpret_cast<float4 *>(dx);
+        const float4 *w4 = reinterpret_cast<const float4 *>(w);
+        for (int c = lane; c < H / 4; c += 64) {
+            const float4 wv = w4[c];
+            float4 o = add_mode ? dx4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            o.x += dpre * wv.x; o.y += dpre * wv.y; o.z += dpre * wv.z; o.w += dpre * wv.w;
+            dx4[c] = o;
+        }
+    } else
+        for (int c = lane; c < H; c += 64) dx[c] = (add_mode ? dx[c] : 0.f) + dpre * w[c];
     if (lane == 0) {
         dpre_out[row] = dpre;
         if (dextra) unsafeAtomicAdd(dextra + g, dpre);
@@ -628,7 +738,15 @@ __global__ void weighted_colsum_kernel(const float *X, int64_t ld, const int32_t
     if (c >= H) return;
     const int rbeg = blockIdx.y * slab, rend = min(rows, rbeg + slab);
     float acc = 0.f;
-    for (int r = rbeg; r < rend; ++r) acc += scale[r] * X[(int64_t)idx_or_id(x_idx, r) * ld + c];
+    int r = rbeg;
+    for (; r + 8 <= rend; r += 8) {          // eight independent loads in flight per thread (one at a time: 64 round trips per block)
+        float sc[8], xv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sc[j] = scale[r + j]; xv[j] = X[(int64_t)idx_or_id(x_idx, r + j) * ld + c]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += sc[j] * xv[j];
+    }
+    for (; r < rend; ++r) acc += scale[r] * X[(int64_t)idx_or_id(x_idx, r) * ld + c];
     unsafeAtomicAdd(out + c, acc);
 }
 int launch_weighted_colsum(const float *X, int64_t ld, const int32_t *x_idx, const float *scale, float *out, int rows, int H,
@@ -784,23 +902,36 @@ int launch_choose_bwd(const float *vec, float *dvec, const int32_t *k1, const in
 __global__ void superlative_pool_bwd_kernel(const float *S, const float *rowbase, float *drowbase, const int32_t *row_id,
                                             const int32_t *row_start, const int32_t *row_cnt, int is_min, const float *dpre,
                                             float *dS, int n, int T, int H, const int32_t *len) {
-    extern __shared__ float sm[];    // w[Ka], dw[Ka]
+    extern __shared__ float sm[];    // w[Ka], dw[Ka], row ids [Ka]
     const int i = blockIdx.x;
     const int r0 = row_start[i], Ka = row_cnt[i];
     const int L = len ? len[i] : T;
     float *w = sm, *dw = sm + Ka;
+    int *rid = reinterpret_cast<int *>(sm + 2 * Ka);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float *dp = dpre + (int64_t)i * H;
-    for (int a = wave; a < Ka; a += kWavesPerBlock) {
-        const float *sr = S + (int64_t)(r0 + a) * T;
-        float acc = 0.f;
-        for (int t = lane; t < L; t += 64) acc += sr[t];
-        acc = wave_sum(acc);
-        const float *row = rowbase + (int64_t)row_id[r0 + a] * H;
-        float d = 0.f;
-        for (int c = lane; c < H; c += 64) d += dp[c] * row[c];
-        d = wave_sum(d);
-        if (lane == 0) { w[a] = acc; dw[a] = is_min ? -d : d; }
+    for (int a = threadIdx.x; a < Ka; a += blockDim.x) rid[a] = row_id[r0 + a];
+    __syncthreads();
+    // four rows per wave and pass: their loads are independent and issued together (one row at a time, each row's two
+    // reductions waited for its own loads: 16 round trips per wave, ~40 us of a 137 us launch)
+    for (int a0 = wave; a0 < Ka; a0 += 4 * kWavesPerBlock) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f}, d[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int a = a0 + j * kWavesPerBlock;
+            if (a < Ka) {
+                const float *sr = S + (int64_t)(r0 + a) * T;
+                for (int t = lane; t < L; t += 64) acc[j] += sr[t];
+                const float *row = rowbase + (int64_t)rid[a] * H;
+                for (int c = lane; c < H; c += 64) d[j] += dp[c] * row[c];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int a = a0 + j * kWavesPerBlock;
+            const float as = wave_sum(acc[j]), ds = wave_sum(d[j]);
+            if (a < Ka && lane == 0) { w[a] = as; dw[a] = is_min ? -ds : ds; }
+        }
     }
     __syncthreads();
     __shared__ float s_dot;
@@ -824,7 +955,7 @@ __global__ void superlative_pool_bwd_kernel(const float *S, const float *rowbase
     for (int c = threadIdx.x; c < H; c += blockDim.x) {
         const float g = dp[c];
         for (int a = 0; a < Ka; ++a)
-            unsafeAtomicAdd(drowbase + (int64_t)row_id[r0 + a] * H + c, (is_min ? 1.f - w[a] : w[a]) * g);
+            unsafeAtomicAdd(drowbase + (int64_t)rid[a] * H + c, (is_min ? 1.f - w[a] : w[a]) * g);
     }
 }
 int launch_superlative_pool_bwd(const float *S, const float *rowbase, float *drowbase, const int32_t *row_id,
@@ -832,7 +963,7 @@ int launch_superlative_pool_bwd(const float *S, const float *rowbase, float *dro
                                 int n, int T, int H, hipStream_t s, const int32_t *len) {
     if (n == 0) return 0;
     STAIR_ACCT("superlative_pool_bwd_kernel", 0);
-    hipLaunchKernelGGL(superlative_pool_bwd_kernel, dim3(n), dim3(kBlock), (size_t)2 * std::max(T, 2) * sizeof(float), s, S, rowbase,
+    hipLaunchKernelGGL(superlative_pool_bwd_kernel, dim3(n), dim3(kBlock), (size_t)3 * std::max(T, 2) * sizeof(float), s, S, rowbase,
                        drowbase, row_id, row_start, row_cnt, is_min, dpre, dS, n, T, H, len);
     STAIR_LAUNCH_CHECK();
     return 0;
