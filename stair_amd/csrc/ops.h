@@ -14,6 +14,8 @@ enum PackMode { PACK_CAT2 = 0, PACK_EXISTS = 1, PACK_XOR = 2 };
 int launch_pack(int mode, const float *A, const int32_t *ia, const float *B, const int32_t *ib, float *out, int n,
                 int H, hipStream_t s);
 
+int launch_cosine_attn_grouped(const float *F, int64_t f_gstride, const float *Kmat, const int32_t *pair_start, const int32_t *pair_cnt,
+                               float *att, int n, int npairs, int T, int H, int ka_max, hipStream_t s);
 int launch_cosine_attn(const float *F, int64_t f_gstride, const int32_t *f_idx, const float *Kmat,
                        const int32_t *k_idx, float *att, const int32_t *out_idx, int npairs, int T, int H,
                        hipStream_t s);

@@ -1137,7 +1137,10 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
                 RUN(drop(tmpA, TH, nullptr, c, TH, 0));
                 RUN(dense(s, tmpA, H, TH, nullptr, W.lv3, H, tmpB, H, TH, nullptr, c, T, H, H, 0));
                 RUN(dense(s, ws, H, H, I4, W.lk, H, kbuf, H, H, nullptr, b.nrows, 1, H, H, 0));
-                RUN(launch_cosine_attn(tmpB, TH, I5, kbuf, nullptr, sup, nullptr, b.nrows, T, H, s));
+                if (T <= 128 && H % 64 == 0)      // one block per instance: its pairs share the tile (csrc/rowops.hip)
+                    RUN(launch_cosine_attn_grouped(tmpB, TH, kbuf, I1, I2, sup, c, b.nrows, T, H, T, s));
+                else
+                    RUN(launch_cosine_attn(tmpB, TH, I5, kbuf, nullptr, sup, nullptr, b.nrows, T, H, s));
                 RUN(launch_superlative_pool(sup, ws, I4, I1, I2, b.variant, cat, c, T, H, s, LEN));
                 RUN(dense(s, cat, H, H, nullptr, W.supdense, H, vec, H, H, I3, c, 1, H, H, 1));
                 break;

@@ -87,6 +87,108 @@ __global__ void cosine_attn_kernel(const float *F, int64_t f_gstride, const int3
         att[(int64_t)idx_or_id(out_idx, p) * T + t] = (c + 1.0f) * 0.49f;
     }
 }
+// Grouped form for Superlative (modules.py:220-248): ALL Ka pairs of an instance score the same private [T,H] tile, so the
+// scores of an instance are one [Ka x H] . [H x T] product.  One block per instance walks H in 64-column chunks: the chunk's
+// K [Ka][64] and F [T][64] slices in LDS (rows 65 floats apart: conflict-free for both operand orders), the products on
+// v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate), the row norms summed from the same loaded values.
+// (cosine_attn_kernel above re-reads the instance's tile once per pair: 2 GB through L2 for 254 instances with Ka = T = 64,
+// 317 us of the training step's forward pass.)
+using f32x16_ro = __attribute__((ext_vector_type(16))) float;
+__global__ __launch_bounds__(256) void cosine_attn_grouped_kernel(const float *F, int64_t f_gstride, const float *Kmat,
+                                                                  const int32_t *pair_start, const int32_t *pair_cnt, float *att,
+                                                                  int n, int T, int H, int ka_max) {
+    extern __shared__ float sm[];          // kt [KP][65] | ft [TP][65] | nk [KP] | nf [TP]
+    const int i = blockIdx.x;
+    const int p0 = pair_start[i], Ka = pair_cnt[i];
+    const int TP = (T + 31) / 32 * 32, KP = (ka_max + 31) / 32 * 32;
+    float *kt = sm, *ft = kt + KP * 65, *nks = ft + TP * 65, *nfs = nks + KP;
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int r = lane & 31, kk = lane >> 5;
+    const float *f = F + (int64_t)i * f_gstride;
+    const int tilesT = TP / 32, tilesK = (Ka + 31) / 32, tiles = tilesT * tilesK;     // <= 16 (T, Ka <= 128)
+    f32x16_ro acc[4];                       // tiles part, part + 4, ...: up to 4 per wave
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
+    float sqf[4][8], sqk[4][8];             // row 32 m + part + 4 j of F / K: squares of this lane's column, summed over the chunks
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sqf[m][j] = sqk[m][j] = 0.f;
+    for (int c0 = 0; c0 < H; c0 += 64) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {               // loads first (8 independent ones per thread), then the LDS stores
+            if (32 * m >= TP) continue;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const int t = 32 * m + part + 4 * j; v[j] = t < T ? f[(int64_t)t * H + c0 + lane] : 0.f; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { ft[(32 * m + part + 4 * j) * 65 + lane] = v[j]; sqf[m][j] += v[j] * v[j]; }
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            if (32 * m >= KP) continue;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const int a = 32 * m + part + 4 * j; v[j] = a < Ka ? Kmat[(int64_t)(p0 + a) * H + c0 + lane] : 0.f; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { kt[(32 * m + part + 4 * j) * 65 + lane] = v[j]; sqk[m][j] += v[j] * v[j]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int tile = part + 4 * q;
+            if (tile < tiles) {
+                const int at = tile / tilesT, tt = tile - at * tilesT;
+                const float *ka = kt + (32 * at + r) * 65 + kk, *fb = ft + (32 * tt + r) * 65 + kk;
+                for (int c = 0; c < 64; c += 2) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[c], fb[c], acc[q], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // row norms: row 32 m + part + 4 j belongs to this wave alone
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float a = wave_sum(sqf[m][j]), b = wave_sum(sqk[m][j]);
+            if (lane == 0) {
+                if (32 * m < TP) nfs[32 * m + part + 4 * j] = a;
+                if (32 * m < KP) nks[32 * m + part + 4 * j] = b;
+            }
+        }
+    __syncthreads();
+    const float eps = 1e-8f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int tile = part + 4 * q;
+        if (tile >= tiles) continue;
+        const int at = tile / tilesT, tt = tile - at * tilesT;
+        const int t = 32 * tt + r;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int a = 32 * at + 8 * (e >> 2) + 4 * kk + (e & 3);
+            if (a < Ka && t < T) {
+                const float c = acc[q][e] / (fmaxf(sqrtf(nfs[t]), eps) * fmaxf(sqrtf(nks[a]), eps));
+                att[(int64_t)(p0 + a) * T + t] = (c + 1.0f) * 0.49f;
+            }
+        }
+    }
+}
+int launch_cosine_attn_grouped(const float *F, int64_t f_gstride, const float *Kmat, const int32_t *pair_start, const int32_t *pair_cnt,
+                               float *att, int n, int npairs, int T, int H, int ka_max, hipStream_t s) {
+    if (n == 0) return 0;
+    STAIR_ACCT("cosine_attn_grouped_kernel", ((int64_t)n * T * H + (int64_t)npairs * H + (int64_t)npairs * T) * 4);
+    STAIR_CHECK(H % 64 == 0 && T <= 128 && ka_max <= 128, "grouped cosine: H % 64 == 0, T and pairs per instance <= 128");
+    const int TP = (T + 31) / 32 * 32, KP = (ka_max + 31) / 32 * 32;
+    const size_t shmem = ((size_t)(KP + TP) * 65 + KP + TP) * sizeof(float);
+    if (shmem > 48 * 1024)
+        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cosine_attn_grouped_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(cosine_attn_grouped_kernel, dim3(n), dim3(256), shmem, s, F, f_gstride, Kmat, pair_start, pair_cnt, att, n, T, H, ka_max);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
 int launch_cosine_attn(const float *F, int64_t f_gstride, const int32_t *f_idx, const float *Kmat,
                        const int32_t *k_idx, float *att, const int32_t *out_idx, int npairs, int T, int H,
                        hipStream_t s) {
