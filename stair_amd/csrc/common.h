@@ -69,6 +69,12 @@ int launch_lstm_bwd(const stair_lstm_bwd_args &a, hipStream_t s);
 // STAIR_GEMM_TRACE=1: every GEMM launcher prints its shape to stderr (tools/gemm_shapes.py joins the lines with a rocprofv3 kernel trace)
 inline bool gemm_trace_on() { static const bool on = [] { const char *e = getenv("STAIR_GEMM_TRACE"); return e && e[0] == '1'; }(); return on; }
 
+struct TransposeBatch {          // up to 32 matrices transposed by one launch (launch_transpose_many)
+    const float *in[32]; float *out[32];
+    int rows[32], cols[32], first_tile[32];
+    int count;
+};
+int launch_transpose_many(const TransposeBatch &tb, int total_tiles, hipStream_t s);
 int launch_gemm_tn_tr(const stair_gemm_tn_args &a, hipStream_t s);      // -1: not this kernel's shape
 int launch_lstm_rec_coop(const stair_lstm_args &a, hipStream_t s);
 bool lstm_coop_usable(int Hh);

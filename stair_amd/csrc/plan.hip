@@ -1250,11 +1250,19 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
                              &W.f3[1], &W.f3[2], &W.f3[3], &W.fdense, &W.ff0[0], &W.ff0[1], &W.ff0[2], &W.ff3[0], &W.ff3[1],
                              &W.ff3[2], &W.ffdense, &W.hi0, &W.lv0, &W.lv3, &W.lk, &W.supdense, &W.tdense, &W.ta0, &W.ta3,
                              &W.xorl, &W.dec0, &W.dec3};
+        TransposeBatch tb;
+        tb.count = 0;
+        int tiles = 0;
+        static_assert(sizeof(lins) / sizeof(lins[0]) <= 32, "TransposeBatch holds 32 matrices");
         for (const Lin *l : lins) {
             const int64_t rows = ctx->numel[l->id + 1];                 // bias length = out features
             const int64_t cols = ctx->numel[l->id] / rows;
-            RUN(launch_transpose(l->w, B.wt + B.wt_off[l->id], (int)rows, (int)cols, s));
+            const int m = tb.count++;
+            tb.in[m] = l->w; tb.out[m] = B.wt + B.wt_off[l->id];
+            tb.rows[m] = (int)rows; tb.cols[m] = (int)cols; tb.first_tile[m] = tiles;
+            tiles += (int)(((rows + 31) / 32) * ((cols + 31) / 32));
         }
+        RUN(launch_transpose_many(tb, tiles, s));       // one launch for all 31 images
     }
 
     // ---- loss + decoder ------------------------------------------------------------------------
