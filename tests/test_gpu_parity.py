@@ -537,6 +537,23 @@ def test_captured_plan_replays_bit_exactly(matmul):
         model.forward_batch(qs, train=True).capture_graph()
 
 
+def test_forward_pass_is_bit_reproducible(matmul):
+    """The inference pass has no atomics (split-K partials are reduced in a fixed order, the cooperative recurrence adds its
+    exchanged pieces in a fixed order): 20 runs of one batch, every form, full hidden size, must agree bit for bit -- a data race
+    in one of the cross-workgroup hand-offs would show up here as a rare difference."""
+    config = dict(spec.DEFAULT_CONFIG)
+    model = _model(config, 4)
+    qs = synth.make_questions(config, 77, 40, forms=synth.ALL_FORMS)
+    first = model.forward_batch(qs).logits.clone()
+    for it in range(20):
+        again = model.forward_batch(qs).logits
+        if not torch.equal(again, first):
+            d = (again - first).abs().amax(1)
+            rows = d.nonzero().flatten().tolist()
+            raise AssertionError('run %d differs in %d rows (max %.3g): %s' % (it, len(rows), float(d.max()),
+                                                                           [(i, qs[i]['nmn_program_list'][0]) for i in rows[:8]]))
+
+
 def test_missing_gpu_tensor_fails_loudly():
     from stair_amd import ops
     with pytest.raises(RuntimeError):
