@@ -554,6 +554,24 @@ def test_forward_pass_is_bit_reproducible(matmul):
                                                                            [(i, qs[i]['nmn_program_list'][0]) for i in rows[:8]]))
 
 
+def test_forward_reads_no_uninitialised_workspace():
+    """Every workspace float a kernel reads was written earlier in the same pass: with the (reused) workspace filled with
+    NaN, 1e30 or -7 before the pass, the logits do not change by a bit -- uniform and mixed clip lengths."""
+    config = dict(spec.DEFAULT_CONFIG)
+    model = _model(config, 4)
+    batches = [synth.make_questions(config, 31, 24, forms=synth.ALL_FORMS), synth.make_questions(config, 32, 33, forms=synth.ALL_FORMS, T=40)]
+    ragged = synth.make_questions(config, 5, 24, forms=synth.ALL_FORMS)
+    for i, q in enumerate(ragged):
+        q['video_features'] = torch.as_tensor(q['video_features'])[:64 - (i * 7) % 40].clone()
+    batches.append(ragged)
+    for qs in batches:
+        ref = model.forward_batch(qs).logits.clone()
+        for poison in (float('nan'), 1e30, -7.0):
+            model._ws.fill_(poison)
+            got = model.forward_batch(qs).logits
+            assert torch.equal(got, ref), (poison, int(got.isnan().sum()))
+
+
 def test_missing_gpu_tensor_fails_loudly():
     from stair_amd import ops
     with pytest.raises(RuntimeError):
