@@ -588,3 +588,49 @@ def test_validation_loop_matches_reference(matmul):
             assert valid[module] == float('inf'), module
         else:
             assert valid[module] == pytest.approx(ref, rel=1e-4, abs=2e-5), module
+
+
+@pytest.mark.parametrize('ragged,supervised', [(False, True), (True, False)])
+def test_training_step_reads_no_uninitialised_workspace(ragged, supervised):
+    """Forward saves, gradient arenas, scratch: everything the backward pass reads was written in the same step.  With the
+    (reused) workspace filled with NaN / 1e30 before the step, the gradients carry no NaN and differ from the clean step only by
+    the order of the fp32 atomics (relative L2 < 1e-5)."""
+    from stair_amd import losses as L
+    from stair_amd.module_net import VideoNMN
+    from stair_amd.train import Trainer
+    config = dict(spec.DEFAULT_CONFIG)
+    w = synth.make_weights(config, 4)
+
+    def grads(poison):
+        model = VideoNMN(config, pretrain_modules=set(L.CRITERION_MODULES))
+        model.load_state_dict({k: torch.from_numpy(w[k].copy()) for k in spec.state_dict_keys(config)})
+        model = model.to(DEV)
+        tr = Trainer(model, dropout=0.0, lr=0.0)
+        qs = synth.make_questions(config, 31, 48, forms=synth.ALL_FORMS)
+        for q in qs:
+            sg = synth.make_gold(config, 0, q, T=64)
+            q['sg_res_by_step'] = {k: ([(n, torch.from_numpy(np.asarray(e))) for n, e in v] if isinstance(v, list) else v) for k, v in sg.items()}
+        video = torch.stack([torch.as_tensor(q['video_features']) for q in qs]).to(DEV)
+        vl = None
+        if ragged:
+            vl = [64 - (i * 7) % 40 for i in range(len(qs))]
+            for i, l in enumerate(vl):
+                video[i, l:] = 0
+        q_lens = [q['question'].shape[0] for q in qs]
+        question = torch.cat([torch.as_tensor(q['question']) for q in qs]).to(DEV)
+        answers = torch.tensor([q['answer'] for q in qs], dtype=torch.int32, device=DEV)
+        progs = [q['nmn_program_list'] for q in qs]
+        spans = [q['prog_str_to_question_tokens'] for q in qs]
+        kw = dict(questions=qs if supervised else None, video_len=vl)
+        tr.step(progs, spans, video, question, q_lens, answers, **kw)        # allocates the workspace
+        if poison is not None:
+            model._ws.fill_(poison)
+        tr.step(progs, spans, video, question, q_lens, answers, **kw)
+        torch.cuda.synchronize()
+        return tr.flat_g.clone()
+
+    ref = grads(None)
+    for poison in (float('nan'), 1e30):
+        g = grads(poison)
+        assert int(g.isnan().sum()) == 0, poison
+        assert float((g - ref).norm() / ref.norm()) < 1e-5, poison
