@@ -1,3 +1,7 @@
+#!/bin/bash
+# Runs on the GPU box (gpurun -- 'bash tools/collect_artefacts.sh'): the measurement set kept under profiles/ -- default bench line,
+# graph bench, 2-rank gloo rehearsal of bench.py on one card, rocprofv3 kernel stats of the training bench, row-kernel byte accounting.
+# Outputs go to gpurun_out/ (prefix r02_l_); copy what is to be judged into profiles/.
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
