@@ -244,6 +244,21 @@ int stair_temporal_relate_fwd(const float *att, const int32_t *att_idx, const in
                               float *out, const int32_t *out_idx, int32_t n, int32_t T, int32_t mode,
                               int32_t conv, int32_t ksize, const float *const w[6], stair_stream stream);
 
+/* Adjoint of stair_cosine_attn_fwd (autograd of nn.CosineSimilarity in modules.py:170-177,203-216): given d_att rows
+ * (gradient w.r.t. the (cos+1)*0.49 outputs, row out_idx[p]) ADD the gradients into dF (tile f_idx[p], same layout as F)
+ * and dK (row k_idx[p]); both must be initialised by the caller (several pairs may share a tile or a keyword row:
+ * fp32 atomics). */
+int stair_cosine_attn_bwd(const float *F, int64_t f_gstride, const int32_t *f_idx, const float *Kmat, const int32_t *k_idx,
+                          const float *d_att, const int32_t *out_idx, float *dF, float *dK, int32_t npairs, int32_t T,
+                          int32_t H, stair_stream stream);
+/* Adjoint of stair_temporal_relate_fwd (TemporalModule's relate nets, modules.py:255-277,317-323): d_out row out_idx[i]
+ * is the gradient w.r.t. the relate output of instance i; the gradient w.r.t. each of its att_k[i] attention rows is ADDED
+ * into d_att (rows att_idx[i] .. +att_k[i]-1, the mean over K splits evenly), the gradients of the three layers' weights
+ * and biases are ADDED into dw[6] (same order as w[6]); mode 0 (`while`) has no parameters. */
+int stair_temporal_relate_bwd(const float *att, const int32_t *att_idx, const int32_t *att_k, const float *d_out,
+                              const int32_t *out_idx, float *d_att, int32_t n, int32_t T, int32_t mode, int32_t conv,
+                              int32_t ksize, const float *const w[6], float *const dw[6], stair_stream stream);
+
 /* out[i] = x[i] / max(||x[i]||_2, 1e-12): L2Normalize, the contrastive / pretrain head of Filter,
  * Superlative and ToAction (module_net.py:21, 211-216).  x, out [n,H]. */
 int stair_l2normalize_fwd(const float *x, float *out, int32_t n, int32_t H, stair_stream stream);

@@ -1066,3 +1066,21 @@ int launch_scale_rows(float *G, const float *rs, int64_t rows, int H, hipStream_
     return 0;
 }
 }  // namespace stair
+
+// ---- C ABI: the backward halves of the building-block families exported in forward form (include/stair_hip.h) ----
+extern "C" int stair_cosine_attn_bwd(const float *F, int64_t f_gstride, const int32_t *f_idx, const float *Kmat, const int32_t *k_idx,
+                                     const float *d_att, const int32_t *out_idx, float *dF, float *dK, int32_t npairs, int32_t T,
+                                     int32_t H, stair_stream stream) {
+    STAIR_CHECK(F && Kmat && d_att && dF && dK && npairs >= 0 && T > 0 && H > 0, "bad argument");
+    return stair::launch_cosine_attn_bwd(F, f_gstride, f_idx, Kmat, k_idx, d_att, out_idx, dF, dK, npairs, T, H,
+                                         static_cast<hipStream_t>(stream));
+}
+extern "C" int stair_temporal_relate_bwd(const float *att, const int32_t *att_idx, const int32_t *att_k, const float *d_out,
+                                         const int32_t *out_idx, float *d_att, int32_t n, int32_t T, int32_t mode, int32_t conv,
+                                         int32_t ksize, const float *const w[6], float *const dw[6], stair_stream stream) {
+    STAIR_CHECK(att && att_idx && att_k && d_out && out_idx && d_att && n >= 0 && T > 0, "bad argument");
+    STAIR_CHECK(mode >= 0 && mode <= 3 && (mode == 0 || (w && dw)), "mode 1..3 needs the relate net's weights and gradient buffers");
+    return stair::launch_temporal_relate_bwd(att, att_idx, att_k, d_out, out_idx, d_att, n, T, mode, conv, ksize, w, dw,
+                                             static_cast<hipStream_t>(stream), nullptr);
+}
+

@@ -242,6 +242,15 @@ def cosine_attn(F, f_idx, Kmat, k_idx, npairs, T, H, out=None, out_idx=None):
     return out
 
 
+def cosine_attn_bwd(F, f_idx, Kmat, k_idx, d_att, npairs, T, H, out_idx=None):
+    """Adjoint of cosine_attn: returns (dF like F, dK like Kmat) for d_att [npairs (or rows of out_idx), T]."""
+    _req(F, 'F'); _req(Kmat, 'Kmat'); _req(d_att, 'd_att')
+    dF, dK = torch.zeros_like(F), torch.zeros_like(Kmat)
+    check(lib.stair_cosine_attn_bwd(_ptr(F), T * H, _ptr(f_idx), _ptr(Kmat), _ptr(k_idx), _ptr(d_att), _ptr(out_idx), _ptr(dF), _ptr(dK),
+                                    npairs, T, H, _stream()))
+    return dF, dK
+
+
 def cosine_topk(queries, keys, k, q_idx=None, n=None):
     """k best rows of `keys` [C,H] by cosine similarity for each query row (evaluate.py:95-98).  queries [rows,H];
     q_idx (int32, optional) picks the rows to rank.  Returns (idx [n,k] int32, sim [n,k]) best first."""
@@ -268,3 +277,16 @@ def temporal_relate(att, att_idx, att_k, n, T, mode, conv, ksize, w6):
     check(lib.stair_temporal_relate_fwd(_ptr(att), _ptr(att_idx), _ptr(att_k), _ptr(out), None, n, T, mode,
                                         1 if conv else 0, ksize, arr, _stream()))
     return out
+
+
+def temporal_relate_bwd(att, att_idx, att_k, d_out, n, T, mode, conv, ksize, w6):
+    """Adjoint of temporal_relate: returns (d_att like att, [dw0, db0, dw2, db2, dw4, db4] like w6) for d_out [n, T]."""
+    _req(att, 'att'); _req(d_out, 'd_out')
+    d_att = torch.zeros_like(att)
+    dws = [torch.zeros_like(w) if w is not None else None for w in w6]
+    arr = (C.c_void_p * 6)(*[(w.data_ptr() if w is not None else None) for w in w6])
+    darr = (C.c_void_p * 6)(*[(w.data_ptr() if w is not None else None) for w in dws])
+    out_idx = torch.arange(n, dtype=torch.int32, device=att.device)
+    check(lib.stair_temporal_relate_bwd(_ptr(att), _ptr(att_idx), _ptr(att_k), _ptr(d_out), _ptr(out_idx), _ptr(d_att), n, T, mode,
+                                        1 if conv else 0, ksize, arr, darr, _stream()))
+    return d_att, dws
