@@ -80,6 +80,13 @@ int launch_lstm_rec_coop(const stair_lstm_args &a, hipStream_t s);
 bool lstm_coop_usable(int Hh);
 int64_t lstm_coop_ws_bytes(int n);
 int launch_lstm_bwd_coop(const stair_lstm_bwd_args &a, hipStream_t s);
+int launch_lstm_rec_coop_pair(const stair_lstm_args &a, const stair_lstm_args &b, hipStream_t s);          // -1: not applicable
+int launch_lstm_bwd_coop_pair(const stair_lstm_bwd_args &a, const stair_lstm_bwd_args &b, hipStream_t s);  // -1: not applicable
+int launch_lstm_project(const stair_lstm_args &a, hipStream_t s);
+int launch_lstm_recur(const stair_lstm_args &a, hipStream_t s);
+int launch_lstm_bwd_recur(const stair_lstm_bwd_args &a, hipStream_t s);
+int launch_lstm_bwd_weights(const stair_lstm_bwd_args &a, hipStream_t s);
+bool lstm_bwd_takes_coop(const stair_lstm_bwd_args &a);
 int64_t lstm_coop_bwd_ws_bytes(int n);
 int launch_gemm_bf16x3(const stair_gemm_args &a, hipStream_t s);
 int launch_gemm_tn_bf16x3(const stair_gemm_tn_args &a, hipStream_t s);

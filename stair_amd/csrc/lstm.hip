@@ -743,7 +743,13 @@ __global__ __launch_bounds__(NWAVES * 64) void lstm_bwd_x3_kernel(LstmBwdParams 
 #undef B3_MFMA
 }
 
-int launch_lstm_bwd(const stair_lstm_bwd_args &a, hipStream_t s) {
+bool lstm_bwd_takes_coop(const stair_lstm_bwd_args &a) {
+    const char *cmax = getenv("STAIR_LSTM_COOP_BWD_MAX_N");
+    return a.coop_ws && lstm_coop_usable(a.Hh) && a.n <= (cmax ? atoi(cmax) : 1024);
+}
+
+// reverse-time recurrence only: gates (activated, saved by the forward pass) -> gate pre-activation gradients, in place
+int launch_lstm_bwd_recur(const stair_lstm_bwd_args &a, hipStream_t s) {
     STAIR_CHECK(a.n >= 0 && a.rows >= 0 && a.I > 0 && a.Hh > 0, "bad shape");
     STAIR_CHECK(a.Hh % 32 == 0 && a.Hh <= 256, "LSTM hidden size must be a multiple of 32, at most 256");
     STAIR_CHECK(a.gates && a.cbuf && a.out && a.d_out && a.whh_pack_ws && a.hprev_ws, "null buffer");
@@ -752,8 +758,7 @@ int launch_lstm_bwd(const stair_lstm_bwd_args &a, hipStream_t s) {
     // Cooperative BPTT (csrc/lstm_coop.hip) while every 32-sequence tile gets a group of its own: 338 us at n = 8 and 819 us at
     // n = 1024 against 727 / 920 us of the one-workgroup kernel; beyond that both are bound by the saved-state traffic
     // (2.8 GB per launch at n = 2048) and the one-workgroup kernel's 1.1 ms beats two tiles per group (1.6 ms).
-    const char *cmax = getenv("STAIR_LSTM_COOP_BWD_MAX_N");
-    if (a.coop_ws && lstm_coop_usable(Hh) && a.n <= (cmax ? atoi(cmax) : 1024)) {
+    if (lstm_bwd_takes_coop(a)) {
         if (int rc = launch_lstm_bwd_coop(a, s)) return rc;
     } else {
         const bool split = matmul_mode() != STAIR_MATMUL_F32 && Hh % 64 == 0;
@@ -790,6 +795,13 @@ int launch_lstm_bwd(const stair_lstm_bwd_args &a, hipStream_t s) {
         else hipLaunchKernelGGL((lstm_bwd_kernel<1, 2>), grid, dim3(128), shmem, s, p);
         STAIR_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+// h(t-1) rows + the four weight-gradient products of a layer whose gate gradients are in a.gates
+int launch_lstm_bwd_weights(const stair_lstm_bwd_args &a, hipStream_t s) {
+    if (a.n == 0 || a.rows == 0) return 0;
+    const int Hh = a.Hh;
     hipLaunchKernelGGL(lstm_hprev_kernel, dim3(a.n), dim3(256), 0, s, a.out, a.ldo, a.seq_off, a.seq_len, a.n, Hh, a.hprev_ws, a.gates);
     STAIR_LAUNCH_CHECK();
     // weight gradients: dW_ih = dG^T X, dW_hh = dG^T Hprev, db_ih = db_hh = colsum(dG)
@@ -809,7 +821,13 @@ int launch_lstm_bwd(const stair_lstm_bwd_args &a, hipStream_t s) {
     return 0;
 }
 
-int launch_lstm(const stair_lstm_args &a, hipStream_t s) {
+int launch_lstm_bwd(const stair_lstm_bwd_args &a, hipStream_t s) {
+    if (int rc = launch_lstm_bwd_recur(a, s)) return rc;
+    return launch_lstm_bwd_weights(a, s);
+}
+
+// input projection (+ bias sums, tail zeroing) of a layer: everything of launch_lstm before the recurrence
+int launch_lstm_project(const stair_lstm_args &a, hipStream_t s) {
     STAIR_CHECK(a.n >= 0 && a.rows >= 0 && a.I > 0 && a.Hh > 0, "bad shape");
     STAIR_CHECK(a.Hh % 32 == 0 && a.Hh <= 256, "LSTM hidden size must be a multiple of 32, at most 256");
     STAIR_CHECK(a.I % 4 == 0 && a.ldx % 4 == 0, "LSTM input size / ldx must be multiples of 4");
@@ -848,6 +866,13 @@ int launch_lstm(const stair_lstm_args &a, hipStream_t s) {
         hipLaunchKernelGGL(lstm_zero_tail_kernel, dim3(a.n), dim3(256), 0, s, a.out, a.ldo, a.seq_off, a.seq_len, Hh);
         STAIR_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+// the recurrence over projected inputs (a.xproj_ws)
+int launch_lstm_recur(const stair_lstm_args &a, hipStream_t s) {
+    if (a.n == 0 || a.rows == 0) return 0;
+    const int Hh = a.Hh;
     if (a.coop_ws && lstm_coop_usable(Hh)) return launch_lstm_rec_coop(a, s);   // hidden units split over co-resident workgroups
     const bool split = matmul_mode() != STAIR_MATMUL_F32 && Hh % 64 == 0;     // the split kernel walks k blocks in pairs
     if (split) {
@@ -877,6 +902,11 @@ int launch_lstm(const stair_lstm_args &a, hipStream_t s) {
     else hipLaunchKernelGGL((lstm_rec_kernel<1, 2>), grid, dim3(128), shmem, s, p);
     STAIR_LAUNCH_CHECK();
     return 0;
+}
+
+int launch_lstm(const stair_lstm_args &a, hipStream_t s) {
+    if (int rc = launch_lstm_project(a, s)) return rc;
+    return launch_lstm_recur(a, s);
 }
 
 }  // namespace stair

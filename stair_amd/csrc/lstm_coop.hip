@@ -65,13 +65,13 @@ __device__ __forceinline__ int lds_unit(int seq, int chunk) { return (seq * 32 +
 // middle of the next compute (by then the stores have drained: the wait costs nothing), its slab loads are ISSUED at the
 // start of the compute after that and WRITTEN to LDS at its end -- with NT = 3 that is exactly when tile x is next, so no
 // phase waits for memory; NT = 2 and 1 expose part of the latency (small batches).
-template <bool TRAIN, int NT, bool PROF = false>
-__global__ __launch_bounds__(512, 1) void lstm_rec_coop_kernel(CoopParams p) {
-    extern __shared__ __attribute__((aligned(16))) char hl[];      // [NT tiles][2 planes][32 seq][256] bf16, swizzled
+template <bool TRAIN, int NT, bool PROF>
+__device__ __forceinline__ void lstm_rec_coop_body(const CoopParams &p, const int b, char *hl) {
+    // hl: [NT tiles][2 planes][32 seq][256] bf16, swizzled
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    // group placement: blocks with equal blockIdx % 8 share an XCD (speed only); the 4 workgroups of a group do
-    const int b = blockIdx.x, q8 = b >> 3;
+    // group placement: blocks with equal b % 8 share an XCD (speed only); the 4 workgroups of a group do
+    const int q8 = b >> 3;
     const int j = q8 & 3, g = (b & 7) + 8 * (q8 >> 2);
     const int G = 2 * p.gpd;
     if (g >= G) return;                                            // whole groups only: nobody waits for this workgroup
@@ -306,8 +306,25 @@ __global__ __launch_bounds__(512, 1) void lstm_rec_coop_kernel(CoopParams p) {
         ebase += lmax + 1;
         __syncthreads();                                           // LDS is re-zeroed for the next chunk
     }
-    if (PROF && blockIdx.x == 0 && tid == 0)
+    if (PROF && b == 0 && tid == 0)
         for (int i = 0; i < 8; ++i) reinterpret_cast<unsigned long long *>(p.err + 8)[i] = prof[i];
+}
+
+template <bool TRAIN, int NT, bool PROF = false>
+__global__ __launch_bounds__(512, 1) void lstm_rec_coop_kernel(CoopParams p) {
+    extern __shared__ __attribute__((aligned(16))) char hl_dyn[];
+    lstm_rec_coop_body<TRAIN, NT, PROF>(p, (int)blockIdx.x, hl_dyn);
+}
+
+// Two recurrences in ONE launch (the video and the text encoder of a batch small enough that both sets of groups are
+// co-resident: nb_a + nb_b workgroups <= CUs): blocks [0, nb_a) run `a`, the rest run `b`.  At 128 questions the two
+// encoders occupy 32 workgroups each and their per-step latency (4 exchange hops) is what a recurrence costs, so running
+// them one after the other left seven eighths of the chip idle twice.
+template <bool TRAIN>
+__global__ __launch_bounds__(512, 1) void lstm_rec_coop_pair_kernel(CoopParams a, CoopParams b, int nb_a) {
+    extern __shared__ __attribute__((aligned(16))) char hl_dyn[];
+    if ((int)blockIdx.x < nb_a) lstm_rec_coop_body<TRAIN, 1, false>(a, (int)blockIdx.x, hl_dyn);
+    else lstm_rec_coop_body<TRAIN, 1, false>(b, (int)blockIdx.x - nb_a, hl_dyn);
 }
 
 // tiles per group: 3 once the batch fills most of the chip that way, else as many as it takes to use all groups
@@ -331,16 +348,25 @@ bool lstm_coop_usable(int Hh) {
     return on && Hh == CH && matmul_mode() != STAIR_MATMUL_F32;
 }
 
-int launch_lstm_rec_coop(const stair_lstm_args &a, hipStream_t s) {
+static int coop_cu_count() {
+    static const int n = [] {
+        int dev = 0, v = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 256;
+        return v;
+    }();
+    return n;
+}
+
+// fills the kernel parameters of one recurrence and enqueues its per-launch memsets (flags, h_n)
+static int coop_prepare(const stair_lstm_args &a, hipStream_t s, CoopParams &p, int &nt, int &blocks) {
     STAIR_CHECK(a.Hh == CH, "cooperative recurrence is built for Hh = 256");
     STAIR_CHECK(a.coop_ws && a.coop_ws_bytes >= lstm_coop_ws_bytes(a.n), "coop_ws missing or too small");
     STAIR_CHECK((reinterpret_cast<uintptr_t>(a.coop_ws) & 255) == 0, "coop_ws must be 256-byte aligned");
     STAIR_CHECK(a.ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.h_n) & 15) == 0,
                 "out / h_n must be 16-byte aligned with ldo % 4 == 0");
-    CoopParams p;
     p.xproj = a.xproj_ws; p.w_hh[0] = a.w_hh[0]; p.w_hh[1] = a.w_hh[1]; p.seq_off = a.seq_off; p.seq_len = a.seq_len;
     p.out = a.out; p.ldo = a.ldo; p.h_n = a.h_n; p.cbuf = a.cbuf; p.n = a.n;
-    int nt = 1;
+    nt = 1;
     coop_geometry(a.n, nt, p.gpd);
     const int G = 2 * p.gpd;
     char *base = static_cast<char *>(a.coop_ws);
@@ -353,17 +379,29 @@ int launch_lstm_rec_coop(const stair_lstm_args &a, hipStream_t s) {
     STAIR_HIP(hipMemsetAsync(p.flags, 0, (size_t)flag_words * 4, s));
     // h_n of empty sequences is zero and the kernel only writes it at a sequence's last step
     STAIR_HIP(hipMemsetAsync(a.h_n, 0, (size_t)a.n * 2 * CH * sizeof(float), s));
-    const int blocks = 32 * ((G + 7) / 8);                       // group g = (b & 7) + 8 * (b >> 5); workgroup (b >> 3) & 3
+    blocks = 32 * ((G + 7) / 8);                                 // group g = (b & 7) + 8 * (b >> 5); workgroup (b >> 3) & 3
+    return 0;
+}
+
+static void coop_attrs() {
     static bool attr_set = false;
-    if (!attr_set) {
-#define C_ATTR(TR_, NT_) STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_rec_coop_kernel<TR_, NT_>), hipFuncAttributeMaxDynamicSharedMemorySize, NT_ * TILE_BYTES + 64));
-        C_ATTR(false, 1) C_ATTR(false, 2) C_ATTR(false, 3) C_ATTR(true, 1) C_ATTR(true, 2) C_ATTR(true, 3)
+    if (attr_set) return;
+#define C_ATTR(TR_, NT_) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_rec_coop_kernel<TR_, NT_>), hipFuncAttributeMaxDynamicSharedMemorySize, NT_ * TILE_BYTES + 64);
+    C_ATTR(false, 1) C_ATTR(false, 2) C_ATTR(false, 3) C_ATTR(true, 1) C_ATTR(true, 2) C_ATTR(true, 3)
 #undef C_ATTR
-        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_rec_coop_kernel<false, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 1 * TILE_BYTES + 64));
-        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_rec_coop_kernel<false, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE_BYTES + 64));
-        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_rec_coop_kernel<false, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * TILE_BYTES + 64));
-        attr_set = true;
-    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_rec_coop_kernel<false, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 1 * TILE_BYTES + 64);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_rec_coop_kernel<false, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE_BYTES + 64);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_rec_coop_kernel<false, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * TILE_BYTES + 64);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_rec_coop_pair_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 1 * TILE_BYTES + 64);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_rec_coop_pair_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 1 * TILE_BYTES + 64);
+    attr_set = true;
+}
+
+int launch_lstm_rec_coop(const stair_lstm_args &a, hipStream_t s) {
+    CoopParams p;
+    int nt = 1, blocks = 0;
+    if (int rc = coop_prepare(a, s, p, nt, blocks)) return rc;
+    coop_attrs();
     static const bool prof = [] { const char *e = getenv("STAIR_LSTM_COOP_PROF"); return e && e[0] == '1'; }();   // diagnostic build, never the product
     if (prof && !a.cbuf) {
         if (nt == 1) hipLaunchKernelGGL((lstm_rec_coop_kernel<false, 1, true>), dim3(blocks), dim3(512), 1 * TILE_BYTES + 64, s, p);
@@ -381,6 +419,33 @@ int launch_lstm_rec_coop(const stair_lstm_args &a, hipStream_t s) {
     return 0;
 }
 
+// Both recurrences in one launch when each has one sequence tile per group and all their workgroups are co-resident;
+// -1: not applicable (the caller runs them one after the other).  a and b need DISJOINT coop_ws regions.
+int launch_lstm_rec_coop_pair(const stair_lstm_args &a, const stair_lstm_args &b, hipStream_t s) {
+    static const bool on = [] { const char *e = getenv("STAIR_LSTM_COOP_PAIR"); return !(e && e[0] == '0'); }();
+    if (!on || !a.coop_ws || !b.coop_ws || a.coop_ws == b.coop_ws || !lstm_coop_usable(a.Hh) || !lstm_coop_usable(b.Hh)) return -1;
+    if ((a.cbuf != nullptr) != (b.cbuf != nullptr) || a.n <= 0 || b.n <= 0) return -1;
+    int nta = 1, ntb = 1, ga = 0, gb = 0;
+    coop_geometry(a.n, nta, ga);
+    coop_geometry(b.n, ntb, gb);
+    if (nta != 1 || ntb != 1) return -1;
+    if (32 * ((2 * ga + 7) / 8) + 32 * ((2 * gb + 7) / 8) > coop_cu_count()) return -1;
+    static const bool prof = [] { const char *e = getenv("STAIR_LSTM_COOP_PROF"); return e && e[0] == '1'; }();
+    if (prof) return -1;
+    CoopParams pa, pb;
+    int blocks_a = 0, blocks_b = 0;
+    if (int rc = coop_prepare(a, s, pa, nta, blocks_a)) return rc;
+    if (int rc = coop_prepare(b, s, pb, ntb, blocks_b)) return rc;
+    coop_attrs();
+    if (a.cbuf) hipLaunchKernelGGL(lstm_rec_coop_pair_kernel<true>, dim3(blocks_a + blocks_b), dim3(512), 1 * TILE_BYTES + 64, s, pa, pb, blocks_a);
+    else hipLaunchKernelGGL(lstm_rec_coop_pair_kernel<false>, dim3(blocks_a + blocks_b), dim3(512), 1 * TILE_BYTES + 64, s, pa, pb, blocks_a);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace stair
+
+namespace stair {
 
 // =============================================================================================
 // Cooperative BPTT: the reverse-time recurrence with the same ownership as the forward kernel above.
@@ -418,11 +483,11 @@ struct CoopBwdParams {
 }  // namespace
 
 template <int NT>
-__global__ __launch_bounds__(512, 1) void lstm_bwd_coop_kernel(CoopBwdParams p) {
-    extern __shared__ __attribute__((aligned(16))) char hl[];      // [NT tiles][2 planes][32 seq][256 local gate rows] bf16, swizzled; counters
+__device__ __forceinline__ void lstm_bwd_coop_body(const CoopBwdParams &p, const int b, char *hl) {
+    // hl: [NT tiles][2 planes][32 seq][256 local gate rows] bf16, swizzled; counters
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    const int b = blockIdx.x, q8 = b >> 3;
+    const int q8 = b >> 3;
     const int j = q8 & 3, g = (b & 7) + 8 * (q8 >> 2);
     const int G = 2 * p.gpd;
     if (g >= G) return;
@@ -607,22 +672,34 @@ __global__ __launch_bounds__(512, 1) void lstm_bwd_coop_kernel(CoopBwdParams p) 
     }
 }
 
+template <int NT>
+__global__ __launch_bounds__(512, 1) void lstm_bwd_coop_kernel(CoopBwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) char hl_dyn[];
+    lstm_bwd_coop_body<NT>(p, (int)blockIdx.x, hl_dyn);
+}
+
+// BPTT of two encoders in one launch (see lstm_rec_coop_pair_kernel)
+__global__ __launch_bounds__(512, 1) void lstm_bwd_coop_pair_kernel(CoopBwdParams a, CoopBwdParams b, int nb_a) {
+    extern __shared__ __attribute__((aligned(16))) char hl_dyn[];
+    if ((int)blockIdx.x < nb_a) lstm_bwd_coop_body<1>(a, (int)blockIdx.x, hl_dyn);
+    else lstm_bwd_coop_body<1>(b, (int)blockIdx.x - nb_a, hl_dyn);
+}
+
 int64_t lstm_coop_bwd_ws_bytes(int n) {
     (void)n;
     const int G = 64;
     return (int64_t)2 * G * 2 * BSLAB_BYTES + (int64_t)(G * 2 * CP * FLAG_STRIDE + 64) * 4;
 }
 
-int launch_lstm_bwd_coop(const stair_lstm_bwd_args &a, hipStream_t s) {
+static int coop_bwd_prepare(const stair_lstm_bwd_args &a, hipStream_t s, CoopBwdParams &p, int &nt, int &blocks) {
     STAIR_CHECK(a.Hh == CH, "cooperative BPTT is built for Hh = 256");
     STAIR_CHECK(a.coop_ws && a.coop_ws_bytes >= lstm_coop_bwd_ws_bytes(a.n), "coop_ws missing or too small");
     STAIR_CHECK((reinterpret_cast<uintptr_t>(a.coop_ws) & 255) == 0, "coop_ws must be 256-byte aligned");
     STAIR_CHECK(a.ldd % 4 == 0 && (reinterpret_cast<uintptr_t>(a.d_out) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.gates) & 15) == 0 &&
                 (reinterpret_cast<uintptr_t>(a.cbuf) & 15) == 0, "gates / cbuf / d_out must be 16-byte aligned with ldd % 4 == 0");
-    CoopBwdParams p;
     p.G = a.gates; p.cbuf = a.cbuf; p.d_out = a.d_out; p.ldd = a.ldd; p.d_hn = a.d_hn;
     p.w_hh[0] = a.w_hh[0]; p.w_hh[1] = a.w_hh[1]; p.seq_off = a.seq_off; p.seq_len = a.seq_len; p.n = a.n;
-    int nt = 1;
+    nt = 1;
     coop_geometry(a.n, nt, p.gpd);
     if (nt > 2) nt = 2;
     p.gpd = std::max(1, std::min((a.n + 32 * nt - 1) / (32 * nt), 32));
@@ -634,15 +711,46 @@ int launch_lstm_bwd_coop(const stair_lstm_bwd_args &a, hipStream_t s) {
     p.flags = reinterpret_cast<unsigned *>(base + slab_bytes);
     p.err = p.flags + G * nt * CP * FLAG_STRIDE;
     STAIR_HIP(hipMemsetAsync(p.flags, 0, (size_t)flag_words * 4, s));
-    const int blocks = 32 * ((G + 7) / 8);
+    blocks = 32 * ((G + 7) / 8);
+    return 0;
+}
+
+static void coop_bwd_attrs() {
     static bool attr_set = false;
-    if (!attr_set) {
-        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_bwd_coop_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 1 * TILE_BYTES + 64));
-        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_bwd_coop_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE_BYTES + 64));
-        attr_set = true;
-    }
+    if (attr_set) return;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_bwd_coop_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 1 * TILE_BYTES + 64);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_bwd_coop_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE_BYTES + 64);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_bwd_coop_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 1 * TILE_BYTES + 64);
+    attr_set = true;
+}
+
+int launch_lstm_bwd_coop(const stair_lstm_bwd_args &a, hipStream_t s) {
+    CoopBwdParams p;
+    int nt = 1, blocks = 0;
+    if (int rc = coop_bwd_prepare(a, s, p, nt, blocks)) return rc;
+    coop_bwd_attrs();
     if (nt == 1) hipLaunchKernelGGL((lstm_bwd_coop_kernel<1>), dim3(blocks), dim3(512), 1 * TILE_BYTES + 64, s, p);
     else hipLaunchKernelGGL((lstm_bwd_coop_kernel<2>), dim3(blocks), dim3(512), 2 * TILE_BYTES + 64, s, p);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
+// BPTT of two encoders in one launch; -1: not applicable.  a and b need DISJOINT coop_ws regions.
+int launch_lstm_bwd_coop_pair(const stair_lstm_bwd_args &a, const stair_lstm_bwd_args &b, hipStream_t s) {
+    static const bool on = [] { const char *e = getenv("STAIR_LSTM_COOP_PAIR"); return !(e && e[0] == '0'); }();
+    if (!on || !a.coop_ws || !b.coop_ws || a.coop_ws == b.coop_ws || !lstm_coop_usable(a.Hh) || !lstm_coop_usable(b.Hh)) return -1;
+    if (a.n <= 0 || b.n <= 0) return -1;
+    int nta = 1, ntb = 1, ga = 0, gb = 0;
+    coop_geometry(a.n, nta, ga);
+    coop_geometry(b.n, ntb, gb);
+    if (nta != 1 || ntb != 1) return -1;
+    if (32 * ((2 * ga + 7) / 8) + 32 * ((2 * gb + 7) / 8) > coop_cu_count()) return -1;
+    CoopBwdParams pa, pb;
+    int blocks_a = 0, blocks_b = 0;
+    if (int rc = coop_bwd_prepare(a, s, pa, nta, blocks_a)) return rc;
+    if (int rc = coop_bwd_prepare(b, s, pb, ntb, blocks_b)) return rc;
+    coop_bwd_attrs();
+    hipLaunchKernelGGL(lstm_bwd_coop_pair_kernel, dim3(blocks_a + blocks_b), dim3(512), 1 * TILE_BYTES + 64, s, pa, pb, blocks_a);
     STAIR_LAUNCH_CHECK();
     return 0;
 }

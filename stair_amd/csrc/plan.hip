@@ -317,7 +317,7 @@ struct stair_plan {
     int64_t coop_bytes = 0;
     // workspace layout (float offsets)
     int64_t o_idx = 0, o_vec = 0, o_map = 0, o_att = 0, o_tok = 0, o_qfeat = 0, o_vhn = 0, o_xpv = 0, o_xpt = 0,
-            o_bias = 0, o_wpack = 0, o_wplanes = 0, o_coop = 0, o_splitk = 0, o_tmpA = 0, o_tmpB = 0, o_kbuf = 0, o_cat = 0, o_hid = 0, o_rs = 0, o_sup = 0, o_extra = 0,
+            o_bias = 0, o_wpack = 0, o_wplanes = 0, o_coop = 0, o_coop2 = 0, o_splitk = 0, o_tmpA = 0, o_tmpB = 0, o_kbuf = 0, o_cat = 0, o_hid = 0, o_rs = 0, o_sup = 0, o_extra = 0,
             o_logits = 0, total = 0;
     // training only
     bool train = false;
@@ -694,7 +694,8 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
     pl->o_wplanes = ctx->cfg.video_size % 32 == 0 ? take(4 * H * ctx->cfg.video_size, 64) : 0;   // video W_ih hi/lo planes (bf16 features): 2 x [4H, V] bf16
     pl->coop_bytes = std::max(lstm_coop_ws_bytes(pl->n_vid), lstm_coop_ws_bytes(n));
     if (pl->train) pl->coop_bytes = std::max(pl->coop_bytes, std::max(lstm_coop_bwd_ws_bytes(pl->n_vid), lstm_coop_bwd_ws_bytes(n)));
-    pl->o_coop = take((pl->coop_bytes + 3) / 4, 64);   // h exchange slabs + flags of the cooperative recurrence (both encoders, in turn)
+    pl->o_coop = take((pl->coop_bytes + 3) / 4, 64);   // exchange slabs + flags of the cooperative recurrence (video encoder)
+    pl->o_coop2 = take((pl->coop_bytes + 3) / 4, 64);  // the text encoder's: the two recurrences share a launch when both fit on the chip
     pl->o_splitk = take(kSplitKFloats, 64);      // partial sums of split-K launches (<= 64 output tiles x 16 pieces)
     pl->o_tmpA = take((int64_t)std::max(pl->maxI, 1) * T * H, 64);
     pl->o_tmpB = take((int64_t)std::max(pl->maxI, 1) * T * H, 64);
@@ -1003,7 +1004,7 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
     };
     // ---- encoders (module_net.py:74-75) ------------------------------------------------------
     {
-        stair_lstm_args a = {};
+        stair_lstm_args a = {}, t = {};
         a.x = video; a.ldx = V; a.rows = pl->n_vid * T; a.n = pl->n_vid; a.max_len = T; a.I = V; a.Hh = Hh;
         if (flags & STAIR_RUN_VIDEO_BF16) {
             STAIR_CHECK(V % 32 == 0, "bf16 clip features need video_size % 32 == 0");
@@ -1019,21 +1020,28 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
         a.out = map; a.ldo = H; a.h_n = ws + pl->o_vhn;
         a.coop_ws = ws + pl->o_coop; a.coop_ws_bytes = pl->coop_bytes;
         a.cbuf = pl->train ? ws + pl->o_cv : nullptr;
-        RUN(launch_lstm(a, s));
-    }
-    {
-        stair_lstm_args a = {};
-        a.x = question; a.ldx = E; a.rows = pl->rows_q; a.n = n; a.max_len = pl->max_q; a.I = E; a.Hh = Hh;
-        a.seq_off = didx + pl->off_seqt;
+
+        t.x = question; t.ldx = E; t.rows = pl->rows_q; t.n = n; t.max_len = pl->max_q; t.I = E; t.Hh = Hh;
+        t.seq_off = didx + pl->off_seqt;
         for (int d = 0; d < 2; ++d) {
-            a.w_ih[d] = W.enc[1][4 * d]; a.w_hh[d] = W.enc[1][4 * d + 1];
-            a.b_ih[d] = W.enc[1][4 * d + 2]; a.b_hh[d] = W.enc[1][4 * d + 3];
+            t.w_ih[d] = W.enc[1][4 * d]; t.w_hh[d] = W.enc[1][4 * d + 1];
+            t.b_ih[d] = W.enc[1][4 * d + 2]; t.b_hh[d] = W.enc[1][4 * d + 3];
         }
-        a.xproj_ws = ws + pl->o_xpt; a.bias_ws = ws + pl->o_bias + 4 * H; a.whh_pack_ws = ws + pl->o_wpack + 2 * (int64_t)H * H;
-        a.out = tok; a.ldo = H; a.h_n = qfeat;
-        a.coop_ws = ws + pl->o_coop; a.coop_ws_bytes = pl->coop_bytes;
-        a.cbuf = pl->train ? ws + pl->o_ct : nullptr;
-        RUN(launch_lstm(a, s));
+        t.xproj_ws = ws + pl->o_xpt; t.bias_ws = ws + pl->o_bias + 4 * H; t.whh_pack_ws = ws + pl->o_wpack + 2 * (int64_t)H * H;
+        t.out = tok; t.ldo = H; t.h_n = qfeat;
+        t.coop_ws = ws + pl->o_coop2; t.coop_ws_bytes = pl->coop_bytes;
+        t.cbuf = pl->train ? ws + pl->o_ct : nullptr;
+
+        // both input projections, then the two recurrences -- in ONE launch while all their workgroups fit on the chip
+        // (csrc/lstm_coop.hip, lstm_rec_coop_pair_kernel), else one after the other
+        RUN(launch_lstm_project(a, s));
+        RUN(launch_lstm_project(t, s));
+        const int rc_pair = launch_lstm_rec_coop_pair(a, t, s);
+        if (rc_pair > 0) return rc_pair;
+        if (rc_pair < 0) {
+            RUN(launch_lstm_recur(a, s));
+            RUN(launch_lstm_recur(t, s));
+        }
     }
 
     // ---- program levels ----------------------------------------------------------------------
@@ -1403,27 +1411,42 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
     }
 
     // ---- encoders ------------------------------------------------------------------------------------
-    for (int e = 1; e >= 0; --e) {
-        stair_lstm_bwd_args a = {};
-        if (e == 0) {
-            a.x = video; a.ldx = V; a.rows = pl->n_vid * T; a.max_len = T; a.I = V; a.seq_off = didx + pl->off_seqv;
-            if (pl->ragged) a.seq_len = didx + pl->off_lenv;
-            if (flags & STAIR_RUN_VIDEO_BF16) { a.x = nullptr; a.x_bf16 = video; }
-            a.gates = ws + pl->o_xpv; a.cbuf = ws + pl->o_cv; a.out = map; a.d_out = g_map; a.d_hn = nullptr;
-            a.whh_pack_ws = ws + pl->o_wpack;
+    {
+        stair_lstm_bwd_args enc[2] = {};
+        for (int e = 0; e < 2; ++e) {
+            stair_lstm_bwd_args &a = enc[e];
+            if (e == 0) {
+                a.x = video; a.ldx = V; a.rows = pl->n_vid * T; a.max_len = T; a.I = V; a.seq_off = didx + pl->off_seqv;
+                if (pl->ragged) a.seq_len = didx + pl->off_lenv;
+                if (flags & STAIR_RUN_VIDEO_BF16) { a.x = nullptr; a.x_bf16 = video; }
+                a.gates = ws + pl->o_xpv; a.cbuf = ws + pl->o_cv; a.out = map; a.d_out = g_map; a.d_hn = nullptr;
+                a.whh_pack_ws = ws + pl->o_wpack;
+                a.coop_ws = ws + pl->o_coop;
+            } else {
+                a.x = question; a.ldx = E; a.rows = pl->rows_q; a.max_len = pl->max_q; a.I = E; a.seq_off = didx + pl->off_seqt;
+                a.gates = ws + pl->o_xpt; a.cbuf = ws + pl->o_ct; a.out = ws + pl->o_tok; a.d_out = g_tok; a.d_hn = g_qfeat;
+                a.whh_pack_ws = ws + pl->o_wpack + 2 * (int64_t)H * H;
+                a.coop_ws = ws + pl->o_coop2;
+            }
+            a.n = e == 0 ? pl->n_vid : n; a.Hh = Hh; a.ldo = H; a.ldd = H; a.hprev_ws = ws + pl->o_hprev;
+            a.coop_ws_bytes = pl->coop_bytes;
+            for (int d = 0; d < 2; ++d) {
+                a.w_hh[d] = W.enc[e][4 * d + 1];
+                a.dw_ih[d] = W.denc[e][4 * d]; a.dw_hh[d] = W.denc[e][4 * d + 1];
+                a.db_ih[d] = W.denc[e][4 * d + 2]; a.db_hh[d] = W.denc[e][4 * d + 3];
+            }
+        }
+        // the two reverse-time recurrences in one launch while both fit on the chip, then each layer's weight gradients
+        int rc_pair = -1;
+        if (lstm_bwd_takes_coop(enc[0]) && lstm_bwd_takes_coop(enc[1])) rc_pair = launch_lstm_bwd_coop_pair(enc[1], enc[0], s);
+        if (rc_pair > 0) return rc_pair;
+        if (rc_pair < 0) {
+            RUN(launch_lstm_bwd(enc[1], s));
+            RUN(launch_lstm_bwd(enc[0], s));
         } else {
-            a.x = question; a.ldx = E; a.rows = pl->rows_q; a.max_len = pl->max_q; a.I = E; a.seq_off = didx + pl->off_seqt;
-            a.gates = ws + pl->o_xpt; a.cbuf = ws + pl->o_ct; a.out = ws + pl->o_tok; a.d_out = g_tok; a.d_hn = g_qfeat;
-            a.whh_pack_ws = ws + pl->o_wpack + 2 * (int64_t)H * H;
+            RUN(launch_lstm_bwd_weights(enc[1], s));
+            RUN(launch_lstm_bwd_weights(enc[0], s));
         }
-        a.n = e == 0 ? pl->n_vid : n; a.Hh = Hh; a.ldo = H; a.ldd = H; a.hprev_ws = ws + pl->o_hprev;
-        a.coop_ws = ws + pl->o_coop; a.coop_ws_bytes = pl->coop_bytes;
-        for (int d = 0; d < 2; ++d) {
-            a.w_hh[d] = W.enc[e][4 * d + 1];
-            a.dw_ih[d] = W.denc[e][4 * d]; a.dw_hh[d] = W.denc[e][4 * d + 1];
-            a.db_ih[d] = W.denc[e][4 * d + 2]; a.db_hh[d] = W.denc[e][4 * d + 3];
-        }
-        RUN(launch_lstm_bwd(a, s));
     }
 #undef RUN
     return 0;
@@ -1515,6 +1538,7 @@ extern "C" int stair_plan_regions(stair_plan *pl, const stair_ctx *ctx, const ch
     add("wpack", pl->o_wpack, 4 * H * H);
     if (ctx->cfg.video_size % 32 == 0) add("wplanes", pl->o_wplanes, 4 * H * ctx->cfg.video_size);
     add("coop", pl->o_coop, (pl->coop_bytes + 3) / 4);
+    add("coop2", pl->o_coop2, (pl->coop_bytes + 3) / 4);
     add("splitk", pl->o_splitk, kSplitKFloats);
     add("tmpA", pl->o_tmpA, (int64_t)std::max(pl->maxI, 1) * T * H);
     add("tmpB", pl->o_tmpB, (int64_t)std::max(pl->maxI, 1) * T * H);
