@@ -443,10 +443,6 @@ int launch_lstm_rec_coop_pair(const stair_lstm_args &a, const stair_lstm_args &b
     return 0;
 }
 
-}  // namespace stair
-
-namespace stair {
-
 // =============================================================================================
 // Cooperative BPTT: the reverse-time recurrence with the same ownership as the forward kernel above.
 //
