@@ -17,7 +17,9 @@
 //     MI355X_MICROARCH.md "Valid forms"): every storing wave drains vmcnt, the workgroup barrier, ONE lane stores the
 //     epoch flag; a consumer polls the four flags relaxed, then every load of the slab is an sc1 load.  Two sequence
 //     tiles (A, B) are interleaved so that the hand-off of one tile hides behind the MFMAs of the other.
-// Every spin is bounded; on a timeout an error word is set and the launch still drains.
+// Every spin is bounded; on a timeout an error word is set, the launch still drains, and the wave that gave up writes NaN
+// from then on (hidden states forward, gate gradients backward), so the failure reaches the logits / the gradients instead of
+// passing as a plausible result.
 #include <algorithm>
 #include <cstdlib>
 
@@ -228,6 +230,7 @@ __device__ __forceinline__ void lstm_rec_coop_body(const CoopParams &p, const in
                     hv[i] = so[i] * tanh_fast(cn[i]);
                     creg[x][i] = cn[i];
                 }
+                if (dead) hv = v4f{NAN, NAN, NAN, NAN};           // a hand-off timed out: fail LOUDLY -- NaN through out / h_n into the logits
                 bf16x4 ph, pl;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { ph[i] = (__bf16)hv[i]; pl[i] = (__bf16)(hv[i] - (float)ph[i]); }
@@ -614,6 +617,7 @@ __device__ __forceinline__ void lstm_bwd_coop_body(const CoopBwdParams &p, const
                         dg[i] = dct * gi[i] * (1.0f - gg[i] * gg[i]);
                         dc[x][i] = dct * gf[i];
                     }
+                    if (dead) di = v4f{NAN, NAN, NAN, NAN};       // a hand-off timed out: fail loudly (NaN into every weight gradient)
                     float *gs = p.G + row * ldx + xcol;
                     *(__attribute__((address_space(1))) v4f *)(gs) = di;
                     *(__attribute__((address_space(1))) v4f *)(gs + Hh) = df;
