@@ -331,12 +331,24 @@ __global__ __launch_bounds__(512, 1) void lstm_rec_coop_pair_kernel(CoopParams a
 }
 
 // tiles per group: 3 once the batch fills most of the chip that way, else as many as it takes to use all groups
+static int coop_cu_count() {
+    static const int n = [] {
+        int dev = 0, v = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 256;
+        return v;
+    }();
+    return n;
+}
+
 static void coop_geometry(int n, int &nt, int &gpd) {
     static const int force = [] { const char *e = getenv("STAIR_LSTM_COOP_TILES"); return e ? atoi(e) : 0; }();
     // measured (profiles/r02_b_lstm_coop.txt): one tile per group while every tile gets a group of its own (n <= 1024), then two;
     // three tiles need more registers than a wave has (spills) and lose
     nt = force >= 1 && force <= 3 ? force : (n > 32 * 32 ? 2 : 1);
-    gpd = std::max(1, std::min((n + 32 * nt - 1) / (32 * nt), 32));        // <= 32 groups per direction x 2 x 4 workgroups = 256 CUs
+    // every workgroup of the launch must be resident at once (they wait for each other): groups per direction <= CUs / 8
+    // (2 directions x 4 workgroups), i.e. 32 on the 256-CU part, fewer on a partitioned device; the cap keeps whole XCD rounds
+    const int cap = std::max(1, std::min(32, coop_cu_count() / 8));
+    gpd = std::max(1, std::min((n + 32 * nt - 1) / (32 * nt), cap));
 }
 
 int64_t lstm_coop_ws_bytes(int n) {
@@ -349,15 +361,6 @@ int64_t lstm_coop_ws_bytes(int n) {
 bool lstm_coop_usable(int Hh) {
     static const bool on = [] { const char *e = getenv("STAIR_LSTM_COOP"); return !(e && e[0] == '0'); }();
     return on && Hh == CH && matmul_mode() != STAIR_MATMUL_F32;
-}
-
-static int coop_cu_count() {
-    static const int n = [] {
-        int dev = 0, v = 256;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 256;
-        return v;
-    }();
-    return n;
 }
 
 // fills the kernel parameters of one recurrence and enqueues its per-launch memsets (flags, h_n)
@@ -702,7 +705,7 @@ static int coop_bwd_prepare(const stair_lstm_bwd_args &a, hipStream_t s, CoopBwd
     nt = 1;
     coop_geometry(a.n, nt, p.gpd);
     if (nt > 2) nt = 2;
-    p.gpd = std::max(1, std::min((a.n + 32 * nt - 1) / (32 * nt), 32));
+    p.gpd = std::max(1, std::min((a.n + 32 * nt - 1) / (32 * nt), std::max(1, std::min(32, coop_cu_count() / 8))));
     const int G = 2 * p.gpd;
     char *base = static_cast<char *>(a.coop_ws);
     const int64_t slab_bytes = (int64_t)2 * G * nt * BSLAB_BYTES;
