@@ -442,6 +442,11 @@ int stair_score_cosine_to_mean(const float *vec, const int32_t *slot, const floa
 int stair_loss_filterframe(const float *map, float *d_map, const int32_t *slot, const float *gold, const float *W,
                            const float *b, float *dW, float *db, int32_t n, int32_t T, int32_t H, int32_t O,
                            float scale, float *loss, stair_stream stream);
+/* The same for clips of different lengths in one batch: len[i] = frames of item i's clip (the tile keeps stride T; gold
+ * [n][T][O] is built for len[i] frames, rows past it are ignored); the mean runs over len[i] * O. */
+int stair_loss_filterframe_len(const float *map, float *d_map, const int32_t *slot, const float *gold, const float *W,
+                               const float *b, float *dW, float *db, const int32_t *len, int32_t n, int32_t T, int32_t H,
+                               int32_t O, float scale, float *loss, stair_stream stream);
 
 /* Test hook: every region of the workspace layout as (name, begin, end) float offsets; returns the region count.
  * Regions must be pairwise disjoint (tests/test_abi.py checks it for inference and training plans). */

@@ -137,6 +137,8 @@ SIGNATURES = [
                                       C.c_float, C.c_void_p, C.c_int32, C.c_void_p]),
     ('stair_loss_filterframe', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
+    ('stair_loss_filterframe_len', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     ('stair_plan_zero_grads', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ('stair_loss_attention', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                        C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),

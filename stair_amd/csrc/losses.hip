@@ -187,17 +187,22 @@ int launch_loss_contrastive(const float *vec, float *d_vec, const int32_t *slot,
 //   phase 1  wave per frame: x[t][:] in registers, one butterfly reduction per class -> z[t][o] in LDS
 //   phase 2  thread per frame: softmax, loss terms, dz = softmax' . dBCE (torch's backward: (p-g)/max(p(1-p),1e-12))
 //   phase 3  dx[t][:] += dz[t][:] W  (wave per frame),  dW[o][:] += dz[:,o]^T x  (wave per class),  db += colsum(dz)
+// len (optional): frames of item i's clip; the tile keeps the stride T, the criterion sees its first L frames (pred.size(0) of
+// train_module.py:146 is the clip's own length), gold rows past L are ignored
 __global__ __launch_bounds__(256) void loss_filterframe_kernel(const float *map, float *d_map, const int32_t *slot,
                                                                const float *gold, const float *W, const float *b, float *dW,
-                                                               float *db, int T, int H, int O, float scale, float *loss) {
+                                                               float *db, int T, int H, int O, float scale, float *loss,
+                                                               const int32_t *len) {
     extern __shared__ float z[];                 // [T][O]
     __shared__ float s_loss;
     const int i = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float *x = map + (int64_t)slot[i] * T * H;
     const float *g = gold + (int64_t)i * T * O;
     const int nh = H >> 6;                       // floats per lane (H % 64 == 0, H <= 512)
+    const int L = len ? len[i] : T;
     if (threadIdx.x == 0) s_loss = 0.f;
-    for (int t = wave; t < T; t += 4) {
+    for (int e = threadIdx.x + L * O; e < T * O; e += blockDim.x) z[e] = 0.f;       // frames past the clip: no gradient
+    for (int t = wave; t < L; t += 4) {
         float xr[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) xr[j] = j < nh ? x[(int64_t)t * H + j * 64 + lane] : 0.f;
@@ -211,9 +216,9 @@ __global__ __launch_bounds__(256) void loss_filterframe_kernel(const float *map,
         }
     }
     __syncthreads();
-    const float inv = 1.0f / (float)(T * O);
+    const float inv = 1.0f / (float)(L * O);
     float part = 0.f;
-    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    for (int t = threadIdx.x; t < L; t += blockDim.x) {
         float m = -INFINITY;
         for (int o = 0; o < O; ++o) m = fmaxf(m, z[t * O + o]);
         float sum = 0.f;
@@ -270,12 +275,12 @@ __global__ __launch_bounds__(256) void loss_filterframe_kernel(const float *map,
         }
 }
 int launch_loss_filterframe(const float *map, float *d_map, const int32_t *slot, const float *gold, const float *W, const float *b,
-                            float *dW, float *db, int n, int T, int H, int O, float scale, float *loss, hipStream_t s) {
+                            float *dW, float *db, int n, int T, int H, int O, float scale, float *loss, hipStream_t s, const int32_t *len) {
     STAIR_CHECK(H % 64 == 0 && H <= 512, "hidden size must be a multiple of 64, at most 512");
     STAIR_CHECK(T > 0 && O > 0 && (int64_t)T * O * 4 <= 60 * 1024, "T * object_types too large for the LDS tile");
     if (n == 0) return 0;
     hipLaunchKernelGGL(loss_filterframe_kernel, dim3(n), dim3(256), (size_t)T * O * sizeof(float), s, map, d_map, slot, gold, W, b,
-                       dW, db, T, H, O, scale, loss);
+                       dW, db, T, H, O, scale, loss, len);
     STAIR_LAUNCH_CHECK();
     return 0;
 }
@@ -343,7 +348,13 @@ extern "C" int stair_loss_filterframe(const float *map, float *d_map, const int3
                                       const float *b, float *dW, float *db, int32_t n, int32_t T, int32_t H, int32_t O,
                                       float scale, float *loss, stair_stream stream) {
     return stair::launch_loss_filterframe(map, d_map, slot, gold, W, b, dW, db, n, T, H, O, scale, loss,
-                                          static_cast<hipStream_t>(stream));
+                                          static_cast<hipStream_t>(stream), nullptr);
+}
+extern "C" int stair_loss_filterframe_len(const float *map, float *d_map, const int32_t *slot, const float *gold, const float *W,
+                                          const float *b, float *dW, float *db, const int32_t *len, int32_t n, int32_t T, int32_t H,
+                                          int32_t O, float scale, float *loss, stair_stream stream) {
+    return stair::launch_loss_filterframe(map, d_map, slot, gold, W, b, dW, db, n, T, H, O, scale, loss,
+                                          static_cast<hipStream_t>(stream), len);
 }
 extern "C" int stair_loss_decoder_ce(const float *logits, const int32_t *answers, float *loss, int32_t n, int32_t A, stair_stream stream) {
     STAIR_CHECK(logits && answers && loss && n >= 0 && A > 0, "bad argument");

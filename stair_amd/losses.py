@@ -63,7 +63,8 @@ def filterframe_target(gold, T, O, word2index):
 
 
 def _filterframe_launch(model, res, items, scale, grads):
-    """items: [(map slot, gold dict)].  Returns the per-item losses (device tensor)."""
+    """items: [(map slot, gold dict)] or [(map slot, gold dict, frames of the item's clip)] when the batch mixes clip
+    lengths.  Returns the per-item losses (device tensor)."""
     dev = res.logits.device
     H, T, O = model.config['hidden_size'], res.info.T, model.config['object_types']
     index = getattr(model, 'object_index', None)
@@ -72,17 +73,24 @@ def _filterframe_launch(model, res, items, scale, grads):
     head = model.submodules['FilterFrame'].pretrain_head
     if grads and head.weight.grad is None:
         raise RuntimeError('pretrain head of FilterFrame has no .grad buffer (use stair_amd.train.Trainer)')
-    gold = torch.from_numpy(np.stack([filterframe_target(g, T, O, index) for _, g in items])).to(dev)
+    frames = [int(a[2]) if len(a) > 2 else T for a in items]
+
+    def target(gold_dict, L):            # the criterion sees pred.size(0) = the clip's own frames (train_module.py:146)
+        g = np.zeros((T, O), dtype=np.float32)
+        g[:L] = filterframe_target(gold_dict, L, O, index)
+        return g
+    gold = torch.from_numpy(np.stack([target(a[1], L) for a, L in zip(items, frames)])).to(dev)
     slot = torch.tensor([a[0] for a in items], dtype=torch.int32, device=dev)
+    len_d = torch.tensor(frames, dtype=torch.int32, device=dev) if any(L != T for L in frames) else None
     out = torch.empty(len(items), device=dev)
     inf = res.info
     mp = res._ws[inf.map_off: inf.map_off + inf.n_map * T * H]
     gmap = res.grad_arena('map') if grads else None
     p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
-    check(lib.stair_loss_filterframe(p(mp), p(gmap), p(slot), p(gold), p(head.weight), p(head.bias),
-                                     p(head.weight.grad) if grads else None, p(head.bias.grad) if grads else None,
-                                     len(items), T, H, O, C.c_float(scale), p(out),
-                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    check(lib.stair_loss_filterframe_len(p(mp), p(gmap), p(slot), p(gold), p(head.weight), p(head.bias),
+                                         p(head.weight.grad) if grads else None, p(head.bias.grad) if grads else None, p(len_d),
+                                         len(items), T, H, O, C.c_float(scale), p(out),
+                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     return out
 
 
@@ -283,9 +291,8 @@ def prepare_module_losses(model, res, questions, pretrain_modules=CRITERION_MODU
         stage('cont', i32(c_slot), i32([slot_of[(w, n)] for w, n in zip(c_wid, c_name)]),
               i32([win_range[w][0] for w in c_wid]), i32([win_range[w][1] for w in c_wid]), rows,
               i32(np.concatenate([[0], np.cumsum(lens)])), np.ascontiguousarray(np.concatenate(embs)))
-    ff_items = [(int(slot_t[base[qi] + pos]), gold) for qi, p in enumerate(packs) for pos, gold in p.ff]
-    if ff_items and res.question_frames is not None:
-        raise NotImplementedError('the FilterFrame criterion (off by default, args.py:62) takes batches of one clip length')
+    qf_ = res.question_frames
+    ff_items = [(int(slot_t[base[qi] + pos]), gold, int(qf_[qi]) if qf_ is not None else T) for qi, p in enumerate(packs) for pos, gold in p.ff]
     # ---- ONE upload ----
     staging = model.__dict__.setdefault('_loss_staging', _Staging())
     d = staging.upload(up, dev) if up else []
@@ -390,7 +397,7 @@ def evaluate_module_losses(model, res, questions, pretrain_modules=CRITERION_MOD
                 out[module].append(None)
                 embs.extend(torch.as_tensor(e, dtype=torch.float32) for _, e in gold)
             elif module == 'FilterFrame':
-                ff_items.append((slot, gold))
+                ff_items.append((slot, gold) if res.question_frames is None else (slot, gold, int(res.question_frames[qi])))
             else:
                 raise NotImplementedError('validation loss for %s' % module)
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -423,8 +430,6 @@ def evaluate_module_losses(model, res, questions, pretrain_modules=CRITERION_MOD
                                   None, None, len(items), H, C.c_float(0.0), C.c_void_p(val.data_ptr()), stream))
         out[module].extend(val.cpu().tolist())
     if ff_items:
-        if res.question_frames is not None:
-            raise NotImplementedError('the FilterFrame criterion takes batches of one clip length')
         out['FilterFrame'].extend(_filterframe_launch(model, res, ff_items, 0.0, False).cpu().tolist())
     if cont_items:
         reps = model.encode_phrases(embs)                                  # [sum of gold sizes, H], L2-normalised

@@ -492,6 +492,19 @@ def test_filterframe_loss_kernel_matches_reference_fixture():
         check(lib.stair_loss_filterframe(p(xd), None, p(slot), p(tgt), p(Wd), p(bd), None, None, 1, T, H, O,
                                          C.c_float(0.0), p(loss2), stream))
         assert float(loss2) == float(loss)
+        # the same clip stored at a larger stride (a batch that mixes clip lengths): len = the clip's own frames; garbage rows behind it
+        Tp = T + 7
+        xp = torch.full((3, Tp, H), 5.0); xp[1, :T] = x[1]
+        tp = torch.full((1, Tp, O), 0.3); tp[0, :T] = tgt[0].cpu()
+        xpd, tpd = xp.to(DEV), tp.to(DEV)
+        dmap_p, dW_p, db_p = torch.zeros_like(xpd), torch.zeros_like(Wd), torch.zeros_like(bd)
+        loss3 = torch.empty(1, device=DEV)
+        len_d = torch.tensor([T], dtype=torch.int32, device=DEV)
+        check(lib.stair_loss_filterframe_len(p(xpd), p(dmap_p), p(slot), p(tpd), p(Wd), p(bd), p(dW_p), p(db_p), p(len_d), 1, Tp, H, O,
+                                             C.c_float(1.0), p(loss3), stream))
+        assert float(loss3) == float(loss)
+        assert torch.equal(dmap_p[1, :T], dmap[1]) and float(dmap_p[1, T:].abs().max()) == 0.0
+        assert float((dW_p - dW).abs().max()) < 1e-6 and float((db_p - db).abs().max()) < 1e-6
     # random head, two items sharing a slot, scale != 1: vs torch autograd of the oracle criterion
     g = torch.Generator().manual_seed(3)
     T = 40
