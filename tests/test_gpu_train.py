@@ -647,3 +647,53 @@ def test_training_step_reads_no_uninitialised_workspace(ragged, supervised):
         g = grads(poison)
         assert int(g.isnan().sum()) == 0, poison
         assert float((g - ref).norm() / ref.norm()) < 1e-5, poison
+
+
+def test_trainer_windows_match_reference_main_loop(matmul):
+    """L2 pinned to the reference itself: tests/golden/window.npz holds what /root/reference/train_module.py main()
+    produced on CPU for TWO windows of 32 questions (per-module criteria :351-373, decoder CE :376-380, the pooled
+    contrastive pass :388-406, one backward :408, Adam :326/:410, LambdaLR :328-332/:412).  Trainer.step on the same
+    questions must give the same criterion values and the same weights after each optimizer step."""
+    from helpers import window_fixture, window_weights
+    from stair_amd import losses as L
+    from stair_amd.train import Trainer
+    z, meta, qs, records = window_fixture()
+    config, W = meta['config'], meta['window']
+    model = _model(config, meta['seed'])
+    model.pretrain_modules = set(L.CRITERION_MODULES)
+    tr = Trainer(model, lr=meta['lr'], scheduler_total_iters=meta['scheduler_total_iters'], contrastive_window=W,
+                 skip_untouched='window', dropout=0.0)          # 'window': the fixture was made with torch >= 2 (grads set to None)
+    init = synth.make_weights(config, meta['seed'])
+    names = [n for n, _ in spec.weight_table(config)]
+    for wi, rec in enumerate(records):
+        window = qs[wi * W:(wi + 1) * W]
+        progs, spans, video, question, q_lens, answers = _pack(model, window)
+        dec, _ = tr.step(progs, spans, video, question, q_lens, answers, questions=window)
+        assert np.allclose(dec.cpu().numpy(), rec['decoder'], rtol=1e-5, atol=2e-5)
+        got_mod = sorted(torch.cat([v for k, v in tr.module_losses.items() if k != 'contrastive']).cpu().tolist())
+        ref_mod = sorted(v for _, v in rec['module'])
+        assert len(got_mod) == len(ref_mod) and np.allclose(got_mod, ref_mod, rtol=2e-5, atol=2e-6)
+        got_c, ref_c = sorted(tr.module_losses['contrastive'].cpu().tolist()), sorted(v for _, v in rec['contrastive'])
+        assert len(got_c) == len(ref_c) > 10 and np.allclose(got_c, ref_c, rtol=2e-5, atol=2e-6)
+        assert abs(tr.lr * tr.lr_factor() - meta['lr_after_window'][wi]) < 1e-12
+        got = dict(model.named_parameters())
+        worst, moved = (0.0, ''), 0
+        for n in names:
+            ref, g = window_weights(z, meta, wi + 1, n, got[n])
+            diff = np.abs(g - ref)
+            # Adam moves every touched weight by ~lr = 2e-4 per step whatever the gradient's scale; see
+            # test_trainer_steps_match_torch_adam for why the split-product mode is stated as a fraction
+            if matmul == 'f32':
+                assert diff.max() < 2e-5, (wi, n, diff.max())
+            else:
+                assert (diff < 2e-5).mean() > 0.995, (wi, n, (diff < 2e-5).mean())
+                assert diff.max() < 2.5e-4 * (wi + 1), (wi, n, diff.max())
+            worst = max(worst, (float(diff.max()), n))
+            i0 = np.asarray(init[n], dtype=np.float64).reshape(-1)
+            i0 = i0 if i0.size <= meta['large_threshold'] else i0[::meta['stride_large']]
+            if np.abs(ref - i0).max() == 0:                          # never reached by a loss (FilterFrame's head, args.py:62):
+                assert np.array_equal(g, i0), n                      # Adam must skip it, bit for bit
+            else:
+                moved += 1
+        assert moved > 90
+        print('window %d (%s): largest weight difference to the reference %.3g in %s' % (wi + 1, matmul, worst[0], worst[1]))
