@@ -190,9 +190,27 @@ def main():
     ap.add_argument('--no-extras', action='store_true', help='skip the supplementary figures (clean kernel profiles)')
     args = ap.parse_args()
 
+    from stair_amd import launch
+    if args.gpus > 1 and not launch.launched_as_rank():
+        # `python bench.py --gpus N` on its own: start the N ranks (fresh processes; this one has not touched the GPU --
+        # torch.cuda.device_count() does not initialise HIP) and relay rank 0's line.  Never run fewer ranks than asked for.
+        ndev = torch.cuda.device_count()
+        if ndev < args.gpus:
+            print('bench.py: --gpus %d but only %d GPU(s) visible' % (args.gpus, ndev), file=sys.stderr)
+            sys.exit(2)
+        code, line, out = launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus)
+        if line is not None:
+            print(json.dumps(line), flush=True)
+        else:
+            sys.stderr.write(out[-4000:])
+        sys.exit(code)
+
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        print('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     # STAIR_DIST_BACKEND=gloo lets several ranks rehearse the N>1 path on one card (ranks wrap around the visible devices);
     # the driver's runs use the default: nccl (= RCCL), one rank per GPU.
     backend = os.environ.get('STAIR_DIST_BACKEND', 'nccl')
@@ -234,10 +252,13 @@ def main():
         return out
 
     trainer = None
+    gold_qs = gold_questions(qs) if (args.supervision or not args.no_extras) and args.mode == 'train' else None
+    # the contrastive classes of the whole job, one order on every rank: pools of a data-parallel step are then summed on the device
+    class_table = L.ClassTable.from_questions(gold_qs, world) if gold_qs is not None and world > 1 else None
     if args.mode == 'train':
         from stair_amd.train import Trainer
-        trainer = Trainer(model, world=world, rank=rank, dropout=args.dropout, native_allreduce=args.native_allreduce)
-    gold_qs = gold_questions(qs) if (args.supervision or not args.no_extras) and args.mode == 'train' else None
+        trainer = Trainer(model, world=world, rank=rank, dropout=args.dropout, native_allreduce=args.native_allreduce,
+                          class_table=class_table)
     # The batch is a few hundred thousand long-lived Python objects (question dicts, gold packs).  A generation-2 pass of the
     # cyclic collector walks all of them -- 30-50 ms, i.e. two whole steps -- every few supervised steps; a training job's
     # data loader hands batches over from worker processes and never holds this many objects in the stepping process.
@@ -267,6 +288,8 @@ def main():
         barrier()
         return time.perf_counter() - t0, r
 
+    if trainer is not None and world > 1:
+        trainer.allreduce_events = []
     elapsed, res = timed(lambda: run_step(B, args.supervision), args.steps, args.warmup)
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -275,6 +298,54 @@ def main():
     qps = B * args.steps * world / elapsed
 
     extras = {}
+    if world > 1:
+        # how many ranks the collective really spans: a sum of ones through the communicator (and ncclCommCount on the native one)
+        probe = torch.ones(1, device=device)
+        dist.all_reduce(probe)
+        extras['rccl_ranks'] = int(probe.item())
+        extras['collective_backend'] = ('stair_allreduce_grads (RCCL from libstair_hip.so)' if args.native_allreduce else
+                                        'torch.distributed %s' % backend)
+        if trainer is not None:
+            ev = trainer.allreduce_events[-args.steps:]
+            trainer.allreduce_events = None
+            ar = torch.tensor([sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev))], device=device, dtype=torch.float64)
+            dist.all_reduce(ar, op=dist.ReduceOp.MAX)
+            extras['allreduce_ms_per_step'] = round(float(ar.item()), 4)
+            extras['allreduce_bytes_per_step'] = int(trainer.bucket.numel() * 4)
+            if trainer.comm is not None:
+                extras['rccl_ranks_native_comm'] = trainer.comm.ranks()[1]
+        if trainer is not None and not args.no_extras:
+            if not args.native_allreduce and backend == 'nccl':
+                # the same step with the collective through the C ABI, and the two all-reduces compared bit for bit on one bucket
+                from stair_amd.comm import NativeComm
+                comm = NativeComm(rank, world)
+                g = torch.Generator(device=device).manual_seed(77 + rank)
+                a = torch.randn(trainer.bucket.numel(), device=device, generator=g)
+                b = a.clone()
+                dist.all_reduce(a)
+                comm.allreduce_(b)
+                same = torch.tensor([1.0 if torch.equal(a, b) else 0.0], device=device)
+                dist.all_reduce(same, op=dist.ReduceOp.MIN)
+                del a, b
+                trainer.comm = comm
+                dt_n, _ = timed(lambda: run_step(B, False), max(3, args.steps // 2), 2)
+                k_n = max(3, args.steps // 2)
+                tn = torch.tensor([dt_n], device=device, dtype=torch.float64)
+                dist.all_reduce(tn, op=dist.ReduceOp.MAX)
+                extras['native_allreduce'] = {'train_questions_per_s': round(B * k_n * world / float(tn.item()), 1),
+                                              'ms_per_step': round(float(tn.item()) / k_n * 1e3, 3), 'rccl_ranks': comm.ranks()[1],
+                                              'bitwise_equal_to_torch_allreduce': bool(same.item() == 1.0)}
+                trainer.comm = None
+            if not args.supervision:
+                # configs[4] under data parallelism: per-module losses, contrastive pools of the GLOBAL windows via the class table
+                k_s = max(3, args.steps // 2)
+                dt_s, _ = timed(lambda: run_step(B, True), k_s, 2)
+                ts = torch.tensor([dt_s], device=device, dtype=torch.float64)
+                dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+                extras['supervised_step_dp'] = {'train_questions_per_s': round(B * k_s * world / float(ts.item()), 1),
+                                                'ms_per_step': round(float(ts.item()) / k_s * 1e3, 3), 'classes_in_table': len(class_table),
+                                                'note': 'BASELINE configs[4]: gradient all-reduce + one [windows, classes] presence all-reduce on the '
+                                                        'device per step; no host-side collective'}
     if not args.no_extras and world == 1:
         # ---- forward-only rate, shared clips, host-fed pipeline (SURVEY 8d "a second figure including H2D") ----
         dt, r_inf = timed(lambda: model.run_programs(programs, spans, video, question, q_lens), 3, 1)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STAIR_ABI_VERSION 2
+#define STAIR_ABI_VERSION 3
 
 typedef struct stair_ctx stair_ctx;
 typedef struct stair_plan stair_plan;
@@ -77,7 +77,8 @@ int stair_abi_version(void);
 const char *stair_last_error(void);
 
 /* Measurement aid: while enabled, every launch of an HBM-bound row kernel adds the bytes it must move (inputs once +
- * outputs once) to a per-kernel table; stair_acct_dump writes "kernel launches bytes" lines.  tools/row_kernels.py pairs the
+ * outputs once) to a per-kernel table, and every GEMM / recurrence launcher adds the kernel variant it selected with its
+ * algorithmic flops; stair_acct_dump writes "kernel launches bytes flops" lines.  tools/row_kernels.py pairs the
  * table with rocprofv3 kernel durations (GB/s per kernel against the 8 TB/s HBM peak).  Off by default, process-wide. */
 void stair_acct_enable(int32_t on);
 int stair_acct_dump(char *buf, int32_t cap);
@@ -204,9 +205,22 @@ typedef struct stair_lstm_args {
     const int32_t *seq_len; /* optional device [n]: PADDED storage -- sequence s occupies rows seq_off[s] .. seq_off[s+1]-1 but
                     only its first seq_len[s] rows are data (clips of different frame counts stored at one stride,
                     /root/reference/video_nmn/dataset.py:137-143); out rows past the length are written as zero.  NULL: every
-                    row of the span is data. */
+                    row of the span is data.  The padding rows of x must hold FINITE values (zeros): the weight-gradient
+                    products run over all rows with zeroed gate gradients, and 0 * NaN is NaN. */
+    uint32_t *status; /* optional device word, caller-owned and STICKY: the cooperative kernels set it to 1 when a hand-off
+                    between workgroups timed out (the grid was not co-resident after all -- another queue on the device, a
+                    partitioned GPU); the wave that gave up writes NaN from then on.  The library never clears it.  Before
+                    a cooperative launch the launcher checks hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs >= grid for
+                    the kernel on the current device and otherwise runs the one-workgroup kernel; this word covers what that
+                    check cannot see.  stair_plan_run keeps such a word in the plan's workspace (stair_plan_info.status_off);
+                    stair_adam_step refuses to update when its `guard` points at a set word. */
 } stair_lstm_args;
 int64_t stair_lstm_coop_ws_bytes(int32_t n);
+/* Upper bound on the workgroups a cooperative recurrence may use on the current process's devices (default: every CU;
+ * env STAIR_LSTM_COOP_MAX_BLOCKS).  A launch needs 32 workgroups per pair of sequence-tile groups; geometries that do not fit
+ * under the cap -- or under hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs -- run on the one-workgroup kernels instead.
+ * max_blocks < 0 restores the default.  For a GPU shared with another queue, or tests of the fallback. */
+int stair_lstm_coop_limit(int32_t max_blocks);
 int stair_lstm_bidir_fwd(const stair_lstm_args *args, stair_stream stream);
 
 /* Backward through time of the same layer (autograd of nn.LSTM in train_module.py:408).  gates = the
@@ -226,6 +240,7 @@ typedef struct stair_lstm_bwd_args {
     const void *x_bf16; /* optional, as in stair_lstm_args: dW_ih = dG^T X then reads X as exact bf16 (two products per pair) */
     const int32_t *seq_len; /* optional, as in stair_lstm_args (the gate-gradient rows past a sequence's length are cleared) */
     void *coop_ws; int64_t coop_ws_bytes; /* optional: >= stair_lstm_coop_bwd_ws_bytes(n), 256-byte aligned -> cooperative BPTT (Hh = 256, split mode) */
+    uint32_t *status; /* optional sticky timeout word, as in stair_lstm_args */
 } stair_lstm_bwd_args;
 int64_t stair_lstm_coop_bwd_ws_bytes(int32_t n);
 int stair_lstm_bidir_bwd(const stair_lstm_bwd_args *args, stair_stream stream);
@@ -274,6 +289,8 @@ typedef struct stair_comm stair_comm;
 int stair_comm_unique_id(void *id128);
 int stair_comm_create(const void *id128, int32_t rank, int32_t world, stair_comm **out);
 void stair_comm_destroy(stair_comm *comm);
+/* rank and size as the RCCL communicator itself reports them (ncclCommUserRank / ncclCommCount); either may be NULL */
+int stair_comm_info(const stair_comm *comm, int32_t *rank, int32_t *nranks);
 int stair_allreduce_grads(stair_comm *comm, float *bucket, int64_t n, stair_stream stream);
 
 /* ---- program plans: the batched stack interpreter (module_net.py:94-138) -------------------- */
@@ -331,10 +348,19 @@ typedef struct stair_plan_info {
     int64_t workspace_bytes;
     int64_t vec_off, map_off, att_off, tok_off, qfeat_off, logits_off; /* float offsets */
     int64_t gvec_off, gmap_off, gatt_off; /* gradient arenas of a STAIR_PLAN_TRAIN plan (same slot numbering), else -1 */
+    int64_t status_off; /* float offset of the plan's status word (one uint32): cleared by stair_plan_run, set by a cooperative
+                           recurrence whose hand-off timed out (forward or backward); see stair_plan_status */
     int32_t n_vec, n_map, n_att, n_tok_rows;
     int32_t n_nodes, n_launches, n_levels, n_questions, T;
 } stair_plan_info;
 int stair_plan_get_info(const stair_plan *plan, stair_plan_info *info);
+
+/* Reads the plan's status word back (copy on `stream` + stream synchronisation).  Returns 0 when the passes run on this
+ * workspace since the last stair_plan_run completed normally; non-zero (message via stair_last_error) when a cooperative
+ * recurrence timed out -- the logits / gradients of that run contain NaN and must be discarded.  A training loop that does
+ * not want the synchronisation passes the word's device address (workspace + status_off floats) to stair_adam_step as
+ * `guard` and checks later. */
+int stair_plan_status(const stair_plan *plan, const void *workspace, stair_stream stream);
 
 /* kind/slot/aux of program token `tok` (global index into `tokens`); level as stat_module_levels;
  * rel_slot = att-arena row of Temporal's related_attn (-1 otherwise). */
@@ -425,6 +451,14 @@ int stair_loss_head(int32_t nout, const float *vec, float *d_vec, const int32_t 
 int stair_loss_contrastive(const float *vec, float *d_vec, const int32_t *slot, const int32_t *pos,
                            const int32_t *win_start, const int32_t *win_cnt, const float *G, int32_t n, int32_t H,
                            int32_t max_classes, float scale, float *loss, stair_stream stream);
+/* The same criterion against a TABLE of all class representations reps [n_cls, H]: item i's pool is the set of classes c with
+ * presence[win_row[i]][c] > 0 (presence [n_windows, n_cls] floats) and its positive is class pos_class[i].  Under data
+ * parallelism each rank marks the classes of its own questions and the table is summed over ranks ON THE DEVICE (one small
+ * all-reduce on the stream) -- the pools of train_module.py:388-406 without any rank learning the others' class lists on the
+ * host.  The value equals stair_loss_contrastive on the pooled rows up to the order of the softmax sum. */
+int stair_loss_contrastive_table(const float *vec, float *d_vec, const int32_t *slot, const int32_t *pos_class,
+                                 const int32_t *win_row, const float *presence, const float *reps, int32_t n,
+                                 int32_t n_cls, int32_t H, float scale, float *loss, stair_stream stream);
 /* Decoder cross entropy without gradients -- the validation loop's loss (train_module.py:193-194, 246-248):
  * loss[i] = logsumexp(logits[i]) - logits[i][answers[i]]; answers[i] < 0: 0, answers[i] >= A: NaN. */
 int stair_loss_decoder_ce(const float *logits, const int32_t *answers, float *loss, int32_t n, int32_t A, stair_stream stream);
@@ -459,10 +493,14 @@ int stair_plan_touched(const stair_ctx *ctx, const stair_plan *plan, int32_t *to
 /* torch.optim.Adam (train_module.py:326) over a flat fp32 parameter buffer of n floats.  Parameter tensors
  * ("segments") start on multiples of 256 floats; seg_of_block[b] = segment of elements 256b..256b+255;
  * segments with touched[seg] == 0 are skipped (no moment decay, no step), step_of_seg[seg] is the 1-based
- * Adam step of the segment (already incremented by the caller).  All arrays on the device. */
+ * Adam step of the segment (already incremented by the caller).  All arrays on the device.
+ * guard (optional device word): when *guard != 0 at execution time the kernel changes NOTHING -- parameters and both
+ * moments keep their values.  Pass the status word of the plan that produced `grads` (stair_plan_info.status_off): a
+ * recurrence that timed out then cannot feed NaN gradients into the optimizer state. */
 int stair_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq,
                     const int32_t *seg_of_block, const int32_t *touched, const float *step_of_seg, float lr,
-                    float beta1, float beta2, float eps, float weight_decay, int64_t n, stair_stream stream);
+                    float beta1, float beta2, float eps, float weight_decay, int64_t n, const uint32_t *guard,
+                    stair_stream stream);
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('STAIR_LIB_PATH') or os.path.join(_HERE, 'lib', 'libstair_hip.so')   # override: kernel experiments
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)
 
@@ -59,7 +59,7 @@ class LstmArgs(C.Structure):
                 ('xproj_ws', C.c_void_p), ('bias_ws', C.c_void_p), ('whh_pack_ws', C.c_void_p),
                 ('out', C.c_void_p), ('ldo', C.c_int64), ('h_n', C.c_void_p), ('cbuf', C.c_void_p),
                 ('x_bf16', C.c_void_p), ('wih_planes_ws', C.c_void_p), ('coop_ws', C.c_void_p), ('coop_ws_bytes', C.c_int64),
-                ('seq_len', C.c_void_p)]
+                ('seq_len', C.c_void_p), ('status', C.c_void_p)]
 
 
 class LstmBwdArgs(C.Structure):
@@ -70,13 +70,14 @@ class LstmBwdArgs(C.Structure):
                 ('d_out', C.c_void_p), ('ldd', C.c_int64), ('d_hn', C.c_void_p),
                 ('whh_pack_ws', C.c_void_p), ('hprev_ws', C.c_void_p),
                 ('dw_ih', C.c_void_p * 2), ('dw_hh', C.c_void_p * 2), ('db_ih', C.c_void_p * 2), ('db_hh', C.c_void_p * 2),
-                ('x_bf16', C.c_void_p), ('seq_len', C.c_void_p), ('coop_ws', C.c_void_p), ('coop_ws_bytes', C.c_int64)]
+                ('x_bf16', C.c_void_p), ('seq_len', C.c_void_p), ('coop_ws', C.c_void_p), ('coop_ws_bytes', C.c_int64),
+                ('status', C.c_void_p)]
 
 
 class PlanInfo(C.Structure):
     _fields_ = [('workspace_bytes', C.c_int64), ('vec_off', C.c_int64), ('map_off', C.c_int64), ('att_off', C.c_int64),
                 ('tok_off', C.c_int64), ('qfeat_off', C.c_int64), ('logits_off', C.c_int64),
-                ('gvec_off', C.c_int64), ('gmap_off', C.c_int64), ('gatt_off', C.c_int64),
+                ('gvec_off', C.c_int64), ('gmap_off', C.c_int64), ('gatt_off', C.c_int64), ('status_off', C.c_int64),
                 ('n_vec', C.c_int32), ('n_map', C.c_int32), ('n_att', C.c_int32), ('n_tok_rows', C.c_int32),
                 ('n_nodes', C.c_int32), ('n_launches', C.c_int32), ('n_levels', C.c_int32), ('n_questions', C.c_int32),
                 ('T', C.c_int32)]
@@ -98,6 +99,7 @@ SIGNATURES = [
     ('stair_set_matmul_mode', C.c_int, [C.c_int32]),
     ('stair_get_matmul_mode', C.c_int, []),
     ('stair_set_split_min_rows', C.c_int, [C.c_int32]),
+    ('stair_lstm_coop_limit', C.c_int, [C.c_int32]),
     ('stair_gemm_f32', C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     ('stair_gemm_tn_f32', C.c_int, [C.POINTER(GemmTnArgs), C.c_void_p]),
     ('stair_split_planes', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
@@ -128,6 +130,7 @@ SIGNATURES = [
     ('stair_comm_unique_id', C.c_int, [C.c_void_p]),
     ('stair_comm_create', C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     ('stair_comm_destroy', None, [C.c_void_p]),
+    ('stair_comm_info', C.c_int, [C.c_void_p, c_int32_p, c_int32_p]),
     ('stair_allreduce_grads', C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     ('stair_loss_decoder_ce', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     ('stair_score_cosine_to_mean', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
@@ -146,12 +149,14 @@ SIGNATURES = [
                                   C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     ('stair_loss_contrastive', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
+    ('stair_loss_contrastive_table', C.c_int, [C.c_void_p] * 7 + [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     ('stair_plan_regions', C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32]),
     ('stair_plan_touched', C.c_int, [C.c_void_p, C.c_void_p, c_int32_p, C.c_int32]),
     ('stair_adam_step', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                  C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64, C.c_void_p]),
+                                  C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64, C.c_void_p, C.c_void_p]),
     ('stair_plan_destroy', None, [C.c_void_p]),
     ('stair_plan_get_info', C.c_int, [C.c_void_p, C.POINTER(PlanInfo)]),
+    ('stair_plan_status', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ('stair_plan_node', C.c_int, [C.c_void_p, C.c_int32, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p]),
     ('stair_plan_nodes', C.c_int, [C.c_void_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p, C.c_int32]),
     ('stair_plan_run', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,

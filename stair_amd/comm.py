@@ -33,9 +33,18 @@ class NativeComm:
                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         return flat
 
+    def ranks(self):
+        """(rank, size) as the RCCL communicator reports them (ncclCommUserRank, ncclCommCount)."""
+        r, n = C.c_int32(-1), C.c_int32(-1)
+        check(lib.stair_comm_info(self._comm, C.byref(r), C.byref(n)))
+        return r.value, n.value
+
     def close(self):
-        if getattr(self, '_comm', None):
-            lib.stair_comm_destroy(self._comm)
-            self._comm = None
+        comm, self._comm = getattr(self, '_comm', None), None
+        if comm:
+            try:
+                lib.stair_comm_destroy(comm)
+            except Exception:           # interpreter shutdown: the library handle may already be gone
+                pass
 
     __del__ = close

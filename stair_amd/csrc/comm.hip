@@ -9,6 +9,7 @@
 #include <dlfcn.h>
 
 #include <cstring>
+#include <mutex>
 
 #include "common.h"
 
@@ -24,14 +25,19 @@ struct Rccl {
     int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     int (*CommDestroy)(ncclComm_t) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*CommCount)(const ncclComm_t, int *) = nullptr;
+    int (*CommUserRank)(const ncclComm_t, int *) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
 };
 
+static void rccl_load(Rccl &r);
 Rccl *rccl() {
     static Rccl r;
-    static bool tried = false;
-    if (tried) return r.AllReduce ? &r : nullptr;
-    tried = true;
+    static std::once_flag once;
+    std::call_once(once, [] { rccl_load(r); });
+    return r.AllReduce ? &r : nullptr;
+}
+static void rccl_load(Rccl &r) {
     for (const char *name : {"librccl.so", "librccl.so.1"}) {
         r.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
         if (r.lib) break;
@@ -41,14 +47,15 @@ Rccl *rccl() {
             r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (r.lib) break;
         }
-    if (!r.lib) return nullptr;
+    if (!r.lib) return;
     r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
     r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
     r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.lib, "ncclAllReduce"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
-    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce) { r.AllReduce = nullptr; return nullptr; }
-    return &r;
+    r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(r.lib, "ncclCommCount"));
+    r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(dlsym(r.lib, "ncclCommUserRank"));
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce) r.AllReduce = nullptr;
 }
 
 int fail(Rccl *r, const char *what, int rc) {
@@ -92,6 +99,16 @@ extern "C" void stair_comm_destroy(stair_comm *c) {
     Rccl *r = rccl();
     if (r && c->comm) (void)r->CommDestroy(c->comm);
     delete c;
+}
+
+extern "C" int stair_comm_info(const stair_comm *c, int32_t *rank, int32_t *nranks) {
+    STAIR_CHECK(c && c->comm, "null communicator");
+    Rccl *r = rccl();
+    STAIR_CHECK(r && r->CommCount && r->CommUserRank, "RCCL (ncclCommCount / ncclCommUserRank) could not be resolved");
+    int v = 0;
+    if (nranks) { if (int rc = r->CommCount(c->comm, &v)) return fail(r, "ncclCommCount", rc); *nranks = v; }
+    if (rank) { if (int rc = r->CommUserRank(c->comm, &v)) return fail(r, "ncclCommUserRank", rc); *rank = v; }
+    return 0;
 }
 
 extern "C" int stair_allreduce_grads(stair_comm *c, float *bucket, int64_t n, stair_stream stream) {

@@ -58,9 +58,11 @@ static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * 
 // ---- algorithmic-byte accounting of the HBM-bound row kernels (measurement aid, off unless stair_acct_enable(1)) --------
 // Each row-kernel launcher reports the bytes its launch MUST move (inputs read once + outputs written once, the figure of
 // SURVEY.md section 8d); tools/row_kernels.py divides the per-kernel sums by the rocprofv3 kernel durations of the same run.
-void acct_add(const char *kernel, int64_t bytes);
+void acct_add(const char *kernel, int64_t bytes, int64_t flops = 0);
 extern bool g_acct_on;
 #define STAIR_ACCT(name, bytes) do { if (::stair::g_acct_on) ::stair::acct_add(name, (int64_t)(bytes)); } while (0)
+// the MFMA-bound kernels: which variant a launcher selected, with its algorithmic flops (2MNK) and bytes (operands once + result once)
+#define STAIR_ACCT_MFMA(name, bytes, flops) do { if (::stair::g_acct_on) ::stair::acct_add(name, (int64_t)(bytes), (int64_t)(flops)); } while (0)
 
 // ---- internal launchers shared between the C ABI and the plan runner ----------------------
 int launch_gemm(const stair_gemm_args &a, hipStream_t s);

@@ -613,6 +613,7 @@ int launch_gemm_bf16x3(const stair_gemm_args &a, hipStream_t s) {
         q.tilesM = t2m; q.tilesN = t2n;
         const size_t shmem2 = 2 * 2 * 2 * IMG2 * sizeof(__bf16);       // 128 KB
         const dim3 grid2(t2m * t2n);
+        STAIR_ACCT_MFMA("gemm_bf16x3_t256", (M * a.K + (int64_t)a.N * a.K + M * a.N) * 4, 2 * M * a.N * a.K);
         static bool attr_set = false;
         if (!attr_set) {
             const void *fns[6] = {reinterpret_cast<const void *>(&gemm_bf16x3_t256_kernel<0, 3>), reinterpret_cast<const void *>(&gemm_bf16x3_t256_kernel<1, 3>),
@@ -649,6 +650,7 @@ int launch_gemm_bf16x3(const stair_gemm_args &a, hipStream_t s) {
             p.ksplit = ksplit; p.kchunk = kchunk;
             p.part = staged ? a.splitk_ws : nullptr;
             const dim3 gridk(tiles128, ksplit);
+            STAIR_ACCT_MFMA("gemm_bf16x3_splitk", (M * a.K + (int64_t)a.N * a.K + M * a.N) * 4, 2 * M * a.N * a.K);
             if (plain && one) hipLaunchKernelGGL((gemm_bf16x3_kernel<0, true, 1>), gridk, block, shmem, s, p);
             else if (plain) hipLaunchKernelGGL((gemm_bf16x3_kernel<0, true, 3>), gridk, block, shmem, s, p);
             else if (one) hipLaunchKernelGGL((gemm_bf16x3_kernel<0, false, 1>), gridk, block, shmem, s, p);
@@ -664,6 +666,7 @@ int launch_gemm_bf16x3(const stair_gemm_args &a, hipStream_t s) {
         }
     }
     const bool w8 = gemm_w8_enabled() && p.tilesM * p.tilesN >= 512;   // enough tiles for two 8-wave workgroups on every CU
+    STAIR_ACCT_MFMA(w8 ? "gemm_bf16x3_w8" : "gemm_bf16x3", (M * a.K + (int64_t)a.N * a.K + M * a.N) * 4, 2 * M * a.N * a.K);
 #define X_LAUNCH1(ACT_, NP_)                                                                                       \
     if (w8 && plain) hipLaunchKernelGGL((gemm_bf16x3_w8_kernel<ACT_, true, NP_>), grid, dim3(512), shmem, s, p);    \
     else if (w8) hipLaunchKernelGGL((gemm_bf16x3_w8_kernel<ACT_, false, NP_>), grid, dim3(512), shmem, s, p);       \
@@ -1030,6 +1033,7 @@ int launch_gemm_tn_bf16x3(const stair_gemm_tn_args &a, hipStream_t s) {
             slabs = (slabs + 7) / 8 * 8;
             q.mslab = ((a.M + slabs - 1) / slabs + 63) / 64 * 64;
             const size_t shmem2 = 2 * 2 * 2 * IMG2 * sizeof(__bf16);
+            STAIR_ACCT_MFMA("gemm_tn_bf16x3_t256", ((int64_t)a.M * a.N * 4 + (int64_t)a.M * a.K * (bx ? 2 : 4) + (int64_t)a.N * a.K * 4), 2ll * a.M * a.N * a.K);
             static bool attr_set = false;
             if (!attr_set) {
                 STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tn_bf16x3_t256_kernel<3>),
@@ -1057,6 +1061,7 @@ int launch_gemm_tn_bf16x3(const stair_gemm_tn_args &a, hipStream_t s) {
     p.mslab = ((a.M + slabs - 1) / slabs + 63) / 64 * 64;
     const size_t shmem = 2 * 2 * 2 * IMG * sizeof(__bf16);
     const bool plain = !p.row_scale && a.M % 64 == 0 && p.mslab % 64 == 0;
+    STAIR_ACCT_MFMA("gemm_tn_bf16x3", ((int64_t)a.M * a.N * 4 + (int64_t)a.M * a.K * (bx ? 2 : 4) + (int64_t)a.N * a.K * 4), 2ll * a.M * a.N * a.K);
     if (bx) {
         STAIR_CHECK(p.fast8 != 0, "internal: bf16 B rows need a plain row matrix");
         if (plain) hipLaunchKernelGGL((gemm_tn_bf16x3_kernel<true, 3, true>), dim3(tiles * slabs), dim3(256), shmem, s, p);

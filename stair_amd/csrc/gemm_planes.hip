@@ -413,6 +413,7 @@ int launch_gemm_planes(const stair_gemm_planes_args &a, hipStream_t s) {
     p.M = a.M; p.N = a.N; p.K = a.K;
     p.tilesM = (a.M + 255) / 256; p.tilesN = (a.N + 255) / 256;
     const int nb = p.tilesM * p.tilesN;
+    STAIR_ACCT_MFMA("gemm_planes", (int64_t)a.M * a.K * (a.A_lo ? 4 : 2) + (int64_t)a.N * a.K * 4 + (int64_t)a.M * a.N * 4, 2ll * a.M * a.N * a.K);
     static const int ncu = [] {
         int dev = 0, n = 256;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;

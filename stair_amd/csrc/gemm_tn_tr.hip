@@ -303,6 +303,7 @@ int launch_gemm_tn_tr(const stair_gemm_tn_args &a, hipStream_t s) {
     }
     static const int abl = [] { const char *e = getenv("STAIR_TN_TR_ABLATE"); return e ? atoi(e) : 0; }();     // timing experiments: wrong results
     const dim3 grid(8 * p.tilesN * p.tilesK);
+    STAIR_ACCT_MFMA("gemm_tn_tr", (int64_t)a.M * a.N * 4 + (int64_t)a.M * a.K * 2 + (int64_t)a.N * a.K * 4, 2ll * a.M * a.N * a.K);
     if (abl == 1) hipLaunchKernelGGL(gemm_tn_tr_kernel<1>, grid, dim3(512), shmem, s, p);
     else if (abl == 2) hipLaunchKernelGGL(gemm_tn_tr_kernel<2>, grid, dim3(512), shmem, s, p);
     else if (abl == 3) hipLaunchKernelGGL(gemm_tn_tr_kernel<3>, grid, dim3(512), shmem, s, p);

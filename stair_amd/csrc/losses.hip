@@ -116,12 +116,16 @@ int launch_loss_head(int nout, const float *vec, float *d_vec, const int32_t *sl
 // Contrastive CE of Filter / ToAction / Superlative (:113-125 with the window pooling of :388-406):
 //   pred = L2Normalize(x) (module_net.py:211-216); logits_c = G[c] . pred over the classes of the item's window;
 //   loss = -log softmax(logits)[positive].   Gradient goes back through the normalisation into d_vec.
+// Table form (presence != NULL): G is the table of ALL class representations [n_cls, H], the item's pool is the set of
+// classes c with presence[win_row[i]][c] > 0 (a window's pool summed over the data-parallel ranks, so no rank needs the
+// others' class lists on the host), pos[i] the positive CLASS id; absent classes take no part in the softmax.
 __global__ void loss_contrastive_kernel(const float *vec, float *d_vec, const int32_t *slot, const int32_t *pos,
                                         const int32_t *win_start, const int32_t *win_cnt, const float *G, int n, int H,
-                                        float scale, float *loss) {
+                                        float scale, float *loss, const float *presence, const int32_t *win_row, int n_cls) {
     extern __shared__ float sm[];      // [C] logits -> softmax probs, then [H] dpred
     const int i = blockIdx.x;
-    const int c0 = win_start[i], C = win_cnt[i];
+    const int c0 = presence ? 0 : win_start[i], C = presence ? n_cls : win_cnt[i];
+    const float *mask = presence ? presence + (int64_t)win_row[i] * n_cls : nullptr;
     float *prob = sm, *dpred = sm + C;
     __shared__ float s_nrm, s_dot;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -139,7 +143,7 @@ __global__ void loss_contrastive_kernel(const float *vec, float *d_vec, const in
         float d = 0.f;
         for (int h = lane; h < H; h += 64) d += g[h] * x[h];
         d = wave_sum(d);
-        if (lane == 0) prob[c] = d * inv;
+        if (lane == 0) prob[c] = (mask && !(mask[c] > 0.f)) ? -INFINITY : d * inv;
     }
     __syncthreads();
     if (wave == 0) {
@@ -176,7 +180,16 @@ int launch_loss_contrastive(const float *vec, float *d_vec, const int32_t *slot,
                             hipStream_t s) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(loss_contrastive_kernel, dim3(n), dim3(kBlock), (size_t)(max_classes + H) * sizeof(float), s, vec, d_vec,
-                       slot, pos, win_start, win_cnt, G, n, H, scale, loss);
+                       slot, pos, win_start, win_cnt, G, n, H, scale, loss, (const float *)nullptr, (const int32_t *)nullptr, 0);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+int launch_loss_contrastive_table(const float *vec, float *d_vec, const int32_t *slot, const int32_t *pos_class, const int32_t *win_row,
+                                  const float *presence, const float *reps, int n, int n_cls, int H, float scale, float *loss, hipStream_t s) {
+    if (n == 0) return 0;
+    STAIR_CHECK(n_cls > 0 && (size_t)(n_cls + H) * sizeof(float) <= 60 * 1024, "class table too large for the loss kernel's LDS (n_cls + H floats)");
+    hipLaunchKernelGGL(loss_contrastive_kernel, dim3(n), dim3(kBlock), (size_t)(n_cls + H) * sizeof(float), s, vec, d_vec,
+                       slot, pos_class, (const int32_t *)nullptr, (const int32_t *)nullptr, reps, n, H, scale, loss, presence, win_row, n_cls);
     STAIR_LAUNCH_CHECK();
     return 0;
 }
@@ -343,6 +356,13 @@ extern "C" int stair_loss_contrastive(const float *vec, float *d_vec, const int3
                                       int32_t max_classes, float scale, float *loss, stair_stream stream) {
     return stair::launch_loss_contrastive(vec, d_vec, slot, pos, win_start, win_cnt, G, n, H, max_classes, scale, loss,
                                           static_cast<hipStream_t>(stream));
+}
+extern "C" int stair_loss_contrastive_table(const float *vec, float *d_vec, const int32_t *slot, const int32_t *pos_class,
+                                            const int32_t *win_row, const float *presence, const float *reps, int32_t n,
+                                            int32_t n_cls, int32_t H, float scale, float *loss, stair_stream stream) {
+    STAIR_CHECK(vec && slot && pos_class && win_row && presence && reps && loss, "null argument");
+    return stair::launch_loss_contrastive_table(vec, d_vec, slot, pos_class, win_row, presence, reps, n, n_cls, H, scale, loss,
+                                                static_cast<hipStream_t>(stream));
 }
 extern "C" int stair_loss_filterframe(const float *map, float *d_map, const int32_t *slot, const float *gold, const float *W,
                                       const float *b, float *dW, float *db, int32_t n, int32_t T, int32_t H, int32_t O,

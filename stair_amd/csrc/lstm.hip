@@ -758,9 +758,10 @@ int launch_lstm_bwd_recur(const stair_lstm_bwd_args &a, hipStream_t s) {
     // Cooperative BPTT (csrc/lstm_coop.hip) while every 32-sequence tile gets a group of its own: 338 us at n = 8 and 819 us at
     // n = 1024 against 727 / 920 us of the one-workgroup kernel; beyond that both are bound by the saved-state traffic
     // (2.8 GB per launch at n = 2048) and the one-workgroup kernel's 1.1 ms beats two tiles per group (1.6 ms).
-    if (lstm_bwd_takes_coop(a)) {
-        if (int rc = launch_lstm_bwd_coop(a, s)) return rc;
-    } else {
+    int rc_coop = -1;
+    if (lstm_bwd_takes_coop(a)) rc_coop = launch_lstm_bwd_coop(a, s);      // -1: not co-resident on this device
+    if (rc_coop > 0) return rc_coop;
+    if (rc_coop < 0) {
         const bool split = matmul_mode() != STAIR_MATMUL_F32 && Hh % 64 == 0;
         if (split) {
             const int64_t n8 = 2 * 8 * (int64_t)Hh * Hh / 8;
@@ -785,6 +786,7 @@ int launch_lstm_bwd_recur(const stair_lstm_bwd_args &a, hipStream_t s) {
             STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_bwd_x3_kernel<2, 8>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         }
+        STAIR_ACCT_MFMA(split ? "lstm_bwd_x3" : "lstm_bwd_f32", 0, 2ll * 2 * a.rows * 4 * Hh * Hh);
         if (split) {
             if (tiles > 8) hipLaunchKernelGGL((lstm_bwd_x3_kernel<2, 8>), grid, dim3(512), shmem, s, p);
             else if (tiles > 4) hipLaunchKernelGGL((lstm_bwd_x3_kernel<1, 8>), grid, dim3(512), shmem, s, p);
@@ -873,7 +875,10 @@ int launch_lstm_project(const stair_lstm_args &a, hipStream_t s) {
 int launch_lstm_recur(const stair_lstm_args &a, hipStream_t s) {
     if (a.n == 0 || a.rows == 0) return 0;
     const int Hh = a.Hh;
-    if (a.coop_ws && lstm_coop_usable(Hh)) return launch_lstm_rec_coop(a, s);   // hidden units split over co-resident workgroups
+    if (a.coop_ws && lstm_coop_usable(Hh)) {          // hidden units split over co-resident workgroups
+        const int rc = launch_lstm_rec_coop(a, s);
+        if (rc >= 0) return rc;                       // -1: the grid does not fit this device at once -> one-workgroup kernel below
+    }
     const bool split = matmul_mode() != STAIR_MATMUL_F32 && Hh % 64 == 0;     // the split kernel walks k blocks in pairs
     if (split) {
         const int64_t n8 = 2 * 8 * (int64_t)Hh * Hh / 8;
@@ -892,6 +897,7 @@ int launch_lstm_recur(const stair_lstm_args &a, hipStream_t s) {
     const dim3 grid((a.n + 15) / 16, 2);
     const size_t shmem = 2 * 16 * (Hh + 4) * sizeof(float);
     const int tiles = Hh / 16;
+    STAIR_ACCT_MFMA(split ? "lstm_rec_x3" : "lstm_rec_f32", 0, 2ll * 2 * a.rows * 4 * Hh * Hh);
     if (split) {
         if (tiles > 8) hipLaunchKernelGGL((lstm_rec_x3_kernel<2, 8>), grid, dim3(512), shmem, s, p);
         else if (tiles > 4) hipLaunchKernelGGL((lstm_rec_x3_kernel<1, 8>), grid, dim3(512), shmem, s, p);

@@ -54,7 +54,8 @@ struct CoopParams {
     float *cbuf;              // [rows, 2 Hh] or null
     char *xh;                 // exchange slabs [2 parity][groups][NT tiles][TILE_BYTES]
     unsigned *flags;          // [groups][NT tiles][CP] epochs, FLAG_STRIDE words apart; zeroed before the launch
-    unsigned *err;            // one word: set to 1 when a spin timed out
+    unsigned *err;            // one word: set to 1 when a spin timed out (inside coop_ws, cleared before every launch)
+    unsigned *status;         // optional caller-owned STICKY word (stair_lstm_args.status): also set on a timeout, never cleared here
     int n, gpd;               // sequences, groups per direction
 };
 
@@ -147,7 +148,10 @@ __device__ __forceinline__ void lstm_rec_coop_body(const CoopParams &p, const in
                 unsigned spins = 0;
                 while (!__all((int)(seen - ep) >= 0)) {
                     if (++spins > SPIN_LIMIT) {
-                        if (lane == 0) __hip_atomic_store((gu32 *)p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (lane == 0) {
+                            __hip_atomic_store((gu32 *)p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (p.status) __hip_atomic_store((gu32 *)p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
                         dead = true;                               // this wave polls no more; the results are void, the launch drains
                         break;
                     }
@@ -331,13 +335,49 @@ __global__ __launch_bounds__(512, 1) void lstm_rec_coop_pair_kernel(CoopParams a
 }
 
 // tiles per group: 3 once the batch fills most of the chip that way, else as many as it takes to use all groups
-static int coop_cu_count() {
-    static const int n = [] {
-        int dev = 0, v = 256;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 256;
-        return v;
-    }();
-    return n;
+// Per-DEVICE launch state (a process may drive several GPUs): CU count, "dynamic LDS attribute set" and the occupancy the
+// runtime reports for each kernel variant.  STAIR_LSTM_COOP_MAX_BLOCKS caps the number of workgroups a cooperative launch may
+// use (tests: forces the smaller geometries and the fallback to the one-workgroup kernels).
+constexpr int MAX_DEVICES = 64;
+struct CoopDevice {
+    int cus = 0;
+    bool rec_attrs = false, bwd_attrs = false;
+    int occ[16] = {};          // max co-resident workgroups of variant v on this device (0 = not asked yet)
+};
+static CoopDevice &coop_device() {
+    static CoopDevice devs[MAX_DEVICES];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) dev = 0;
+    CoopDevice &d = devs[dev];
+    if (d.cus == 0) {
+        int v = 256;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        d.cus = v;
+    }
+    return d;
+}
+static int g_coop_cap = -1;          // stair_lstm_coop_limit; -1 = STAIR_LSTM_COOP_MAX_BLOCKS or no cap
+static int coop_block_cap() {
+    static const int env_cap = [] { const char *e = getenv("STAIR_LSTM_COOP_MAX_BLOCKS"); return e ? std::max(0, atoi(e)) : 1 << 30; }();
+    return std::min(g_coop_cap >= 0 ? g_coop_cap : env_cap, coop_device().cus);
+}
+static int coop_cu_count() { return coop_block_cap(); }
+
+// All workgroups of a cooperative launch wait for each other, so the whole grid must be resident at once.  The contract is
+// checked against the runtime's own occupancy figure for THIS kernel on THIS device (registers, LDS, workgroup size), not
+// assumed from __launch_bounds__: false -> the caller falls back to the one-workgroup-per-16-sequences kernels.
+template <typename K>
+static bool coop_fits(K kernel, int variant, int blocks, size_t shmem) {
+    CoopDevice &d = coop_device();
+    if (d.occ[variant] == 0) {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kernel), 512, shmem) != hipSuccess || per_cu < 1) {
+            (void)hipGetLastError();
+            per_cu = 0;
+        }
+        d.occ[variant] = per_cu > 0 ? per_cu * d.cus : -1;
+    }
+    return d.occ[variant] > 0 && blocks <= std::min(d.occ[variant], coop_block_cap());
 }
 
 static void coop_geometry(int n, int &nt, int &gpd) {
@@ -351,6 +391,9 @@ static void coop_geometry(int n, int &nt, int &gpd) {
     gpd = std::max(1, std::min((n + 32 * nt - 1) / (32 * nt), cap));
 }
 
+// workgroups of a launch with `gpd` groups per direction: group g = (b & 7) + 8 * (b >> 5); workgroup (b >> 3) & 3
+static int coop_blocks(int gpd) { return 32 * ((2 * gpd + 7) / 8); }
+
 int64_t lstm_coop_ws_bytes(int n) {
     // sized for the largest geometry (3 tiles, 32 groups per direction): the choice above may change with n
     const int G = 64;
@@ -360,7 +403,8 @@ int64_t lstm_coop_ws_bytes(int n) {
 
 bool lstm_coop_usable(int Hh) {
     static const bool on = [] { const char *e = getenv("STAIR_LSTM_COOP"); return !(e && e[0] == '0'); }();
-    return on && Hh == CH && matmul_mode() != STAIR_MATMUL_F32;
+    // even the smallest launch (one group per direction) needs 32 co-resident workgroups
+    return on && Hh == CH && matmul_mode() != STAIR_MATMUL_F32 && coop_block_cap() >= 32;
 }
 
 // fills the kernel parameters of one recurrence and enqueues its per-launch memsets (flags, h_n)
@@ -371,7 +415,7 @@ static int coop_prepare(const stair_lstm_args &a, hipStream_t s, CoopParams &p, 
     STAIR_CHECK(a.ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.h_n) & 15) == 0,
                 "out / h_n must be 16-byte aligned with ldo % 4 == 0");
     p.xproj = a.xproj_ws; p.w_hh[0] = a.w_hh[0]; p.w_hh[1] = a.w_hh[1]; p.seq_off = a.seq_off; p.seq_len = a.seq_len;
-    p.out = a.out; p.ldo = a.ldo; p.h_n = a.h_n; p.cbuf = a.cbuf; p.n = a.n;
+    p.out = a.out; p.ldo = a.ldo; p.h_n = a.h_n; p.cbuf = a.cbuf; p.n = a.n; p.status = a.status;
     nt = 1;
     coop_geometry(a.n, nt, p.gpd);
     const int G = 2 * p.gpd;
@@ -385,12 +429,12 @@ static int coop_prepare(const stair_lstm_args &a, hipStream_t s, CoopParams &p, 
     STAIR_HIP(hipMemsetAsync(p.flags, 0, (size_t)flag_words * 4, s));
     // h_n of empty sequences is zero and the kernel only writes it at a sequence's last step
     STAIR_HIP(hipMemsetAsync(a.h_n, 0, (size_t)a.n * 2 * CH * sizeof(float), s));
-    blocks = 32 * ((G + 7) / 8);                                 // group g = (b & 7) + 8 * (b >> 5); workgroup (b >> 3) & 3
+    blocks = coop_blocks(p.gpd);
     return 0;
 }
 
 static void coop_attrs() {
-    static bool attr_set = false;
+    bool &attr_set = coop_device().rec_attrs;
     if (attr_set) return;
 #define C_ATTR(TR_, NT_) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_rec_coop_kernel<TR_, NT_>), hipFuncAttributeMaxDynamicSharedMemorySize, NT_ * TILE_BYTES + 64);
     C_ATTR(false, 1) C_ATTR(false, 2) C_ATTR(false, 3) C_ATTR(true, 1) C_ATTR(true, 2) C_ATTR(true, 3)
@@ -403,11 +447,23 @@ static void coop_attrs() {
     attr_set = true;
 }
 
+// -1: the grid would not be co-resident on this device (the caller runs the one-workgroup kernel)
 int launch_lstm_rec_coop(const stair_lstm_args &a, hipStream_t s) {
     CoopParams p;
     int nt = 1, blocks = 0;
-    if (int rc = coop_prepare(a, s, p, nt, blocks)) return rc;
     coop_attrs();
+    {
+        int gpd = 0;
+        coop_geometry(a.n, nt, gpd);
+        const int nb = coop_blocks(gpd);
+        const size_t sh = (size_t)nt * TILE_BYTES + 64;
+        const bool tr = a.cbuf != nullptr;
+        const bool ok = nt == 1 ? (tr ? coop_fits(&lstm_rec_coop_kernel<true, 1>, 0, nb, sh) : coop_fits(&lstm_rec_coop_kernel<false, 1>, 1, nb, sh))
+                      : nt == 2 ? (tr ? coop_fits(&lstm_rec_coop_kernel<true, 2>, 2, nb, sh) : coop_fits(&lstm_rec_coop_kernel<false, 2>, 3, nb, sh))
+                                : (tr ? coop_fits(&lstm_rec_coop_kernel<true, 3>, 4, nb, sh) : coop_fits(&lstm_rec_coop_kernel<false, 3>, 5, nb, sh));
+        if (!ok) return -1;
+    }
+    if (int rc = coop_prepare(a, s, p, nt, blocks)) return rc;
     static const bool prof = [] { const char *e = getenv("STAIR_LSTM_COOP_PROF"); return e && e[0] == '1'; }();   // diagnostic build, never the product
     if (prof && !a.cbuf) {
         if (nt == 1) hipLaunchKernelGGL((lstm_rec_coop_kernel<false, 1, true>), dim3(blocks), dim3(512), 1 * TILE_BYTES + 64, s, p);
@@ -416,6 +472,7 @@ int launch_lstm_rec_coop(const stair_lstm_args &a, hipStream_t s) {
         STAIR_LAUNCH_CHECK();
         return 0;
     }
+    STAIR_ACCT_MFMA("lstm_rec_coop", 0, 2ll * 2 * a.rows * 4 * CH * CH);
 #define C_LAUNCH(NT_)                                                                                                              \
     if (a.cbuf) hipLaunchKernelGGL((lstm_rec_coop_kernel<true, NT_>), dim3(blocks), dim3(512), NT_ * TILE_BYTES + 64, s, p);        \
     else hipLaunchKernelGGL((lstm_rec_coop_kernel<false, NT_>), dim3(blocks), dim3(512), NT_ * TILE_BYTES + 64, s, p);
@@ -435,14 +492,17 @@ int launch_lstm_rec_coop_pair(const stair_lstm_args &a, const stair_lstm_args &b
     coop_geometry(a.n, nta, ga);
     coop_geometry(b.n, ntb, gb);
     if (nta != 1 || ntb != 1) return -1;
-    if (32 * ((2 * ga + 7) / 8) + 32 * ((2 * gb + 7) / 8) > coop_cu_count()) return -1;
+    if (coop_blocks(ga) + coop_blocks(gb) > coop_cu_count()) return -1;
     static const bool prof = [] { const char *e = getenv("STAIR_LSTM_COOP_PROF"); return e && e[0] == '1'; }();
     if (prof) return -1;
+    coop_attrs();
+    if (a.cbuf ? !coop_fits(&lstm_rec_coop_pair_kernel<true>, 6, coop_blocks(ga) + coop_blocks(gb), TILE_BYTES + 64)
+               : !coop_fits(&lstm_rec_coop_pair_kernel<false>, 7, coop_blocks(ga) + coop_blocks(gb), TILE_BYTES + 64)) return -1;
     CoopParams pa, pb;
     int blocks_a = 0, blocks_b = 0;
     if (int rc = coop_prepare(a, s, pa, nta, blocks_a)) return rc;
     if (int rc = coop_prepare(b, s, pb, ntb, blocks_b)) return rc;
-    coop_attrs();
+    STAIR_ACCT_MFMA("lstm_rec_coop_pair", 0, 2ll * 2 * (a.rows + b.rows) * 4 * CH * CH);
     if (a.cbuf) hipLaunchKernelGGL(lstm_rec_coop_pair_kernel<true>, dim3(blocks_a + blocks_b), dim3(512), 1 * TILE_BYTES + 64, s, pa, pb, blocks_a);
     else hipLaunchKernelGGL(lstm_rec_coop_pair_kernel<false>, dim3(blocks_a + blocks_b), dim3(512), 1 * TILE_BYTES + 64, s, pa, pb, blocks_a);
     STAIR_LAUNCH_CHECK();
@@ -478,7 +538,7 @@ struct CoopBwdParams {
     const float *w_hh[2];
     const int32_t *seq_off, *seq_len;
     char *xh;                 // partial-sum slabs [2 parity][groups][NT][BSLAB_BYTES]
-    unsigned *flags, *err;
+    unsigned *flags, *err, *status;
     int n, gpd;
 };
 
@@ -584,7 +644,10 @@ __device__ __forceinline__ void lstm_bwd_coop_body(const CoopBwdParams &p, const
                         unsigned spins = 0, seen = __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         while (!__all((int)(seen - ep) >= 0)) {
                             if (++spins > SPIN_LIMIT) {
-                                if (lane == 0) __hip_atomic_store((gu32 *)p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (lane == 0) {
+                            __hip_atomic_store((gu32 *)p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (p.status) __hip_atomic_store((gu32 *)p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
                                 dead = true;
                                 break;
                             }
@@ -694,6 +757,13 @@ int64_t lstm_coop_bwd_ws_bytes(int n) {
     return (int64_t)2 * G * 2 * BSLAB_BYTES + (int64_t)(G * 2 * CP * FLAG_STRIDE + 64) * 4;
 }
 
+static void coop_bwd_geometry(int n, int &nt, int &gpd) {
+    nt = 1;
+    coop_geometry(n, nt, gpd);
+    if (nt > 2) nt = 2;
+    gpd = std::max(1, std::min((n + 32 * nt - 1) / (32 * nt), std::max(1, std::min(32, coop_cu_count() / 8))));
+}
+
 static int coop_bwd_prepare(const stair_lstm_bwd_args &a, hipStream_t s, CoopBwdParams &p, int &nt, int &blocks) {
     STAIR_CHECK(a.Hh == CH, "cooperative BPTT is built for Hh = 256");
     STAIR_CHECK(a.coop_ws && a.coop_ws_bytes >= lstm_coop_bwd_ws_bytes(a.n), "coop_ws missing or too small");
@@ -701,11 +771,8 @@ static int coop_bwd_prepare(const stair_lstm_bwd_args &a, hipStream_t s, CoopBwd
     STAIR_CHECK(a.ldd % 4 == 0 && (reinterpret_cast<uintptr_t>(a.d_out) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.gates) & 15) == 0 &&
                 (reinterpret_cast<uintptr_t>(a.cbuf) & 15) == 0, "gates / cbuf / d_out must be 16-byte aligned with ldd % 4 == 0");
     p.G = a.gates; p.cbuf = a.cbuf; p.d_out = a.d_out; p.ldd = a.ldd; p.d_hn = a.d_hn;
-    p.w_hh[0] = a.w_hh[0]; p.w_hh[1] = a.w_hh[1]; p.seq_off = a.seq_off; p.seq_len = a.seq_len; p.n = a.n;
-    nt = 1;
-    coop_geometry(a.n, nt, p.gpd);
-    if (nt > 2) nt = 2;
-    p.gpd = std::max(1, std::min((a.n + 32 * nt - 1) / (32 * nt), std::max(1, std::min(32, coop_cu_count() / 8))));
+    p.w_hh[0] = a.w_hh[0]; p.w_hh[1] = a.w_hh[1]; p.seq_off = a.seq_off; p.seq_len = a.seq_len; p.n = a.n; p.status = a.status;
+    coop_bwd_geometry(a.n, nt, p.gpd);
     const int G = 2 * p.gpd;
     char *base = static_cast<char *>(a.coop_ws);
     const int64_t slab_bytes = (int64_t)2 * G * nt * BSLAB_BYTES;
@@ -714,12 +781,12 @@ static int coop_bwd_prepare(const stair_lstm_bwd_args &a, hipStream_t s, CoopBwd
     p.flags = reinterpret_cast<unsigned *>(base + slab_bytes);
     p.err = p.flags + G * nt * CP * FLAG_STRIDE;
     STAIR_HIP(hipMemsetAsync(p.flags, 0, (size_t)flag_words * 4, s));
-    blocks = 32 * ((G + 7) / 8);
+    blocks = coop_blocks(p.gpd);
     return 0;
 }
 
 static void coop_bwd_attrs() {
-    static bool attr_set = false;
+    bool &attr_set = coop_device().bwd_attrs;
     if (attr_set) return;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_bwd_coop_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 1 * TILE_BYTES + 64);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_bwd_coop_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE_BYTES + 64);
@@ -727,11 +794,19 @@ static void coop_bwd_attrs() {
     attr_set = true;
 }
 
+// -1: the grid would not be co-resident on this device (the caller runs the one-workgroup BPTT kernel)
 int launch_lstm_bwd_coop(const stair_lstm_bwd_args &a, hipStream_t s) {
     CoopBwdParams p;
     int nt = 1, blocks = 0;
-    if (int rc = coop_bwd_prepare(a, s, p, nt, blocks)) return rc;
     coop_bwd_attrs();
+    {
+        int gpd = 0;
+        coop_bwd_geometry(a.n, nt, gpd);
+        const size_t sh = (size_t)nt * TILE_BYTES + 64;
+        if (nt == 1 ? !coop_fits(&lstm_bwd_coop_kernel<1>, 8, coop_blocks(gpd), sh) : !coop_fits(&lstm_bwd_coop_kernel<2>, 9, coop_blocks(gpd), sh)) return -1;
+    }
+    if (int rc = coop_bwd_prepare(a, s, p, nt, blocks)) return rc;
+    STAIR_ACCT_MFMA("lstm_bwd_coop", 0, 2ll * 2 * a.rows * 4 * CH * CH);
     if (nt == 1) hipLaunchKernelGGL((lstm_bwd_coop_kernel<1>), dim3(blocks), dim3(512), 1 * TILE_BYTES + 64, s, p);
     else hipLaunchKernelGGL((lstm_bwd_coop_kernel<2>), dim3(blocks), dim3(512), 2 * TILE_BYTES + 64, s, p);
     STAIR_LAUNCH_CHECK();
@@ -747,12 +822,14 @@ int launch_lstm_bwd_coop_pair(const stair_lstm_bwd_args &a, const stair_lstm_bwd
     coop_geometry(a.n, nta, ga);
     coop_geometry(b.n, ntb, gb);
     if (nta != 1 || ntb != 1) return -1;
-    if (32 * ((2 * ga + 7) / 8) + 32 * ((2 * gb + 7) / 8) > coop_cu_count()) return -1;
+    if (coop_blocks(ga) + coop_blocks(gb) > coop_cu_count()) return -1;
+    coop_bwd_attrs();
+    if (!coop_fits(&lstm_bwd_coop_pair_kernel, 10, coop_blocks(ga) + coop_blocks(gb), TILE_BYTES + 64)) return -1;
     CoopBwdParams pa, pb;
     int blocks_a = 0, blocks_b = 0;
     if (int rc = coop_bwd_prepare(a, s, pa, nta, blocks_a)) return rc;
     if (int rc = coop_bwd_prepare(b, s, pb, ntb, blocks_b)) return rc;
-    coop_bwd_attrs();
+    STAIR_ACCT_MFMA("lstm_bwd_coop_pair", 0, 2ll * 2 * (a.rows + b.rows) * 4 * CH * CH);
     hipLaunchKernelGGL(lstm_bwd_coop_pair_kernel, dim3(blocks_a + blocks_b), dim3(512), 1 * TILE_BYTES + 64, s, pa, pb, blocks_a);
     STAIR_LAUNCH_CHECK();
     return 0;
@@ -760,5 +837,6 @@ int launch_lstm_bwd_coop_pair(const stair_lstm_bwd_args &a, const stair_lstm_bwd
 
 }  // namespace stair
 
+extern "C" int stair_lstm_coop_limit(int32_t max_blocks) { stair::g_coop_cap = max_blocks; return 0; }
 extern "C" int64_t stair_lstm_coop_ws_bytes(int32_t n) { return stair::lstm_coop_ws_bytes(n); }
 extern "C" int64_t stair_lstm_coop_bwd_ws_bytes(int32_t n) { return stair::lstm_coop_bwd_ws_bytes(n); }

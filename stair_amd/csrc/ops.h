@@ -112,7 +112,7 @@ int launch_scale_rows(float *G, const float *rs, int64_t rows, int H, hipStream_
 int launch_ce_loss(const float *logits, const int32_t *answers, float scale, float *loss, float *dlogits, int n, int A,
                    hipStream_t s);
 int launch_adam(float *p, const float *g, float *m, float *v, const int32_t *seg_of_block, const int32_t *touched,
-                const float *step_of_seg, float lr, float b1, float b2, float eps, float wd, int64_t n, hipStream_t s);
+                const float *step_of_seg, float lr, float b1, float b2, float eps, float wd, int64_t n, const uint32_t *guard, hipStream_t s);
 int launch_argmax(const float *logits, int32_t *out, int n, int A, hipStream_t s);
 
 }  // namespace stair

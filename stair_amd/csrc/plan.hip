@@ -25,11 +25,13 @@ static thread_local std::string g_err;
 void set_error(const std::string &msg) { g_err = msg; }
 
 bool g_acct_on = false;
-static std::map<std::string, std::pair<int64_t, int64_t>> g_acct;       // kernel -> (launches, algorithmic bytes)
-void acct_add(const char *kernel, int64_t bytes) {
+struct AcctEntry { int64_t launches = 0, bytes = 0, flops = 0; };
+static std::map<std::string, AcctEntry> g_acct;       // kernel -> (launches, algorithmic bytes, algorithmic flops)
+void acct_add(const char *kernel, int64_t bytes, int64_t flops) {
     auto &e = g_acct[kernel];
-    e.first += 1;
-    e.second += bytes;
+    e.launches += 1;
+    e.bytes += bytes;
+    e.flops += flops;
 }
 
 }  // namespace stair
@@ -147,9 +149,10 @@ static void build_weight_table(stair_ctx *c) {
 
 extern "C" int stair_abi_version(void) { return STAIR_ABI_VERSION; }
 extern "C" void stair_acct_enable(int32_t on) { g_acct_on = on != 0; if (on) g_acct.clear(); }
-extern "C" int stair_acct_dump(char *buf, int32_t cap) {        // "kernel launches bytes\n" lines; returns the length needed
+extern "C" int stair_acct_dump(char *buf, int32_t cap) {        // "kernel launches bytes flops\n" lines; returns the length needed
     std::string out;
-    for (auto &kv : g_acct) out += kv.first + " " + std::to_string(kv.second.first) + " " + std::to_string(kv.second.second) + "\n";
+    for (auto &kv : g_acct)
+        out += kv.first + " " + std::to_string(kv.second.launches) + " " + std::to_string(kv.second.bytes) + " " + std::to_string(kv.second.flops) + "\n";
     if (buf && cap > 0) { const size_t n = std::min<size_t>(out.size(), (size_t)cap - 1); memcpy(buf, out.data(), n); buf[n] = 0; }
     return (int)out.size() + 1;
 }
@@ -318,7 +321,7 @@ struct stair_plan {
     // workspace layout (float offsets)
     int64_t o_idx = 0, o_vec = 0, o_map = 0, o_att = 0, o_tok = 0, o_qfeat = 0, o_vhn = 0, o_xpv = 0, o_xpt = 0,
             o_bias = 0, o_wpack = 0, o_wplanes = 0, o_coop = 0, o_coop2 = 0, o_splitk = 0, o_tmpA = 0, o_tmpB = 0, o_kbuf = 0, o_cat = 0, o_hid = 0, o_rs = 0, o_sup = 0, o_extra = 0,
-            o_logits = 0, total = 0;
+            o_logits = 0, o_status = 0, total = 0;
     // training only
     bool train = false;
     float drop_p = 0.0f;            // training-mode dropout (stair_plan_set_dropout); 0 = off
@@ -706,6 +709,7 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
     pl->o_sup = take((int64_t)std::max(pl->maxSupRows, 1) * T, 64);
     pl->o_extra = take(std::max(pl->maxI, 1), 64);
     pl->o_logits = take((int64_t)n * A, 64);
+    pl->o_status = take(64, 64);                 // word 0: sticky "a cooperative hand-off timed out" flag of this plan's passes
     for (Bucket &b : pl->buckets) {
         b.svA = pl->o_tmpA; b.svB = pl->o_tmpB; b.svK = pl->o_kbuf; b.svCat = pl->o_cat; b.svHid = pl->o_hid;
         b.svRs = pl->o_rs; b.svSup = pl->o_sup; b.svExtra = pl->o_extra;
@@ -776,11 +780,23 @@ extern "C" int stair_plan_get_info(const stair_plan *pl, stair_plan_info *info) 
     info->gvec_off = pl->train ? pl->o_gblock : -1;
     info->gmap_off = pl->train ? pl->o_gblock + (pl->o_map - pl->o_vec) : -1;
     info->gatt_off = pl->train ? pl->o_gatt : -1;
+    info->status_off = pl->o_status;
     info->n_vec = pl->n_vec; info->n_map = pl->n_map; info->n_att = pl->n_att; info->n_tok_rows = pl->rows_q;
     info->n_nodes = (int)pl->nodes.size();
     int launches = 0;
     for (const Bucket &b : pl->buckets) launches += b.cnt > 0;
     info->n_launches = launches; info->n_levels = pl->n_levels; info->n_questions = pl->n; info->T = pl->T;
+    return 0;
+}
+
+extern "C" int stair_plan_status(const stair_plan *pl, const void *workspace, stair_stream stream) {
+    STAIR_CHECK(pl && workspace, "null argument");
+    uint32_t word = 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    STAIR_HIP(hipMemcpyAsync(&word, static_cast<const float *>(workspace) + pl->o_status, sizeof(word), hipMemcpyDeviceToHost, s));
+    STAIR_HIP(hipStreamSynchronize(s));
+    STAIR_CHECK(word == 0, "a cooperative LSTM hand-off timed out (its workgroups were not co-resident: another queue on this GPU, or a "
+                           "partitioned device); the results of this run contain NaN.  Set STAIR_LSTM_COOP=0 to use the one-workgroup kernels");
     return 0;
 }
 
@@ -988,6 +1004,8 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
 
     if (!(flags & STAIR_RUN_INDEX_RESIDENT))
         if (int rc_ = upload_index_image(pl, didx, s)) return rc_;
+    uint32_t *status = reinterpret_cast<uint32_t *>(ws + pl->o_status);
+    STAIR_HIP(hipMemsetAsync(status, 0, 64 * sizeof(float), s));      // a new run of this plan starts clean; the backward pass keeps it
 
     struct SplitKScope {            // forward products of this call may stage split-K partials in the workspace
         explicit SplitKScope(float *p) { g_splitk_ws = p; }
@@ -1018,7 +1036,7 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
         }
         a.xproj_ws = ws + pl->o_xpv; a.bias_ws = ws + pl->o_bias; a.whh_pack_ws = ws + pl->o_wpack;
         a.out = map; a.ldo = H; a.h_n = ws + pl->o_vhn;
-        a.coop_ws = ws + pl->o_coop; a.coop_ws_bytes = pl->coop_bytes;
+        a.coop_ws = ws + pl->o_coop; a.coop_ws_bytes = pl->coop_bytes; a.status = status;
         a.cbuf = pl->train ? ws + pl->o_cv : nullptr;
 
         t.x = question; t.ldx = E; t.rows = pl->rows_q; t.n = n; t.max_len = pl->max_q; t.I = E; t.Hh = Hh;
@@ -1029,7 +1047,7 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
         }
         t.xproj_ws = ws + pl->o_xpt; t.bias_ws = ws + pl->o_bias + 4 * H; t.whh_pack_ws = ws + pl->o_wpack + 2 * (int64_t)H * H;
         t.out = tok; t.ldo = H; t.h_n = qfeat;
-        t.coop_ws = ws + pl->o_coop2; t.coop_ws_bytes = pl->coop_bytes;
+        t.coop_ws = ws + pl->o_coop2; t.coop_ws_bytes = pl->coop_bytes; t.status = status;
         t.cbuf = pl->train ? ws + pl->o_ct : nullptr;
 
         // both input projections, then the two recurrences -- in ONE launch while all their workgroups fit on the chip
@@ -1430,6 +1448,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
             }
             a.n = e == 0 ? pl->n_vid : n; a.Hh = Hh; a.ldo = H; a.ldd = H; a.hprev_ws = ws + pl->o_hprev;
             a.coop_ws_bytes = pl->coop_bytes;
+            a.status = reinterpret_cast<uint32_t *>(ws + pl->o_status);
             for (int d = 0; d < 2; ++d) {
                 a.w_hh[d] = W.enc[e][4 * d + 1];
                 a.dw_ih[d] = W.denc[e][4 * d]; a.dw_hh[d] = W.denc[e][4 * d + 1];
@@ -1509,10 +1528,11 @@ extern "C" int stair_plan_touched(const stair_ctx *ctx, const stair_plan *pl, in
 
 extern "C" int stair_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq,
                                const int32_t *seg_of_block, const int32_t *touched, const float *step_of_seg, float lr,
-                               float beta1, float beta2, float eps, float weight_decay, int64_t n, stair_stream stream) {
+                               float beta1, float beta2, float eps, float weight_decay, int64_t n, const uint32_t *guard,
+                               stair_stream stream) {
     STAIR_CHECK(params && grads && exp_avg && exp_avg_sq && seg_of_block && touched && step_of_seg, "null argument");
     return launch_adam(params, grads, exp_avg, exp_avg_sq, seg_of_block, touched, step_of_seg, lr, beta1, beta2, eps, weight_decay, n,
-                       static_cast<hipStream_t>(stream));
+                       guard, static_cast<hipStream_t>(stream));
 }
 
 // Layout introspection for tests: every workspace region as (name, begin, end) in floats.
@@ -1549,6 +1569,7 @@ extern "C" int stair_plan_regions(stair_plan *pl, const stair_ctx *ctx, const ch
     add("sup", pl->o_sup, (int64_t)std::max(pl->maxSupRows, 1) * T);
     add("extra", pl->o_extra, std::max(pl->maxI, 1));
     add("logits", pl->o_logits, n * A);
+    add("status", pl->o_status, 64);
     if (pl->train) {
         int bi = 0;
         for (const Bucket &b : pl->buckets) {

@@ -1017,9 +1017,11 @@ int launch_ce_loss(const float *logits, const int32_t *answers, float scale, flo
 // (modules that no program of the window used) -- their moments and step count do not advance.
 // one workgroup of 64 threads per 256-float block (= one segment granule), 16 bytes per thread
 __global__ void adam_kernel(float *p, const float *g, float *m, float *v, const int32_t *seg_of_block, const int32_t *touched,
-                            const float *step_of_seg, float lr, float b1, float b2, float eps, float wd, int64_t n) {
+                            const float *step_of_seg, float lr, float b1, float b2, float eps, float wd, int64_t n,
+                            const uint32_t *guard) {
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= n) return;
+    if (guard && *guard) return;                      // the pass that produced g reported a failure: leave p, m, v untouched
     const int seg = seg_of_block[blockIdx.x];
     if (!touched[seg]) return;
     const float t = step_of_seg[seg];                 // already incremented for this step
@@ -1038,12 +1040,13 @@ __global__ void adam_kernel(float *p, const float *g, float *m, float *v, const 
     *reinterpret_cast<v4f *>(p + i) = pv; *reinterpret_cast<v4f *>(m + i) = mv; *reinterpret_cast<v4f *>(v + i) = vv;
 }
 int launch_adam(float *p, const float *g, float *m, float *v, const int32_t *seg_of_block, const int32_t *touched,
-                const float *step_of_seg, float lr, float b1, float b2, float eps, float wd, int64_t n, hipStream_t s) {
+                const float *step_of_seg, float lr, float b1, float b2, float eps, float wd, int64_t n, const uint32_t *guard,
+                hipStream_t s) {
     if (n == 0) return 0;
     STAIR_ACCT("adam_kernel", 7ll * n * 4);
     STAIR_CHECK(n % 256 == 0, "the flat parameter buffer is made of whole 256-float blocks");
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)(n / 256)), dim3(64), 0, s, p, g, m, v, seg_of_block, touched,
-                       step_of_seg, lr, b1, b2, eps, wd, n);
+                       step_of_seg, lr, b1, b2, eps, wd, n, guard);
     STAIR_LAUNCH_CHECK();
     return 0;
 }

@@ -35,12 +35,36 @@ from . import frontend
 # ----------------------------------------------------------------------------------------------
 # question records
 # ----------------------------------------------------------------------------------------------
+class _DataUnpickler(pickle.Unpickler):
+    """The reference stores question records and GloVe tables as pickles of plain containers, strings, numbers and numpy
+    arrays (utils/agqa_lite.py:122-143, dataset.py:235-246).  Only those may be rebuilt: any other global a file names
+    (os.system, a class with __reduce__, ...) is refused instead of imported, so a dataset file cannot run code here."""
+    _ALLOWED = {('builtins', n) for n in ('dict', 'list', 'tuple', 'set', 'frozenset', 'str', 'bytes', 'bytearray', 'int', 'float',
+                                          'bool', 'complex', 'slice', 'range')} | {
+        ('collections', 'OrderedDict'), ('collections', 'defaultdict'),
+        ('numpy', 'ndarray'), ('numpy', 'dtype'), ('numpy', 'float32'), ('numpy', 'float64'), ('numpy', 'int32'), ('numpy', 'int64'),
+        ('numpy.core.multiarray', '_reconstruct'), ('numpy._core.multiarray', '_reconstruct'),
+        ('numpy.core.multiarray', 'scalar'), ('numpy._core.multiarray', 'scalar'),
+        ('numpy.core.numeric', '_frombuffer'), ('numpy._core.numeric', '_frombuffer')}
+
+    def find_class(self, module, name):
+        if (module, name) not in self._ALLOWED:
+            raise pickle.UnpicklingError('refusing to load %s.%s from a dataset pickle: only containers, numbers, strings and numpy '
+                                         'arrays are data' % (module, name))
+        return super().find_class(module, name)
+
+
+def _load_data_pickle(path):
+    with open(path, 'rb') as f:
+        return _DataUnpickler(f).load()
+
+
 def load_question_records(path):
     """List of question dicts from `.pkl` (the reference's format), `.json` or `.jsonl`.  JSON turns the integer
-    keys of the span / gold dicts into strings and tuples into lists; both are restored."""
+    keys of the span / gold dicts into strings and tuples into lists; both are restored.  Pickles go through a restricted
+    unpickler (containers, numbers, strings, numpy arrays only)."""
     if path.endswith('.pkl'):
-        with open(path, 'rb') as f:
-            return pickle.load(f)
+        return _load_data_pickle(path)
     if path.endswith('.jsonl'):
         with open(path) as f:
             recs = [json.loads(line) for line in f if line.strip()]
@@ -102,8 +126,22 @@ def filter_records(records, split, novel_comp=None, more_steps=None):
 # ----------------------------------------------------------------------------------------------
 # clip features
 # ----------------------------------------------------------------------------------------------
-def load_clip_features(appearance_path, video_ids, max_video_length, motion_path=None, str2num=None):
-    """{video_id: float32 tensor [T, V]} as dataset.py:131-172 builds `self.video_feats`."""
+def load_clip_features(appearance_path, video_ids, max_video_length, motion_path=None, str2num=None, dtype='f32'):
+    """{video_id: tensor [T, V]} as dataset.py:131-172 builds `self.video_feats`.
+    dtype 'f32': float32, the reference's in-memory format.  dtype 'bf16': the clips are rounded ONCE to bfloat16 here, where
+    they are staged (BASELINE.json configs[1]: "[T=64,2048] feats, bf16"): pack_questions / VideoNMN.forward_batch keep such
+    clips in bf16 on the device and the video encoder's input projection then runs on the stored rows directly (plane GEMM,
+    two MFMA products per operand pair).  Parity for bf16 storage is defined against an fp32 computation on the same rounded
+    values (tests/test_gpu_planes.py, tests/test_gpu_bench_path.py)."""
+    if dtype not in ('f32', 'bf16'):
+        raise ValueError("dtype must be 'f32' or 'bf16'")
+    feats = _load_clip_features_f32(appearance_path, video_ids, max_video_length, motion_path, str2num)
+    if dtype == 'bf16':
+        feats = {k: v.to(torch.float32).to(torch.bfloat16) for k, v in feats.items()}
+    return feats
+
+
+def _load_clip_features_f32(appearance_path, video_ids, max_video_length, motion_path=None, str2num=None):
     wanted = set(video_ids)
     feats = {}
     if os.path.isdir(appearance_path):
@@ -151,8 +189,7 @@ def _h5(path, what):
 def load_glove(path):
     """{word: float64 ndarray} from the text format (first line `count dim`) or a pickled dict (:235-246)."""
     if path.endswith('.pkl'):
-        with open(path, 'rb') as f:
-            return pickle.load(f)
+        return _load_data_pickle(path)
     table = {}
     with open(path) as f:
         for n, line in enumerate(f):
@@ -291,7 +328,10 @@ def pack_questions(items, device, share_clips=True, pin=True):
         index.append(keys[k])
     frames = [int(c.shape[0]) for c in order]
     Tm = max(frames)
-    video = torch.stack([torch.nn.functional.pad(torch.as_tensor(c, dtype=torch.float32), (0, 0, 0, Tm - int(c.shape[0]))) for c in order])
+    order = [torch.as_tensor(c) for c in order]
+    # clips stored as bf16 (load_clip_features(..., dtype='bf16')) stay bf16: half the H2D bytes and the plane-GEMM input path
+    vdtype = torch.bfloat16 if all(c.dtype == torch.bfloat16 for c in order) else torch.float32
+    video = torch.stack([torch.nn.functional.pad(c.to(vdtype), (0, 0, 0, Tm - int(c.shape[0]))) for c in order])
     qs = [torch.as_tensor(d['question'], dtype=torch.float32) for d in items]
     question = torch.cat(qs)
     answers = torch.tensor([int(d['answer']) for d in items], dtype=torch.int32) if 'answer' in items[0] else None
@@ -307,7 +347,7 @@ def pack_questions(items, device, share_clips=True, pin=True):
     b = PackedBatch()
     b.programs = [d['nmn_program_list'] for d in items]
     b.spans = [d['prog_str_to_question_tokens'] for d in items]
-    b.h2d_bytes = video.numel() * 4 + question.numel() * 4 + (answers.numel() * 4 if answers is not None else 0)
+    b.h2d_bytes = video.numel() * video.element_size() + question.numel() * 4 + (answers.numel() * 4 if answers is not None else 0)
     b.video, b.question, b.answers = up(video), up(question), up(answers)
     b.video_index = index if len(order) < n else None
     b.q_lens = [int(q.shape[0]) for q in qs]

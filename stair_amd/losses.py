@@ -191,6 +191,57 @@ def contrastive_windows(entries, window, world=1):
     return names, [first[n] for n in names], np.asarray(rows, dtype=np.int32), win_range, slot_of
 
 
+class ClassTable:
+    """Every class name the contrastive criteria can meet (AGQA: the phrases of data/AGQA/filter_answers.json) in ONE order
+    shared by all ranks, with its word embeddings [L, text_size] (dataset.py:200-221 hands them over per question).  With
+    a table the data-parallel step needs no per-step exchange of class lists between hosts: a rank marks the classes of its
+    own questions in a [windows, classes] presence matrix on the device and that matrix is summed over the ranks by one
+    small all-reduce on the stream (prepare_module_losses); stair_loss_contrastive_table reads the pools from it."""
+
+    def __init__(self, names, embeddings):
+        order = sorted(range(len(names)), key=lambda i: names[i])
+        self.names = [names[i] for i in order]
+        if len(set(self.names)) != len(self.names):
+            raise ValueError('duplicate class names')
+        self.embeddings = [np.asarray(embeddings[i], dtype=np.float32) for i in order]
+        self.index = {n: i for i, n in enumerate(self.names)}
+        self._dev = None
+
+    def __len__(self):
+        return len(self.names)
+
+    @classmethod
+    def from_questions(cls, questions, world=1):
+        """Collect the table from the gold intermediates of a dataset (every rank: its own shard; the shards' tables are
+        merged ONCE here, at start-up -- this is the only host-side exchange of class names)."""
+        found = {}
+        for q in questions:
+            for gold in (q.get('sg_res_by_step') or {}).values():
+                if isinstance(gold, list):
+                    for name, emb in gold:
+                        found.setdefault(name, np.asarray(emb, dtype=np.float32))
+        if world > 1:
+            import torch.distributed as dist
+            parts = [None] * world
+            dist.all_gather_object(parts, found)
+            found = {}
+            for part in parts:
+                for name, emb in part.items():
+                    found.setdefault(name, emb)
+        names = sorted(found)
+        return cls(names, [found[n] for n in names])
+
+    def device_rows(self, device, text_size):
+        """(x [sum L, E], seq_off [n_cls + 1], max L) on the device, uploaded once."""
+        if self._dev is None or self._dev[0].device != device:
+            embs = [e.reshape(-1, text_size) for e in self.embeddings]
+            lens = [int(e.shape[0]) for e in embs]
+            x = torch.from_numpy(np.ascontiguousarray(np.concatenate(embs))).to(device)
+            off = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32, device=device)
+            self._dev = (x, off, max(lens))
+        return self._dev
+
+
 class _Staging:
     """One pinned host buffer + one device buffer per model: every index / label / interval array of a step's loss launches
     goes to the GPU in ONE asynchronous copy (a pageable `.to(device)` per array blocks the host on the stream each time)."""
@@ -224,11 +275,13 @@ class _Staging:
 
 
 def prepare_module_losses(model, res, questions, pretrain_modules=CRITERION_MODULES, no_intermediate=('FilterFrame',), window=32,
-                          world=1, rank=0, window_base=0):
+                          world=1, rank=0, window_base=0, class_table=None, global_batch=None):
     """Everything of apply_module_losses that needs the PLAN but not the forward results: the index / target arrays of every
     criterion (one upload), the contrastive class tables and the encoding of the distinct classes.  Call it from
     VideoNMN.run_programs(before_run=...) so that this host work (a few ms per 2048 questions) is done before the forward
     pass is enqueued and the stream goes from the forward straight into the loss kernels and the backward pass.
+    class_table (a ClassTable shared by all ranks) + global_batch: the contrastive pools are exchanged as a presence matrix on
+    the device instead of class lists between hosts (see ClassTable).
     Returns an opaque dict for launch_module_losses."""
     dev = res.pred.device
     H, T = model.config['hidden_size'], res.info.T
@@ -281,9 +334,22 @@ def prepare_module_losses(model, res, questions, pretrain_modules=CRITERION_MODU
             for class_name, emb in gold:
                 c_slot.append(s_); c_wid.append(wid); c_name.append(class_name)
                 entries.append((gpos, class_name, emb))
-    cw = contrastive_windows(entries, window, world) if (c_slot or world > 1) else None
+    table_mode = class_table is not None
+    if table_mode:
+        G_ = int(global_batch if global_batch is not None else len(questions) * world)
+        wid0 = window_base // window if window else 0
+        n_win = ((window_base + G_ - 1) // window if window else 0) - wid0 + 1
+        presence = np.zeros((n_win, len(class_table)), dtype=np.float32)
+        try:
+            c_cls = [class_table.index[n] for n in c_name]
+        except KeyError as e:
+            raise KeyError('class %s is not in the ClassTable (build it from the whole dataset: ClassTable.from_questions)' % e)
+        if c_slot:
+            presence[np.asarray(c_wid) - wid0, np.asarray(c_cls)] = 1.0
+        stage('cont', i32(c_slot), i32(c_cls), i32(np.asarray(c_wid, dtype=np.int64) - wid0), presence.reshape(-1))
+    cw = contrastive_windows(entries, window, world) if ((c_slot or world > 1) and not table_mode) else None
     lens, max_classes = [], 0
-    if c_slot:
+    if c_slot and not table_mode:
         names, embs, rows, win_range, slot_of = cw
         embs = [np.asarray(e, dtype=np.float32).reshape(-1, model.config['text_size']) for e in embs]
         lens = [int(e.shape[0]) for e in embs]
@@ -299,7 +365,16 @@ def prepare_module_losses(model, res, questions, pretrain_modules=CRITERION_MODU
     got = lambda key: d[plan[key][0]: plan[key][0] + plan[key][1]]
     prep = {'n_att': n_att, 'n_head': n_head, 'n_cont': len(c_slot), 'ff_items': ff_items, 'max_classes': max_classes,
             'att': got('att') if n_att else None, 'head': {m: got(m) for m in n_head}}
-    if c_slot:
+    if table_mode:
+        slot_d, cls_d, win_d, pres_d = got('cont')
+        if world > 1:                       # the pools of the GLOBAL windows: one small device all-reduce, no host round trip
+            import torch.distributed as dist
+            dist.all_reduce(pres_d, op=dist.ReduceOp.SUM)
+        if c_slot:
+            x, seq_off, max_len = class_table.device_rows(dev, model.config['text_size'])
+            _, h_n = ops.lstm_bidir(x, seq_off, max_len, [w.detach() for w in model._lstm_weights('text_encoder')])
+            prep['cont_table'] = (slot_d, cls_d, win_d, pres_d, ops.l2normalize(h_n), len(class_table))
+    elif c_slot:
         # class representations: text encoder without gradient + L2Normalize (module_net.py:78-89); they depend on the weights
         # only, so they are encoded here, ahead of the forward pass, on the same stream
         slot_d, pos_d, ws_d, wc_d, rows_d, seq_off, x = got('cont')
@@ -337,7 +412,13 @@ def launch_module_losses(model, res, prep, scale):
     if prep['ff_items']:
         losses['FilterFrame'] = _filterframe_launch(model, res, prep['ff_items'], scale, True)
         touched.update({'submodules.FilterFrame.pretrain_head.weight', 'submodules.FilterFrame.pretrain_head.bias'})
-    if prep['n_cont']:
+    if prep['n_cont'] and 'cont_table' in prep:
+        slot_d, cls_d, win_d, pres_d, reps, n_cls = prep['cont_table']
+        out = torch.empty(prep['n_cont'], device=dev)
+        check(lib.stair_loss_contrastive_table(P(vec), P(gvec), P(slot_d), P(cls_d), P(win_d), P(pres_d), P(reps), prep['n_cont'],
+                                               n_cls, H, C.c_float(scale), P(out), stream))
+        losses['contrastive'] = out
+    elif prep['n_cont']:
         slot_d, pos_d, ws_d, wc_d, G = prep['cont']
         out = torch.empty(prep['n_cont'], device=dev)
         check(lib.stair_loss_contrastive(P(vec), P(gvec), P(slot_d), P(pos_d), P(ws_d), P(wc_d), P(G), prep['n_cont'], H,
@@ -347,7 +428,8 @@ def launch_module_losses(model, res, prep, scale):
 
 
 def apply_module_losses(model, res, questions, scale, pretrain_modules=CRITERION_MODULES,
-                        no_intermediate=('FilterFrame',), window=32, world=1, rank=0, window_base=0):
+                        no_intermediate=('FilterFrame',), window=32, world=1, rank=0, window_base=0, class_table=None,
+                        global_batch=None):
     """Evaluate every intermediate loss of the batch and add scale * gradient into res's gradient arenas
     (call res.zero_grad_arenas() first and res.backward(..., keep_arenas=True) afterwards).
     Local question i sits at global position window_base + rank + i * world of the accumulation window (the round-robin
@@ -356,7 +438,8 @@ def apply_module_losses(model, res, questions, scale, pretrain_modules=CRITERION
     one gather through the plan's node table and ONE upload; no per-node library call.  = prepare_module_losses +
     launch_module_losses; Trainer.step calls the two halves either side of the forward pass.
     Returns ({loss_kind: per-item losses tensor}, set of extra parameter names that received a gradient)."""
-    prep = prepare_module_losses(model, res, questions, pretrain_modules, no_intermediate, window, world, rank, window_base)
+    prep = prepare_module_losses(model, res, questions, pretrain_modules, no_intermediate, window, world, rank, window_base,
+                                 class_table, global_batch)
     return launch_module_losses(model, res, prep, scale)
 
 

@@ -97,6 +97,16 @@ class BatchResult:
         self._video, self._question = video, question
         self.question_frames = None          # [n] frames per question when the batch mixes clip lengths, else None (all info.T)
 
+    def status_word(self):
+        """The plan's status word (int32 view of one workspace element): 0 = every pass on this workspace since run_programs
+        completed normally; 1 = a cooperative recurrence timed out (stair_lstm_args.status) and the results hold NaN."""
+        off = self.info.status_off
+        return self._ws[off: off + 1].view(torch.int32)
+
+    def check(self):
+        """Synchronises and raises StairError when a pass of this batch reported a failure (stair_plan_status)."""
+        check(lib.stair_plan_status(self._plan, C.c_void_p(self._ws.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
     def zero_grad_arenas(self):
         check(lib.stair_plan_zero_grads(self._plan, C.c_void_p(self._ws.data_ptr()),
                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)))
@@ -335,7 +345,9 @@ class VideoNMN(nn.Module):
         [n_videos,T,V] and each clip is encoded once instead of once per question (module_net.py:74 encodes per
         question; the results are identical).
         video_len (optional, [n_videos] ints): clips of different frame counts in one batch -- clip v holds video_len[v]
-        <= T frames at the front of video[v], padding behind (dataset.py:137-143 keeps every clip's own length); each
+        <= T frames at the front of video[v], ZERO (at least finite) padding behind -- data.pack_questions and forward_batch
+        pad with zeros; the padded rows take part in the weight-gradient products with zero coefficients, so NaN / Inf there
+        would poison dW_ih (dataset.py:137-143 keeps every clip's own length); each
         question is computed as the reference computes a clip of its own length (stair_plan_build_ragged).
         before_run (optional): called with the BatchResult after the plan is built (node table, slots and offsets are
         known) and BEFORE the pass is enqueued -- host work that only needs the plan (the loss driver's index arrays)

@@ -290,3 +290,23 @@ def temporal_relate_bwd(att, att_idx, att_k, d_out, n, T, mode, conv, ksize, w6)
     check(lib.stair_temporal_relate_bwd(_ptr(att), _ptr(att_idx), _ptr(att_k), _ptr(d_out), _ptr(out_idx), _ptr(d_att), n, T, mode,
                                         1 if conv else 0, ksize, arr, darr, _stream()))
     return d_att, dws
+
+
+class kernel_accounting:
+    """Context manager over stair_acct_enable / stair_acct_dump: which kernel variants the launchers selected inside the
+    block, with launch counts, algorithmic bytes and algorithmic flops.  `.table` = {kernel: (launches, bytes, flops)}."""
+
+    def __enter__(self):
+        lib.stair_acct_enable(1)
+        self.table = {}
+        return self
+
+    def __exit__(self, *exc):
+        n = lib.stair_acct_dump(None, 0)
+        buf = C.create_string_buffer(n)
+        lib.stair_acct_dump(buf, n)
+        lib.stair_acct_enable(0)
+        for line in buf.value.decode().splitlines():
+            k, c, b, f = line.split()
+            self.table[k] = (int(c), int(b), int(f))
+        return False

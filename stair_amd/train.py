@@ -74,13 +74,18 @@ class Trainer:
                  module_loss_weight=1.0, contrastive_window=32, no_intermediate=('FilterFrame',),
                  scheduler_start_factor=1.0, scheduler_end_factor=0.1, scheduler_total_iters=200000, world=1,
                  skip_untouched='ever', train_module_before_iters=1e10, train_decoder_after_iters=0, rank=0,
-                 dropout=None, dropout_seed=0, native_allreduce=False):
+                 dropout=None, dropout_seed=0, native_allreduce=False, class_table=None):
         """skip_untouched: 'ever'   -- a parameter is skipped by Adam until the first window that sends it a gradient
                                       (torch 1.13, which the reference pins: zero_grad() keeps zero tensors afterwards);
                            'window' -- skipped in every window that does not touch it (torch >= 2.0, set_to_none=True)."""
         # train_module.py:350,376 gate the two loss families by the reference's global_steps (one per QUESTION there):
         # intermediate losses while global_steps < train_module_before_iters, decoder loss once global_steps >
         # train_decoder_after_iters.  Question i of a rank's shard has global step seen + 1 + rank + i * world.
+        # class_table (losses.ClassTable, the same on every rank): the contrastive pools of a data-parallel step are then
+        # exchanged as a [windows, classes] presence matrix summed on the device -- without it every supervised step at
+        # world > 1 gathers the ranks' class lists through the host (all_gather_object), a blocking second collective.
+        self.class_table = class_table
+        self.allreduce_events = None                        # set to [] to collect (start, end) events around the step's collective
         self.before_iters, self.after_iters, self.rank = train_module_before_iters, train_decoder_after_iters, rank
         self.questions_seen = 0
         # nn.Dropout(config['dropout']) of the reference's model.train() (modules.py `D` positions, args.py:31).  Default:
@@ -125,6 +130,7 @@ class Trainer:
         self.steps = torch.zeros(len(names), device=dev)     # per-tensor Adam step counts
         self.touched = torch.zeros(len(names), dtype=torch.int32, device=dev)
         self._mask_ring = _PinnedRing(len(names))
+        self._status = []                                    # (step, pinned int32 copy of the plan's status word, event) per step in flight
         self.comm = None
         if native_allreduce and world > 1:          # the step's one collective through the C ABI (stair_allreduce_grads)
             from .comm import NativeComm
@@ -150,6 +156,7 @@ class Trainer:
             dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
             global_batch = int(cnt.item())
         G = global_batch or n
+        self.check(wait=False)                                # a failed earlier step surfaces here at the latest
         self.flat_g.zero_()                                   # optimizer.zero_grad()
         gstep = [self.questions_seen + 1 + self.rank + i * self.world for i in range(n)]
         self.questions_seen += G
@@ -164,7 +171,8 @@ class Trainer:
 
         def prepare(res_):        # host side of the intermediate losses: needs the plan only, runs before the pass is enqueued
             prep['p'] = L.prepare_module_losses(self.model, res_, questions, no_intermediate=self.no_intermediate,
-                                                window=self.contrastive_window, world=self.world, rank=self.rank)
+                                                window=self.contrastive_window, world=self.world, rank=self.rank,
+                                                class_table=self.class_table, global_batch=G)
         res = self.model.run_programs(programs, spans, video, question, q_lens, train=True, video_index=video_index, dropout=drop,
                                       video_len=video_len, before_run=prepare if supervised else None)
         extra = set()
@@ -178,7 +186,14 @@ class Trainer:
         if extra:
             tl = [t_ or (nme in extra) for t_, nme in zip(tl, self.model._weight_names)]
         t = self._mask_ring.upload(tl, self.touched.device)
-        reduce_gradients(self.flat_g, t, self.world, self.bucket, self.comm)       # ONE flat bucket over RCCL / xGMI
+        if self.allreduce_events is not None and self.world > 1:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            reduce_gradients(self.flat_g, t, self.world, self.bucket, self.comm)
+            e1.record()
+            self.allreduce_events.append((e0, e1))
+        else:
+            reduce_gradients(self.flat_g, t, self.world, self.bucket, self.comm)   # ONE flat bucket over RCCL / xGMI
         if self.skip_untouched == 'ever':
             self.touched = torch.maximum(self.touched, t)
         else:
@@ -190,6 +205,30 @@ class Trainer:
                                   C.c_void_p(self.seg_of_block.data_ptr()), C.c_void_p(self.touched.data_ptr()),
                                   C.c_void_p(self.steps.data_ptr()), C.c_float(lr), C.c_float(self.betas[0]),
                                   C.c_float(self.betas[1]), C.c_float(self.eps), C.c_float(self.wd), self.n,
+                                  C.c_void_p(res.status_word().data_ptr()),          # guard: no update from a failed pass
                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        host = torch.empty(1, dtype=torch.int32).pin_memory() if len(self._status) < 16 else self._status.pop(0)[1]
+        host.copy_(res.status_word(), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._status.append((self.iters, host, ev))
         self.iters += 1                                       # scheduler.step()
         return loss, res
+
+    def check(self, wait=True):
+        """Raises StairError if a step reported a failed pass (a cooperative LSTM hand-off that timed out: the gradients of
+        that step held NaN).  The optimizer kernel has already refused the update on the device (stair_adam_step's guard), so
+        parameters and moments are those of the last good step.  wait=False looks only at steps the GPU has finished."""
+        from ._lib import StairError
+        keep = []
+        for step, host, ev in self._status:
+            if not wait and not ev.query():
+                keep.append((step, host, ev))
+                continue
+            ev.synchronize()
+            if int(host[0]) != 0:
+                self._status = []
+                raise StairError('optimizer step %d was skipped: a cooperative LSTM recurrence timed out (its workgroups were not '
+                                 'co-resident -- another queue on this GPU?); weights and Adam moments are those of the last good '
+                                 'step.  STAIR_LSTM_COOP=0 selects the one-workgroup kernels' % step)
+        self._status = keep[-16:]

@@ -140,3 +140,48 @@ def test_checkpoint_round_trip_and_refusal_of_pickled_modules(tmp_path):
     torch.save(torch.nn.Linear(2, 2), str(tmp_path / 'bad' / 'pytorch_model.bin'))
     with pytest.raises(ValueError, match='state_dict'):
         D.load_checkpoint(str(tmp_path / 'bad'))
+
+
+def test_bf16_clip_storage_and_packing(tmp_path):
+    """load_clip_features(dtype='bf16') rounds once at staging (BASELINE configs[1]); pack_questions keeps such clips bf16."""
+    rng = np.random.default_rng(0)
+    d = tmp_path / 'clips'
+    d.mkdir()
+    for vid, frames in (('A1', 20), ('B2', 14)):
+        np.save(d / (vid + '.npy'), rng.standard_normal((frames, 64)).astype(np.float32))
+    f32 = D.load_clip_features(str(d), ['A1', 'B2'], 8)
+    b16 = D.load_clip_features(str(d), ['A1', 'B2'], 8, dtype='bf16')
+    assert b16['A1'].dtype == torch.bfloat16 and tuple(b16['A1'].shape) == (8, 64) and tuple(b16['B2'].shape) == (7, 64)
+    assert torch.equal(b16['A1'], f32['A1'].to(torch.bfloat16))
+    with pytest.raises(ValueError):
+        D.load_clip_features(str(d), ['A1'], 8, dtype='fp8')
+    items = [{'video_features': b16[v], 'question': torch.zeros(3, 8), 'nmn_program_list': ['x'], 'prog_str_to_question_tokens': {},
+              'answer': torch.tensor(1), 'video_id': v} for v in ('A1', 'B2', 'A1')]
+    b = D.pack_questions(items, 'cpu')
+    assert b.video.dtype == torch.bfloat16 and tuple(b.video.shape) == (2, 8, 64) and b.video_len == [8, 7]
+    assert b.h2d_bytes == 2 * 8 * 64 * 2 + 9 * 8 * 4 + 3 * 4
+    mixed = [dict(items[0]), dict(items[1], video_features=f32['B2'])]
+    assert D.pack_questions(mixed, 'cpu').video.dtype == torch.float32
+
+
+def test_dataset_pickles_cannot_run_code(tmp_path):
+    """The reference's .pkl formats hold plain data; a file that names any other global is refused, not imported."""
+    import pickle
+    recs = [{'question': 'q', 'answer': 'yes', 'nmn_program_span_by_word': {0: (1, 2)}, 'emb': np.arange(6, dtype=np.float32).reshape(2, 3)}]
+    p = tmp_path / 'ok.pkl'
+    D.save_question_records(recs, str(p))
+    back = D.load_question_records(str(p))
+    assert back[0]['nmn_program_span_by_word'] == {0: (1, 2)} and np.array_equal(back[0]['emb'], recs[0]['emb'])
+
+    class Evil:
+        def __reduce__(self):
+            import os
+            return (os.system, ('echo pwned > %s' % (tmp_path / 'pwned'),))
+    bad = tmp_path / 'bad.pkl'
+    with open(bad, 'wb') as f:
+        pickle.dump([Evil()], f)
+    with pytest.raises(pickle.UnpicklingError, match='refusing'):
+        D.load_question_records(str(bad))
+    with pytest.raises(pickle.UnpicklingError, match='refusing'):
+        D.load_glove(str(bad))
+    assert not (tmp_path / 'pwned').exists()

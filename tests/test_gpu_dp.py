@@ -52,13 +52,17 @@ def _pack(qs, dev, bf16):
             [q['question'].shape[0] for q in qs], answers)
 
 
-def _run(rank, world, supervised, bf16, out):
+def _run(rank, world, supervised, bf16, out, table=False):
+    from stair_amd import losses as L
     from stair_amd.train import Trainer
     dev = torch.device('cuda', 0)
     qs = _questions(supervised)
     mine = qs[rank::world]                                    # local i <-> global position rank + i * world
     model = _model(dev)
-    tr = Trainer(model, world=world, rank=rank, dropout=0.0, contrastive_window=WINDOW, lr=1e-3)
+    # table: the contrastive pools travel as a presence matrix summed on the device (losses.ClassTable), built from each
+    # rank's OWN shard and merged once -- instead of the per-step all_gather_object of the class lists
+    class_table = L.ClassTable.from_questions(mine, world) if table else None
+    tr = Trainer(model, world=world, rank=rank, dropout=0.0, contrastive_window=WINDOW, lr=1e-3, class_table=class_table)
     state = {}
     for it in range(2):                                        # the second step exercises 'ever'-touched bookkeeping
         progs, spans, video, question, q_lens, answers = _pack(mine, dev, bf16)
@@ -71,12 +75,12 @@ def _run(rank, world, supervised, bf16, out):
     torch.save(state, out)
 
 
-def _worker(rank, world, port, supervised, bf16, out_dir):
+def _worker(rank, world, port, supervised, bf16, out_dir, table=False):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        _run(rank, world, supervised, bf16, os.path.join(out_dir, 'rank%d.pt' % rank))
+        _run(rank, world, supervised, bf16, os.path.join(out_dir, 'rank%d.pt' % rank), table)
     finally:
         dist.destroy_process_group()
 
@@ -89,12 +93,12 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize('supervised,bf16', [(False, False), (True, False), (True, True)])
-def test_two_rank_trainer_step_equals_single_process_step(supervised, bf16):
+@pytest.mark.parametrize('supervised,bf16,table', [(False, False, False), (True, False, False), (True, True, False), (True, False, True)])
+def test_two_rank_trainer_step_equals_single_process_step(supervised, bf16, table):
     import torch.multiprocessing as mp
     with tempfile.TemporaryDirectory() as d:
-        _run(0, 1, supervised, bf16, os.path.join(d, 'solo.pt'))
-        mp.spawn(_worker, args=(2, _free_port(), supervised, bf16, d), nprocs=2, join=True)
+        _run(0, 1, supervised, bf16, os.path.join(d, 'solo.pt'))          # the solo run pools by class lists (no table)
+        mp.spawn(_worker, args=(2, _free_port(), supervised, bf16, d, table), nprocs=2, join=True)
         solo = torch.load(os.path.join(d, 'solo.pt'))
         ranks = [torch.load(os.path.join(d, 'rank%d.pt' % r)) for r in range(2)]
     assert solo['seen'] == ranks[0]['seen'] == ranks[1]['seen'] == 2 * N_Q

@@ -84,3 +84,80 @@ def test_cooperative_kernels_are_deterministic():
         runs.append([out, h_n, gates])      # gates now holds the gate gradients: fixed-order sums of the exchanged partials
     for a, b_ in zip(*runs):
         assert torch.equal(a, b_)
+
+
+@pytest.mark.parametrize('cap', [0, 31, 64, 100])
+def test_capped_device_falls_back_and_matches(cap):
+    """stair_lstm_coop_limit: with fewer co-resident workgroups than a geometry needs, the launchers take smaller
+    geometries (cap 64, 100: one or two groups per direction, several chunks per group) or the one-workgroup kernels
+    (cap < 32) -- the results must not change beyond rounding, and nothing may be left waiting."""
+    from stair_amd import ops
+    from stair_amd._lib import lib
+    I, n = 64, 300
+    ws = _weights(I, 5)
+    lens, off, seq_len, x, d_out, d_hn = _case(n, 1, 16, I, 21, False)
+    rows_ = _data_rows(lens, off, seq_len)
+    ref = ops.lstm_bidir(x, off, 16, ws, save=True, coop=False)
+    ref = [t.clone() for t in ref]
+    gref = ops.lstm_bidir_bwd(x, off, 16, ws, ref[0], ref[2].clone(), ref[3], d_out, d_hn, coop=False)
+    try:
+        lib.stair_lstm_coop_limit(cap)
+        with ops.kernel_accounting() as acct:
+            got = ops.lstm_bidir(x, off, 16, ws, save=True, coop=True)
+            g = ops.lstm_bidir_bwd(x, off, 16, ws, ref[0], ref[2].clone(), ref[3], d_out, d_hn, coop=True)
+        torch.cuda.synchronize()
+    finally:
+        lib.stair_lstm_coop_limit(-1)
+    if cap < 32:
+        assert 'lstm_rec_x3' in acct.table and 'lstm_bwd_x3' in acct.table and 'lstm_rec_coop' not in acct.table, sorted(acct.table)
+    else:
+        assert 'lstm_rec_coop' in acct.table and 'lstm_bwd_coop' in acct.table, sorted(acct.table)
+    for a, b_ in zip(got, ref):
+        sel = rows_ if a.shape[0] == x.shape[0] else slice(None)
+        assert float((a[sel] - b_[sel]).abs().max()) < 2e-5
+    for a, b_ in zip(g, gref):
+        assert float((a - b_).abs().max()) < 1e-4 * max(1.0, float(b_.abs().max()))
+
+
+def test_timeout_word_blocks_the_optimizer_and_raises():
+    """The error path of a cooperative hand-off that timed out, with the flag INJECTED (no real timeout is provoked): the
+    plan's status word is set between forward and backward, as the kernel would set it -> stair_adam_step's guard leaves
+    parameters and moments untouched, Trainer.check() / the next step raise StairError, BatchResult.check() raises too."""
+    from stair_amd import spec, synth
+    from stair_amd._lib import StairError
+    from stair_amd.module_net import BatchResult, VideoNMN
+    from stair_amd.train import Trainer
+    config = dict(spec.DEFAULT_CONFIG, hidden_size=64, video_size=128, answer_vocab_length=16, max_video_length=40, object_types=10)
+    m = VideoNMN(config)
+    w = synth.make_weights(config, 0)
+    m.load_state_dict({k: torch.from_numpy(w[k].copy()) for k in spec.state_dict_keys(config)})
+    m = m.to(DEV)
+    qs = [synth.make_question(config, 2, i, form=synth.ALL_FORMS[i % 12]) for i in range(12)]
+    video = torch.stack([torch.as_tensor(q['video_features']) for q in qs]).to(DEV)
+    question = torch.cat([torch.as_tensor(q['question']) for q in qs]).to(DEV)
+    args = ([q['nmn_program_list'] for q in qs], [q['prog_str_to_question_tokens'] for q in qs], video, question,
+            [q['question'].shape[0] for q in qs], torch.tensor([q['answer'] for q in qs], dtype=torch.int32, device=DEV))
+    tr = Trainer(m, dropout=0.0)
+    tr.step(*args)                                   # a good step: moments are non-zero afterwards
+    tr.check()
+    before = (tr.flat_p.clone(), tr.exp_avg.clone(), tr.exp_avg_sq.clone())
+    orig = BatchResult.backward
+
+    def failing_backward(self, *a, **k):
+        self.status_word().fill_(1)                  # what lstm_rec_coop_kernel does when a spin runs out
+        return orig(self, *a, **k)
+    BatchResult.backward = failing_backward
+    try:
+        _, res = tr.step(*args)
+    finally:
+        BatchResult.backward = orig
+    torch.cuda.synchronize()
+    for a, b_ in zip(before, (tr.flat_p, tr.exp_avg, tr.exp_avg_sq)):
+        assert torch.equal(a, b_)                    # the guard refused the update on the device
+    with pytest.raises(StairError, match='timed out'):
+        res.check()
+    with pytest.raises(StairError, match='skipped'):
+        tr.check()
+    tr.step(*args)                                   # the next plan starts with a clean word
+    tr.check()
+    assert not torch.equal(before[0], tr.flat_p)

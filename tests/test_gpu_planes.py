@@ -236,3 +236,34 @@ def test_bf16_clip_features_training_step_gradients():
     for n in names:
         ref = wt[n].grad if wt[n].grad is not None else torch.zeros_like(wt[n])
         assert _maxerr(sd[n].grad, ref) < 2e-4 * gmax, (n, _maxerr(sd[n].grad, ref), gmax)
+
+
+def test_bf16_stored_clips_from_disk_to_logits(tmp_path):
+    """The product data pipeline reaches the benched input path: .npy clips -> data.load_clip_features(dtype='bf16') ->
+    data.pack_questions (bf16 on the device) -> run_programs selects the plane GEMM -> logits vs the oracle fed the same
+    rounded clip values (1e-4, identical top-1)."""
+    from stair_amd import data as D, ops
+    config = dict(spec.DEFAULT_CONFIG, hidden_size=64, video_size=64, answer_vocab_length=16, max_video_length=40, object_types=10)
+    rng = np.random.default_rng(3)
+    clip_dir = tmp_path / 'clips'
+    clip_dir.mkdir()
+    vids = ['V%02d' % i for i in range(8)]
+    for v in vids:
+        np.save(clip_dir / (v + '.npy'), rng.standard_normal((80, 64)).astype(np.float32))      # every 2nd frame is kept: 40
+    clips = D.load_clip_features(str(clip_dir), vids, 40, dtype='bf16')
+    model, weights = _model(config, 2)
+    items = []
+    for i in range(20):
+        q = synth.make_question(config, 6, i, form=synth.ALL_FORMS[i % len(synth.ALL_FORMS)], with_video=False)
+        q['video_features'], q['video_id'] = clips[vids[i % 8]], vids[i % 8]
+        q['question'] = torch.as_tensor(q['question'])
+        items.append(q)
+    b = D.pack_questions(items, DEV)
+    assert b.video.dtype == torch.bfloat16 and b.n_clips == 8
+    with ops.kernel_accounting() as acct:
+        res = model.run_programs(b.programs, b.spans, b.video, b.question, b.q_lens, video_index=b.video_index)
+    assert 'gemm_planes' in acct.table, sorted(acct.table)
+    wt = O.to_torch(weights)
+    for i, q in enumerate(items):
+        ref = O.forward(wt, config, dict(q, video_features=q['video_features'].float()), return_res_by_step=False)['logits']
+        assert _maxerr(res.logits[i], ref) < 1e-4 and int(res.pred[i]) == int(torch.argmax(ref)), q['form']

@@ -697,3 +697,30 @@ def test_trainer_windows_match_reference_main_loop(matmul):
                 moved += 1
         assert moved > 90
         print('window %d (%s): largest weight difference to the reference %.3g in %s' % (wi + 1, matmul, worst[0], worst[1]))
+
+
+def test_contrastive_pools_from_a_class_table_equal_the_pooled_lists(matmul):
+    """stair_loss_contrastive_table (pools = rows of a [windows, classes] presence matrix over a table of all classes) against
+    stair_loss_contrastive on the explicitly pooled class lists (train_module.py:388-406): same loss per item, same gradients."""
+    from stair_amd import losses as L
+    z, meta = load_golden('tiny_conv')
+    config, T = meta['config'], meta['T']
+    qs = _with_gold(config, 3, [question_for(meta, q) for q in meta['questions']] +
+                    [synth.make_question(config, 8, 50 + i, form=f, T=T) for i, f in enumerate(synth.ALL_FORMS)], T)
+    table = L.ClassTable.from_questions(qs + [{'sg_res_by_step': {0: [('zz_unused', np.ones((2, config['text_size']), np.float32))]}}])
+    out = {}
+    for mode in ('lists', 'table'):
+        model = _model(config, meta['seed'])
+        model.pretrain_modules = set(L.CRITERION_MODULES)
+        for p in model.parameters():
+            p.grad = torch.zeros_like(p)
+        progs, spans, video, question, q_lens, answers = _pack(model, qs)
+        res = model.run_programs(progs, spans, video, question, q_lens, train=True)
+        res.zero_grad_arenas()
+        losses, _ = L.apply_module_losses(model, res, qs, 1.0 / len(qs), window=7, class_table=table if mode == 'table' else None)
+        res.backward(answers, 1.0 / len(qs), keep_arenas=True)
+        out[mode] = (losses['contrastive'].cpu(), {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters()})
+    assert out['lists'][0].numel() > 10
+    assert torch.allclose(out['lists'][0], out['table'][0], rtol=1e-5, atol=1e-6)
+    for n, g in out['lists'][1].items():
+        assert float((g - out['table'][1][n]).abs().max()) <= 2e-5 * max(float(g.abs().max()), 1e-3), n

@@ -53,8 +53,9 @@ def run(out):
     lib.stair_acct_enable(0)
     table = {}
     for line in buf.value.decode().splitlines():
-        k, c, b = line.split()
-        table[k] = [int(c) / STEPS, int(b) / STEPS]
+        k, c, b, f = line.split()
+        if int(f) == 0 and int(b) > 0:                     # the HBM-bound row kernels (MFMA kernels carry flops)
+            table[k] = [int(c) / STEPS, int(b) / STEPS]
     json.dump({'steps_accounted': STEPS, 'steps_profiled': STEPS + WARM, 'per_step': table}, open(out, 'w'), indent=1)
 
 
