@@ -245,6 +245,61 @@ typedef struct stair_lstm_bwd_args {
 int64_t stair_lstm_coop_bwd_ws_bytes(int32_t n);
 int stair_lstm_bidir_bwd(const stair_lstm_bwd_args *args, stair_stream stream);
 
+/* ---- fused per-clip tile operators (stair_tile_mlp) ------------------------------------------
+ * One workgroup carries one [T, H] tile (the T <= 64 frames of one module instance, H = 512) through up to three Linear
+ * layers and the module's tile-local tail; the intermediates stay in LDS (csrc/tile_mlp.hip).  Replaces the GEMM -> HBM ->
+ * GEMM -> HBM -> row-kernel sequences of /root/reference/video_nmn/modules.py: Localize :199-217 (2 layers + cosine tail),
+ * Filter :363-378 (2 layers + sum over frames), FilterFrame :399-414 (3 layers, sigmoid attention between 2 and 3), HasItem
+ * :123-138 (1 layer + row-dot sigmoid), Temporal :310-327 (row-scaled input, 1 layer + LayerNorm).
+ * Weights are passed as bf16 hi / lo planes in MFMA fragment order, written by stair_pack_wfrag (2 * N * K * 2 bytes each);
+ * products are the split-bf16 three-product form of STAIR_MATMUL_BF16X3 with fp32 accumulation (the only mode supported).
+ *   tile of instance i   X + (x_idx ? x_idx[i] : i) * x_gstride, T rows of H floats; rows are multiplied by
+ *                        row_scale[(rs_idx ? rs_idx[i] : i) * T + t] when row_scale is set
+ *   layer l              act[l] (0 none, 1 ReLU) of tile . W[l]^T + bias[l]; save[l] (optional, [cnt, T, H]) receives that
+ *                        activation -- what a backward pass needs, written once
+ *   mid_rowdot           (3 layers) after layer 2: a_t = sigmoid(vw . row_t + extra[i] + vb[0]), rs_out[i*T + t] = a_t
+ *                        (optional), and layer 3 runs on a_t * row_t
+ *   tail                 on the last layer's activation F [T, H]:
+ *     STORE           out + o * out_gstride <- F                              (o = out_idx ? out_idx[i] : i)
+ *     SUM_ROWS        out[o * out_gstride + n] = sum over t < len[i] (or T) of F[t][n]
+ *     COSINE          for pair j in pair_first[i] .. +pair_cnt[i]: att[att_idx[j] * T + t] = (cos(F[t], kb[j]) + 1) * 0.49
+ *     ROWDOT_SIGMOID  out[o * out_gstride + t] = sigmoid(vw . F[t] + vb[0] + (extra ? extra[i] : 0))
+ *     LAYERNORM       out + o * out_gstride <- LayerNorm_H(F) * gamma + beta, eps = ln_eps, biased variance
+ *     ACCUMULATE      out + o * out_gstride += F (atomic)
+ * Rows t >= T of a tile do not exist (nothing is read or written there). */
+enum stair_tile_tail { STAIR_TILE_NONE = 0, STAIR_TILE_STORE = 1, STAIR_TILE_SUM_ROWS = 2, STAIR_TILE_COSINE = 3,
+                       STAIR_TILE_ROWDOT_SIGMOID = 4, STAIR_TILE_LAYERNORM = 5, STAIR_TILE_ACCUMULATE = 6 };
+typedef struct stair_tile_mlp_args {
+    const float *X; int64_t x_gstride; const int32_t *x_idx;
+    const float *row_scale; const int32_t *rs_idx;
+    const void *W[3]; const float *bias[3]; int32_t act[3]; int32_t n_layers;
+    float *save[3];
+    int32_t mid_rowdot; const float *vw, *vb, *extra; float *rs_out;
+    int32_t tail;
+    float *out; int64_t out_gstride; const int32_t *out_idx;
+    const float *gamma, *beta; float ln_eps;
+    const float *kb; const int32_t *pair_first, *pair_cnt, *att_idx; float *att;
+    const int32_t *len;
+    int32_t cnt, T, H;
+    /* backward chains (autograd of the same modules: dX = (dZ2 W2 * relu'(Z1)) W1 on the tile, stair_plan_backward):
+     *   act[l] == 3      the layer's result is multiplied by act_scale where act_mask[l][i][t][n] > 0, else 0 (relu' of a saved
+     *                    activation, [cnt, T, H]); W[l] then holds the planes of W^T (stair_pack_wfrag(transpose = 1))
+     *   in_mask          the input tile is multiplied the same way by relu'(in_mask + (in_mask_idx ? in_mask_idx[i] : i) * in_mask_gstride)
+     *                    and in_scale;  x_broadcast: the tile's rows t < len[i] are all the ONE row X + x * x_gstride (x_gstride = H)
+     *   save_in          [cnt, T, H]: the transformed input tile (the dZ a weight-gradient product needs)
+     *   tail ACCUMULATE  out + o * out_gstride += F with fp32 atomics (several instances may share a gradient tile) */
+    const float *act_mask[3]; float act_scale;
+    const float *in_mask; int64_t in_mask_gstride; const int32_t *in_mask_idx; float in_scale; int32_t x_broadcast;
+    float *save_in;
+} stair_tile_mlp_args;
+int stair_tile_mlp_fwd(const stair_tile_mlp_args *args, stair_stream stream);
+/* stair_plan_run uses the fused operators where they apply (hidden_size 512, T <= 64, split matmul mode, no dropout);
+ * on = 0 keeps the GEMM / row-kernel sequences everywhere, on < 0 restores the default (env STAIR_TILE_MLP, default on). */
+int stair_set_tile_mlp(int32_t on);
+/* W [N, K] fp32 row-major -> planes: [N/32][K/16][hi, lo][64 lanes][8 bf16] (2 * N * K * 2 bytes, 16-byte aligned);
+ * N % 32 == 0, K % 16 == 0.  transpose != 0: W is stored [K, N] and the planes are those of W^T (backward chains). */
+int stair_pack_wfrag(const float *W, void *planes, int32_t N, int32_t K, int32_t transpose, stair_stream stream);
+
 /* att[p][t] = (cos(F[f_idx[p]][t][:], Kmat[k_idx[p]][:]) + 1) * 0.49 -- nn.CosineSimilarity(dim=-1,
  * eps=1e-8) of LocalizeModule / ExistsFrameModule (modules.py:162-217) without materialising the
  * [K,T,H] expands.  F tile p at F + f_idx[p]*f_gstride, [T,H]; output row att + out_idx[p]*T. */
@@ -315,6 +370,12 @@ int stair_cosine_topk(const float *queries, int64_t ldq, const int32_t *q_idx, c
  * Errors (non-zero) mirror the reference's failures: invalid program (assert len(stack)==1,
  * module_net.py:135), operand of the wrong kind, span outside the question. */
 #define STAIR_PLAN_TRAIN 1 /* flags: keep every intermediate and lay out gradient arenas for stair_plan_backward */
+#define STAIR_PLAN_NO_CSE 2 /* flags: compute every node of every question, as module_net.py:100-106 does.  By default a node whose
+                               operands are the encoded clip, keyword strings, identical question spans or other such nodes is
+                               computed ONCE per batch and every other occurrence -- in another question about the same clip, or
+                               again in the same program -- aliases its slot (same value; gradients of all users add up in it).
+                               Filter's tensor keyword does not enter the comparison: its attention is identically 1
+                               (modules.py:354,373).  Env STAIR_PLAN_CSE=0 has the same effect. */
 int stair_plan_build(stair_ctx *ctx, int32_t n, const int32_t *prog_off, const int32_t *tokens,
                      const int32_t *span_lo, const int32_t *span_hi, const int32_t *q_off, int32_t T,
                      int32_t flags, stair_plan **out);
@@ -352,6 +413,7 @@ typedef struct stair_plan_info {
                            recurrence whose hand-off timed out (forward or backward); see stair_plan_status */
     int32_t n_vec, n_map, n_att, n_tok_rows;
     int32_t n_nodes, n_launches, n_levels, n_questions, T;
+    int32_t n_aliased; /* program nodes that alias another node's value (common subexpressions, see STAIR_PLAN_NO_CSE) */
 } stair_plan_info;
 int stair_plan_get_info(const stair_plan *plan, stair_plan_info *info);
 

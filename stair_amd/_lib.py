@@ -74,13 +74,30 @@ class LstmBwdArgs(C.Structure):
                 ('status', C.c_void_p)]
 
 
+class TileMlpArgs(C.Structure):
+    _fields_ = [('X', C.c_void_p), ('x_gstride', C.c_int64), ('x_idx', C.c_void_p),
+                ('row_scale', C.c_void_p), ('rs_idx', C.c_void_p),
+                ('W', C.c_void_p * 3), ('bias', C.c_void_p * 3), ('act', C.c_int32 * 3), ('n_layers', C.c_int32),
+                ('save', C.c_void_p * 3),
+                ('mid_rowdot', C.c_int32), ('vw', C.c_void_p), ('vb', C.c_void_p), ('extra', C.c_void_p), ('rs_out', C.c_void_p),
+                ('tail', C.c_int32),
+                ('out', C.c_void_p), ('out_gstride', C.c_int64), ('out_idx', C.c_void_p),
+                ('gamma', C.c_void_p), ('beta', C.c_void_p), ('ln_eps', C.c_float),
+                ('kb', C.c_void_p), ('pair_first', C.c_void_p), ('pair_cnt', C.c_void_p), ('att_idx', C.c_void_p), ('att', C.c_void_p),
+                ('len', C.c_void_p),
+                ('cnt', C.c_int32), ('T', C.c_int32), ('H', C.c_int32),
+                ('act_mask', C.c_void_p * 3), ('act_scale', C.c_float),
+                ('in_mask', C.c_void_p), ('in_mask_gstride', C.c_int64), ('in_mask_idx', C.c_void_p), ('in_scale', C.c_float),
+                ('x_broadcast', C.c_int32), ('save_in', C.c_void_p)]
+
+
 class PlanInfo(C.Structure):
     _fields_ = [('workspace_bytes', C.c_int64), ('vec_off', C.c_int64), ('map_off', C.c_int64), ('att_off', C.c_int64),
                 ('tok_off', C.c_int64), ('qfeat_off', C.c_int64), ('logits_off', C.c_int64),
                 ('gvec_off', C.c_int64), ('gmap_off', C.c_int64), ('gatt_off', C.c_int64), ('status_off', C.c_int64),
                 ('n_vec', C.c_int32), ('n_map', C.c_int32), ('n_att', C.c_int32), ('n_tok_rows', C.c_int32),
                 ('n_nodes', C.c_int32), ('n_launches', C.c_int32), ('n_levels', C.c_int32), ('n_questions', C.c_int32),
-                ('T', C.c_int32)]
+                ('T', C.c_int32), ('n_aliased', C.c_int32)]
 
 
 # every symbol include/stair_hip.h declares: (name, restype, argtypes)
@@ -100,6 +117,9 @@ SIGNATURES = [
     ('stair_get_matmul_mode', C.c_int, []),
     ('stair_set_split_min_rows', C.c_int, [C.c_int32]),
     ('stair_lstm_coop_limit', C.c_int, [C.c_int32]),
+    ('stair_set_tile_mlp', C.c_int, [C.c_int32]),
+    ('stair_tile_mlp_fwd', C.c_int, [C.POINTER(TileMlpArgs), C.c_void_p]),
+    ('stair_pack_wfrag', C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     ('stair_gemm_f32', C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     ('stair_gemm_tn_f32', C.c_int, [C.POINTER(GemmTnArgs), C.c_void_p]),
     ('stair_split_planes', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),

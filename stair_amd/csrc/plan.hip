@@ -315,20 +315,20 @@ struct stair_plan {
     int64_t off_seqv = 0, off_seqt = 0, off_roots = 0, off_lenv = 0;
     bool ragged = false;            // clips of different frame counts in this batch (padded to T; per-instance lengths in col[6])
     std::vector<int32_t> vlen;      // frames per clip [n_vid]
-    int n_vec = 0, n_map = 0, n_att = 0;
+    int n_vec = 0, n_map = 0, n_att = 0, n_aliased = 0;     // n_aliased: nodes that share another node's value (common subexpressions)
     int maxI = 0, maxV = 0, maxK = 0, maxSupRows = 0, n_levels = 0;
     int64_t coop_bytes = 0;
     // workspace layout (float offsets)
     int64_t o_idx = 0, o_vec = 0, o_map = 0, o_att = 0, o_tok = 0, o_qfeat = 0, o_vhn = 0, o_xpv = 0, o_xpt = 0,
             o_bias = 0, o_wpack = 0, o_wplanes = 0, o_coop = 0, o_coop2 = 0, o_splitk = 0, o_tmpA = 0, o_tmpB = 0, o_kbuf = 0, o_cat = 0, o_hid = 0, o_rs = 0, o_sup = 0, o_extra = 0,
-            o_logits = 0, o_status = 0, total = 0;
+            o_logits = 0, o_status = 0, o_wfrag = 0, total = 0;
     // training only
     bool train = false;
     float drop_p = 0.0f;            // training-mode dropout (stair_plan_set_dropout); 0 = off
     uint64_t drop_seed = 0;
     int64_t o_cv = 0, o_ct = 0, o_hprev = 0, o_gblock = 0, o_gatt = 0, o_gtok = 0, o_gqfeat = 0, o_gA = 0, o_gB = 0,
             o_gK = 0, o_gV0 = 0, o_gV1 = 0, o_gCat = 0, o_gS = 0, o_gRs = 0, o_gRs2 = 0, o_gExtra = 0, o_gStats = 0,
-            o_wt = 0, o_dlogits = 0, o_loss = 0, o_zero_beg = 0, o_zero_end = 0;
+            o_wt = 0, o_dlogits = 0, o_loss = 0, o_zero_beg = 0, o_zero_end = 0, o_wfragT = 0, o_gC = 0;
 };
 
 namespace {
@@ -411,6 +411,16 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
     STAIR_CHECK(!pl->ragged || ctx->conv, "clips of different lengths need the Conv1d Temporal nets (Linear(T,T) fixes T, modules.py:266-277)");
     Builder B{pl};
     std::vector<int> stack;
+    // Common-subexpression sharing across the batch (module_net.py:100-106 evaluates every node of every question; a node
+    // whose operands are the encoded clip, keyword strings, identical question spans or other such nodes has the SAME value
+    // wherever it occurs -- in another question about the same clip, or twice in one program).  key[i] names the computation
+    // of token i ("" = not shareable); the first node with a key is computed, later ones alias its slot.  Filter ignores its
+    // tensor keyword (its attention is identically 1, modules.py:354,373), so that operand does not enter the key.
+    static const bool cse_env = [] { const char *e = getenv("STAIR_PLAN_CSE"); return !(e && e[0] == '0'); }();
+    const bool cse_on = cse_env && !(flags & STAIR_PLAN_NO_CSE);
+    std::vector<std::string> key(cse_on ? ntok : 0);
+    std::unordered_map<std::string, int> cse;
+    pl->n_aliased = 0;
 
     for (int q = 0; q < n; ++q) {
         const int Q = q_off[q + 1] - q_off[q];
@@ -433,6 +443,29 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
                     lvl = std::max(lvl, pl->nodes[ch[k]].level);
                 }
                 nd.level = lvl + 1;
+                if (cse_on) {
+                    std::string k = std::to_string(tok);
+                    bool ok = true;
+                    for (int j = 0; j < ar && ok; ++j) {
+                        const bool ignored = tok == STAIR_OP_FILTER && j == 1 && pl->nodes[ch[1]].kind == STAIR_VAL_VEC;
+                        if (ignored) { k += "(*)"; continue; }
+                        if (key[ch[j]].empty()) ok = false;
+                        else { k += '('; k += key[ch[j]]; k += ')'; }
+                    }
+                    if (ok) {
+                        auto hit = cse.find(k);
+                        if (hit != cse.end()) {            // computed already: alias it (same value, same level by construction)
+                            const Node &o = pl->nodes[hit->second];
+                            nd.kind = o.kind; nd.slot = o.slot; nd.aux = o.aux; nd.rel = o.rel;
+                            key[i] = std::move(k);
+                            ++pl->n_aliased;
+                            stack.push_back(i);
+                            continue;
+                        }
+                        cse.emplace(k, i);
+                        key[i] = std::move(k);
+                    }
+                }
                 const Node &c0 = pl->nodes[ch[0]];
                 const Node &c1 = ar > 1 ? pl->nodes[ch[1]] : c0;
                 const Node &c2 = ar > 2 ? pl->nodes[ch[2]] : c0;
@@ -602,12 +635,26 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
             } else if (tok >= STAIR_KW_FORWARD && tok <= STAIR_KW_RELATIONS) {
                 if (tok == STAIR_KW_VIDEO) {        // module_net.py:103-104
                     nd.kind = STAIR_VAL_MAP; nd.slot = video_of_question ? video_of_question[q] : q;
+                    if (cse_on) key[i] = "V" + std::to_string(nd.slot);
                 } else {
                     nd.kind = STAIR_VAL_STR; nd.aux = tok;
+                    if (cse_on) key[i] = "K" + std::to_string(tok);
                 }
             } else if (tok == STAIR_TOK_SPAN) {     // module_net.py:126-129
                 const int lo = span_lo[i], hi = std::min(span_hi[i], Q);
                 STAIR_CHECK(lo >= 0 && lo < hi, "empty or out-of-range question span at " + where(q, i, tok));
+                if (cse_on) {                       // the same words of the same question: one span mean
+                    key[i] = "S" + std::to_string(q) + ":" + std::to_string(lo) + ":" + std::to_string(hi);
+                    auto hit = cse.find(key[i]);
+                    if (hit != cse.end()) {
+                        const Node &o = pl->nodes[hit->second];
+                        nd.kind = o.kind; nd.slot = o.slot;
+                        ++pl->n_aliased;
+                        stack.push_back(i);
+                        continue;
+                    }
+                    cse.emplace(key[i], i);
+                }
                 nd.kind = STAIR_VAL_VEC; nd.slot = pl->n_vec++;
                 Bucket &b = B.bucket(0, OP_SPAN, 0, 0);
                 b.col[0].push_back(q_off[q] + lo); b.col[1].push_back(hi - lo); b.col[2].push_back(nd.slot);
@@ -709,6 +756,7 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
     pl->o_sup = take((int64_t)std::max(pl->maxSupRows, 1) * T, 64);
     pl->o_extra = take(std::max(pl->maxI, 1), 64);
     pl->o_logits = take((int64_t)n * A, 64);
+    pl->o_wfrag = (H == 512 && T <= 64) ? take(19 * H * H, 64) : 0;     // bf16 hi/lo fragment-order planes of the fused tile operators' weights
     pl->o_status = take(64, 64);                 // word 0: sticky "a cooperative hand-off timed out" flag of this plan's passes
     for (Bucket &b : pl->buckets) {
         b.svA = pl->o_tmpA; b.svB = pl->o_tmpB; b.svK = pl->o_kbuf; b.svCat = pl->o_cat; b.svHid = pl->o_hid;
@@ -743,6 +791,10 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
         pl->o_wt = take(ctx_weight_floats(ctx), 64);
         pl->o_gA = take(I * T * H, 64);
         pl->o_gB = take(I * T * H, 64);
+        if (pl->o_wfrag > 0) {               // backward chains of the fused tile operators: planes of the transposed weights, a third dZ tile set
+            pl->o_wfragT = take(19 * H * H, 64);
+            pl->o_gC = take(I * T * H, 64);
+        }
         pl->o_gV0 = take(Vv * 2 * H, 64);
         pl->o_gV1 = take(Vv * 2 * H, 64);
         pl->o_gCat = take(Vv * 3 * H, 64);
@@ -786,6 +838,7 @@ extern "C" int stair_plan_get_info(const stair_plan *pl, stair_plan_info *info) 
     int launches = 0;
     for (const Bucket &b : pl->buckets) launches += b.cnt > 0;
     info->n_launches = launches; info->n_levels = pl->n_levels; info->n_questions = pl->n; info->T = pl->T;
+    info->n_aliased = pl->n_aliased;
     return 0;
 }
 
@@ -1062,6 +1115,42 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
         }
     }
 
+    // ---- fused per-clip tile operators (csrc/tile_mlp.hip): weights of the buckets that run fused, as fragment-order planes ----
+    const bool fused = pl->o_wfrag > 0 && tile_mlp_usable(H, T) && dp <= 0.0f;
+    enum { WF_F0 = 0, WF_F3 = 4, WF_FF0 = 8, WF_FF3 = 11, WF_FFD = 14, WF_HI0 = 15, WF_LV0 = 16, WF_LV3 = 17, WF_TD = 18, WF_COUNT = 19 };
+    auto WF = [&](int slot) { return static_cast<const void *>(ws + pl->o_wfrag + (int64_t)slot * H * H); };
+    if (fused) {
+        const Lin *lin_of[WF_COUNT] = {&W.f0[0], &W.f0[1], &W.f0[2], &W.f0[3], &W.f3[0], &W.f3[1], &W.f3[2], &W.f3[3], &W.ff0[0], &W.ff0[1], &W.ff0[2],
+                                       &W.ff3[0], &W.ff3[1], &W.ff3[2], &W.ffdense, &W.hi0, &W.lv0, &W.lv3, &W.tdense};
+        bool need[WF_COUNT] = {};
+        for (const Bucket &b : pl->buckets) {
+            if (b.cnt == 0) continue;
+            switch (b.op) {
+                case STAIR_OP_FILTER: need[WF_F0 + b.variant] = need[WF_F3 + b.variant] = true; break;
+                case STAIR_OP_FILTERFRAME: need[WF_FF0 + b.variant] = need[WF_FF3 + b.variant] = need[WF_FFD] = true; break;
+                case STAIR_OP_HASITEM: need[WF_HI0] = true; break;
+                case STAIR_OP_LOCALIZE: case STAIR_OP_SUPERLATIVE: need[WF_LV0] = need[WF_LV3] = true; break;
+                case STAIR_OP_TEMPORAL: need[WF_TD] = true; break;
+                default: break;
+            }
+        }
+        const float *src[WF_COUNT];
+        void *dst[WF_COUNT];
+        int cnt_w = 0;
+        for (int i = 0; i < WF_COUNT; ++i)
+            if (need[i]) { src[cnt_w] = lin_of[i]->w; dst[cnt_w] = const_cast<void *>(WF(i)); ++cnt_w; }
+        if (cnt_w) RUN(launch_pack_wfrag_many(src, dst, cnt_w, H, H, s));
+    }
+    auto tile_args = [&](const int32_t *x_idx, int cnt_) {
+        stair_tile_mlp_args a = {};
+        a.X = map; a.x_gstride = TH; a.x_idx = x_idx; a.cnt = cnt_; a.T = T; a.H = H; a.ln_eps = 1e-5f;
+        return a;
+    };
+    auto tile_layer = [&](stair_tile_mlp_args &a, int slot, const Lin &l, int act, float *save) {
+        const int i = a.n_layers++;
+        a.W[i] = WF(slot); a.bias[i] = l.b; a.act[i] = act; a.save[i] = pl->train ? save : nullptr;
+    };
+
     // ---- program levels ----------------------------------------------------------------------
     for (const Bucket &b : pl->buckets) {
         ++bucket_no;
@@ -1117,6 +1206,15 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
                 break;
             case STAIR_OP_FILTER: {     // modules.py:343-378 (attention == 1 exactly, see oracle op_filter)
                 const int v = b.variant;
+                if (fused) {            // both layers and the sum over frames on the tile, one launch
+                    stair_tile_mlp_args a = tile_args(I0, c);
+                    tile_layer(a, WF_F0 + v, W.f0[v], 1, tmpA);
+                    tile_layer(a, WF_F3 + v, W.f3[v], 1, tmpB);
+                    a.tail = STAIR_TILE_SUM_ROWS; a.out = cat; a.out_gstride = H; a.len = LEN;
+                    RUN(launch_tile_mlp(a, s));
+                    RUN(dense(s, cat, H, H, nullptr, W.fdense, H, vec, H, H, I1, c, 1, H, H, 1));
+                    break;
+                }
                 RUN(dense(s, map, H, TH, I0, W.f0[v], H, tmpA, H, TH, nullptr, c, T, H, H, 1));
                 RUN(drop(tmpA, TH, nullptr, c, TH, 0));
                 RUN(dense(s, tmpA, H, TH, nullptr, W.f3[v], H, tmpB, H, TH, nullptr, c, T, H, H, 1));
@@ -1127,6 +1225,17 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
             }
             case STAIR_OP_FILTERFRAME: {   // modules.py:381-414
                 const int v = b.variant;
+                if (fused) {            // three layers with the sigmoid attention in between, one launch
+                    if (v == 0) RUN(launch_vecdot(vec, I1, W.ffatt.w + H, extra, c, H, s));
+                    stair_tile_mlp_args a = tile_args(I0, c);
+                    tile_layer(a, WF_FF0 + v, W.ff0[v], 1, tmpA);
+                    tile_layer(a, WF_FF3 + v, W.ff3[v], 1, tmpB);
+                    tile_layer(a, WF_FFD, W.ffdense, 1, nullptr);
+                    if (v == 0) { a.mid_rowdot = 1; a.vw = W.ffatt.w; a.vb = W.ffatt.b; a.extra = extra; a.rs_out = rsb; }
+                    a.tail = STAIR_TILE_STORE; a.out = map; a.out_gstride = TH; a.out_idx = I2;
+                    RUN(launch_tile_mlp(a, s));
+                    break;
+                }
                 RUN(dense(s, map, H, TH, I0, W.ff0[v], H, tmpA, H, TH, nullptr, c, T, H, H, 1));
                 RUN(drop(tmpA, TH, nullptr, c, TH, 0));
                 RUN(dense(s, tmpA, H, TH, nullptr, W.ff3[v], H, tmpB, H, TH, nullptr, c, T, H, H, 1));
@@ -1143,12 +1252,28 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
                 break;
             }
             case STAIR_OP_HASITEM:      // modules.py:123-138
+                if (fused) {
+                    stair_tile_mlp_args a = tile_args(I0, c);
+                    tile_layer(a, WF_HI0, W.hi0, 1, tmpA);
+                    a.tail = STAIR_TILE_ROWDOT_SIGMOID; a.vw = W.hi3.w; a.vb = W.hi3.b; a.out = att; a.out_gstride = T; a.out_idx = I1;
+                    RUN(launch_tile_mlp(a, s));
+                    break;
+                }
                 RUN(dense(s, map, H, TH, I0, W.hi0, H, tmpA, H, TH, nullptr, c, T, H, H, 1));
                 RUN(drop(tmpA, TH, nullptr, c, TH, 0));
                 RUN(launch_rowdot_sigmoid(tmpA, c, T, H, W.hi3.w, W.hi3.b, nullptr, att, I1, T, s));
                 RUN(drop(att, T, I1, c, T, 1));
                 break;
             case STAIR_OP_LOCALIZE:     // modules.py:181-217
+                if (fused) {            // keyword rows first (a vector-level product), then both layers + the cosine on the tile
+                    RUN(dense(s, vec, H, H, I2, W.lk, H, kbuf, H, H, nullptr, b.nrows, 1, H, H, 0));
+                    stair_tile_mlp_args a = tile_args(I0, c);
+                    tile_layer(a, WF_LV0, W.lv0, 1, tmpA);
+                    tile_layer(a, WF_LV3, W.lv3, 0, tmpB);
+                    a.tail = STAIR_TILE_COSINE; a.kb = kbuf; a.pair_first = I4; a.pair_cnt = I5; a.att_idx = I3; a.att = att;
+                    RUN(launch_tile_mlp(a, s));
+                    break;
+                }
                 RUN(dense(s, map, H, TH, I0, W.lv0, H, tmpA, H, TH, nullptr, c, T, H, H, 1));
                 RUN(drop(tmpA, TH, nullptr, c, TH, 0));
                 RUN(dense(s, tmpA, H, TH, nullptr, W.lv3, H, tmpB, H, TH, nullptr, c, T, H, H, 0));
@@ -1159,9 +1284,17 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
                 RUN(launch_relate_softmax(att, I0, I1, W.beta, b.variant == 0 ? 1.0f : -1.0f, c, T, s, LEN));
                 break;
             case STAIR_OP_SUPERLATIVE:  // modules.py:220-248 (shares Localize's weights, module_net.py:31-32)
-                RUN(dense(s, map, H, TH, I0, W.lv0, H, tmpA, H, TH, nullptr, c, T, H, H, 1));
-                RUN(drop(tmpA, TH, nullptr, c, TH, 0));
-                RUN(dense(s, tmpA, H, TH, nullptr, W.lv3, H, tmpB, H, TH, nullptr, c, T, H, H, 0));
+                if (fused) {
+                    stair_tile_mlp_args a = tile_args(I0, c);
+                    tile_layer(a, WF_LV0, W.lv0, 1, tmpA);
+                    tile_layer(a, WF_LV3, W.lv3, 0, nullptr);
+                    a.tail = STAIR_TILE_STORE; a.out = tmpB; a.out_gstride = TH;
+                    RUN(launch_tile_mlp(a, s));
+                } else {
+                    RUN(dense(s, map, H, TH, I0, W.lv0, H, tmpA, H, TH, nullptr, c, T, H, H, 1));
+                    RUN(drop(tmpA, TH, nullptr, c, TH, 0));
+                    RUN(dense(s, tmpA, H, TH, nullptr, W.lv3, H, tmpB, H, TH, nullptr, c, T, H, H, 0));
+                }
                 RUN(dense(s, ws, H, H, I4, W.lk, H, kbuf, H, H, nullptr, b.nrows, 1, H, H, 0));
                 if (T <= 128 && H % 64 == 0)      // one block per instance: its pairs share the tile (csrc/rowops.hip)
                     RUN(launch_cosine_attn_grouped(tmpB, TH, kbuf, I1, I2, sup, c, b.nrows, T, H, T, s));
@@ -1174,6 +1307,14 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
                 const int mode = b.variant;
                 RUN(launch_temporal_relate(att, I1, I2, att, I3, c, T, mode, ctx->conv ? 1 : 0, ctx->ksize,
                                            mode ? W.relate[mode - 1] : nullptr, s, LEN));
+                if (fused) {            // r_t feat_t -> Lin . ReLU -> LayerNorm on the tile
+                    stair_tile_mlp_args a = tile_args(I0, c);
+                    tile_layer(a, WF_TD, W.tdense, 1, tmpA);
+                    a.row_scale = att; a.rs_idx = I3;
+                    a.tail = STAIR_TILE_LAYERNORM; a.gamma = W.ln_w; a.beta = W.ln_b; a.out = map; a.out_gstride = TH; a.out_idx = I4;
+                    RUN(launch_tile_mlp(a, s));
+                    break;
+                }
                 RUN(dense(s, map, H, TH, I0, W.tdense, H, tmpA, H, TH, nullptr, c, T, H, H, 1, att, T, I3));
                 RUN(drop(tmpA, TH, nullptr, c, TH, 0));
                 RUN(launch_layernorm(tmpA, map, TH, I4, c, T, H, W.ln_w, W.ln_b, 1e-5f, s));
@@ -1290,6 +1431,32 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
         }
         RUN(launch_transpose_many(tb, tiles, s));       // one launch for all 31 images
     }
+    // ---- backward chains of the fused tile operators (csrc/tile_mlp.hip): dX = (dZ2 W2 * relu'(Z1)) W1 stays on the tile ----
+    const bool fused = pl->o_wfragT > 0 && tile_mlp_usable(H, T) && pl->drop_p <= 0.0f;
+    enum { WF_F0 = 0, WF_F3 = 4, WF_FF0 = 8, WF_FF3 = 11, WF_FFD = 14, WF_HI0 = 15, WF_LV0 = 16, WF_LV3 = 17, WF_TD = 18, WF_COUNT = 19 };
+    auto WFT = [&](int slot) { return static_cast<const void *>(ws + pl->o_wfragT + (int64_t)slot * H * H); };
+    float *gC = pl->o_gC > 0 ? ws + pl->o_gC : nullptr;
+    if (fused) {
+        const Lin *lin_of[WF_COUNT] = {&W.f0[0], &W.f0[1], &W.f0[2], &W.f0[3], &W.f3[0], &W.f3[1], &W.f3[2], &W.f3[3], &W.ff0[0], &W.ff0[1], &W.ff0[2],
+                                       &W.ff3[0], &W.ff3[1], &W.ff3[2], &W.ffdense, &W.hi0, &W.lv0, &W.lv3, &W.tdense};
+        bool need[WF_COUNT] = {};
+        for (const Bucket &b : pl->buckets) {
+            if (b.cnt == 0) continue;
+            switch (b.op) {
+                case STAIR_OP_FILTER: need[WF_F0 + b.variant] = need[WF_F3 + b.variant] = true; break;
+                case STAIR_OP_FILTERFRAME: if (b.variant) need[WF_FF0 + b.variant] = need[WF_FF3 + b.variant] = need[WF_FFD] = true; break;
+                case STAIR_OP_HASITEM: need[WF_HI0] = true; break;
+                case STAIR_OP_LOCALIZE: case STAIR_OP_SUPERLATIVE: need[WF_LV0] = need[WF_LV3] = true; break;
+                default: break;
+            }
+        }
+        const float *src[WF_COUNT];
+        void *dst[WF_COUNT];
+        int cnt_w = 0;
+        for (int i = 0; i < WF_COUNT; ++i)          // the transposed fp32 images are there already: their planes are those of W^T
+            if (need[i]) { src[cnt_w] = B.wt + B.wt_off[lin_of[i]->id]; dst[cnt_w] = const_cast<void *>(WFT(i)); ++cnt_w; }
+        if (cnt_w) RUN(launch_pack_wfrag_many(src, dst, cnt_w, H, H, s));
+    }
 
     // ---- loss + decoder ------------------------------------------------------------------------
     RUN(launch_ce_loss(logits, answers, loss_scale, loss, dlogits, n, A, s));
@@ -1312,6 +1479,24 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
         const float *svA = ws + b.svA, *svB = ws + b.svB, *svK = ws + b.svK, *svCat = ws + b.svCat, *svHid = ws + b.svHid;
         const float *svRs = ws + b.svRs, *svSup = ws + b.svSup;
         // tail shared by Filter / FilterFrame / Localize / Superlative: gB = d(second linear output)
+        // the same on the tile: the chain's two dX products, the ReLU mask between them and the accumulation into the input's
+        // gradient tile in ONE launch; the two weight-gradient products (reductions over all instances) stay TN GEMMs.
+        // in_bcast: Filter -- the incoming gradient is ONE row per instance (the sum over frames), broadcast and masked on load.
+        auto mlp_tail_fused = [&](const Lin &l3, const Lin &l0, int slot3, int slot0, bool relu_second, const float *bcast_row) -> int {
+            stair_tile_mlp_args a = {};
+            a.cnt = c; a.T = T; a.H = H; a.len = LEN;
+            if (bcast_row) { a.X = bcast_row; a.x_gstride = H; a.x_broadcast = 1; }
+            else { a.X = gB; a.x_gstride = TH; }
+            if (bcast_row || relu_second) { a.in_mask = svB; a.in_mask_gstride = TH; a.in_scale = inv_keep; a.save_in = gB; }
+            a.n_layers = 2;
+            a.W[0] = WFT(slot3); a.act[0] = 3; a.act_mask[0] = svA; a.act_scale = inv_keep; a.save[0] = gA;
+            a.W[1] = WFT(slot0); a.act[1] = 0;
+            a.tail = STAIR_TILE_ACCUMULATE; a.out = g_map; a.out_gstride = TH; a.out_idx = I0;
+            RUN(launch_tile_mlp(a, s));
+            RUN(dense_bwd(B, gB, c, T, H, H, svA, H, TH, nullptr, l3, nullptr, H, TH, nullptr, 0));
+            RUN(dense_bwd(B, gA, c, T, H, H, map, H, TH, I0, l0, nullptr, H, TH, I0, 1));
+            return 0;
+        };
         auto mlp_tail = [&](const Lin &l3, const Lin &l0, bool relu_second) -> int {
             if (relu_second) RUN(launch_mask_relu(gB, gB, TH, nullptr, svB, TH, nullptr, c, (int)TH, s, inv_keep));
             RUN(dense_bwd(B, gB, c, T, H, H, svA, H, TH, nullptr, l3, gA, H, TH, nullptr, 0));
@@ -1366,12 +1551,29 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
                 const int v = b.variant;
                 RUN(launch_mask_relu(gV0, g_vec, H, I1, vec, H, I1, c, H, s));
                 RUN(dense_bwd(B, gV0, c, 1, H, H, svCat, H, H, nullptr, W.fdense, gV1, H, H, nullptr, 0));
+                if (fused) { RUN(mlp_tail_fused(W.f3[v], W.f0[v], WF_F3 + v, WF_F0 + v, false, gV1)); break; }
                 RUN(launch_bcast_mask_relu(gB, gV1, svB, c, T, H, s, inv_keep, LEN));
                 RUN(mlp_tail(W.f3[v], W.f0[v], false));
                 break;
             }
             case STAIR_OP_FILTERFRAME: {
                 const int v = b.variant;
+                if (fused && v != 0) {        // three-layer chain on the tile: dZ3 -> (ffdense) -> dZ2 -> (ff3) -> dZ1 -> (ff0) -> += g_map[I0]
+                    stair_tile_mlp_args a = {};
+                    a.cnt = c; a.T = T; a.H = H;
+                    a.X = g_map; a.x_gstride = TH; a.x_idx = I2;
+                    a.in_mask = map; a.in_mask_gstride = TH; a.in_mask_idx = I2; a.in_scale = inv_keep; a.save_in = gC;
+                    a.n_layers = 3; a.act_scale = inv_keep;
+                    a.W[0] = WFT(WF_FFD); a.act[0] = 3; a.act_mask[0] = svB; a.save[0] = gB;
+                    a.W[1] = WFT(WF_FF3 + v); a.act[1] = 3; a.act_mask[1] = svA; a.save[1] = gA;
+                    a.W[2] = WFT(WF_FF0 + v); a.act[2] = 0;
+                    a.tail = STAIR_TILE_ACCUMULATE; a.out = g_map; a.out_gstride = TH; a.out_idx = I0;
+                    RUN(launch_tile_mlp(a, s));
+                    RUN(dense_bwd(B, gC, c, T, H, H, svB, H, TH, nullptr, W.ffdense, nullptr, H, TH, nullptr, 0));
+                    RUN(dense_bwd(B, gB, c, T, H, H, svA, H, TH, nullptr, W.ff3[v], nullptr, H, TH, nullptr, 0));
+                    RUN(dense_bwd(B, gA, c, T, H, H, map, H, TH, I0, W.ff0[v], nullptr, H, TH, I0, 1));
+                    break;
+                }
                 RUN(launch_mask_relu(gA, g_map, TH, I2, map, TH, I2, c, (int)TH, s, inv_keep));        // dZ of the dense layer
                 if (v == 0) {
                     // dense input is a_t * f_t: weight grads see the scaled input, G = dZ.W is d(a*f)
@@ -1395,13 +1597,24 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
                 RUN(launch_rowdot_sigmoid_bwd(g_att, T, I1, att, T, I1, W.hi3.w, gA, 0, gRs2, nullptr, c, T, H, s, 1.0f / inv_keep));
                 RUN(launch_weighted_colsum(svA, H, nullptr, gRs2, W.hi3.dw, c * T, H, s));
                 RUN(launch_sum_all(gRs2, W.hi3.db, c * T, s));
+                if (fused) {
+                    stair_tile_mlp_args a = {};
+                    a.cnt = c; a.T = T; a.H = H;
+                    a.X = gA; a.x_gstride = TH; a.in_mask = svA; a.in_mask_gstride = TH; a.in_scale = inv_keep; a.save_in = gA;
+                    a.n_layers = 1; a.W[0] = WFT(WF_HI0); a.act[0] = 0;
+                    a.tail = STAIR_TILE_ACCUMULATE; a.out = g_map; a.out_gstride = TH; a.out_idx = I0;
+                    RUN(launch_tile_mlp(a, s));
+                    RUN(dense_bwd(B, gA, c, T, H, H, map, H, TH, I0, W.hi0, nullptr, H, TH, I0, 1));
+                    break;
+                }
                 RUN(launch_mask_relu(gA, gA, TH, nullptr, svA, TH, nullptr, c, (int)TH, s, inv_keep));
                 RUN(dense_bwd(B, gA, c, T, H, H, map, H, TH, I0, W.hi0, g_map, H, TH, I0, 1));
                 break;
             case STAIR_OP_LOCALIZE:
                 RUN(launch_cosine_attn_bwd_grouped(svB, svK, att, I3, g_att, I3, I4, I5, gB, gK, gRs2, gStats, c, b.nrows, T, H, 2, s));
                 RUN(dense_bwd(B, gK, b.nrows, 1, H, H, vec, H, H, I2, W.lk, g_vec, H, H, I2, 1));
-                RUN(mlp_tail(W.lv3, W.lv0, false));
+                if (fused) RUN(mlp_tail_fused(W.lv3, W.lv0, WF_LV3, WF_LV0, false, nullptr));
+                else RUN(mlp_tail(W.lv3, W.lv0, false));
                 break;
             case STAIR_OP_RELATE:
                 RUN(launch_relate_softmax_bwd(att, g_att, I0, I1, W.dbeta, b.variant == 0 ? 1.0f : -1.0f, c, T, s, LEN));
@@ -1412,7 +1625,8 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
                 RUN(launch_superlative_pool_bwd(svSup, ws, gws, I4, I1, I2, b.variant, gV1, gS, c, T, H, s, LEN));
                 RUN(launch_cosine_attn_bwd_grouped(svB, svK, svSup, nullptr, gS, nullptr, I1, I2, gB, gK, gRs2, gStats, c, b.nrows, T, H, T, s));
                 RUN(dense_bwd(B, gK, b.nrows, 1, H, H, ws, H, H, I4, W.lk, gws, H, H, I4, 1));
-                RUN(mlp_tail(W.lv3, W.lv0, false));
+                if (fused) RUN(mlp_tail_fused(W.lv3, W.lv0, WF_LV3, WF_LV0, false, nullptr));
+                else RUN(mlp_tail(W.lv3, W.lv0, false));
                 break;
             case STAIR_OP_TEMPORAL: {
                 const int mode = b.variant;
@@ -1570,6 +1784,7 @@ extern "C" int stair_plan_regions(stair_plan *pl, const stair_ctx *ctx, const ch
     add("extra", pl->o_extra, std::max(pl->maxI, 1));
     add("logits", pl->o_logits, n * A);
     add("status", pl->o_status, 64);
+    if (H == 512 && T <= 64) add("wfrag", pl->o_wfrag, 19 * H * H);
     if (pl->train) {
         int bi = 0;
         for (const Bucket &b : pl->buckets) {
@@ -1591,6 +1806,7 @@ extern "C" int stair_plan_regions(stair_plan *pl, const stair_ctx *ctx, const ch
         add("wt", pl->o_wt, ctx_weight_floats(ctx));
         add("gA", pl->o_gA, I * T * H);
         add("gB", pl->o_gB, I * T * H);
+        if (pl->o_wfragT > 0) { add("wfragT", pl->o_wfragT, 19 * H * H); add("gC", pl->o_gC, I * T * H); }
         add("gV0", pl->o_gV0, Vv * 2 * H);
         add("gV1", pl->o_gV1, Vv * 2 * H);
         add("gCat", pl->o_gCat, Vv * 3 * H);

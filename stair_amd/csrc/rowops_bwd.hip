@@ -502,7 +502,9 @@ int launch_temporal_relate_bwd(const float *att, const int32_t *att_idx, const i
                                const int32_t *rel_idx, float *datt, int n, int T, int mode, int conv, int ksize,
                                const float *const w[6], float *const dw[6], hipStream_t s, const int32_t *len) {
     if (n == 0) return 0;
-    STAIR_ACCT("temporal_relate_bwd_kernel", 0);
+    // reads: K attention rows in (the mean over K; K <= 2, counted as 2), the relate output's gradient; writes: K attention-row
+    // gradients; the three layers' filters / matrices and their gradients are a few hundred floats per launch
+    STAIR_ACCT("temporal_relate_bwd_kernel", (int64_t)n * T * 4 * (2 + 1 + 2));
     RelateWB W;
     for (int i = 0; i < 6; ++i) { W.w[i] = (mode && w) ? w[i] : nullptr; W.dw[i] = (mode && dw) ? dw[i] : nullptr; }
     hipLaunchKernelGGL(temporal_relate_bwd_kernel, dim3(n), dim3(64), 6 * T * sizeof(float), s, att, att_idx, att_k, drel,
@@ -962,7 +964,9 @@ int launch_superlative_pool_bwd(const float *S, const float *rowbase, float *dro
                                 const int32_t *row_start, const int32_t *row_cnt, int is_min, const float *dpre, float *dS,
                                 int n, int T, int H, hipStream_t s, const int32_t *len) {
     if (n == 0) return 0;
-    STAIR_ACCT("superlative_pool_bwd_kernel", 0);
+    // per instance: scores S [Ka, T] in, dS [Ka, T] out, the Ka action rows [Ka, H] in and their gradient rows out (read-modify-
+    // write), the pooled vector's gradient [H] in; Ka = T for the map-valued action lists of the AGQA programs
+    STAIR_ACCT("superlative_pool_bwd_kernel", (int64_t)n * ((int64_t)2 * T * T + (int64_t)3 * T * H + H) * 4);
     hipLaunchKernelGGL(superlative_pool_bwd_kernel, dim3(n), dim3(kBlock), (size_t)3 * std::max(T, 2) * sizeof(float), s, S, rowbase,
                        drowbase, row_id, row_start, row_cnt, is_min, dpre, dS, n, T, H, len);
     STAIR_LAUNCH_CHECK();

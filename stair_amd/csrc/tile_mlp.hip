@@ -1,0 +1,472 @@
+// Fused per-clip tile operators: one workgroup carries one [T, H] tile (T <= 64 frames of one module instance, H = 512)
+// through up to three Linear layers and the module's tile-local tail WITHOUT the intermediates leaving the CU.
+//
+// Replaces, per module of /root/reference/video_nmn/modules.py, the launch sequences GEMM -> HBM -> GEMM -> HBM -> row kernel:
+//   Localize   (:199-217)  Lin . ReLU . Lin on the tile, then (cos(f_t, k_j) + 1) * 0.49 against the K keyword rows
+//   Filter     (:363-378)  Lin . ReLU . Lin . ReLU, then sum over the frames (its attention is identically 1)
+//   FilterFrame(:399-414)  Lin . ReLU . Lin . ReLU = f, a_t = sigmoid(w[:H] . f_t + w[H:] . kw + b), ReLU(Lin(a_t f_t))
+//   HasItem    (:123-138)  Lin . ReLU, then sigmoid(w . row + b)
+//   Temporal   (:310-327)  ReLU(Lin(r_t feat_t)), then LayerNorm over H
+//   Superlative(:220-248)  Localize's two layers (the scores against Ka = T action rows stay in cosine_attn_grouped_kernel)
+//
+// Mapping to the CU (8 waves, one workgroup per CU, 140 KB of LDS):
+//   * the tile lives in LDS as bf16 hi + lo planes (x = hi + lo), laid out per 32-wide k stage as [64 rows][4 slots of 16 B]
+//     with the slot swizzle of csrc/gemm_planes.hip (conflict-free ds_read_b128 fragment reads);
+//   * a layer is computed TRANSPOSED, Z^T = W . tile^T: the weight rows are the MFMA A operand.  Wave w owns output columns
+//     [64 w, 64 w + 64) and nobody else needs those weight rows, so W never goes through LDS: its bf16 hi / lo planes are
+//     stored in HBM in FRAGMENT ORDER (stair_pack_wfrag: 1 KB per (32-row tile, 16-wide k step, plane)) and each wave streams
+//     its own fragments global -> VGPR with three k steps in flight; the tile (the B operand) is the only thing read from
+//     LDS, 4 KB per wave and k step for 12 v_mfma_f32_32x32x16_bf16 (hi.hi + lo.hi + hi.lo, fp32 accumulate);
+//   * the k loop has NO barrier (the tile is read-only during a layer, W is private to the wave); the workgroup meets only
+//     where the tile is rewritten: in the transposed accumulator layout a lane holds, for its frame t, runs of 4 consecutive
+//     output columns, i.e. 8-byte pieces of the next layer's bf16 operand row -- written back with ds_write_b64;
+//   * the last layer's output is staged once as fp32 [T][H] in LDS (rows 516 floats apart) and every tail -- coalesced row
+//     stores, the sum over frames, cosine / dot products per row, LayerNorm -- reads it from there.
+// Training plans additionally write each activation the backward pass needs ONCE, from registers / the staged rows.
+#include <algorithm>
+#include <cstdlib>
+
+#include "common.h"
+#include "ops.h"
+
+namespace stair {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+using v4f = __attribute__((ext_vector_type(4))) float;
+
+namespace {
+
+constexpr int TM_H = 512;                       // hidden size the kernel is built for (the reference's, args.py:27)
+constexpr int TM_ROWS = 64;                     // frames per tile
+constexpr int TM_KS = TM_H / 16;                // 16-wide k steps per layer
+constexpr int TM_STAGE = 8192;                  // one 32-wide k stage of the tile image: hi plane 4 KB, lo plane 4 KB
+constexpr int TM_IMG = (TM_H / 32) * TM_STAGE;  // 128 KB
+constexpr int TM_FLD = TM_H + 4;                // row stride of the fp32 staging (floats): 16-byte rows, conflict-free float4 writes
+constexpr int TM_F_BYTES = TM_ROWS * TM_FLD * 4;
+constexpr int TM_RED_OFF = TM_F_BYTES;          // cross-wave scratch behind both images: [8 waves][64 rows] floats
+constexpr int TM_LDS = TM_RED_OFF + 8 * 64 * 4;
+static_assert(TM_F_BYTES >= TM_IMG, "the fp32 staging covers the bf16 image");
+
+// slot swizzle of the tile image (as pl_swz of csrc/gemm_planes.hip)
+__device__ __forceinline__ int tm_swz(int R) {
+    const int q0 = (R >> 2) & 1, q1 = (R >> 3) & 1;
+    return ((q0 ^ q1) << 1) | q1;
+}
+
+struct TmParams {
+    stair_tile_mlp_args a;
+};
+
+}  // namespace
+
+// hi = bf16(x), lo = bf16(x - hi) of 8 consecutive floats
+__device__ __forceinline__ void tm_split8(const v4f a, const v4f b, bf16x8 &hi, bf16x8 &lo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        hi[j] = (__bf16)a[j]; lo[j] = (__bf16)(a[j] - (float)hi[j]);
+        hi[4 + j] = (__bf16)b[j]; lo[4 + j] = (__bf16)(b[j] - (float)hi[4 + j]);
+    }
+}
+
+__global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
+    const stair_tile_mlp_args &p = pp.a;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    float *F = reinterpret_cast<float *>(lds);
+    float *red = reinterpret_cast<float *>(lds + TM_RED_OFF);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int T = p.T;
+    // B-operand fragment offsets (bytes inside a stage plane, chunk 0) of this lane's two frame tiles
+    int offT[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int R = 32 * tt + r;
+        offT[tt] = (R * 4 + tm_swz(R)) * 16;
+    }
+
+    for (int inst = blockIdx.x; inst < p.cnt; inst += gridDim.x) {
+        // ---- the input tile: fp32 rows -> (row scale) -> bf16 hi / lo image ------------------------------------------
+        const float *x = p.X + (int64_t)(p.x_idx ? p.x_idx[inst] : inst) * p.x_gstride;
+        const float *rsrow = p.row_scale ? p.row_scale + (int64_t)(p.rs_idx ? p.rs_idx[inst] : inst) * T : nullptr;
+        const float *imask = p.in_mask ? p.in_mask + (int64_t)(p.in_mask_idx ? p.in_mask_idx[inst] : inst) * p.in_mask_gstride : nullptr;
+        const int Lrows = p.x_broadcast ? (p.len ? p.len[inst] : T) : T;     // a broadcast row fills the clip's own frames only
+        __syncthreads();                          // the previous instance's tail has finished reading the staging
+        for (int u = tid; u < TM_ROWS * 64; u += 512) {
+            const int t = u >> 6, c8 = u & 63;
+            v4f a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+            if (t < Lrows) {
+                const float *xr = x + (p.x_broadcast ? 0 : (int64_t)t * TM_H) + 8 * c8;
+                a = *reinterpret_cast<const v4f *>(xr);
+                b = *reinterpret_cast<const v4f *>(xr + 4);
+                if (rsrow) { const float s = rsrow[t]; a *= s; b *= s; }
+                if (imask) {                  // backward chains: the incoming gradient times relu'(saved activation) (x in_scale)
+                    const v4f m0 = *reinterpret_cast<const v4f *>(imask + (int64_t)t * TM_H + 8 * c8), m1 = *reinterpret_cast<const v4f *>(imask + (int64_t)t * TM_H + 8 * c8 + 4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { a[i] = m0[i] > 0.f ? a[i] * p.in_scale : 0.f; b[i] = m1[i] > 0.f ? b[i] * p.in_scale : 0.f; }
+                }
+            }
+            if (p.save_in && t < T) {
+                float *d = p.save_in + ((int64_t)inst * T + t) * TM_H + 8 * c8;
+                *reinterpret_cast<v4f *>(d) = a; *reinterpret_cast<v4f *>(d + 4) = b;
+            }
+            bf16x8 hi, lo;
+            tm_split8(a, b, hi, lo);
+            const int off = (c8 >> 2) * TM_STAGE + (t * 4 + ((c8 & 3) ^ tm_swz(t))) * 16;
+            *reinterpret_cast<bf16x8 *>(lds + off) = hi;
+            *reinterpret_cast<bf16x8 *>(lds + off + 4096) = lo;
+        }
+        __syncthreads();
+
+        f32x16 acc[2][2];
+        for (int ph = 0; ph < p.n_layers; ++ph) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+            // ---- Z^T[n][t] += W[n][k] tile[t][k]: this wave's 64 weight rows straight from HBM / L2 in fragment order ----
+            {
+                const bf16x8 *wq = static_cast<const bf16x8 *>(p.W[ph]) + (int64_t)(2 * wave) * TM_KS * 2 * 64 + lane;
+                bf16x8 wf[4][2][2];
+#define TM_LOADW(slot_, ks_)                                                                                  \
+    _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_)                                                       \
+        _Pragma("unroll") for (int pl_ = 0; pl_ < 2; ++pl_)                                                   \
+            wf[slot_][nt_][pl_] = wq[((nt_ * TM_KS + (ks_)) * 2 + pl_) * 64];
+                TM_LOADW(0, 0) TM_LOADW(1, 1) TM_LOADW(2, 2)
+                for (int ks0 = 0; ks0 < TM_KS; ks0 += 4) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int ks = ks0 + u;
+                        if (ks + 3 < TM_KS) { TM_LOADW((u + 3) & 3, ks + 3) }
+                        const char *sb = lds + (ks >> 1) * TM_STAGE;
+                        const int cx = (2 * (u & 1) + h) << 4;
+                        bf16x8 zh[2], zl[2];
+#pragma unroll
+                        for (int tt = 0; tt < 2; ++tt) {
+                            zh[tt] = *reinterpret_cast<const bf16x8 *>(sb + (offT[tt] ^ cx));
+                            zl[tt] = *reinterpret_cast<const bf16x8 *>(sb + 4096 + (offT[tt] ^ cx));
+                        }
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                            for (int tt = 0; tt < 2; ++tt) {
+                                acc[nt][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u][nt][1], zh[tt], acc[nt][tt], 0, 0, 0);
+                                acc[nt][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u][nt][0], zl[tt], acc[nt][tt], 0, 0, 0);
+                                acc[nt][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u][nt][0], zh[tt], acc[nt][tt], 0, 0, 0);
+                            }
+                    }
+                }
+#undef TM_LOADW
+            }
+            // ---- bias + activation in the accumulator layout: lane (r, h) holds frame t = 32 tt + r, columns
+            //      n = 64 wave + 32 nt + 8 q + 4 h + i for e = 4 q + i ----------------------------------------------------
+            const float *bias = p.bias[ph];
+            const int act = p.act[ph];
+            const float *amask = act == 3 ? p.act_mask[ph] + (int64_t)inst * T * TM_H : nullptr;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const v4f bv = bias ? *reinterpret_cast<const v4f *>(bias + 64 * wave + 32 * nt + 8 * q + 4 * h) : v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) {
+                        v4f mv = {1.f, 1.f, 1.f, 1.f};
+                        if (amask && 32 * tt + r < T) mv = *reinterpret_cast<const v4f *>(amask + (int64_t)(32 * tt + r) * TM_H + 64 * wave + 32 * nt + 8 * q + 4 * h);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float v = acc[nt][tt][4 * q + i] + bv[i];
+                            if (act == 1) v = fmaxf(v, 0.0f);
+                            if (act == 3) v = mv[i] > 0.f ? v * p.act_scale : 0.f;     // backward chain: x relu'(saved activation)
+                            acc[nt][tt][4 * q + i] = v;
+                        }
+                    }
+                }
+            const bool last = ph + 1 == p.n_layers;
+            __syncthreads();                      // every wave has finished reading the tile image of this layer
+            if (!last) {
+                // the activation the backward pass needs, written once from registers (32-byte pieces, merged in L2)
+                float *sv = p.save[ph];
+                float scale[2] = {1.0f, 1.0f};
+                if (p.mid_rowdot && ph == 1) {
+                    // FilterFrame: a_t = sigmoid(w[:H] . f_t + extra + b) from the registers, then the tile becomes a_t f_t
+                    float part[2] = {0.f, 0.f};
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const v4f wv = *reinterpret_cast<const v4f *>(p.vw + 64 * wave + 32 * nt + 8 * q + 4 * h);
+#pragma unroll
+                            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) part[tt] += acc[nt][tt][4 * q + i] * wv[i];
+                        }
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) {
+                        part[tt] += __shfl_xor(part[tt], 32, 64);
+                        if (h == 0) red[wave * 64 + 32 * tt + r] = part[tt];
+                    }
+                    __syncthreads();
+                    const float add = p.vb[0] + (p.extra ? p.extra[inst] : 0.f);
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) {
+                        float d = 0.f;
+#pragma unroll
+                        for (int w8 = 0; w8 < 8; ++w8) d += red[w8 * 64 + 32 * tt + r];
+                        scale[tt] = sigmoid_acc(d + add);
+                        if (p.rs_out && wave == 0 && h == 0 && 32 * tt + r < T) p.rs_out[(int64_t)inst * T + 32 * tt + r] = scale[tt];
+                    }
+                }
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) {
+                        const int t = 32 * tt + r;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            v4f z = {acc[nt][tt][4 * q], acc[nt][tt][4 * q + 1], acc[nt][tt][4 * q + 2], acc[nt][tt][4 * q + 3]};
+                            if (sv && t < T)
+                                *reinterpret_cast<v4f *>(sv + ((int64_t)inst * T + t) * TM_H + 64 * wave + 32 * nt + 8 * q + 4 * h) = z;
+                            z *= scale[tt];
+                            bf16x4 zh4, zl4;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) { zh4[i] = (__bf16)z[i]; zl4[i] = (__bf16)(z[i] - (float)zh4[i]); }
+                            const int off = (2 * wave + nt) * TM_STAGE + (t * 4 + (q ^ tm_swz(t))) * 16 + 8 * h;
+                            *reinterpret_cast<bf16x4 *>(lds + off) = zh4;
+                            *reinterpret_cast<bf16x4 *>(lds + off + 4096) = zl4;
+                        }
+                    }
+                __syncthreads();
+            } else {
+                // ---- the last layer's output as fp32 rows in LDS ------------------------------------------------------
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) {
+                        const int t = 32 * tt + r;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            *reinterpret_cast<v4f *>(F + t * TM_FLD + 64 * wave + 32 * nt + 8 * q + 4 * h) =
+                                v4f{acc[nt][tt][4 * q], acc[nt][tt][4 * q + 1], acc[nt][tt][4 * q + 2], acc[nt][tt][4 * q + 3]};
+                    }
+                __syncthreads();
+            }
+        }
+
+        // ---- tails, from the staged rows ---------------------------------------------------------------------------------
+        float *svl = p.save[p.n_layers - 1];
+        if (svl)                                      // the last layer's rows for the backward pass (coalesced 2 KB rows)
+            for (int t = wave; t < T; t += 8) {
+                float *dst = svl + ((int64_t)inst * T + t) * TM_H;
+                *reinterpret_cast<v4f *>(dst + 4 * lane) = *reinterpret_cast<const v4f *>(F + t * TM_FLD + 4 * lane);
+                *reinterpret_cast<v4f *>(dst + 256 + 4 * lane) = *reinterpret_cast<const v4f *>(F + t * TM_FLD + 256 + 4 * lane);
+            }
+        const int64_t oslot = p.out_idx ? p.out_idx[inst] : inst;
+        switch (p.tail) {
+            case STAIR_TILE_STORE:
+                for (int t = wave; t < T; t += 8) {
+                    float *dst = p.out + oslot * p.out_gstride + (int64_t)t * TM_H;
+                    *reinterpret_cast<v4f *>(dst + 4 * lane) = *reinterpret_cast<const v4f *>(F + t * TM_FLD + 4 * lane);
+                    *reinterpret_cast<v4f *>(dst + 256 + 4 * lane) = *reinterpret_cast<const v4f *>(F + t * TM_FLD + 256 + 4 * lane);
+                }
+                break;
+            case STAIR_TILE_ACCUMULATE:               // backward chains: dX added into a gradient tile several instances may share
+                for (int t = wave; t < T; t += 8) {
+                    float *dst = p.out + oslot * p.out_gstride + (int64_t)t * TM_H;
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const v4f v = *reinterpret_cast<const v4f *>(F + t * TM_FLD + 256 * half + 4 * lane);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) unsafeAtomicAdd(dst + 256 * half + 4 * lane + i, v[i]);
+                    }
+                }
+                break;
+            case STAIR_TILE_SUM_ROWS: {               // Filter: sum over the clip's own frames (modules.py:374,376)
+                const int L = p.len ? p.len[inst] : T;
+                float s = 0.f;
+                for (int t = 0; t < L; ++t) s += F[t * TM_FLD + tid];
+                p.out[oslot * p.out_gstride + tid] = s;
+                break;
+            }
+            case STAIR_TILE_COSINE: {                 // Localize: (cos(f_t, k_j) + 1) * 0.49, nn.CosineSimilarity eps 1e-8
+                const int first = p.pair_first[inst], cn = p.pair_cnt[inst];
+                for (int t = wave; t < T; t += 8) {
+                    const v4f f0 = *reinterpret_cast<const v4f *>(F + t * TM_FLD + 4 * lane), f1 = *reinterpret_cast<const v4f *>(F + t * TM_FLD + 256 + 4 * lane);
+                    float nf = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) nf += f0[i] * f0[i] + f1[i] * f1[i];
+                    nf = wave_sum(nf);
+                    for (int j = 0; j < cn; ++j) {
+                        const float *k = p.kb + (int64_t)(first + j) * TM_H;
+                        const v4f k0 = *reinterpret_cast<const v4f *>(k + 4 * lane), k1 = *reinterpret_cast<const v4f *>(k + 256 + 4 * lane);
+                        float d = 0.f, nk = 0.f;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { d += f0[i] * k0[i] + f1[i] * k1[i]; nk += k0[i] * k0[i] + k1[i] * k1[i]; }
+                        d = wave_sum(d); nk = wave_sum(nk);
+                        if (lane == 0) {
+                            const float eps = 1e-8f;
+                            const float c = d / (fmaxf(sqrtf(nf), eps) * fmaxf(sqrtf(nk), eps));
+                            p.att[(int64_t)p.att_idx[first + j] * T + t] = (c + 1.0f) * 0.49f;
+                        }
+                    }
+                }
+                break;
+            }
+            case STAIR_TILE_ROWDOT_SIGMOID:           // HasItem: sigmoid(w . row + b) (modules.py:131-137)
+                for (int t = wave; t < T; t += 8) {
+                    const v4f f0 = *reinterpret_cast<const v4f *>(F + t * TM_FLD + 4 * lane), f1 = *reinterpret_cast<const v4f *>(F + t * TM_FLD + 256 + 4 * lane);
+                    const v4f w0 = *reinterpret_cast<const v4f *>(p.vw + 4 * lane), w1 = *reinterpret_cast<const v4f *>(p.vw + 256 + 4 * lane);
+                    float d = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) d += f0[i] * w0[i] + f1[i] * w1[i];
+                    d = wave_sum(d);
+                    if (lane == 0) p.out[oslot * p.out_gstride + t] = sigmoid_acc(d + p.vb[0] + (p.extra ? p.extra[inst] : 0.f));
+                }
+                break;
+            case STAIR_TILE_LAYERNORM:                // Temporal: LayerNorm over H, eps 1e-5, biased variance (modules.py:283,327)
+                for (int t = wave; t < T; t += 8) {
+                    v4f f0 = *reinterpret_cast<const v4f *>(F + t * TM_FLD + 4 * lane), f1 = *reinterpret_cast<const v4f *>(F + t * TM_FLD + 256 + 4 * lane);
+                    float sum = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sum += f0[i] + f1[i];
+                    const float mean = wave_sum(sum) / (float)TM_H;
+                    float sq = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { const float a = f0[i] - mean, b = f1[i] - mean; sq += a * a + b * b; }
+                    const float rstd = rsqrtf(wave_sum(sq) / (float)TM_H + p.ln_eps);
+                    const v4f g0 = *reinterpret_cast<const v4f *>(p.gamma + 4 * lane), g1 = *reinterpret_cast<const v4f *>(p.gamma + 256 + 4 * lane);
+                    const v4f b0 = *reinterpret_cast<const v4f *>(p.beta + 4 * lane), b1 = *reinterpret_cast<const v4f *>(p.beta + 256 + 4 * lane);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { f0[i] = (f0[i] - mean) * rstd * g0[i] + b0[i]; f1[i] = (f1[i] - mean) * rstd * g1[i] + b1[i]; }
+                    float *dst = p.out + oslot * p.out_gstride + (int64_t)t * TM_H;
+                    *reinterpret_cast<v4f *>(dst + 4 * lane) = f0;
+                    *reinterpret_cast<v4f *>(dst + 256 + 4 * lane) = f1;
+                }
+                break;
+            default: break;
+        }
+    }
+}
+
+// W [N, K] fp32 row-major -> bf16 hi / lo planes in MFMA fragment order: the A operand of v_mfma_f32_32x32x16_bf16 for the
+// 32-row tile nt and the 16-wide k step ks is 64 lanes x 8 bf16, lane (r, h) = W[32 nt + r][16 ks + 8 h + 0..7]; the image is
+// [N/32][K/16][hi, lo][64 lanes][8].  One thread per (row, 8 columns).
+struct WfragBatch { const float *w[32]; __bf16 *o[32]; int count, blocks_per; };
+// TRANSPOSE: the planes of W^T (the "weight" of a backward chain, dX = dZ W): image row n <-> column n of the stored W [K, N]
+template <bool TRANSPOSE>
+__global__ void pack_wfrag_kernel(WfragBatch tb, int N, int K) {
+    const int m = blockIdx.x / tb.blocks_per;
+    const int64_t i = (int64_t)(blockIdx.x - m * tb.blocks_per) * blockDim.x + threadIdx.x;
+    const int k8n = K / 8;
+    if (i >= (int64_t)N * k8n) return;
+    int n, k8;
+    v4f a, b;
+    if (!TRANSPOSE) {
+        n = (int)(i / k8n); k8 = (int)(i - (int64_t)n * k8n);
+        const float *src = tb.w[m] + (int64_t)n * K + 8 * k8;
+        a = *reinterpret_cast<const v4f *>(src); b = *reinterpret_cast<const v4f *>(src + 4);
+    } else {                            // consecutive threads walk n: the strided reads of a column run coalesce across the wave
+        k8 = (int)(i / N); n = (int)(i - (int64_t)k8 * N);
+        const float *src = tb.w[m] + (int64_t)(8 * k8) * N + n;      // stored matrix is [K, N] row-major
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[j] = src[(int64_t)j * N]; b[j] = src[(int64_t)(4 + j) * N]; }
+    }
+    bf16x8 hi, lo;
+    tm_split8(a, b, hi, lo);
+    const int nt = n >> 5, r = n & 31, ks = k8 >> 1, h = k8 & 1;
+    __bf16 *dst = tb.o[m] + ((int64_t)(nt * (K / 16) + ks) * 2 * 64 + (r + 32 * h)) * 8;
+    *reinterpret_cast<bf16x8 *>(dst) = hi;
+    *reinterpret_cast<bf16x8 *>(dst + 64 * 8) = lo;
+}
+
+// up to 32 matrices of one shape in ONE launch (the tables travel as kernel arguments: no copy, no host wait)
+int launch_pack_wfrag_many(const float *const *W, void *const *out, int count, int N, int K, hipStream_t s, bool transpose) {
+    STAIR_CHECK(count >= 1 && count <= 32, "1..32 matrices per launch");
+    STAIR_CHECK(N % 32 == 0 && K % 16 == 0, "N % 32 == 0 and K % 16 == 0");
+    WfragBatch t;
+    t.count = count;
+    t.blocks_per = (int)(((int64_t)N * (K / 8) + 255) / 256);
+    for (int m = 0; m < 32; ++m) {
+        t.w[m] = m < count ? W[m] : nullptr;
+        t.o[m] = m < count ? static_cast<__bf16 *>(out[m]) : nullptr;
+        STAIR_CHECK(m >= count || (t.w[m] && t.o[m] && ((reinterpret_cast<uintptr_t>(t.w[m]) | reinterpret_cast<uintptr_t>(t.o[m])) & 15) == 0),
+                    "null or unaligned matrix");
+    }
+    if (transpose) hipLaunchKernelGGL(pack_wfrag_kernel<true>, dim3(t.blocks_per * count), dim3(256), 0, s, t, N, K);
+    else hipLaunchKernelGGL(pack_wfrag_kernel<false>, dim3(t.blocks_per * count), dim3(256), 0, s, t, N, K);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
+static int g_tile_on = -1;          // stair_set_tile_mlp; -1 = the environment's STAIR_TILE_MLP (default on)
+bool tile_mlp_usable(int H, int T) {
+    static const bool env_on = [] { const char *e = getenv("STAIR_TILE_MLP"); return !(e && e[0] == '0'); }();
+    const bool on = g_tile_on >= 0 ? g_tile_on != 0 : env_on;
+    return on && H == TM_H && T >= 1 && T <= TM_ROWS && matmul_mode() == STAIR_MATMUL_BF16X3;
+}
+
+int launch_tile_mlp(const stair_tile_mlp_args &a, hipStream_t s) {
+    STAIR_CHECK(a.H == TM_H, "the fused tile operators are built for hidden_size 512");
+    STAIR_CHECK(a.T >= 1 && a.T <= TM_ROWS, "a tile holds 1..64 frames");
+    STAIR_CHECK(a.n_layers >= 1 && a.n_layers <= 3, "1..3 layers");
+    STAIR_CHECK(a.X && a.cnt >= 0, "null input");
+    STAIR_CHECK(matmul_mode() == STAIR_MATMUL_BF16X3, "the fused tile operators compute split-bf16 products (STAIR_MATMUL_BF16X3)");
+    for (int l = 0; l < a.n_layers; ++l)
+        STAIR_CHECK(a.W[l] && (reinterpret_cast<uintptr_t>(a.W[l]) & 15) == 0, "weight planes (stair_pack_wfrag) missing or unaligned");
+    for (int l = 0; l < a.n_layers; ++l) STAIR_CHECK(a.act[l] != 3 || a.act_mask[l], "act 3 multiplies by relu'(act_mask[l])");
+    STAIR_CHECK(!a.x_broadcast || a.x_gstride == a.H, "a broadcast input is one [H] row per instance");
+    STAIR_CHECK(!a.mid_rowdot || (a.n_layers == 3 && a.vw && a.vb), "mid_rowdot is FilterFrame's attention between layers 2 and 3");
+    STAIR_CHECK(a.x_gstride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.X) & 15) == 0, "input tiles must be 16-byte aligned");
+    switch (a.tail) {
+        case STAIR_TILE_STORE: case STAIR_TILE_SUM_ROWS: case STAIR_TILE_ACCUMULATE:
+            STAIR_CHECK(a.out && a.out_gstride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0, "out missing or unaligned"); break;
+        case STAIR_TILE_COSINE: STAIR_CHECK(a.kb && a.pair_first && a.pair_cnt && a.att_idx && a.att, "cosine tail: keyword rows / pair tables / att"); break;
+        case STAIR_TILE_ROWDOT_SIGMOID: STAIR_CHECK(a.vw && a.vb && a.out, "row-dot tail: vw, vb, out"); break;
+        case STAIR_TILE_LAYERNORM: STAIR_CHECK(a.gamma && a.beta && a.out && a.out_gstride % 4 == 0, "LayerNorm tail: gamma, beta, out"); break;
+        case STAIR_TILE_NONE: break;
+        default: STAIR_FAIL("unknown tail");
+    }
+    if (a.cnt == 0) return 0;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    static int cus[64] = {};
+    if (!attr_set[dev]) {
+        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_mlp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TM_LDS));
+        int v = 256;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cus[dev] = v;
+        attr_set[dev] = true;
+    }
+    const int64_t M = (int64_t)a.cnt * a.T;
+    STAIR_ACCT_MFMA("tile_mlp", (M * TM_H * 2 + (int64_t)a.n_layers * TM_H * TM_H) * 4, 2 * M * TM_H * TM_H * a.n_layers);
+    TmParams pp;
+    pp.a = a;
+    hipLaunchKernelGGL(tile_mlp_kernel, dim3(std::min(a.cnt, cus[dev])), dim3(512), TM_LDS, s, pp);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace stair
+
+extern "C" int stair_set_tile_mlp(int32_t on) { stair::g_tile_on = on; return 0; }
+
+extern "C" int stair_tile_mlp_fwd(const stair_tile_mlp_args *args, stair_stream stream) {
+    if (!args) {
+        stair::set_error("stair_tile_mlp_fwd: null args");
+        return 1;
+    }
+    return stair::launch_tile_mlp(*args, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int stair_pack_wfrag(const float *W, void *planes, int32_t N, int32_t K, int32_t transpose, stair_stream stream) {
+    if (!W || !planes) {
+        stair::set_error("stair_pack_wfrag: null argument");
+        return 1;
+    }
+    const float *w[1] = {W};
+    void *o[1] = {planes};
+    return stair::launch_pack_wfrag_many(w, o, 1, N, K, static_cast<hipStream_t>(stream), transpose != 0);
+}

@@ -334,7 +334,7 @@ class VideoNMN(nn.Module):
 
     # ---------------------------------------------------------------------------------------
     def run_programs(self, programs, spans, video, question, q_lens, train=False, video_index=None, dropout=None, video_len=None,
-                     before_run=None):
+                     before_run=None, cse=True):
         """Batched pass.  programs: list of token lists; spans: list of {pos: (lo, hi)}; video
         [n,T,V] and question [sum(q_lens), E] float32 on the GPU.  Returns a BatchResult.
 
@@ -349,6 +349,9 @@ class VideoNMN(nn.Module):
         pad with zeros; the padded rows take part in the weight-gradient products with zero coefficients, so NaN / Inf there
         would poison dW_ih (dataset.py:137-143 keeps every clip's own length); each
         question is computed as the reference computes a clip of its own length (stair_plan_build_ragged).
+        cse: share common subexpressions across the batch (include/stair_hip.h STAIR_PLAN_NO_CSE): a node that depends only on
+        the clip, keyword strings and identical question spans is computed once and aliased by every other occurrence; the
+        values are those of the expanded computation (module_net.py:100-106), gradients of all users accumulate.
         before_run (optional): called with the BatchResult after the plan is built (node table, slots and offsets are
         known) and BEFORE the pass is enqueued -- host work that only needs the plan (the loss driver's index arrays)
         then overlaps the previous step's GPU work instead of sitting between this step's forward and backward."""
@@ -386,7 +389,7 @@ class VideoNMN(nn.Module):
                 video_len = None
         check(lib.stair_plan_build_ragged(self._ctx, n, ip(prog_off), ip(tokens), ip(lo), ip(hi), ip(q_off), video.shape[0],
                                           ip(video_index) if video_index is not None else None,
-                                          ip(video_len) if video_len is not None else None, T, 1 if train else 0,
+                                          ip(video_len) if video_len is not None else None, T, (1 if train else 0) | (0 if cse else 2),
                                           C.byref(plan)))
         try:
             info = PlanInfo()

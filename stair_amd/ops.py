@@ -10,7 +10,7 @@ import ctypes as C
 
 import torch
 
-from ._lib import GemmArgs, GemmPlanesArgs, GemmTnArgs, LstmArgs, LstmBwdArgs, check, lib
+from ._lib import GemmArgs, GemmPlanesArgs, GemmTnArgs, LstmArgs, LstmBwdArgs, TileMlpArgs, check, lib
 
 ACT = {None: 0, 'none': 0, 'relu': 1, 'sigmoid': 2}
 MATMUL_MODES = {'f32': 0, 'bf16x3': 1, 'bf16': 2}
@@ -310,3 +310,60 @@ class kernel_accounting:
             k, c, b, f = line.split()
             self.table[k] = (int(c), int(b), int(f))
         return False
+
+
+TILE_TAILS = {None: 0, 'store': 1, 'sum_rows': 2, 'cosine': 3, 'rowdot_sigmoid': 4, 'layernorm': 5}
+
+
+def pack_wfrag(weight, transpose=False):
+    """fp32 [N, K] weight -> bf16 hi / lo planes in MFMA fragment order for tile_mlp (stair_pack_wfrag); transpose: the planes
+    of weight.T (weight is then stored [K, N])."""
+    _req(weight, 'weight')
+    N, K = (weight.shape[1], weight.shape[0]) if transpose else weight.shape
+    planes = torch.empty(2 * N * K, dtype=torch.bfloat16, device=weight.device)
+    check(lib.stair_pack_wfrag(_ptr(weight), _ptr(planes), N, K, 1 if transpose else 0, _stream()))
+    return planes
+
+
+def tile_mlp(x, layers, tail, x_idx=None, row_scale=None, rs_idx=None, save=False, mid_rowdot=None, **kw):
+    """Fused per-clip tile operator (stair_tile_mlp_fwd): x [n_tiles, T, 512] fp32, layers = [(weight, bias, act)] with act in
+    (None, 'relu'); tail in TILE_TAILS with its operands in kw (out, out_idx, out_gstride, kb, pair_first, pair_cnt, att_idx,
+    att, vw, vb, extra, gamma, beta, eps, len).  mid_rowdot = (vw, vb, extra): FilterFrame's attention between layers 2 and 3.
+    Returns (saves: one [cnt, T, H] tensor per layer when save=True, rs_out or None)."""
+    _req(x, 'x')
+    T, H = x.shape[-2], x.shape[-1]
+    cnt = int(x_idx.numel()) if x_idx is not None else x.shape[0]
+    a = TileMlpArgs()
+    a.X, a.x_gstride, a.x_idx = x.data_ptr(), T * H, (x_idx.data_ptr() if x_idx is not None else None)
+    if row_scale is not None:
+        a.row_scale, a.rs_idx = row_scale.data_ptr(), (rs_idx.data_ptr() if rs_idx is not None else None)
+    keep = []
+    for l, (w, b, act) in enumerate(layers):
+        planes = pack_wfrag(w)
+        keep.append(planes)
+        a.W[l], a.bias[l], a.act[l] = planes.data_ptr(), (b.data_ptr() if b is not None else None), ACT[act]
+    a.n_layers = len(layers)
+    saves = []
+    if save:
+        for l in range(len(layers)):
+            sv = torch.empty(cnt, T, H, device=x.device)
+            saves.append(sv)
+            a.save[l] = sv.data_ptr()
+    rs_out = None
+    if mid_rowdot is not None:
+        vw, vb, extra = mid_rowdot
+        rs_out = torch.empty(cnt, T, device=x.device)
+        a.mid_rowdot, a.vw, a.vb, a.extra, a.rs_out = 1, vw.data_ptr(), vb.data_ptr(), (extra.data_ptr() if extra is not None else None), rs_out.data_ptr()
+    a.tail = TILE_TAILS[tail]
+    for name in ('out', 'out_idx', 'kb', 'pair_first', 'pair_cnt', 'att_idx', 'att', 'gamma', 'beta', 'len'):
+        if kw.get(name) is not None:
+            setattr(a, name, kw[name].data_ptr())
+    if mid_rowdot is None:
+        for name in ('vw', 'vb', 'extra'):
+            if kw.get(name) is not None:
+                setattr(a, name, kw[name].data_ptr())
+    a.out_gstride = int(kw.get('out_gstride', T * H))
+    a.ln_eps = float(kw.get('eps', 1e-5))
+    a.cnt, a.T, a.H = cnt, T, H
+    check(lib.stair_tile_mlp_fwd(C.byref(a), _stream()))
+    return saves, rs_out

@@ -189,3 +189,61 @@ def test_workspace_regions_are_disjoint(train):
     assert regs[-1][2] == 'END' and regs[-1][0] * 4 == info.workspace_bytes
     lib.stair_plan_destroy(plan)
     lib.stair_ctx_destroy(h)
+
+
+def test_common_subexpressions_are_aliased_not_recomputed():
+    """STAIR_PLAN_NO_CSE off (default): nodes that depend only on the clip / keyword strings / identical spans alias the first
+    occurrence -- across questions about one clip and inside one program (P0 evaluates the same Localize / Temporal / Filter
+    chain twice); with the flag every node gets a slot of its own, as module_net.py:100-106 computes it."""
+    from stair_amd._lib import PlanInfo
+    config = dict(spec.DEFAULT_CONFIG, hidden_size=64, video_size=128, answer_vocab_length=16, max_video_length=40, object_types=10)
+    h = _ctx(config)
+    forms = ['P1', 'P1', 'P3', 'P3', 'P0', 'P7']
+    progs = [synth.CORPUS[f][0] for f in forms]
+    enc = [np.asarray(spec.encode_program(p), dtype=np.int32) for p in progs]
+    n = len(progs)
+    prog_off = np.zeros(n + 1, np.int32); np.cumsum([len(e) for e in enc], out=prog_off[1:])
+    tokens = np.concatenate(enc)
+    # every span token of a program gets the span (1 + its phrase id): equal phrases -> equal spans
+    lo = np.zeros(len(tokens), np.int32); hi = np.zeros(len(tokens), np.int32)
+    for q in range(n):
+        phrase = {}
+        for i, c in enumerate(enc[q]):
+            if c == spec.TOK_SPAN:
+                k = phrase.setdefault(progs[q][i], len(phrase))
+                lo[prog_off[q] + i], hi[prog_off[q] + i] = 1 + k, 2 + k
+    q_off = np.zeros(n + 1, np.int32); np.cumsum([9] * n, out=q_off[1:])
+    clip = np.asarray([0, 0, 1, 1, 2, 0], dtype=np.int32)       # questions 0, 1, 5 ask about clip 0; 2, 3 about clip 1
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    info = {}
+    slots = {}
+    for flag in (0, 2):
+        plan = C.c_void_p()
+        check(lib.stair_plan_build_shared(h, n, ip(prog_off), ip(tokens), ip(lo), ip(hi), ip(q_off), 3, ip(clip), 40, flag, C.byref(plan)))
+        inf = PlanInfo()
+        check(lib.stair_plan_get_info(plan, C.byref(inf)))
+        info[flag] = inf
+        tab = [np.empty(inf.n_nodes, np.int32) for _ in range(5)]
+        check(lib.stair_plan_nodes(plan, *[ip(t) for t in tab], inf.n_nodes))
+        slots[flag] = tab
+        lib.stair_plan_destroy(plan)
+    assert info[2].n_aliased == 0 and info[0].n_aliased > 10
+    assert info[0].n_map < info[2].n_map and info[0].n_vec < info[2].n_vec and info[0].workspace_bytes < info[2].workspace_bytes
+    kind, slot = slots[0][0], slots[0][1]
+    # question 1 is question 0 again on the same clip, but 'dish' is its own words: Filter(video, objects) is shared, Exists is not
+    p0, p1 = prog_off[0], prog_off[1]
+    assert slot[p0 + 2] == slot[p1 + 2] and slot[p0 + 0] != slot[p1 + 0]
+    # P7 on clip 0 reuses that same Filter(video, objects) node (its token 10)
+    p5 = prog_off[5]
+    assert progs[5][10] == 'Filter' and slot[p5 + 10] == slot[p0 + 2]
+    # P3 = Superlative(max, FilterFrame(video, actions), video): the whole program depends on the clip only
+    p2, p3 = prog_off[2], prog_off[3]
+    assert slot[p2 + 0] == slot[p3 + 0]
+    # inside P0 the two identical Filter(Temporal(between, video, Localize(video, Array2(..))), holding) chains are one
+    p4 = prog_off[4]
+    assert progs[4][3] == 'Filter' and progs[4][17] == 'Filter' and slot[p4 + 3] == slot[p4 + 17]
+    assert np.array_equal(slots[0][3], slots[2][3])              # levels do not change
+    # without sharing every module node owns its slot
+    k2, s2 = slots[2][0], slots[2][1]
+    mods = [(k2[i], s2[i]) for q in range(n) for i in range(prog_off[q], prog_off[q + 1]) if progs[q][i - prog_off[q]] in spec.ARITY and progs[q][i - prog_off[q]] != 'Array2']
+    assert len(set(mods)) == len(mods)

@@ -63,3 +63,123 @@ def test_temporal_relate_backward_matches_autograd(mode, T, conv):
         for nm, dw in zip(names, dws):
             ref = w[nm].grad.reshape(dw.shape)
             assert float((dw.cpu().double() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max())), nm
+
+
+# ---------------------------------------------------------------------------------------------
+# fused per-clip tile operators (stair_tile_mlp_fwd, csrc/tile_mlp.hip) against the oracle's module operators
+# ---------------------------------------------------------------------------------------------
+P_ = 'submodules.'
+
+
+def _tile_setup(T, n_tiles=5, seed=0):
+    from stair_amd import synth
+    config = dict(spec.DEFAULT_CONFIG)
+    w = oracle_weights(config, seed)
+    g = torch.Generator().manual_seed(100 + T)
+    feat = torch.randn(n_tiles, T, 512, generator=g)
+    dw = {k: v.to(DEV) for k, v in w.items() if k.startswith(P_) and not k.startswith(P_ + 'video_encoder')}
+    return config, w, dw, feat, g
+
+
+def _lin3(dw, prefix, act):
+    return (dw[prefix + '.weight'], dw[prefix + '.bias'], act)
+
+
+@pytest.mark.parametrize('T', [64, 40, 7])
+def test_tile_localize_matches_oracle(T):
+    """modules.py:199-217: video_linear (Lin . ReLU . Lin) on the tile + cosine against K keyword rows, K = 1 and 2 mixed,
+    tiles gathered through an index (several instances read one clip)."""
+    from stair_amd import ops
+    config, w, dw, feat, g = _tile_setup(T)
+    x_idx = torch.tensor([0, 3, 3, 1, 4, 2], dtype=torch.int32)
+    K = [1, 2, 1, 2, 2, 1]
+    kws = [torch.randn(k, 512, generator=g) for k in K]
+    kb = torch.cat([O._lin(w, P_ + 'Localize.keyword_linear.0', kw) for kw in kws])           # keyword_linear rows (a separate small GEMM)
+    first = np.concatenate([[0], np.cumsum(K)])[:-1]
+    att = torch.zeros(sum(K) + 3, T, device=DEV)
+    att_idx = torch.arange(sum(K), dtype=torch.int32) + 2
+    i32 = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.int32).to(DEV)
+    saves, _ = ops.tile_mlp(feat.to(DEV), [_lin3(dw, P_ + 'Localize.video_linear.0', 'relu'), _lin3(dw, P_ + 'Localize.video_linear.3', None)],
+                            'cosine', x_idx=x_idx.to(DEV), save=True, kb=kb.to(DEV), pair_first=i32(first), pair_cnt=i32(K),
+                            att_idx=att_idx.to(DEV), att=att)
+    for i in range(len(K)):
+        ref = O.op_localize(w, feat[int(x_idx[i])], kws[i])
+        got = att[2 + first[i]: 2 + first[i] + K[i]].cpu()
+        assert float((got - ref).abs().max()) < 2e-5, i
+        f1 = torch.relu(O._lin(w, P_ + 'Localize.video_linear.0', feat[int(x_idx[i])]))
+        assert float((saves[0][i].cpu() - f1).abs().max()) < 1e-4 * max(1.0, float(f1.abs().max()))
+        f2 = O._lin(w, P_ + 'Localize.video_linear.3', f1)
+        assert float((saves[1][i].cpu() - f2).abs().max()) < 1e-4 * max(1.0, float(f2.abs().max()))
+    assert float(att[:2].abs().max()) == 0.0 and float(att[2 + sum(K):].abs().max()) == 0.0      # nothing written outside the pairs' rows
+
+
+@pytest.mark.parametrize('T', [64, 33])
+@pytest.mark.parametrize('kw', ['representation', 'actions'])
+def test_tile_filter_matches_oracle(T, kw):
+    """modules.py:363-378 up to the sum over frames (its attention is identically 1), with per-instance clip lengths."""
+    from stair_amd import ops
+    config, w, dw, feat, g = _tile_setup(T, seed=1)
+    lens = [T, max(1, T - 5), T, 1, T // 2]
+    out = torch.empty(5, 512, device=DEV)
+    pre = P_ + 'Filter.param.' + kw
+    ops.tile_mlp(feat.to(DEV), [_lin3(dw, pre + '.0', 'relu'), _lin3(dw, pre + '.3', 'relu')], 'sum_rows', out=out, out_gstride=512,
+                 len=torch.tensor(lens, dtype=torch.int32, device=DEV))
+    for i in range(5):
+        ref = O._mlp2(w, pre, feat[i][:lens[i]]).sum(0)
+        assert float((out[i].cpu() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max())), i
+
+
+@pytest.mark.parametrize('T', [64, 24])
+@pytest.mark.parametrize('tensor_kw', [True, False])
+def test_tile_filterframe_matches_oracle(T, tensor_kw):
+    """modules.py:399-414: three layers with the sigmoid attention between the second and the third."""
+    from stair_amd import ops
+    config, w, dw, feat, g = _tile_setup(T, seed=2)
+    out = torch.zeros(7, T, 512, device=DEV)
+    out_idx = torch.tensor([6, 0, 2, 5, 3], dtype=torch.int32, device=DEV)
+    kind = 'representation' if tensor_kw else 'relations'
+    pre = P_ + 'FilterFrame.param.' + kind
+    layers = [_lin3(dw, pre + '.0', 'relu'), _lin3(dw, pre + '.3', 'relu'), _lin3(dw, P_ + 'FilterFrame.dense.0', 'relu')]
+    kws = torch.randn(5, 512, generator=g)
+    mid = None
+    if tensor_kw:
+        wa = dw[P_ + 'FilterFrame.attention.0.weight'].reshape(-1)
+        extra = (kws.to(DEV) * wa[512:]).sum(1).contiguous()
+        mid = (wa[:512].contiguous(), dw[P_ + 'FilterFrame.attention.0.bias'], extra)
+    saves, rs = ops.tile_mlp(feat.to(DEV), layers, 'store', save=True, mid_rowdot=mid, out=out, out_idx=out_idx)
+    for i in range(5):
+        ref = O.op_filterframe(w, feat[i], kws[i] if tensor_kw else kind)
+        got = out[int(out_idx[i])].cpu()
+        assert float((got - ref).abs().max()) < 3e-5 * max(1.0, float(ref.abs().max())), i
+        f = O._mlp2(w, pre, feat[i])
+        assert float((saves[1][i].cpu() - f).abs().max()) < 1e-4 * max(1.0, float(f.abs().max()))          # f, NOT a_t f
+        if tensor_kw:
+            fk = torch.cat([f, kws[i].unsqueeze(0).expand(T, -1)], dim=1)
+            a = torch.sigmoid(O._lin(w, P_ + 'FilterFrame.attention.0', fk)).reshape(-1)
+            assert float((rs[i].cpu() - a).abs().max()) < 1e-5
+    assert float(out[1].abs().max()) == 0.0 and float(out[4].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('T', [64, 9])
+def test_tile_hasitem_and_temporal_match_oracle(T):
+    """modules.py:123-138 (Lin . ReLU + row-dot sigmoid) and :310-327 (row-scaled input, Lin . ReLU, LayerNorm)."""
+    from stair_amd import ops
+    config, w, dw, feat, g = _tile_setup(T, seed=3)
+    att = torch.zeros(8, T, device=DEV)
+    oi = torch.tensor([1, 7, 3, 4, 0], dtype=torch.int32, device=DEV)
+    ops.tile_mlp(feat.to(DEV), [_lin3(dw, P_ + 'HasItem.param.0', 'relu')], 'rowdot_sigmoid', out=att, out_idx=oi, out_gstride=T,
+                 vw=dw[P_ + 'HasItem.param.3.weight'].reshape(-1).contiguous(), vb=dw[P_ + 'HasItem.param.3.bias'])
+    for i in range(5):
+        assert float((att[int(oi[i])].cpu() - O.op_hasitem(w, feat[i]).reshape(T)).abs().max()) < 1e-5, i
+    # Temporal's dense + LayerNorm on r_t feat_t (the relate net that produces r is its own kernel)
+    r = torch.rand(6, T, generator=g)
+    rs_idx = torch.tensor([5, 0, 2, 2, 1], dtype=torch.int32, device=DEV)
+    out = torch.empty(5, T, 512, device=DEV)
+    saves, _ = ops.tile_mlp(feat.to(DEV), [_lin3(dw, P_ + 'Temporal.dense.0', 'relu')], 'layernorm', row_scale=r.to(DEV), rs_idx=rs_idx, save=True,
+                            out=out, gamma=dw[P_ + 'Temporal.layer_norm.weight'], beta=dw[P_ + 'Temporal.layer_norm.bias'], eps=1e-5)
+    for i in range(5):
+        ri = r[int(rs_idx[i])]
+        y = torch.relu(O._lin(w, P_ + 'Temporal.dense.0', ri.unsqueeze(-1) * feat[i]))
+        ref = torch.nn.functional.layer_norm(y, (512,), w[P_ + 'Temporal.layer_norm.weight'], w[P_ + 'Temporal.layer_norm.bias'], 1e-5)
+        assert float((out[i].cpu() - ref).abs().max()) < 5e-5, i
+        assert float((saves[0][i].cpu() - y).abs().max()) < 1e-4 * max(1.0, float(y.abs().max()))

@@ -1,0 +1,101 @@
+"""The fused per-clip tile operators inside the plan runner (csrc/tile_mlp.hip; DEFAULT_CONFIG: H = 512, T <= 64) against
+(1) the oracle, node by node, on every program form, and (2) the GEMM -> row-kernel launch sequences they replace
+(stair_set_tile_mlp(0)), forward values and every parameter gradient.  `-m gpu`."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nmn_oracle as O
+from stair_amd import spec, synth
+from helpers import oracle_weights
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _model(config, seed=0):
+    from stair_amd.module_net import VideoNMN
+    m = VideoNMN(config)
+    w = synth.make_weights(config, seed)
+    m.load_state_dict({k: torch.from_numpy(w[k].copy()) for k in spec.state_dict_keys(config)})
+    return m.to(DEV)
+
+
+@pytest.fixture
+def unfused():
+    """switches the plan runner back to the kernel sequences for the duration of a `with`-free block"""
+    from stair_amd._lib import lib
+
+    def set_(on):
+        lib.stair_set_tile_mlp(on)
+    yield set_
+    lib.stair_set_tile_mlp(-1)
+
+
+@pytest.mark.parametrize('T', [64, 40])
+def test_every_node_at_full_width_matches_the_oracle(T):
+    """Every intermediate value of all 12 program forms at H = 512 (the tiny-config node tests never reach the fused
+    operators): vec / map / attention values against the oracle's interpreter, 2e-5 relative to the value's scale."""
+    from stair_amd import ops
+    config = dict(spec.DEFAULT_CONFIG)
+    model = _model(config, 2)
+    w = oracle_weights(config, 2)
+    qs = [synth.make_question(config, 9, i, form=f, T=T) for i, f in enumerate(synth.ALL_FORMS)]
+    with ops.kernel_accounting() as acct:
+        res = model.forward_batch(qs)
+    assert 'tile_mlp' in acct.table and acct.table['tile_mlp'][0] >= 8, sorted(acct.table)
+    checked = 0
+    for qi, q in enumerate(qs):
+        r = O.forward(w, config, q, return_res_by_step=False, return_result_of_each_step=True, pretrain_modules=frozenset())
+        assert float((res.logits[qi].cpu() - r['logits']).abs().max()) < 1e-4
+        for i, (params, ref) in enumerate(r['result_of_each_step']):
+            if not isinstance(ref, torch.Tensor):
+                continue
+            got = res.node(qi, i)
+            got = got.cpu() if isinstance(got, torch.Tensor) else got
+            err = float((got.reshape(ref.shape) - ref).abs().max())
+            assert err < 2e-5 * max(1.0, float(ref.abs().max())), (q['form'], i, q['nmn_program_list'][i], err)
+            checked += 1
+    assert checked > 100
+
+
+def test_fused_and_sequenced_paths_agree_forward_and_backward(unfused):
+    """Same batch through both runners: logits, every node, per-question loss and every parameter gradient.  The two compute the
+    same split-bf16 products in another order, so only rounding separates them."""
+    config = dict(spec.DEFAULT_CONFIG)
+    qs = [synth.make_question(config, 4, i, form=f) for i, f in enumerate(synth.ALL_FORMS * 2)]
+    out = {}
+    for mode in (1, 0):
+        unfused(mode)
+        model = _model(config, 3)
+        for p in model.parameters():
+            p.grad = torch.zeros_like(p)
+        res = model.forward_batch(qs, train=True)
+        nodes = []
+        for qi, q in enumerate(qs):
+            for i in range(len(q['nmn_program_list'])):
+                v = res.node(qi, i)
+                if isinstance(v, torch.Tensor):
+                    nodes.append(v.detach().cpu().clone())
+        answers = torch.tensor([q['answer'] for q in qs], dtype=torch.int32, device=DEV)
+        loss = res.backward(answers, 1.0 / len(qs))
+        out[mode] = (res.logits.cpu().clone(), nodes, loss.cpu().clone(), {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters()})
+    assert float((out[1][0] - out[0][0]).abs().max()) < 2e-5
+    for a, b in zip(out[1][1], out[0][1]):
+        assert float((a - b).abs().max()) < 2e-5 * max(1.0, float(b.abs().max()))
+    assert torch.allclose(out[1][2], out[0][2], rtol=1e-5, atol=1e-5)
+    gmax = max(float(g.abs().max()) for g in out[0][3].values())
+    for n, g in out[0][3].items():
+        assert float((out[1][3][n] - g).abs().max()) < 2e-4 * max(float(g.abs().max()), 1e-3 * gmax), n
+
+
+def test_ragged_batch_through_the_fused_operators():
+    """Clips of different lengths in one launch batch (padded to the longest): each question equals its solo run."""
+    config = dict(spec.DEFAULT_CONFIG)
+    model = _model(config, 5)
+    lens = [64, 17, 40, 64, 33, 8, 51, 64, 29, 12, 64, 45]
+    qs = [synth.make_question(config, 6, i, form=f, T=lens[i]) for i, f in enumerate(synth.ALL_FORMS)]
+    batch = model.forward_batch(qs).logits.cpu().clone()
+    for i, q in enumerate(qs):
+        solo = model.forward_batch([q]).logits.cpu()
+        assert float((batch[i] - solo[0]).abs().max()) < 2e-5, (q['form'], lens[i])
