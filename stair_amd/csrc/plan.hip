@@ -217,7 +217,12 @@ struct Node {
     int kind = -1, slot = -1, aux = -1, level = 0, rel = -1;
 };
 
+// The module-level Linear layers that act on [T, H] tiles, as one table (fused tile operators pack their planes by these
+// ids; the backward pass groups the weight-gradient products by them).
+enum { WF_F0 = 0, WF_F3 = 4, WF_FF0 = 8, WF_FF3 = 11, WF_FFD = 14, WF_HI0 = 15, WF_LV0 = 16, WF_LV3 = 17, WF_TD = 18, WF_COUNT = 19 };
+
 struct Bucket {
+    int64_t dzA = -1, dzB = -1;   // training: this bucket's blocks inside the per-WEIGHT dZ regions (first / second layer of its tile MLP)
     int level, op, variant, sub;
     int cnt = 0;        // instances
     int nrows = 0;      // secondary count (Localize pairs / Superlative action rows)
@@ -227,6 +232,20 @@ struct Bucket {
     // training: private regions, kept until stair_plan_backward has consumed them.
     int64_t svA = 0, svB = 0, svK = 0, svCat = 0, svHid = 0, svRs = 0, svSup = 0, svExtra = 0;
 };
+
+// first-layer weight (reads the module's input tile) and second-layer weight (reads the saved first activation) of a bucket's
+// tile MLP, as WF_* ids; -1 = none
+void bucket_weights(const Bucket &b, int &w0, int &w3) {
+    w0 = w3 = -1;
+    switch (b.op) {
+        case STAIR_OP_FILTER: w0 = WF_F0 + b.variant; w3 = WF_F3 + b.variant; break;
+        case STAIR_OP_FILTERFRAME: w0 = WF_FF0 + b.variant; w3 = WF_FF3 + b.variant; break;
+        case STAIR_OP_HASITEM: w0 = WF_HI0; break;
+        case STAIR_OP_LOCALIZE: case STAIR_OP_SUPERLATIVE: w0 = WF_LV0; w3 = WF_LV3; break;
+        case STAIR_OP_TEMPORAL: w0 = WF_TD; break;
+        default: break;
+    }
+}
 
 }  // namespace
 
@@ -318,6 +337,11 @@ struct stair_plan {
     int n_vec = 0, n_map = 0, n_att = 0, n_aliased = 0;     // n_aliased: nodes that share another node's value (common subexpressions)
     int maxI = 0, maxV = 0, maxK = 0, maxSupRows = 0, n_levels = 0;
     int64_t coop_bytes = 0;
+    // training: weight-gradient products grouped per WEIGHT (WF_* ids).  Every bucket that uses a weight writes its dZ into its
+    // block of wg_dz[w]; the matching X operand is the input tiles gathered through wg_off_idx[w] (first-layer weights) or the
+    // saved first activations, which lie in the same order in wg_sx[w] (second-layer weights).  ONE long-reduction TN GEMM per
+    // weight at the end of stair_plan_backward instead of one per bucket.
+    int64_t wg_rows[WF_COUNT] = {}, wg_dz[WF_COUNT] = {}, wg_sx[WF_COUNT] = {}, wg_off_idx[WF_COUNT] = {}, wg_off_rs[WF_COUNT] = {};
     // workspace layout (float offsets)
     int64_t o_idx = 0, o_vec = 0, o_map = 0, o_att = 0, o_tok = 0, o_qfeat = 0, o_vhn = 0, o_xpv = 0, o_xpt = 0,
             o_bias = 0, o_wpack = 0, o_wplanes = 0, o_coop = 0, o_coop2 = 0, o_splitk = 0, o_tmpA = 0, o_tmpB = 0, o_kbuf = 0, o_cat = 0, o_hid = 0, o_rs = 0, o_sup = 0, o_extra = 0,
@@ -722,6 +746,19 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
     int64_t idx_ints = (int64_t)pl->idx.size();
     for (Bucket &b : pl->buckets)
         for (int c = 0; c < 8; ++c) idx_ints += align_up((int64_t)b.col[c].size(), 4);
+    // per-weight gather columns of the deferred weight-gradient products: the input tile of every instance that uses the weight
+    // as a first layer, bucket after bucket (Temporal: also the rows of its per-frame scale)
+    std::vector<int32_t> wg_idx[WF_COUNT], wg_rs[WF_COUNT];
+    if (pl->train) {
+        for (const Bucket &b : pl->buckets) {
+            int w0, w3;
+            bucket_weights(b, w0, w3);
+            if (w0 < 0 || b.cnt == 0) continue;
+            wg_idx[w0].insert(wg_idx[w0].end(), b.col[0].begin(), b.col[0].end());
+            if (b.op == STAIR_OP_TEMPORAL) wg_rs[w0].insert(wg_rs[w0].end(), b.col[3].begin(), b.col[3].end());
+        }
+        for (int w = 0; w < WF_COUNT; ++w) idx_ints += align_up((int64_t)wg_idx[w].size(), 4) + align_up((int64_t)wg_rs[w].size(), 4);
+    }
     pl->o_idx = take(idx_ints, 64);
     pl->o_vec = take((int64_t)pl->n_vec * H, H);
     pl->o_map = take((int64_t)pl->n_map * T * H, H);
@@ -732,6 +769,8 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
     STAIR_CHECK((pl->o_map + (int64_t)pl->n_map * T * H) / H < (1ll << 31), "batch too large for 32-bit row ids");
     for (Bucket &b : pl->buckets)
         for (int c = 0; c < 8; ++c) b.off[c] = push(b.col[c]);
+    if (pl->train)
+        for (int w = 0; w < WF_COUNT; ++w) { pl->wg_off_idx[w] = push(wg_idx[w]); pl->wg_off_rs[w] = push(wg_rs[w]); }
     STAIR_CHECK((int64_t)pl->idx.size() == idx_ints, "internal: idx size");
     pl->o_att = take((int64_t)std::max(pl->n_att, 1) * T, 64);
     pl->o_tok = take((int64_t)pl->rows_q * H, 64);
@@ -764,17 +803,18 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
         if (!pl->train) continue;
         const int64_t c = b.cnt;
         switch (b.op) {
+            // (svA of Filter / FilterFrame / Localize / Superlative lives in the per-weight region wg_sx, assigned below)
             case STAIR_OP_FILTER:
-                b.svA = take(c * T * H, 64); b.svB = take(c * T * H, 64); b.svCat = take(c * H, 64); break;
+                b.svB = take(c * T * H, 64); b.svCat = take(c * H, 64); break;
             case STAIR_OP_FILTERFRAME:
-                b.svA = take(c * T * H, 64); b.svB = take(c * T * H, 64); b.svRs = take(c * T, 64); b.svExtra = take(c, 64); break;
+                b.svB = take(c * T * H, 64); b.svRs = take(c * T, 64); b.svExtra = take(c, 64); break;
             case STAIR_OP_HASITEM:
             case STAIR_OP_TEMPORAL:
                 b.svA = take(c * T * H, 64); break;
             case STAIR_OP_LOCALIZE:
-                b.svA = take(c * T * H, 64); b.svB = take(c * T * H, 64); b.svK = take((int64_t)b.nrows * H, 64); break;
+                b.svB = take(c * T * H, 64); b.svK = take((int64_t)b.nrows * H, 64); break;
             case STAIR_OP_SUPERLATIVE:
-                b.svA = take(c * T * H, 64); b.svB = take(c * T * H, 64); b.svK = take((int64_t)b.nrows * H, 64);
+                b.svB = take(c * T * H, 64); b.svK = take((int64_t)b.nrows * H, 64);
                 b.svSup = take((int64_t)b.nrows * T, 64); b.svCat = take(c * H, 64); break;
             case STAIR_OP_COMPARE: case STAIR_OP_EQUALS: case STAIR_OP_XOR:
                 b.svCat = take(c * 3 * H, 64); break;
@@ -784,6 +824,28 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
         }
     }
     if (pl->train) {
+        // per-weight regions: dZ blocks (and, for second-layer weights, the saved first activations) of all buckets of a weight
+        // lie back to back in bucket order
+        int64_t rows0[WF_COUNT] = {}, rows3[WF_COUNT] = {};
+        for (const Bucket &b : pl->buckets) {
+            int w0, w3;
+            bucket_weights(b, w0, w3);
+            if (w0 >= 0) rows0[w0] += b.cnt;
+            if (w3 >= 0) rows3[w3] += b.cnt;
+        }
+        for (int w = 0; w < WF_COUNT; ++w) {
+            STAIR_CHECK(!(rows0[w] && rows3[w]), "internal: a weight is either a first or a second layer");
+            pl->wg_rows[w] = rows0[w] + rows3[w];
+            if (pl->wg_rows[w]) pl->wg_dz[w] = take(pl->wg_rows[w] * T * H, 64);
+            if (rows3[w]) pl->wg_sx[w] = take(rows3[w] * T * H, 64);
+        }
+        int64_t at[WF_COUNT] = {};
+        for (Bucket &b : pl->buckets) {
+            int w0, w3;
+            bucket_weights(b, w0, w3);
+            if (w0 >= 0) { b.dzA = pl->wg_dz[w0] + at[w0] * T * H; at[w0] += b.cnt; }
+            if (w3 >= 0) { b.dzB = pl->wg_dz[w3] + at[w3] * T * H; b.svA = pl->wg_sx[w3] + at[w3] * T * H; at[w3] += b.cnt; }
+        }
         const int64_t I = std::max(pl->maxI, 1), Vv = pl->maxV;
         pl->o_cv = take((int64_t)pl->n_vid * T * H, 64);
         pl->o_ct = take((int64_t)pl->rows_q * H, 64);
@@ -1117,7 +1179,6 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
 
     // ---- fused per-clip tile operators (csrc/tile_mlp.hip): weights of the buckets that run fused, as fragment-order planes ----
     const bool fused = pl->o_wfrag > 0 && tile_mlp_usable(H, T) && dp <= 0.0f;
-    enum { WF_F0 = 0, WF_F3 = 4, WF_FF0 = 8, WF_FF3 = 11, WF_FFD = 14, WF_HI0 = 15, WF_LV0 = 16, WF_LV3 = 17, WF_TD = 18, WF_COUNT = 19 };
     auto WF = [&](int slot) { return static_cast<const void *>(ws + pl->o_wfrag + (int64_t)slot * H * H); };
     if (fused) {
         const Lin *lin_of[WF_COUNT] = {&W.f0[0], &W.f0[1], &W.f0[2], &W.f0[3], &W.f3[0], &W.f3[1], &W.f3[2], &W.f3[3], &W.ff0[0], &W.ff0[1], &W.ff0[2],
@@ -1346,6 +1407,7 @@ struct BwdCtx {
     float *wt;                       // transposed weight images
     float *splitk = nullptr;         // split-K scratch (plan workspace): dX products that overwrite their target stage partials there
     std::vector<int64_t> wt_off;     // per weight id
+    std::vector<char> deferred;      // per weight id: its weight-gradient product runs once, after all buckets (per-weight regions)
 };
 
 // Backward of Y = act(rs * X W^T + b) given dZ (already multiplied by act'):
@@ -1360,7 +1422,8 @@ int dense_bwd(const BwdCtx &B, const float *dZ, int groups, int R, int N, int K,
     t.row_scale = rs; t.rs_gstride = rs_gs; t.rs_gidx = rs_gidx;
     t.C = l.dw; t.ldc = K; t.M = M; t.rows_per_group = R; t.N = N; t.K = K;
     t.colsum = l.db;                 // db += colsum(dZ), summed while the TN kernel stages dZ
-    if (int rc = launch_gemm_tn(t, B.s)) return rc;
+    if (!(l.id >= 0 && l.id < (int)B.deferred.size() && B.deferred[l.id]))
+        if (int rc = launch_gemm_tn(t, B.s)) return rc;
     if (dX) {
         stair_gemm_args g = {};
         g.A = dZ; g.lda = N; g.a_gstride = (int64_t)R * N;
@@ -1397,7 +1460,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
     float *gws = ws + pl->o_gblock - pl->o_vec;          // gradient of workspace row r lives at gws + r*H
     float *g_vec = ws + pl->o_gblock, *g_map = ws + pl->o_gblock + (pl->o_map - pl->o_vec), *g_att = ws + pl->o_gatt;
     float *g_tok = ws + pl->o_gtok, *g_qfeat = ws + pl->o_gqfeat;
-    float *gA = ws + pl->o_gA, *gB = ws + pl->o_gB, *gK = ws + pl->o_gK, *gV0 = ws + pl->o_gV0, *gV1 = ws + pl->o_gV1;
+    float *scrA = ws + pl->o_gA, *scrB = ws + pl->o_gB, *gK = ws + pl->o_gK, *gV0 = ws + pl->o_gV0, *gV1 = ws + pl->o_gV1;
     float *gCat = ws + pl->o_gCat, *gS = ws + pl->o_gS, *gRs = ws + pl->o_gRs, *gRs2 = ws + pl->o_gRs2;
     float *gExtra = ws + pl->o_gExtra, *gStats = ws + pl->o_gStats, *dlogits = ws + pl->o_dlogits;
     float *loss = loss_out ? loss_out : ws + pl->o_loss;
@@ -1410,6 +1473,13 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
     BwdCtx B;
     B.s = s; B.wt = ws + pl->o_wt; B.splitk = ws + pl->o_splitk;
     B.wt_off.assign(ctx->names.size(), 0);
+    // weight-gradient products of the tile-level layers run ONCE per weight, after all buckets (FilterFrame's dense layer keeps
+    // its per-bucket product: its X operand carries the attention scale only in the tensor-keyword variant)
+    const Lin *lin_of[WF_COUNT] = {&W.f0[0], &W.f0[1], &W.f0[2], &W.f0[3], &W.f3[0], &W.f3[1], &W.f3[2], &W.f3[3], &W.ff0[0], &W.ff0[1], &W.ff0[2],
+                                   &W.ff3[0], &W.ff3[1], &W.ff3[2], &W.ffdense, &W.hi0, &W.lv0, &W.lv3, &W.tdense};
+    B.deferred.assign(ctx->names.size(), 0);
+    for (int w = 0; w < WF_COUNT; ++w)
+        if (w != WF_FFD) B.deferred[lin_of[w]->id] = 1;
     {
         int64_t o = 0;
         for (size_t i = 0; i < ctx->names.size(); ++i) { B.wt_off[i] = o; o += align_up(ctx->numel[i], 64); }
@@ -1433,12 +1503,9 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
     }
     // ---- backward chains of the fused tile operators (csrc/tile_mlp.hip): dX = (dZ2 W2 * relu'(Z1)) W1 stays on the tile ----
     const bool fused = pl->o_wfragT > 0 && tile_mlp_usable(H, T) && pl->drop_p <= 0.0f;
-    enum { WF_F0 = 0, WF_F3 = 4, WF_FF0 = 8, WF_FF3 = 11, WF_FFD = 14, WF_HI0 = 15, WF_LV0 = 16, WF_LV3 = 17, WF_TD = 18, WF_COUNT = 19 };
     auto WFT = [&](int slot) { return static_cast<const void *>(ws + pl->o_wfragT + (int64_t)slot * H * H); };
     float *gC = pl->o_gC > 0 ? ws + pl->o_gC : nullptr;
     if (fused) {
-        const Lin *lin_of[WF_COUNT] = {&W.f0[0], &W.f0[1], &W.f0[2], &W.f0[3], &W.f3[0], &W.f3[1], &W.f3[2], &W.f3[3], &W.ff0[0], &W.ff0[1], &W.ff0[2],
-                                       &W.ff3[0], &W.ff3[1], &W.ff3[2], &W.ffdense, &W.hi0, &W.lv0, &W.lv3, &W.tdense};
         bool need[WF_COUNT] = {};
         for (const Bucket &b : pl->buckets) {
             if (b.cnt == 0) continue;
@@ -1478,6 +1545,8 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
         const int32_t *LEN = pl->ragged ? didx + b.off[6] : nullptr;
         const float *svA = ws + b.svA, *svB = ws + b.svB, *svK = ws + b.svK, *svCat = ws + b.svCat, *svHid = ws + b.svHid;
         const float *svRs = ws + b.svRs, *svSup = ws + b.svSup;
+        // dZ of the bucket's first / second tile layer: its block of the weight's region (the product with X is deferred), else scratch
+        float *gA = b.dzA >= 0 ? ws + b.dzA : scrA, *gB = b.dzB >= 0 ? ws + b.dzB : scrB;
         // tail shared by Filter / FilterFrame / Localize / Superlative: gB = d(second linear output)
         // the same on the tile: the chain's two dX products, the ReLU mask between them and the accumulation into the input's
         // gradient tile in ONE launch; the two weight-gradient products (reductions over all instances) stay TN GEMMs.
@@ -1640,6 +1709,24 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
             default:
                 STAIR_FAIL("internal: unhandled bucket op " + std::to_string(b.op));
         }
+    }
+
+    // ---- the deferred weight-gradient products: one long reduction per weight -------------------------------
+    for (int w = 0; w < WF_COUNT; ++w) {
+        if (w == WF_FFD || pl->wg_rows[w] == 0) continue;
+        const Lin &l = *lin_of[w];
+        stair_gemm_tn_args t = {};
+        t.A = ws + pl->wg_dz[w]; t.lda = H;
+        t.C = l.dw; t.ldc = H; t.colsum = l.db;
+        t.M = (int)(pl->wg_rows[w] * T); t.rows_per_group = T; t.N = H; t.K = H;
+        STAIR_CHECK(pl->wg_rows[w] * T < (1ll << 31), "batch too large for one weight-gradient product");
+        if (pl->wg_sx[w]) {                   // second layer: X = the saved first activations, in the same order
+            t.B = ws + pl->wg_sx[w]; t.ldb = H; t.b_gstride = TH;
+        } else {                              // first layer: X = the instances' input tiles
+            t.B = map; t.ldb = H; t.b_gstride = TH; t.b_gidx = didx + pl->wg_off_idx[w];
+            if (w == WF_TD) { t.row_scale = att; t.rs_gstride = T; t.rs_gidx = didx + pl->wg_off_rs[w]; }
+        }
+        RUN(launch_gemm_tn(t, s));
     }
 
     // ---- encoders ------------------------------------------------------------------------------------
@@ -1807,6 +1894,8 @@ extern "C" int stair_plan_regions(stair_plan *pl, const stair_ctx *ctx, const ch
         add("gA", pl->o_gA, I * T * H);
         add("gB", pl->o_gB, I * T * H);
         if (pl->o_wfragT > 0) { add("wfragT", pl->o_wfragT, 19 * H * H); add("gC", pl->o_gC, I * T * H); }
+        for (int w = 0; w < WF_COUNT; ++w)
+            if (pl->wg_rows[w]) add("wg_dz" + std::to_string(w), pl->wg_dz[w], pl->wg_rows[w] * T * H);
         add("gV0", pl->o_gV0, Vv * 2 * H);
         add("gV1", pl->o_gV1, Vv * 2 * H);
         add("gCat", pl->o_gCat, Vv * 3 * H);

@@ -418,7 +418,7 @@ class VideoNMN(nn.Module):
             res.logits = ws[info.logits_off: info.logits_off + n * A].view(n, A).clone()    # (n x A floats) that survives the next step
         return res
 
-    def forward_batch(self, batch, train=False, share_videos=True, dropout=None):
+    def forward_batch(self, batch, train=False, share_videos=True, dropout=None, cse=True):
         """batch: list of question dicts in the reference layout (dataset.py:191-233).  Clips may differ in their
         number of frames (they are padded to the longest of the batch and run with their own lengths, see run_programs);
         Linear-Temporal configurations (max_video_length <= 32) need every clip at max_video_length, like the reference.
@@ -455,7 +455,7 @@ class VideoNMN(nn.Module):
         question = torch.cat(qs).to(dev, torch.float32).contiguous()
         return self.run_programs([d['nmn_program_list'] for d in batch],
                                  [d['prog_str_to_question_tokens'] for d in batch], video, question,
-                                 [q.shape[0] for q in qs], train=train, video_index=index, dropout=dropout, video_len=video_len)
+                                 [q.shape[0] for q in qs], train=train, video_index=index, dropout=dropout, video_len=video_len, cse=cse)
 
     # ---------------------------------------------------------------------------------------
     @torch.no_grad()

@@ -30,8 +30,10 @@ def _worker(args):
     return lo, per_q, {n: (w[n].grad if w[n].grad is not None else None) for n in names}
 
 
-def window_gradients(config, seed, questions, workers=8, threads=2, tmp_dir=None):
-    """(per-question CE, {name: gradient of mean CE or None}) over `questions` (dicts with CPU tensors)."""
+def window_gradients(config, seed, questions, workers=4, threads=4, tmp_dir=None):
+    """(per-question CE, {name: gradient of mean CE or None}) over `questions` (dicts with CPU tensors).
+    At most 4 workers: a GPU box lets 6 processes touch the card, and the children of a process that has initialised HIP are
+    counted whatever they do (they are started with HIP_VISIBLE_DEVICES empty and never call the GPU)."""
     import tempfile
 
     import torch
@@ -43,7 +45,17 @@ def window_gradients(config, seed, questions, workers=8, threads=2, tmp_dir=None
         step = (n + workers - 1) // workers
         jobs = [(path, lo, min(n, lo + step), n, seed, threads) for lo in range(0, n, step)]
         ctx = mp.get_context('spawn')
-        with ctx.Pool(len(jobs)) as pool:
+        saved = {k: os.environ.get(k) for k in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES')}
+        os.environ['HIP_VISIBLE_DEVICES'] = ''              # inherited by the workers at start-up (the parent's runtime is already up)
+        try:
+            pool = ctx.Pool(min(len(jobs), 4))
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        with pool:
             parts = []
             for done, part in enumerate(pool.imap_unordered(_worker, jobs)):
                 parts.append(part)

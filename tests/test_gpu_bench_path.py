@@ -165,7 +165,7 @@ def test_benched_training_step_matches_oracle_end_to_end():
     M, V, H = B * config['max_video_length'], config['video_size'], config['hidden_size']
     assert acct.table['gemm_planes'][2] == 2 * M * 4 * H * V           # ONE launch: both directions of the input projection
     got_g = {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters()}
-    per_q, grads = window_gradients(config, 0, qs, workers=8, threads=2)
+    per_q, grads = window_gradients(config, 0, qs, workers=4, threads=4)
     assert np.allclose(loss.cpu().numpy(), per_q, rtol=1e-5, atol=3e-5)
     family_max = {}
     for n, ref in grads.items():

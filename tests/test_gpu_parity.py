@@ -311,10 +311,13 @@ def test_questions_sharing_a_clip_encode_it_once(matmul):
     model = _model(config, 3)
     w = oracle_weights(config, 3)
     qs = _questions_sharing_clips(config, 21, 40, 5)
-    shared = model.forward_batch(qs)
+    shared = model.forward_batch(qs, cse=False)              # clip sharing alone: every module node still has a slot of its own
     expanded = model.forward_batch(qs, share_videos=False)
     assert shared._video.shape[0] == 5 and expanded._video.shape[0] == 40
     assert expanded.info.n_map - shared.info.n_map == 35
+    with_cse = model.forward_batch(qs)                       # ... and with clip-level common subexpressions computed once per clip
+    assert with_cse.info.n_aliased > 0 and with_cse.info.n_map <= shared.info.n_map and shared.info.n_aliased == 0
+    assert torch.equal(with_cse.logits, shared.logits)
     assert torch.equal(shared.logits.cpu(), expanded.logits.cpu())
     assert torch.equal(shared.pred.cpu(), expanded.pred.cpu())
     for qi in range(0, 40, 3):

@@ -724,3 +724,46 @@ def test_contrastive_pools_from_a_class_table_equal_the_pooled_lists(matmul):
     assert torch.allclose(out['lists'][0], out['table'][0], rtol=1e-5, atol=1e-6)
     for n, g in out['lists'][1].items():
         assert float((g - out['table'][1][n]).abs().max()) <= 2e-5 * max(float(g.abs().max()), 1e-3), n
+
+
+@pytest.mark.parametrize('name', ['tiny_conv', 'full'])
+def test_common_subexpression_sharing_keeps_values_and_gradients(name, matmul):
+    """Clip-level common subexpressions computed once (stair_plan_build: a node of clip-only operands is aliased by every later
+    occurrence -- other questions about the clip, or the same sub-program twice in one question, as P0 has it) against the
+    plan that computes every node (STAIR_PLAN_NO_CSE, i.e. what module_net.py:100-106 does): same logits, same per-question
+    loss, same parameter gradients -- the users' gradients add up in the shared slot -- incl. intermediate supervision."""
+    from stair_amd import losses as L
+    if name == 'full':
+        config, T = dict(spec.DEFAULT_CONFIG), 64
+        if matmul == 'f32':
+            pytest.skip('one mode is enough at full size')
+    else:
+        z, meta = load_golden(name)
+        config, T = meta['config'], meta['T']
+    forms = synth.ALL_FORMS * 2 + ['P1', 'P3', 'P4', 'P7', 'P3', 'P1']
+    qs = [synth.make_question(config, 12, i, form=f, T=T) for i, f in enumerate(forms)]
+    clips = [torch.as_tensor(qs[c]['video_features']) for c in range(4)]
+    for i, q in enumerate(qs):
+        q['video_features'] = clips[i % 4]
+    qs = _with_gold(config, 5, qs, T)
+    out = []
+    for cse in (False, True):
+        model = _model(config, 7)
+        model.pretrain_modules = set(L.CRITERION_MODULES)
+        for p in model.parameters():
+            p.grad = torch.zeros_like(p)
+        res = model.forward_batch(qs, train=True, cse=cse)
+        assert (res.info.n_aliased > 20) == cse
+        res.zero_grad_arenas()
+        losses, _ = L.apply_module_losses(model, res, qs, 1.0 / len(qs), window=8)
+        dec = res.backward(torch.tensor([q['answer'] for q in qs], dtype=torch.int32, device=DEV), 1.0 / len(qs), keep_arenas=True)
+        out.append((res.logits.cpu().clone(), dec.cpu().clone(), {k: v.cpu().clone() for k, v in losses.items()},
+                    {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters()}, res.info.n_map, res.info.n_vec))
+    (l0, d0, m0, g0, nm0, nv0), (l1, d1, m1, g1, nm1, nv1) = out
+    assert nm1 < nm0 and nv1 < nv0
+    assert float((l0 - l1).abs().max()) < 2e-6 and torch.allclose(d0, d1, rtol=1e-6, atol=1e-6)
+    for k in m0:
+        assert torch.allclose(torch.sort(m0[k]).values, torch.sort(m1[k]).values, rtol=1e-5, atol=1e-6), k
+    gmax = max(float(g.abs().max()) for g in g0.values())
+    for n in g0:
+        assert float((g0[n] - g1[n]).abs().max()) < (2e-5 if matmul == 'f32' else 2e-4) * max(float(g0[n].abs().max()), 1e-3 * gmax), n
