@@ -164,6 +164,62 @@ def cpu_baseline(config, weights, qs, video, question, q_lens, budget_s=8.0, max
     return done / dt, done, preds, torch.stack(logits)
 
 
+GEMM_FAMILIES = {       # accounting key (csrc STAIR_ACCT_MFMA) -> substring of the kernel's name
+    'tile_mlp': 'tile_mlp_kernel', 'gemm_bf16x3_t256': 'gemm_bf16x3_t256_kernel', 'gemm_bf16x3_w8': 'gemm_bf16x3_w8_kernel',
+    'gemm_bf16x3': 'gemm_bf16x3_kernel', 'gemm_bf16x3_splitk': None, 'gemm_tn_bf16x3_t256': 'gemm_tn_bf16x3_t256_kernel',
+    'gemm_tn_bf16x3': 'gemm_tn_bf16x3_kernel', 'gemm_planes': 'gemm_planes_kernel', 'gemm_tn_tr': 'gemm_tn_tr_kernel'}
+
+
+def gemm_family_rooflines(step, device):
+    """Per MFMA-kernel family of ONE training step: algorithmic flops (2MNK, from the launchers' accounting) over the kernel
+    time of the same step (torch.profiler's device trace): time-weighted algorithmic TFLOP/s against the dense bf16 peak.
+    `module_level` = every product except the video encoder's input projection and its weight gradient -- the family the
+    step spends most of its time in.  Returns None when the device trace is unavailable."""
+    from stair_amd import ops
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        step()
+        torch.cuda.synchronize()
+        with ops.kernel_accounting() as acct:
+            with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                step()
+                torch.cuda.synchronize()
+        times = {}
+        for ev in prof.key_averages():
+            us = getattr(ev, 'device_time_total', None)
+            if us is None:
+                us = getattr(ev, 'cuda_time_total', 0.0)
+            times[ev.key] = times.get(ev.key, 0.0) + float(us)
+    except Exception as e:          # no device tracing on this box: say so instead of guessing
+        return {'error': '%s: %s' % (type(e).__name__, str(e)[:120])}
+    fam = {}
+    for key, sub in GEMM_FAMILIES.items():
+        if key not in acct.table:
+            continue
+        launches, nbytes, flops = acct.table[key]
+        name = sub or GEMM_FAMILIES['gemm_bf16x3']
+        us = sum(t for k, t in times.items() if name in k and (name != 'gemm_bf16x3_kernel' or 'tn' not in k))
+        fam.setdefault(name, [0, 0.0, 0])
+        fam[name][0] += launches; fam[name][2] += flops
+        fam[name][1] = us
+    out, mod_us, mod_fl, mod_n = {}, 0.0, 0, 0
+    for name, (launches, us, flops) in fam.items():
+        if us <= 0:
+            continue
+        out[name] = {'launches_per_step': launches, 'ms_per_step': round(us / 1e3, 3), 'algorithmic_TFLOPs': round(flops / us / 1e6, 1),
+                     'frac_of_bf16_peak': round(flops / us / 1e6 / BF16_MFMA_PEAK_TFLOPS, 4)}
+        if name not in ('gemm_planes_kernel', 'gemm_tn_tr_kernel'):
+            mod_us += us; mod_fl += flops; mod_n += launches
+    if mod_us > 0:
+        out['module_level'] = {'bound': 'mfma', 'launches_per_step': mod_n, 'ms_per_step': round(mod_us / 1e3, 3),
+                               'achieved': round(mod_fl / mod_us / 1e6, 1), 'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                               'frac': round(mod_fl / mod_us / 1e6 / BF16_MFMA_PEAK_TFLOPS, 4),
+                               'note': 'all MFMA products of the step except the video input projection and its weight gradient: fused tile operators, '
+                                       'vector-level layers, text-encoder projection, weight-gradient reductions; algorithmic 2MNK / device time of one step '
+                                       '(torch.profiler); three executed MFMAs per algorithmic product'}
+    return out
+
+
 def cpu_model():
     try:
         for line in open('/proc/cpuinfo'):
@@ -195,7 +251,7 @@ def main():
         # `python bench.py --gpus N` on its own: start the N ranks (fresh processes; this one has not touched the GPU --
         # torch.cuda.device_count() does not initialise HIP) and relay rank 0's line.  Never run fewer ranks than asked for.
         ndev = torch.cuda.device_count()
-        if ndev < args.gpus:
+        if ndev < args.gpus and os.environ.get('STAIR_DIST_BACKEND', 'nccl') == 'nccl':      # (a gloo rehearsal wraps the ranks around the visible cards)
             print('bench.py: --gpus %d but only %d GPU(s) visible' % (args.gpus, ndev), file=sys.stderr)
             sys.exit(2)
         code, line, out = launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus)
@@ -396,6 +452,9 @@ def main():
                 sweep.append({'questions_per_step': nq, 'train_ms_per_step': round(dt_t / k * 1e3, 3), 'train_questions_per_s': round(nq * k / dt_t, 1),
                               'infer_ms_per_batch': round(dt_i / k * 1e3, 3), 'infer_questions_per_s': round(nq * k / dt_i, 1)})
             extras['batch_sweep'] = sweep
+            fam = gemm_family_rooflines(lambda: run_step(B, False), device)
+            if fam:
+                extras['roofline_gemm_families'] = fam
             # ---- configs[4]: the step with per-module intermediate supervision, next to the decoder-only step ----
             if not args.supervision:
                 dt_s, _ = timed(lambda: run_step(B, True), 6, 3)
