@@ -429,6 +429,12 @@ int stair_plan_status(const stair_plan *plan, const void *workspace, stair_strea
 int stair_plan_node(const stair_plan *plan, int32_t tok, int32_t *kind, int32_t *slot, int32_t *aux,
                     int32_t *level, int32_t *rel_slot);
 
+/* Introspection for tests: where a STAIR_PLAN_TRAIN plan keeps the activations its backward pass reads (the ReLU masks of
+ * the pass).  which = 0 / 1: first / second saved activation of the node's tile MLP ([T, H] floats: Filter, FilterFrame,
+ * Localize, Superlative; first only: HasItem, Temporal) or the hidden row [H] of Exists / ToAction (which = 0);
+ * tok = -1 - q: the decoder's hidden row [2H] of question q.  *offset = float offset into the workspace, -1 = none. */
+int stair_plan_saved_offset(const stair_plan *plan, int32_t tok, int32_t which, int64_t *offset);
+
 /* The same for every token at once: host arrays of stair_plan_info.n_nodes int32 (any may be NULL).  What a loss driver
  * needs to address the supervised nodes of a whole batch without one call per node. */
 int stair_plan_nodes(const stair_plan *plan, int32_t *kind, int32_t *slot, int32_t *aux, int32_t *level,

@@ -178,6 +178,7 @@ SIGNATURES = [
     ('stair_plan_get_info', C.c_int, [C.c_void_p, C.POINTER(PlanInfo)]),
     ('stair_plan_status', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ('stair_plan_node', C.c_int, [C.c_void_p, C.c_int32, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p]),
+    ('stair_plan_saved_offset', C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]),
     ('stair_plan_nodes', C.c_int, [C.c_void_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p, C.c_int32]),
     ('stair_plan_run', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                  C.c_void_p, C.c_void_p]),

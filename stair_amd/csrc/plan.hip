@@ -17,6 +17,8 @@
 #include <unordered_map>
 #include <vector>
 
+#include <chrono>
+
 #include "ops.h"
 
 namespace stair {
@@ -215,6 +217,7 @@ const char *kOpName[STAIR_OP_COUNT] = {"And", "AttnVideo", "Choose", "Compare", 
 
 struct Node {
     int kind = -1, slot = -1, aux = -1, level = 0, rel = -1;
+    int bop = -1, bvariant = 0, bsub = 0, inst = -1;      // the bucket (level, bop, bvariant, bsub) that computes it and its instance there
 };
 
 // The module-level Linear layers that act on [T, H] tiles, as one table (fused tile operators pack their planes by these
@@ -223,6 +226,7 @@ enum { WF_F0 = 0, WF_F3 = 4, WF_FF0 = 8, WF_FF3 = 11, WF_FFD = 14, WF_HI0 = 15, 
 
 struct Bucket {
     int64_t dzA = -1, dzB = -1;   // training: this bucket's blocks inside the per-WEIGHT dZ regions (first / second layer of its tile MLP)
+    int64_t dzC = -1, gRow = -1;  // training, fused backward: FilterFrame's third dZ tile set; Filter's per-instance gradient row [c, H]
     int level, op, variant, sub;
     int cnt = 0;        // instances
     int nrows = 0;      // secondary count (Localize pairs / Superlative action rows)
@@ -352,7 +356,7 @@ struct stair_plan {
     uint64_t drop_seed = 0;
     int64_t o_cv = 0, o_ct = 0, o_hprev = 0, o_gblock = 0, o_gatt = 0, o_gtok = 0, o_gqfeat = 0, o_gA = 0, o_gB = 0,
             o_gK = 0, o_gV0 = 0, o_gV1 = 0, o_gCat = 0, o_gS = 0, o_gRs = 0, o_gRs2 = 0, o_gExtra = 0, o_gStats = 0,
-            o_wt = 0, o_dlogits = 0, o_loss = 0, o_zero_beg = 0, o_zero_end = 0, o_wfragT = 0, o_gC = 0;
+            o_wt = 0, o_dlogits = 0, o_loss = 0, o_zero_beg = 0, o_zero_end = 0, o_wfragT = 0;
 };
 
 namespace {
@@ -435,6 +439,7 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
     STAIR_CHECK(!pl->ragged || ctx->conv, "clips of different lengths need the Conv1d Temporal nets (Linear(T,T) fixes T, modules.py:266-277)");
     Builder B{pl};
     std::vector<int> stack;
+    const auto t_begin = std::chrono::steady_clock::now();
     // Common-subexpression sharing across the batch (module_net.py:100-106 evaluates every node of every question; a node
     // whose operands are the encoded clip, keyword strings, identical question spans or other such nodes has the SAME value
     // wherever it occurs -- in another question about the same clip, or twice in one program).  key[i] names the computation
@@ -442,8 +447,54 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
     // tensor keyword (its attention is identically 1, modules.py:354,373), so that operand does not enter the key.
     static const bool cse_env = [] { const char *e = getenv("STAIR_PLAN_CSE"); return !(e && e[0] == '0'); }();
     const bool cse_on = cse_env && !(flags & STAIR_PLAN_NO_CSE);
-    std::vector<std::string> key(cse_on ? ntok : 0);
-    std::unordered_map<std::string, int> cse;
+    // keys are interned: a computation is (tag, operand key ids) -> a small integer id; id 0 = not shareable
+    struct CseKey {
+        int32_t v[4];
+        bool operator==(const CseKey &o) const { return v[0] == o.v[0] && v[1] == o.v[1] && v[2] == o.v[2] && v[3] == o.v[3]; }
+    };
+    struct CseHash {
+        size_t operator()(const CseKey &k) const {
+            uint64_t h = 0x9e3779b97f4a7c15ull;
+            for (int j = 0; j < 4; ++j) { h ^= (uint32_t)k.v[j] + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2); h *= 0xff51afd7ed558ccdull; }
+            return (size_t)(h ^ (h >> 32));
+        }
+    };
+    std::vector<int32_t> key(cse_on ? ntok : 0, 0);            // key id of token i
+    std::vector<int32_t> first_node(1, -1);                    // key id -> token that computes it (-1: a leaf, nothing to alias)
+    // open-addressing table of key ids (4 bytes per slot: the whole table stays in the host's L2) over the keys stored by id;
+    // kept per thread and invalidated by a generation stamp, so a build neither allocates nor clears it (the builder runs once
+    // per batch on the training loop's critical host path)
+    size_t cap = 64;
+    while (cse_on && cap < 2 * (size_t)ntok) cap <<= 1;
+    static thread_local std::vector<uint64_t> table;            // (generation << 32) | key id
+    static thread_local std::vector<CseKey> keys;
+    static thread_local uint32_t generation = 0;
+    if (cse_on) {
+        if (table.size() < cap) table.assign(cap, 0);
+        cap = table.size();
+        if (++generation == 0) { std::fill(table.begin(), table.end(), 0); generation = 1; }
+        keys.clear();
+        keys.push_back(CseKey{{0, 0, 0, 0}});
+        first_node.reserve((size_t)ntok + 1);
+    }
+    const uint64_t gen_tag = (uint64_t)generation << 32;
+    long cse_probe_steps = 0, cse_probe_inserts = 0;
+    auto intern = [&](const CseKey &k, int node, bool &fresh) -> int32_t {
+        size_t h = CseHash()(k) & (cap - 1);
+        while ((table[h] >> 32) == generation) {
+            const int32_t id = (int32_t)(table[h] & 0xffffffffu);
+            if (keys[id] == k) { fresh = false; return id; }
+            h = (h + 1) & (cap - 1);
+            ++cse_probe_steps;
+        }
+        const int32_t id = (int32_t)first_node.size();
+        first_node.push_back(node);
+        keys.push_back(k);
+        table[h] = gen_tag | (uint32_t)id;
+        ++cse_probe_inserts;
+        fresh = true;
+        return id;
+    };
     pl->n_aliased = 0;
 
     for (int q = 0; q < n; ++q) {
@@ -468,26 +519,26 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
                 }
                 nd.level = lvl + 1;
                 if (cse_on) {
-                    std::string k = std::to_string(tok);
+                    CseKey k = {{tok, -1, -1, -1}};
                     bool ok = true;
                     for (int j = 0; j < ar && ok; ++j) {
                         const bool ignored = tok == STAIR_OP_FILTER && j == 1 && pl->nodes[ch[1]].kind == STAIR_VAL_VEC;
-                        if (ignored) { k += "(*)"; continue; }
-                        if (key[ch[j]].empty()) ok = false;
-                        else { k += '('; k += key[ch[j]]; k += ')'; }
+                        if (ignored) { k.v[1 + j] = -2; continue; }
+                        if (key[ch[j]] == 0) ok = false;
+                        else k.v[1 + j] = key[ch[j]];
                     }
                     if (ok) {
-                        auto hit = cse.find(k);
-                        if (hit != cse.end()) {            // computed already: alias it (same value, same level by construction)
-                            const Node &o = pl->nodes[hit->second];
+                        bool fresh;
+                        const int32_t id = intern(k, i, fresh);
+                        key[i] = id;
+                        if (!fresh) {                       // computed already: alias it (same value, same level by construction)
+                            const Node &o = pl->nodes[first_node[id]];
                             nd.kind = o.kind; nd.slot = o.slot; nd.aux = o.aux; nd.rel = o.rel;
-                            key[i] = std::move(k);
+                            nd.bop = o.bop; nd.bvariant = o.bvariant; nd.bsub = o.bsub; nd.inst = o.inst;
                             ++pl->n_aliased;
                             stack.push_back(i);
                             continue;
                         }
-                        cse.emplace(k, i);
-                        key[i] = std::move(k);
                     }
                 }
                 const Node &c0 = pl->nodes[ch[0]];
@@ -656,28 +707,44 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
                     default:
                         STAIR_FAIL("unknown module token at " + where(q, i, tok));
                 }
+                if (tok != STAIR_OP_ARRAY2) {         // which bucket computes this node, and as which of its instances
+                    int variant = 0, sub = 0;
+                    switch (tok) {
+                        case STAIR_OP_AND: case STAIR_OP_XORFRAME: sub = c0.kind; break;
+                        case STAIR_OP_FILTER:
+                            variant = c1.kind == STAIR_VAL_VEC ? 0 : (c1.aux == STAIR_KW_ACTIONS ? 1 : (c1.aux == STAIR_KW_OBJECTS ? 2 : 3)); break;
+                        case STAIR_OP_FILTERFRAME: variant = c1.kind == STAIR_VAL_VEC ? 0 : (c1.aux == STAIR_KW_RELATIONS ? 1 : 2); break;
+                        case STAIR_OP_RELATE: variant = c0.aux == STAIR_KW_FORWARD ? 0 : 1; break;
+                        case STAIR_OP_SUPERLATIVE: variant = c0.aux == STAIR_KW_MIN ? 1 : 0; break;
+                        case STAIR_OP_TEMPORAL:
+                            variant = c0.aux == STAIR_KW_WHILE ? 0 : (c0.aux == STAIR_KW_BEFORE ? 1 : (c0.aux == STAIR_KW_AFTER ? 2 : 3)); break;
+                        default: break;
+                    }
+                    nd.bop = tok; nd.bvariant = variant; nd.bsub = sub;
+                    nd.inst = B.bucket(nd.level, tok, variant, sub).cnt - 1;
+                }
             } else if (tok >= STAIR_KW_FORWARD && tok <= STAIR_KW_RELATIONS) {
                 if (tok == STAIR_KW_VIDEO) {        // module_net.py:103-104
                     nd.kind = STAIR_VAL_MAP; nd.slot = video_of_question ? video_of_question[q] : q;
-                    if (cse_on) key[i] = "V" + std::to_string(nd.slot);
+                    if (cse_on) { bool fresh; key[i] = intern(CseKey{{1000, nd.slot, -1, -1}}, -1, fresh); }
                 } else {
                     nd.kind = STAIR_VAL_STR; nd.aux = tok;
-                    if (cse_on) key[i] = "K" + std::to_string(tok);
+                    if (cse_on) { bool fresh; key[i] = intern(CseKey{{1001, tok, -1, -1}}, -1, fresh); }
                 }
             } else if (tok == STAIR_TOK_SPAN) {     // module_net.py:126-129
                 const int lo = span_lo[i], hi = std::min(span_hi[i], Q);
                 STAIR_CHECK(lo >= 0 && lo < hi, "empty or out-of-range question span at " + where(q, i, tok));
                 if (cse_on) {                       // the same words of the same question: one span mean
-                    key[i] = "S" + std::to_string(q) + ":" + std::to_string(lo) + ":" + std::to_string(hi);
-                    auto hit = cse.find(key[i]);
-                    if (hit != cse.end()) {
-                        const Node &o = pl->nodes[hit->second];
+                    bool fresh;
+                    const int32_t id = intern(CseKey{{1002, q, lo, hi}}, i, fresh);
+                    key[i] = id;
+                    if (!fresh) {
+                        const Node &o = pl->nodes[first_node[id]];
                         nd.kind = o.kind; nd.slot = o.slot;
                         ++pl->n_aliased;
                         stack.push_back(i);
                         continue;
                     }
-                    cse.emplace(key[i], i);
                 }
                 nd.kind = STAIR_VAL_VEC; nd.slot = pl->n_vec++;
                 Bucket &b = B.bucket(0, OP_SPAN, 0, 0);
@@ -695,6 +762,9 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
         pl->roots[q] = root.slot;
     }
     pl->rows_q = q_off[n];
+    if (getenv("STAIR_PLAN_DEBUG"))
+        fprintf(stderr, "cse: %ld inserts, %ld extra probes, cap %zu; scan %.3f ms\n", cse_probe_inserts, cse_probe_steps, cap,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
 
     std::sort(pl->buckets.begin(), pl->buckets.end(), [](const Bucket &a, const Bucket &b) {
         return std::tie(a.level, a.op, a.variant, a.sub) < std::tie(b.level, b.op, b.variant, b.sub);
@@ -796,11 +866,20 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
     pl->o_extra = take(std::max(pl->maxI, 1), 64);
     pl->o_logits = take((int64_t)n * A, 64);
     pl->o_wfrag = (H == 512 && T <= 64) ? take(19 * H * H, 64) : 0;     // bf16 hi/lo fragment-order planes of the fused tile operators' weights
-    pl->o_status = take(64, 64);                 // word 0: sticky "a cooperative hand-off timed out" flag of this plan's passes
+    pl->o_status = take(128, 64);                // word 0: sticky "a cooperative hand-off timed out" flag of this plan's passes; words 16..63
+                                                 // and 64..111: work-queue heads of the fused forward / backward launches
     for (Bucket &b : pl->buckets) {
         b.svA = pl->o_tmpA; b.svB = pl->o_tmpB; b.svK = pl->o_kbuf; b.svCat = pl->o_cat; b.svHid = pl->o_hid;
         b.svRs = pl->o_rs; b.svSup = pl->o_sup; b.svExtra = pl->o_extra;
-        if (!pl->train) continue;
+        if (!pl->train) {
+            // inference: the tile operators of one level run in ONE launch (fused path), so what a bucket's tile operator
+            // writes for its own later launches must not be shared with the level's other buckets
+            if (pl->o_wfrag > 0 && b.cnt > 0) {
+                if (b.op == STAIR_OP_FILTER) b.svCat = take((int64_t)b.cnt * H, 64);
+                if (b.op == STAIR_OP_SUPERLATIVE) b.svB = take((int64_t)b.cnt * T * H, 64);
+            }
+            continue;
+        }
         const int64_t c = b.cnt;
         switch (b.op) {
             // (svA of Filter / FilterFrame / Localize / Superlative lives in the per-weight region wg_sx, assigned below)
@@ -843,6 +922,10 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
         for (Bucket &b : pl->buckets) {
             int w0, w3;
             bucket_weights(b, w0, w3);
+            if (pl->o_wfrag > 0 && b.cnt > 0) {          // the level's backward chains share a launch: no scratch in common
+                if (b.op == STAIR_OP_FILTER) b.gRow = take((int64_t)b.cnt * H, 64);
+                if (b.op == STAIR_OP_FILTERFRAME && b.variant != 0) b.dzC = take((int64_t)b.cnt * T * H, 64);
+            }
             if (w0 >= 0) { b.dzA = pl->wg_dz[w0] + at[w0] * T * H; at[w0] += b.cnt; }
             if (w3 >= 0) { b.dzB = pl->wg_dz[w3] + at[w3] * T * H; b.svA = pl->wg_sx[w3] + at[w3] * T * H; at[w3] += b.cnt; }
         }
@@ -853,10 +936,7 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
         pl->o_wt = take(ctx_weight_floats(ctx), 64);
         pl->o_gA = take(I * T * H, 64);
         pl->o_gB = take(I * T * H, 64);
-        if (pl->o_wfrag > 0) {               // backward chains of the fused tile operators: planes of the transposed weights, a third dZ tile set
-            pl->o_wfragT = take(19 * H * H, 64);
-            pl->o_gC = take(I * T * H, 64);
-        }
+        if (pl->o_wfrag > 0) pl->o_wfragT = take(19 * H * H, 64);     // backward chains of the fused tile operators: planes of the transposed weights
         pl->o_gV0 = take(Vv * 2 * H, 64);
         pl->o_gV1 = take(Vv * 2 * H, 64);
         pl->o_gCat = take(Vv * 3 * H, 64);
@@ -880,6 +960,8 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
         pl->o_gExtra = take(I, 64);
     }
     pl->total = align_up(o, 64);
+    if (getenv("STAIR_PLAN_DEBUG"))
+        fprintf(stderr, "plan build total %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
     *out = plp.release();
     return 0;
 }
@@ -912,6 +994,44 @@ extern "C" int stair_plan_status(const stair_plan *pl, const void *workspace, st
     STAIR_HIP(hipStreamSynchronize(s));
     STAIR_CHECK(word == 0, "a cooperative LSTM hand-off timed out (its workgroups were not co-resident: another queue on this GPU, or a "
                            "partitioned device); the results of this run contain NaN.  Set STAIR_LSTM_COOP=0 to use the one-workgroup kernels");
+    return 0;
+}
+
+// Where a training plan keeps the activations its backward pass reads -- for tests that compare the ReLU masks of two
+// implementations.  which = 0 / 1: first / second saved activation of the node's tile MLP ([T, H]: Filter, FilterFrame,
+// Localize, Superlative; first only: HasItem, Temporal) or the hidden row [H] of Exists / ToAction (which = 0);
+// tok = -1 - q: the decoder's hidden row [2H] of question q.  *off = float offset into the workspace, -1 = no such buffer.
+extern "C" int stair_plan_saved_offset(const stair_plan *pl, int32_t tok, int32_t which, int64_t *off) {
+    STAIR_CHECK(pl && off, "null argument");
+    STAIR_CHECK(pl->train, "plan was not built with STAIR_PLAN_TRAIN");
+    *off = -1;
+    const int64_t H = pl->cfg.hidden_size, T = pl->T;
+    if (tok < 0) {
+        const int q = -1 - tok;
+        STAIR_CHECK(q < pl->n, "question index out of range");
+        if (which == 0) *off = pl->o_hid + (int64_t)q * 2 * H;
+        return 0;
+    }
+    STAIR_CHECK(tok < (int)pl->nodes.size(), "token index out of range");
+    const Node &nd = pl->nodes[tok];
+    if (nd.inst < 0) return 0;
+    for (const Bucket &b : pl->buckets) {
+        if (b.level != nd.level || b.op != nd.bop || b.variant != nd.bvariant || b.sub != nd.bsub) continue;
+        switch (b.op) {
+            case STAIR_OP_FILTER: case STAIR_OP_FILTERFRAME: case STAIR_OP_LOCALIZE: case STAIR_OP_SUPERLATIVE:
+                if (which == 0) *off = b.svA + nd.inst * T * H;
+                else if (which == 1) *off = b.svB + nd.inst * T * H;
+                break;
+            case STAIR_OP_HASITEM: case STAIR_OP_TEMPORAL:
+                if (which == 0) *off = b.svA + nd.inst * T * H;
+                break;
+            case STAIR_OP_EXISTS: case STAIR_OP_TOACTION:
+                if (which == 0) *off = b.svHid + nd.inst * H;
+                break;
+            default: break;
+        }
+        return 0;
+    }
     return 0;
 }
 
@@ -1213,15 +1333,25 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
     };
 
     // ---- program levels ----------------------------------------------------------------------
-    for (const Bucket &b : pl->buckets) {
-        ++bucket_no;
-        if (b.cnt == 0) continue;
+    // One bucket's launches.  phase 0: everything (the GEMM / row-kernel sequences).  With the fused tile operators a level runs
+    // in three phases: phase 1 = every bucket's work up to its tile operator, whose arguments are QUEUED; then ONE launch carries
+    // the tiles of all buckets of the level (they are independent: a workgroup that finishes a tile takes the next one, whatever
+    // bucket it belongs to, so a bucket's last partial round is filled by its neighbours); phase 2 = what follows the tile
+    // operator (Filter's dense layer, Superlative's scores and pooling).
+    std::vector<stair_tile_mlp_args> tile_queue;
+    int tile_launches = 0;
+    auto run_bucket = [&](const Bucket &b, const int bno, const int phase) -> int {
+        bucket_no = bno;
+        if (b.cnt == 0) return 0;
         const int c = b.cnt;
         const int32_t *I0 = didx + b.off[0], *I1 = didx + b.off[1], *I2 = didx + b.off[2], *I3 = didx + b.off[3],
                       *I4 = didx + b.off[4], *I5 = didx + b.off[5];
         const int32_t *LEN = pl->ragged ? didx + b.off[6] : nullptr;       // frames of each instance's clip (T-mixing operators)
         float *tmpA = ws + b.svA, *tmpB = ws + b.svB, *kbuf = ws + b.svK, *cat = ws + b.svCat, *hid = ws + b.svHid;
         float *rsb = ws + b.svRs, *sup = ws + b.svSup, *extra = ws + b.svExtra;
+        const bool tile_op = b.op == STAIR_OP_FILTER || b.op == STAIR_OP_FILTERFRAME || b.op == STAIR_OP_HASITEM ||
+                             b.op == STAIR_OP_LOCALIZE || b.op == STAIR_OP_SUPERLATIVE || b.op == STAIR_OP_TEMPORAL;
+        if (phase == 2 && !(fused && tile_op)) return 0;              // everything else ran in phase 1
         switch (b.op) {
             case OP_SPAN:
                 RUN(launch_span_mean(tok, H, I0, I1, vec, I2, c, H, s));
@@ -1267,13 +1397,16 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
                 break;
             case STAIR_OP_FILTER: {     // modules.py:343-378 (attention == 1 exactly, see oracle op_filter)
                 const int v = b.variant;
-                if (fused) {            // both layers and the sum over frames on the tile, one launch
-                    stair_tile_mlp_args a = tile_args(I0, c);
-                    tile_layer(a, WF_F0 + v, W.f0[v], 1, tmpA);
-                    tile_layer(a, WF_F3 + v, W.f3[v], 1, tmpB);
-                    a.tail = STAIR_TILE_SUM_ROWS; a.out = cat; a.out_gstride = H; a.len = LEN;
-                    RUN(launch_tile_mlp(a, s));
-                    RUN(dense(s, cat, H, H, nullptr, W.fdense, H, vec, H, H, I1, c, 1, H, H, 1));
+                if (fused) {            // both layers and the sum over frames on the tile
+                    if (phase == 1) {
+                        stair_tile_mlp_args a = tile_args(I0, c);
+                        tile_layer(a, WF_F0 + v, W.f0[v], 1, tmpA);
+                        tile_layer(a, WF_F3 + v, W.f3[v], 1, tmpB);
+                        a.tail = STAIR_TILE_SUM_ROWS; a.out = cat; a.out_gstride = H; a.len = LEN;
+                        tile_queue.push_back(a);
+                    } else {
+                        RUN(dense(s, cat, H, H, nullptr, W.fdense, H, vec, H, H, I1, c, 1, H, H, 1));
+                    }
                     break;
                 }
                 RUN(dense(s, map, H, TH, I0, W.f0[v], H, tmpA, H, TH, nullptr, c, T, H, H, 1));
@@ -1286,7 +1419,8 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
             }
             case STAIR_OP_FILTERFRAME: {   // modules.py:381-414
                 const int v = b.variant;
-                if (fused) {            // three layers with the sigmoid attention in between, one launch
+                if (fused) {            // three layers with the sigmoid attention in between
+                    if (phase != 1) break;
                     if (v == 0) RUN(launch_vecdot(vec, I1, W.ffatt.w + H, extra, c, H, s));
                     stair_tile_mlp_args a = tile_args(I0, c);
                     tile_layer(a, WF_FF0 + v, W.ff0[v], 1, tmpA);
@@ -1294,7 +1428,7 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
                     tile_layer(a, WF_FFD, W.ffdense, 1, nullptr);
                     if (v == 0) { a.mid_rowdot = 1; a.vw = W.ffatt.w; a.vb = W.ffatt.b; a.extra = extra; a.rs_out = rsb; }
                     a.tail = STAIR_TILE_STORE; a.out = map; a.out_gstride = TH; a.out_idx = I2;
-                    RUN(launch_tile_mlp(a, s));
+                    tile_queue.push_back(a);
                     break;
                 }
                 RUN(dense(s, map, H, TH, I0, W.ff0[v], H, tmpA, H, TH, nullptr, c, T, H, H, 1));
@@ -1314,10 +1448,11 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
             }
             case STAIR_OP_HASITEM:      // modules.py:123-138
                 if (fused) {
+                    if (phase != 1) break;
                     stair_tile_mlp_args a = tile_args(I0, c);
                     tile_layer(a, WF_HI0, W.hi0, 1, tmpA);
                     a.tail = STAIR_TILE_ROWDOT_SIGMOID; a.vw = W.hi3.w; a.vb = W.hi3.b; a.out = att; a.out_gstride = T; a.out_idx = I1;
-                    RUN(launch_tile_mlp(a, s));
+                    tile_queue.push_back(a);
                     break;
                 }
                 RUN(dense(s, map, H, TH, I0, W.hi0, H, tmpA, H, TH, nullptr, c, T, H, H, 1));
@@ -1327,12 +1462,13 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
                 break;
             case STAIR_OP_LOCALIZE:     // modules.py:181-217
                 if (fused) {            // keyword rows first (a vector-level product), then both layers + the cosine on the tile
+                    if (phase != 1) break;
                     RUN(dense(s, vec, H, H, I2, W.lk, H, kbuf, H, H, nullptr, b.nrows, 1, H, H, 0));
                     stair_tile_mlp_args a = tile_args(I0, c);
                     tile_layer(a, WF_LV0, W.lv0, 1, tmpA);
                     tile_layer(a, WF_LV3, W.lv3, 0, tmpB);
                     a.tail = STAIR_TILE_COSINE; a.kb = kbuf; a.pair_first = I4; a.pair_cnt = I5; a.att_idx = I3; a.att = att;
-                    RUN(launch_tile_mlp(a, s));
+                    tile_queue.push_back(a);
                     break;
                 }
                 RUN(dense(s, map, H, TH, I0, W.lv0, H, tmpA, H, TH, nullptr, c, T, H, H, 1));
@@ -1345,12 +1481,15 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
                 RUN(launch_relate_softmax(att, I0, I1, W.beta, b.variant == 0 ? 1.0f : -1.0f, c, T, s, LEN));
                 break;
             case STAIR_OP_SUPERLATIVE:  // modules.py:220-248 (shares Localize's weights, module_net.py:31-32)
-                if (fused) {
+                if (fused && phase == 1) {
                     stair_tile_mlp_args a = tile_args(I0, c);
                     tile_layer(a, WF_LV0, W.lv0, 1, tmpA);
                     tile_layer(a, WF_LV3, W.lv3, 0, nullptr);
                     a.tail = STAIR_TILE_STORE; a.out = tmpB; a.out_gstride = TH;
-                    RUN(launch_tile_mlp(a, s));
+                    tile_queue.push_back(a);
+                    break;
+                } else if (fused) {
+                    // phase 2: the tile operator has written the clip's two-layer features to tmpB
                 } else {
                     RUN(dense(s, map, H, TH, I0, W.lv0, H, tmpA, H, TH, nullptr, c, T, H, H, 1));
                     RUN(drop(tmpA, TH, nullptr, c, TH, 0));
@@ -1366,14 +1505,16 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
                 break;
             case STAIR_OP_TEMPORAL: {   // modules.py:310-327
                 const int mode = b.variant;
+                if (fused && phase == 2) break;
                 RUN(launch_temporal_relate(att, I1, I2, att, I3, c, T, mode, ctx->conv ? 1 : 0, ctx->ksize,
                                            mode ? W.relate[mode - 1] : nullptr, s, LEN));
                 if (fused) {            // r_t feat_t -> Lin . ReLU -> LayerNorm on the tile
+                    if (phase != 1) break;
                     stair_tile_mlp_args a = tile_args(I0, c);
                     tile_layer(a, WF_TD, W.tdense, 1, tmpA);
                     a.row_scale = att; a.rs_idx = I3;
                     a.tail = STAIR_TILE_LAYERNORM; a.gamma = W.ln_w; a.beta = W.ln_b; a.out = map; a.out_gstride = TH; a.out_idx = I4;
-                    RUN(launch_tile_mlp(a, s));
+                    tile_queue.push_back(a);
                     break;
                 }
                 RUN(dense(s, map, H, TH, I0, W.tdense, H, tmpA, H, TH, nullptr, c, T, H, H, 1, att, T, I3));
@@ -1383,6 +1524,27 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
             }
             default:
                 STAIR_FAIL("internal: unhandled bucket op " + std::to_string(b.op));
+        }
+        return 0;
+    };
+    if (!fused) {
+        int bno = 0;
+        for (const Bucket &b : pl->buckets) RUN(run_bucket(b, bno++, 0));
+    } else {
+        unsigned *tile_ctr = reinterpret_cast<unsigned *>(ws + pl->o_status) + 16;      // 48 work-queue heads, zeroed with the status word
+        for (size_t lo_ = 0; lo_ < pl->buckets.size();) {
+            size_t hi_ = lo_;
+            while (hi_ < pl->buckets.size() && pl->buckets[hi_].level == pl->buckets[lo_].level) ++hi_;
+            tile_queue.clear();
+            for (size_t k = lo_; k < hi_; ++k) RUN(run_bucket(pl->buckets[k], (int)k, 1));
+            for (size_t q0 = 0; q0 < tile_queue.size(); q0 += 8) {
+                const int nq = (int)std::min<size_t>(8, tile_queue.size() - q0);
+                STAIR_CHECK(tile_launches < 48, "internal: more fused launches than work-queue heads");
+                RUN(launch_tile_mlp_batch(tile_queue.data() + q0, nq, tile_ctr + tile_launches, s));
+                ++tile_launches;
+            }
+            for (size_t k = lo_; k < hi_; ++k) RUN(run_bucket(pl->buckets[k], (int)k, 2));
+            lo_ = hi_;
         }
     }
 
@@ -1504,7 +1666,6 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
     // ---- backward chains of the fused tile operators (csrc/tile_mlp.hip): dX = (dZ2 W2 * relu'(Z1)) W1 stays on the tile ----
     const bool fused = pl->o_wfragT > 0 && tile_mlp_usable(H, T) && pl->drop_p <= 0.0f;
     auto WFT = [&](int slot) { return static_cast<const void *>(ws + pl->o_wfragT + (int64_t)slot * H * H); };
-    float *gC = pl->o_gC > 0 ? ws + pl->o_gC : nullptr;
     if (fused) {
         bool need[WF_COUNT] = {};
         for (const Bucket &b : pl->buckets) {
@@ -1536,9 +1697,12 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
     }
 
     // ---- program levels in reverse ---------------------------------------------------------------
-    for (auto it = pl->buckets.rbegin(); it != pl->buckets.rend(); ++it) {
-        const Bucket &b = *it;
-        if (b.cnt == 0) continue;
+    // phase 0: a bucket's whole adjoint.  With the fused chains a level runs as: phase 1 = everything up to the tile chain (its
+    // arguments are queued), ONE launch for the chains of all buckets of the level, phase 2 = what needs the chain's outputs.
+    std::vector<stair_tile_mlp_args> chain_queue;
+    int chain_launches = 0;
+    auto bwd_bucket = [&](const Bucket &b, const int phase) -> int {
+        if (b.cnt == 0) return 0;
         const int c = b.cnt;
         const int32_t *I0 = didx + b.off[0], *I1 = didx + b.off[1], *I2 = didx + b.off[2], *I3 = didx + b.off[3],
                       *I4 = didx + b.off[4], *I5 = didx + b.off[5];
@@ -1552,6 +1716,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
         // gradient tile in ONE launch; the two weight-gradient products (reductions over all instances) stay TN GEMMs.
         // in_bcast: Filter -- the incoming gradient is ONE row per instance (the sum over frames), broadcast and masked on load.
         auto mlp_tail_fused = [&](const Lin &l3, const Lin &l0, int slot3, int slot0, bool relu_second, const float *bcast_row) -> int {
+            (void)l3; (void)l0;             // their weight-gradient products run per weight, after all buckets
             stair_tile_mlp_args a = {};
             a.cnt = c; a.T = T; a.H = H; a.len = LEN;
             if (bcast_row) { a.X = bcast_row; a.x_gstride = H; a.x_broadcast = 1; }
@@ -1561,11 +1726,12 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
             a.W[0] = WFT(slot3); a.act[0] = 3; a.act_mask[0] = svA; a.act_scale = inv_keep; a.save[0] = gA;
             a.W[1] = WFT(slot0); a.act[1] = 0;
             a.tail = STAIR_TILE_ACCUMULATE; a.out = g_map; a.out_gstride = TH; a.out_idx = I0;
-            RUN(launch_tile_mlp(a, s));
-            RUN(dense_bwd(B, gB, c, T, H, H, svA, H, TH, nullptr, l3, nullptr, H, TH, nullptr, 0));
-            RUN(dense_bwd(B, gA, c, T, H, H, map, H, TH, I0, l0, nullptr, H, TH, I0, 1));
+            chain_queue.push_back(a);
             return 0;
         };
+        const bool chain_op = fused && (b.op == STAIR_OP_FILTER || (b.op == STAIR_OP_FILTERFRAME && b.variant != 0) || b.op == STAIR_OP_HASITEM ||
+                                        b.op == STAIR_OP_LOCALIZE || b.op == STAIR_OP_SUPERLATIVE);
+        if (phase == 2 && !chain_op) return 0;
         auto mlp_tail = [&](const Lin &l3, const Lin &l0, bool relu_second) -> int {
             if (relu_second) RUN(launch_mask_relu(gB, gB, TH, nullptr, svB, TH, nullptr, c, (int)TH, s, inv_keep));
             RUN(dense_bwd(B, gB, c, T, H, H, svA, H, TH, nullptr, l3, gA, H, TH, nullptr, 0));
@@ -1618,9 +1784,11 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
                 break;
             case STAIR_OP_FILTER: {
                 const int v = b.variant;
+                if (phase == 2) break;
+                float *grow = fused ? ws + b.gRow : gV1;          // the gradient of the sum over frames: one row per instance
                 RUN(launch_mask_relu(gV0, g_vec, H, I1, vec, H, I1, c, H, s));
-                RUN(dense_bwd(B, gV0, c, 1, H, H, svCat, H, H, nullptr, W.fdense, gV1, H, H, nullptr, 0));
-                if (fused) { RUN(mlp_tail_fused(W.f3[v], W.f0[v], WF_F3 + v, WF_F0 + v, false, gV1)); break; }
+                RUN(dense_bwd(B, gV0, c, 1, H, H, svCat, H, H, nullptr, W.fdense, grow, H, H, nullptr, 0));
+                if (fused) { RUN(mlp_tail_fused(W.f3[v], W.f0[v], WF_F3 + v, WF_F0 + v, false, grow)); break; }
                 RUN(launch_bcast_mask_relu(gB, gV1, svB, c, T, H, s, inv_keep, LEN));
                 RUN(mlp_tail(W.f3[v], W.f0[v], false));
                 break;
@@ -1628,6 +1796,11 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
             case STAIR_OP_FILTERFRAME: {
                 const int v = b.variant;
                 if (fused && v != 0) {        // three-layer chain on the tile: dZ3 -> (ffdense) -> dZ2 -> (ff3) -> dZ1 -> (ff0) -> += g_map[I0]
+                    float *gC = ws + b.dzC;
+                    if (phase == 2) {             // FilterFrame's dense layer keeps its per-bucket weight-gradient product (dZ3 is there now)
+                        RUN(dense_bwd(B, gC, c, T, H, H, svB, H, TH, nullptr, W.ffdense, nullptr, H, TH, nullptr, 0));
+                        break;
+                    }
                     stair_tile_mlp_args a = {};
                     a.cnt = c; a.T = T; a.H = H;
                     a.X = g_map; a.x_gstride = TH; a.x_idx = I2;
@@ -1637,10 +1810,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
                     a.W[1] = WFT(WF_FF3 + v); a.act[1] = 3; a.act_mask[1] = svA; a.save[1] = gA;
                     a.W[2] = WFT(WF_FF0 + v); a.act[2] = 0;
                     a.tail = STAIR_TILE_ACCUMULATE; a.out = g_map; a.out_gstride = TH; a.out_idx = I0;
-                    RUN(launch_tile_mlp(a, s));
-                    RUN(dense_bwd(B, gC, c, T, H, H, svB, H, TH, nullptr, W.ffdense, nullptr, H, TH, nullptr, 0));
-                    RUN(dense_bwd(B, gB, c, T, H, H, svA, H, TH, nullptr, W.ff3[v], nullptr, H, TH, nullptr, 0));
-                    RUN(dense_bwd(B, gA, c, T, H, H, map, H, TH, I0, W.ff0[v], nullptr, H, TH, I0, 1));
+                    chain_queue.push_back(a);
                     break;
                 }
                 RUN(launch_mask_relu(gA, g_map, TH, I2, map, TH, I2, c, (int)TH, s, inv_keep));        // dZ of the dense layer
@@ -1663,6 +1833,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
                 break;
             }
             case STAIR_OP_HASITEM:
+                if (phase == 2) break;
                 RUN(launch_rowdot_sigmoid_bwd(g_att, T, I1, att, T, I1, W.hi3.w, gA, 0, gRs2, nullptr, c, T, H, s, 1.0f / inv_keep));
                 RUN(launch_weighted_colsum(svA, H, nullptr, gRs2, W.hi3.dw, c * T, H, s));
                 RUN(launch_sum_all(gRs2, W.hi3.db, c * T, s));
@@ -1672,14 +1843,14 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
                     a.X = gA; a.x_gstride = TH; a.in_mask = svA; a.in_mask_gstride = TH; a.in_scale = inv_keep; a.save_in = gA;
                     a.n_layers = 1; a.W[0] = WFT(WF_HI0); a.act[0] = 0;
                     a.tail = STAIR_TILE_ACCUMULATE; a.out = g_map; a.out_gstride = TH; a.out_idx = I0;
-                    RUN(launch_tile_mlp(a, s));
-                    RUN(dense_bwd(B, gA, c, T, H, H, map, H, TH, I0, W.hi0, nullptr, H, TH, I0, 1));
+                    chain_queue.push_back(a);
                     break;
                 }
                 RUN(launch_mask_relu(gA, gA, TH, nullptr, svA, TH, nullptr, c, (int)TH, s, inv_keep));
                 RUN(dense_bwd(B, gA, c, T, H, H, map, H, TH, I0, W.hi0, g_map, H, TH, I0, 1));
                 break;
             case STAIR_OP_LOCALIZE:
+                if (phase == 2) break;
                 RUN(launch_cosine_attn_bwd_grouped(svB, svK, att, I3, g_att, I3, I4, I5, gB, gK, gRs2, gStats, c, b.nrows, T, H, 2, s));
                 RUN(dense_bwd(B, gK, b.nrows, 1, H, H, vec, H, H, I2, W.lk, g_vec, H, H, I2, 1));
                 if (fused) RUN(mlp_tail_fused(W.lv3, W.lv0, WF_LV3, WF_LV0, false, nullptr));
@@ -1689,6 +1860,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
                 RUN(launch_relate_softmax_bwd(att, g_att, I0, I1, W.dbeta, b.variant == 0 ? 1.0f : -1.0f, c, T, s, LEN));
                 break;
             case STAIR_OP_SUPERLATIVE:
+                if (phase == 2) break;
                 RUN(launch_mask_relu(gV0, g_vec, H, I3, vec, H, I3, c, H, s));
                 RUN(dense_bwd(B, gV0, c, 1, H, H, svCat, H, H, nullptr, W.supdense, gV1, H, H, nullptr, 0));
                 RUN(launch_superlative_pool_bwd(svSup, ws, gws, I4, I1, I2, b.variant, gV1, gS, c, T, H, s, LEN));
@@ -1708,6 +1880,27 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
             }
             default:
                 STAIR_FAIL("internal: unhandled bucket op " + std::to_string(b.op));
+        }
+        return 0;
+    };
+    if (!fused) {
+        for (auto it = pl->buckets.rbegin(); it != pl->buckets.rend(); ++it) RUN(bwd_bucket(*it, 0));
+    } else {
+        unsigned *chain_ctr = reinterpret_cast<unsigned *>(ws + pl->o_status) + 64;      // a second block of 48 work-queue heads
+        STAIR_HIP(hipMemsetAsync(chain_ctr, 0, 48 * sizeof(unsigned), s));
+        for (int64_t hi_ = (int64_t)pl->buckets.size(); hi_ > 0;) {
+            int64_t lo_ = hi_;
+            while (lo_ > 0 && pl->buckets[lo_ - 1].level == pl->buckets[hi_ - 1].level) --lo_;
+            chain_queue.clear();
+            for (int64_t k = hi_ - 1; k >= lo_; --k) RUN(bwd_bucket(pl->buckets[k], 1));
+            for (size_t q0 = 0; q0 < chain_queue.size(); q0 += 8) {
+                const int nq = (int)std::min<size_t>(8, chain_queue.size() - q0);
+                STAIR_CHECK(chain_launches < 48, "internal: more fused launches than work-queue heads");
+                RUN(launch_tile_mlp_batch(chain_queue.data() + q0, nq, chain_ctr + chain_launches, s));
+                ++chain_launches;
+            }
+            for (int64_t k = hi_ - 1; k >= lo_; --k) RUN(bwd_bucket(pl->buckets[k], 2));
+            hi_ = lo_;
         }
     }
 
@@ -1870,7 +2063,7 @@ extern "C" int stair_plan_regions(stair_plan *pl, const stair_ctx *ctx, const ch
     add("sup", pl->o_sup, (int64_t)std::max(pl->maxSupRows, 1) * T);
     add("extra", pl->o_extra, std::max(pl->maxI, 1));
     add("logits", pl->o_logits, n * A);
-    add("status", pl->o_status, 64);
+    add("status", pl->o_status, 128);
     if (H == 512 && T <= 64) add("wfrag", pl->o_wfrag, 19 * H * H);
     if (pl->train) {
         int bi = 0;
@@ -1893,7 +2086,11 @@ extern "C" int stair_plan_regions(stair_plan *pl, const stair_ctx *ctx, const ch
         add("wt", pl->o_wt, ctx_weight_floats(ctx));
         add("gA", pl->o_gA, I * T * H);
         add("gB", pl->o_gB, I * T * H);
-        if (pl->o_wfragT > 0) { add("wfragT", pl->o_wfragT, 19 * H * H); add("gC", pl->o_gC, I * T * H); }
+        if (pl->o_wfragT > 0) add("wfragT", pl->o_wfragT, 19 * H * H);
+        for (const Bucket &b : pl->buckets) {
+            if (b.dzC >= 0) add("dzC", b.dzC, (int64_t)b.cnt * T * H);
+            if (b.gRow >= 0) add("gRow", b.gRow, (int64_t)b.cnt * H);
+        }
         for (int w = 0; w < WF_COUNT; ++w)
             if (pl->wg_rows[w]) add("wg_dz" + std::to_string(w), pl->wg_dz[w], pl->wg_rows[w] * T * H);
         add("gV0", pl->o_gV0, Vv * 2 * H);

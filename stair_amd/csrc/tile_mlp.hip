@@ -55,8 +55,12 @@ __device__ __forceinline__ int tm_swz(int R) {
     return ((q0 ^ q1) << 1) | q1;
 }
 
+constexpr int TM_MAXB = 8;           // module buckets one launch can carry (the argument block stays under the 4 KB kernarg limit)
 struct TmParams {
-    stair_tile_mlp_args a;
+    stair_tile_mlp_args a[TM_MAXB];  // the buckets of one program level: independent of each other, so their tiles share one launch
+    int first[TM_MAXB + 1];          // work item w belongs to bucket b with first[b] <= w < first[b + 1]; its tile is w - first[b]
+    int nb;
+    unsigned *counter;               // work queue head (zeroed before the launch); NULL: tiles are dealt out round robin
 };
 
 }  // namespace
@@ -70,14 +74,29 @@ __device__ __forceinline__ void tm_split8(const v4f a, const v4f b, bf16x8 &hi, 
     }
 }
 
+// NT: the tile's own traffic (input rows, masks, saved activations, output rows) is streamed with the non-temporal hint, so that
+// it does not push the weight planes -- which every workgroup of the XCD re-reads for every tile -- out of the 4 MB L2.
+template <bool NT>
+__device__ __forceinline__ v4f tm_ld(const float *p) {
+    if (NT) return __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p));
+    return *reinterpret_cast<const v4f *>(p);
+}
+template <bool NT>
+__device__ __forceinline__ void tm_st(float *p, const v4f v) {
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(p));
+    else *reinterpret_cast<v4f *>(p) = v;
+}
+
+template <bool NT>
 __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
-    const stair_tile_mlp_args &p = pp.a;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float *F = reinterpret_cast<float *>(lds);
     float *red = reinterpret_cast<float *>(lds + TM_RED_OFF);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int T = p.T;
+    const int T = pp.a[0].T;
+    const int total = pp.first[pp.nb];
+    __shared__ int next_work;
     // B-operand fragment offsets (bytes inside a stage plane, chunk 0) of this lane's two frame tiles
     int offT[2];
 #pragma unroll
@@ -86,30 +105,47 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
         offT[tt] = (R * 4 + tm_swz(R)) * 16;
     }
 
-    for (int inst = blockIdx.x; inst < p.cnt; inst += gridDim.x) {
+    // Work items = tiles of all buckets of the launch, handed out through one atomic counter: a workgroup that finishes a
+    // one-layer tile takes the next item while another is still in a three-layer one, and the last partial round of one
+    // bucket is filled with the next bucket's tiles (the buckets are listed by decreasing layer count).
+    for (int it = 0;; ++it) {
+        int w;
+        __syncthreads();                          // the previous tile's tail has finished reading the staging (and next_work)
+        if (pp.counter) {
+            if (tid == 0) next_work = (int)atomicAdd(pp.counter, 1u);
+            __syncthreads();
+            w = next_work;
+        } else {
+            w = blockIdx.x + it * gridDim.x;
+        }
+        if (w >= total) break;
+        int bsel = 0;
+#pragma unroll
+        for (int j = 1; j < TM_MAXB; ++j) bsel += (j < pp.nb && w >= pp.first[j]) ? 1 : 0;
+        const stair_tile_mlp_args &p = pp.a[bsel];
+        const int inst = w - pp.first[bsel];
         // ---- the input tile: fp32 rows -> (row scale) -> bf16 hi / lo image ------------------------------------------
         const float *x = p.X + (int64_t)(p.x_idx ? p.x_idx[inst] : inst) * p.x_gstride;
         const float *rsrow = p.row_scale ? p.row_scale + (int64_t)(p.rs_idx ? p.rs_idx[inst] : inst) * T : nullptr;
         const float *imask = p.in_mask ? p.in_mask + (int64_t)(p.in_mask_idx ? p.in_mask_idx[inst] : inst) * p.in_mask_gstride : nullptr;
         const int Lrows = p.x_broadcast ? (p.len ? p.len[inst] : T) : T;     // a broadcast row fills the clip's own frames only
-        __syncthreads();                          // the previous instance's tail has finished reading the staging
         for (int u = tid; u < TM_ROWS * 64; u += 512) {
             const int t = u >> 6, c8 = u & 63;
             v4f a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
             if (t < Lrows) {
                 const float *xr = x + (p.x_broadcast ? 0 : (int64_t)t * TM_H) + 8 * c8;
-                a = *reinterpret_cast<const v4f *>(xr);
-                b = *reinterpret_cast<const v4f *>(xr + 4);
+                a = tm_ld<NT>(xr);
+                b = tm_ld<NT>(xr + 4);
                 if (rsrow) { const float s = rsrow[t]; a *= s; b *= s; }
                 if (imask) {                  // backward chains: the incoming gradient times relu'(saved activation) (x in_scale)
-                    const v4f m0 = *reinterpret_cast<const v4f *>(imask + (int64_t)t * TM_H + 8 * c8), m1 = *reinterpret_cast<const v4f *>(imask + (int64_t)t * TM_H + 8 * c8 + 4);
+                    const v4f m0 = tm_ld<NT>(imask + (int64_t)t * TM_H + 8 * c8), m1 = tm_ld<NT>(imask + (int64_t)t * TM_H + 8 * c8 + 4);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { a[i] = m0[i] > 0.f ? a[i] * p.in_scale : 0.f; b[i] = m1[i] > 0.f ? b[i] * p.in_scale : 0.f; }
                 }
             }
             if (p.save_in && t < T) {
                 float *d = p.save_in + ((int64_t)inst * T + t) * TM_H + 8 * c8;
-                *reinterpret_cast<v4f *>(d) = a; *reinterpret_cast<v4f *>(d + 4) = b;
+                tm_st<NT>(d, a); tm_st<NT>(d + 4, b);
             }
             bf16x8 hi, lo;
             tm_split8(a, b, hi, lo);
@@ -136,29 +172,43 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
         _Pragma("unroll") for (int pl_ = 0; pl_ < 2; ++pl_)                                                   \
             wf[slot_][nt_][pl_] = wq[((nt_ * TM_KS + (ks_)) * 2 + pl_) * 64];
                 TM_LOADW(0, 0) TM_LOADW(1, 1) TM_LOADW(2, 2)
+                // tile fragments are read one k step ahead as well (the LDS round trip hides behind the previous step's MFMAs)
+                bf16x8 zh[2][2], zl[2][2];
+#define TM_LOADZ(set_, ks_)                                                                                   \
+    {                                                                                                         \
+        const char *sb_ = lds + ((ks_) >> 1) * TM_STAGE;                                                      \
+        const int cx_ = (2 * ((ks_) & 1) + h) << 4;                                                           \
+        _Pragma("unroll") for (int tt_ = 0; tt_ < 2; ++tt_) {                                                 \
+            zh[set_][tt_] = *reinterpret_cast<const bf16x8 *>(sb_ + (offT[tt_] ^ cx_));                       \
+            zl[set_][tt_] = *reinterpret_cast<const bf16x8 *>(sb_ + 4096 + (offT[tt_] ^ cx_));                \
+        }                                                                                                     \
+    }
+                TM_LOADZ(0, 0)
                 for (int ks0 = 0; ks0 < TM_KS; ks0 += 4) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int ks = ks0 + u;
                         if (ks + 3 < TM_KS) { TM_LOADW((u + 3) & 3, ks + 3) }
-                        const char *sb = lds + (ks >> 1) * TM_STAGE;
-                        const int cx = (2 * (u & 1) + h) << 4;
-                        bf16x8 zh[2], zl[2];
-#pragma unroll
-                        for (int tt = 0; tt < 2; ++tt) {
-                            zh[tt] = *reinterpret_cast<const bf16x8 *>(sb + (offT[tt] ^ cx));
-                            zl[tt] = *reinterpret_cast<const bf16x8 *>(sb + 4096 + (offT[tt] ^ cx));
-                        }
+                        if (ks + 1 < TM_KS) { TM_LOADZ((u + 1) & 1, ks + 1) }
+                        // product-major order: four independent accumulators between two MFMAs on the same one
 #pragma unroll
                         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                            for (int tt = 0; tt < 2; ++tt) {
-                                acc[nt][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u][nt][1], zh[tt], acc[nt][tt], 0, 0, 0);
-                                acc[nt][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u][nt][0], zl[tt], acc[nt][tt], 0, 0, 0);
-                                acc[nt][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u][nt][0], zh[tt], acc[nt][tt], 0, 0, 0);
-                            }
+                            for (int tt = 0; tt < 2; ++tt)
+                                acc[nt][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u][nt][1], zh[u & 1][tt], acc[nt][tt], 0, 0, 0);
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                            for (int tt = 0; tt < 2; ++tt)
+                                acc[nt][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u][nt][0], zl[u & 1][tt], acc[nt][tt], 0, 0, 0);
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                            for (int tt = 0; tt < 2; ++tt)
+                                acc[nt][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u][nt][0], zh[u & 1][tt], acc[nt][tt], 0, 0, 0);
                     }
                 }
+#undef TM_LOADZ
 #undef TM_LOADW
             }
             // ---- bias + activation in the accumulator layout: lane (r, h) holds frame t = 32 tt + r, columns
@@ -174,7 +224,7 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
 #pragma unroll
                     for (int tt = 0; tt < 2; ++tt) {
                         v4f mv = {1.f, 1.f, 1.f, 1.f};
-                        if (amask && 32 * tt + r < T) mv = *reinterpret_cast<const v4f *>(amask + (int64_t)(32 * tt + r) * TM_H + 64 * wave + 32 * nt + 8 * q + 4 * h);
+                        if (amask && 32 * tt + r < T) mv = tm_ld<NT>(amask + (int64_t)(32 * tt + r) * TM_H + 64 * wave + 32 * nt + 8 * q + 4 * h);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             float v = acc[nt][tt][4 * q + i] + bv[i];
@@ -227,8 +277,7 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             v4f z = {acc[nt][tt][4 * q], acc[nt][tt][4 * q + 1], acc[nt][tt][4 * q + 2], acc[nt][tt][4 * q + 3]};
-                            if (sv && t < T)
-                                *reinterpret_cast<v4f *>(sv + ((int64_t)inst * T + t) * TM_H + 64 * wave + 32 * nt + 8 * q + 4 * h) = z;
+                            if (sv && t < T) tm_st<NT>(sv + ((int64_t)inst * T + t) * TM_H + 64 * wave + 32 * nt + 8 * q + 4 * h, z);
                             z *= scale[tt];
                             bf16x4 zh4, zl4;
 #pragma unroll
@@ -260,16 +309,16 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
         if (svl)                                      // the last layer's rows for the backward pass (coalesced 2 KB rows)
             for (int t = wave; t < T; t += 8) {
                 float *dst = svl + ((int64_t)inst * T + t) * TM_H;
-                *reinterpret_cast<v4f *>(dst + 4 * lane) = *reinterpret_cast<const v4f *>(F + t * TM_FLD + 4 * lane);
-                *reinterpret_cast<v4f *>(dst + 256 + 4 * lane) = *reinterpret_cast<const v4f *>(F + t * TM_FLD + 256 + 4 * lane);
+                tm_st<NT>(dst + 4 * lane, *reinterpret_cast<const v4f *>(F + t * TM_FLD + 4 * lane));
+                tm_st<NT>(dst + 256 + 4 * lane, *reinterpret_cast<const v4f *>(F + t * TM_FLD + 256 + 4 * lane));
             }
         const int64_t oslot = p.out_idx ? p.out_idx[inst] : inst;
         switch (p.tail) {
             case STAIR_TILE_STORE:
                 for (int t = wave; t < T; t += 8) {
                     float *dst = p.out + oslot * p.out_gstride + (int64_t)t * TM_H;
-                    *reinterpret_cast<v4f *>(dst + 4 * lane) = *reinterpret_cast<const v4f *>(F + t * TM_FLD + 4 * lane);
-                    *reinterpret_cast<v4f *>(dst + 256 + 4 * lane) = *reinterpret_cast<const v4f *>(F + t * TM_FLD + 256 + 4 * lane);
+                    tm_st<NT>(dst + 4 * lane, *reinterpret_cast<const v4f *>(F + t * TM_FLD + 4 * lane));
+                    tm_st<NT>(dst + 256 + 4 * lane, *reinterpret_cast<const v4f *>(F + t * TM_FLD + 256 + 4 * lane));
                 }
                 break;
             case STAIR_TILE_ACCUMULATE:               // backward chains: dX added into a gradient tile several instances may share
@@ -407,12 +456,11 @@ bool tile_mlp_usable(int H, int T) {
     return on && H == TM_H && T >= 1 && T <= TM_ROWS && matmul_mode() == STAIR_MATMUL_BF16X3;
 }
 
-int launch_tile_mlp(const stair_tile_mlp_args &a, hipStream_t s) {
+static int tile_mlp_check(const stair_tile_mlp_args &a) {
     STAIR_CHECK(a.H == TM_H, "the fused tile operators are built for hidden_size 512");
     STAIR_CHECK(a.T >= 1 && a.T <= TM_ROWS, "a tile holds 1..64 frames");
     STAIR_CHECK(a.n_layers >= 1 && a.n_layers <= 3, "1..3 layers");
     STAIR_CHECK(a.X && a.cnt >= 0, "null input");
-    STAIR_CHECK(matmul_mode() == STAIR_MATMUL_BF16X3, "the fused tile operators compute split-bf16 products (STAIR_MATMUL_BF16X3)");
     for (int l = 0; l < a.n_layers; ++l)
         STAIR_CHECK(a.W[l] && (reinterpret_cast<uintptr_t>(a.W[l]) & 15) == 0, "weight planes (stair_pack_wfrag) missing or unaligned");
     for (int l = 0; l < a.n_layers; ++l) STAIR_CHECK(a.act[l] != 3 || a.act_mask[l], "act 3 multiplies by relu'(act_mask[l])");
@@ -428,26 +476,53 @@ int launch_tile_mlp(const stair_tile_mlp_args &a, hipStream_t s) {
         case STAIR_TILE_NONE: break;
         default: STAIR_FAIL("unknown tail");
     }
-    if (a.cnt == 0) return 0;
+    return 0;
+}
+
+// n buckets (same T) in one launch; counter: a zeroed device word (the dynamic work queue) or NULL
+int launch_tile_mlp_batch(const stair_tile_mlp_args *args, int n, unsigned *counter, hipStream_t s) {
+    STAIR_CHECK(n >= 0 && n <= TM_MAXB, "at most 8 buckets per launch");
+    STAIR_CHECK(matmul_mode() == STAIR_MATMUL_BF16X3, "the fused tile operators compute split-bf16 products (STAIR_MATMUL_BF16X3)");
+    TmParams pp;
+    pp.nb = 0; pp.counter = counter; pp.first[0] = 0;
+    int order[TM_MAXB], m = 0;
+    for (int i = 0; i < n; ++i) {
+        if (int rc = tile_mlp_check(args[i])) return rc;
+        STAIR_CHECK(args[i].T == args[0].T, "the buckets of one launch share T");
+        if (args[i].cnt > 0) order[m++] = i;
+    }
+    if (m == 0) return 0;
+    std::stable_sort(order, order + m, [&](int x, int y) { return args[x].n_layers > args[y].n_layers; });    // long tiles first
+    for (int j = 0; j < m; ++j) {
+        const stair_tile_mlp_args &a = args[order[j]];
+        pp.a[j] = a;
+        pp.first[j + 1] = pp.first[j] + a.cnt;
+        const int64_t M = (int64_t)a.cnt * a.T;
+        STAIR_ACCT_MFMA("tile_mlp", (M * TM_H * 2 + (int64_t)a.n_layers * TM_H * TM_H) * 4, 2 * M * TM_H * TM_H * a.n_layers);
+    }
+    for (int j = m; j < TM_MAXB; ++j) { pp.a[j] = pp.a[0]; pp.first[j + 1] = pp.first[m]; }
+    pp.nb = m;
     static bool attr_set[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     static int cus[64] = {};
     if (!attr_set[dev]) {
-        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_mlp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TM_LDS));
+        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_mlp_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, TM_LDS));
+        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_mlp_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, TM_LDS));
         int v = 256;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
         cus[dev] = v;
         attr_set[dev] = true;
     }
-    const int64_t M = (int64_t)a.cnt * a.T;
-    STAIR_ACCT_MFMA("tile_mlp", (M * TM_H * 2 + (int64_t)a.n_layers * TM_H * TM_H) * 4, 2 * M * TM_H * TM_H * a.n_layers);
-    TmParams pp;
-    pp.a = a;
-    hipLaunchKernelGGL(tile_mlp_kernel, dim3(std::min(a.cnt, cus[dev])), dim3(512), TM_LDS, s, pp);
+    const int grid = std::min(pp.first[m], cus[dev]);
+    static const bool nt = [] { const char *e = getenv("STAIR_TILE_NT"); return e && e[0] == '1'; }();     // measured: plain stores are faster (profiles/r03_e_*)
+    if (nt) hipLaunchKernelGGL(tile_mlp_kernel<true>, dim3(grid), dim3(512), TM_LDS, s, pp);
+    else hipLaunchKernelGGL(tile_mlp_kernel<false>, dim3(grid), dim3(512), TM_LDS, s, pp);
     STAIR_LAUNCH_CHECK();
     return 0;
 }
+
+int launch_tile_mlp(const stair_tile_mlp_args &a, hipStream_t s) { return launch_tile_mlp_batch(&a, 1, nullptr, s); }
 
 }  // namespace stair
 

@@ -198,6 +198,22 @@ class BatchResult:
             return torch.stack([v[slot], v[aux]])
         raise StairError('node has no value')
 
+    def saved(self, q, i, which=0):
+        """Training plans: view of the activation the backward pass keeps for token i of question q (stair_plan_saved_offset):
+        [T,H] tiles of the tile MLPs, the [H] hidden row of Exists / ToAction; i = None: the decoder's hidden row [2H].
+        None when the node keeps no such buffer."""
+        H, T = self._model.config['hidden_size'], self.info.T
+        tok = -1 - q if i is None else int(self._prog_off[q] + i)
+        off = C.c_int64(-1)
+        check(lib.stair_plan_saved_offset(self._plan, tok, which, C.byref(off)))
+        if off.value < 0:
+            return None
+        if i is None:
+            return self._ws[off.value: off.value + 2 * H]
+        if self._programs[q][i] in ('Exists', 'ToAction'):
+            return self._ws[off.value: off.value + H]
+        return self._ws[off.value: off.value + T * H].view(T, H)
+
     def related_attn(self, q, i):
         _, _, _, _, rel = self.node_info(q, i)
         return self._arena(self.info.att_off, self.info.n_att, self.info.T)[rel] if rel >= 0 else None
