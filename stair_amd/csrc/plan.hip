@@ -1156,6 +1156,20 @@ int resolve(const stair_ctx *ctx, Weights &W, bool grads) {
     return 0;
 }
 
+// Where the fused tile operators pay (measured, profiles/r03_*: same box, same build, STAIR_TILE_MLP=0 against 1):
+//   inference          32 / 128 / 512 / 2048 questions per batch: 1.36 / 1.49 / 2.19 / 6.12 ms fused, 1.58 / 1.91 / 2.59 / 6.11 ms sequenced
+//   training step      4.47 / 5.40 / 8.21 / 20.7 ms fused, 4.60 / 5.70 / 8.25 / 18.8 ms sequenced
+// A training tile also WRITES its two saved activations and its backward chain adds dX with atomics; once a bucket holds
+// several rounds of tiles those bytes, not the launches, set the time, and the 128 / 256-row GEMMs (which reuse a weight tile
+// over more rows) win.  Inference plans always run fused; training plans while the largest tile bucket stays within ~1.25
+// rounds of the chip.  STAIR_TILE_TRAIN=1 / 0 forces the choice for training plans.
+bool tile_policy(const stair_plan *pl) {
+    if (!pl->train) return true;
+    static const int force = [] { const char *e = getenv("STAIR_TILE_TRAIN"); return e ? atoi(e) : -1; }();
+    if (force >= 0) return force != 0;
+    return pl->maxI <= 320;
+}
+
 // dense helper: C[g][r] = act(rs * A[g][r] W^T + b)
 float *g_splitk_ws = nullptr;      // set by stair_plan_run for the duration of the call (one ctx per process, not thread-safe)
 
@@ -1298,7 +1312,7 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
     }
 
     // ---- fused per-clip tile operators (csrc/tile_mlp.hip): weights of the buckets that run fused, as fragment-order planes ----
-    const bool fused = pl->o_wfrag > 0 && tile_mlp_usable(H, T) && dp <= 0.0f;
+    const bool fused = pl->o_wfrag > 0 && tile_mlp_usable(H, T) && dp <= 0.0f && tile_policy(pl);
     auto WF = [&](int slot) { return static_cast<const void *>(ws + pl->o_wfrag + (int64_t)slot * H * H); };
     if (fused) {
         const Lin *lin_of[WF_COUNT] = {&W.f0[0], &W.f0[1], &W.f0[2], &W.f0[3], &W.f3[0], &W.f3[1], &W.f3[2], &W.f3[3], &W.ff0[0], &W.ff0[1], &W.ff0[2],
@@ -1537,10 +1551,12 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
             while (hi_ < pl->buckets.size() && pl->buckets[hi_].level == pl->buckets[lo_].level) ++hi_;
             tile_queue.clear();
             for (size_t k = lo_; k < hi_; ++k) RUN(run_bucket(pl->buckets[k], (int)k, 1));
-            for (size_t q0 = 0; q0 < tile_queue.size(); q0 += 8) {
-                const int nq = (int)std::min<size_t>(8, tile_queue.size() - q0);
+            static const int merge_max = [] { const char *e = getenv("STAIR_TILE_MERGE"); return e ? std::max(1, std::min(8, atoi(e))) : 8; }();
+            static const bool use_queue = [] { const char *e = getenv("STAIR_TILE_QUEUE"); return !(e && e[0] == '0'); }();
+            for (size_t q0 = 0; q0 < tile_queue.size(); q0 += merge_max) {
+                const int nq = (int)std::min<size_t>(merge_max, tile_queue.size() - q0);
                 STAIR_CHECK(tile_launches < 48, "internal: more fused launches than work-queue heads");
-                RUN(launch_tile_mlp_batch(tile_queue.data() + q0, nq, tile_ctr + tile_launches, s));
+                RUN(launch_tile_mlp_batch(tile_queue.data() + q0, nq, use_queue ? tile_ctr + tile_launches : nullptr, s));
                 ++tile_launches;
             }
             for (size_t k = lo_; k < hi_; ++k) RUN(run_bucket(pl->buckets[k], (int)k, 2));
@@ -1664,7 +1680,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
         RUN(launch_transpose_many(tb, tiles, s));       // one launch for all 31 images
     }
     // ---- backward chains of the fused tile operators (csrc/tile_mlp.hip): dX = (dZ2 W2 * relu'(Z1)) W1 stays on the tile ----
-    const bool fused = pl->o_wfragT > 0 && tile_mlp_usable(H, T) && pl->drop_p <= 0.0f;
+    const bool fused = pl->o_wfragT > 0 && tile_mlp_usable(H, T) && pl->drop_p <= 0.0f && tile_policy(pl);
     auto WFT = [&](int slot) { return static_cast<const void *>(ws + pl->o_wfragT + (int64_t)slot * H * H); };
     if (fused) {
         bool need[WF_COUNT] = {};

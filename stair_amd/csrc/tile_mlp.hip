@@ -483,6 +483,11 @@ static int tile_mlp_check(const stair_tile_mlp_args &a) {
 int launch_tile_mlp_batch(const stair_tile_mlp_args *args, int n, unsigned *counter, hipStream_t s) {
     STAIR_CHECK(n >= 0 && n <= TM_MAXB, "at most 8 buckets per launch");
     STAIR_CHECK(matmul_mode() == STAIR_MATMUL_BF16X3, "the fused tile operators compute split-bf16 products (STAIR_MATMUL_BF16X3)");
+    // Inside a stream capture the tiles are dealt out round robin: under torch's hipGraph replays the queue form faulted on
+    // the second replay (the ticket word is reset by a captured memset; cause not established -- a raw HIP graph with the same
+    // memset + atomic pattern replays correctly, tools/scratch/graph_memset.hip), and a replayed batch has fixed shapes anyway.
+    hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+    if (counter && hipStreamIsCapturing(s, &cap_status) == hipSuccess && cap_status != hipStreamCaptureStatusNone) counter = nullptr;
     TmParams pp;
     pp.nb = 0; pp.counter = counter; pp.first[0] = 0;
     int order[TM_MAXB], m = 0;
