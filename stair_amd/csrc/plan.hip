@@ -52,6 +52,14 @@ struct stair_ctx {
     std::vector<const float *> ptr;
     std::vector<float *> gptr;           // gradient buffers (training), same ids
     std::unordered_map<std::string, int> by_name;
+    // backward pass: the per-weight gradient products are leaves of the graph, they run on a second stream beside BPTT
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    ~stair_ctx() {
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (side) (void)hipStreamDestroy(side);
+    }
 
     void add(const std::string &name, int64_t n) {
         by_name[name] = (int)names.size();
@@ -1921,6 +1929,20 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
     }
 
     // ---- the deferred weight-gradient products: one long reduction per weight -------------------------------
+    // They are leaves (nothing downstream reads dW before the optimizer), and what follows on `s` -- BPTT through both encoders,
+    // HBM-bound on its saved state -- touches none of their operands: they run on a second stream and meet `s` again at the end.
+    static const bool overlap_tn = [] { const char *e = getenv("STAIR_BWD_OVERLAP"); return !(e && e[0] == '0'); }();
+    hipStream_t s_tn = s;
+    if (overlap_tn) {
+        if (!ctx->side) {
+            STAIR_HIP(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+            STAIR_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+            STAIR_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+        }
+        STAIR_HIP(hipEventRecord(ctx->ev_fork, s));
+        STAIR_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+        s_tn = ctx->side;
+    }
     for (int w = 0; w < WF_COUNT; ++w) {
         if (w == WF_FFD || pl->wg_rows[w] == 0) continue;
         const Lin &l = *lin_of[w];
@@ -1935,8 +1957,9 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
             t.B = map; t.ldb = H; t.b_gstride = TH; t.b_gidx = didx + pl->wg_off_idx[w];
             if (w == WF_TD) { t.row_scale = att; t.rs_gstride = T; t.rs_gidx = didx + pl->wg_off_rs[w]; }
         }
-        RUN(launch_gemm_tn(t, s));
+        RUN(launch_gemm_tn(t, s_tn));
     }
+    if (overlap_tn) STAIR_HIP(hipEventRecord(ctx->ev_join, ctx->side));
 
     // ---- encoders ------------------------------------------------------------------------------------
     {
@@ -1977,6 +2000,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
             RUN(launch_lstm_bwd_weights(enc[0], s));
         }
     }
+    if (overlap_tn) STAIR_HIP(hipStreamWaitEvent(s, ctx->ev_join, 0));      // the optimizer (next on `s`) sees every dW
 #undef RUN
     return 0;
 }
