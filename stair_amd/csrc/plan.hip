@@ -1930,8 +1930,10 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
 
     // ---- the deferred weight-gradient products: one long reduction per weight -------------------------------
     // They are leaves (nothing downstream reads dW before the optimizer), and what follows on `s` -- BPTT through both encoders,
-    // HBM-bound on its saved state -- touches none of their operands: they run on a second stream and meet `s` again at the end.
-    static const bool overlap_tn = [] { const char *e = getenv("STAIR_BWD_OVERLAP"); return !(e && e[0] == '0'); }();
+    // HBM-bound on its saved state -- touches none of their operands, so they CAN run on a second stream beside it
+    // (STAIR_BWD_OVERLAP=1).  Measured (profiles/r03_*): 19.11 ms per 2048-question step with the overlap, 18.72 ms without,
+    // 5.53 against 5.44 ms at 128 questions -- the two streams contend for the same LDS / L2 / HBM paths; off by default.
+    static const bool overlap_tn = [] { const char *e = getenv("STAIR_BWD_OVERLAP"); return e && e[0] == '1'; }();
     hipStream_t s_tn = s;
     if (overlap_tn) {
         if (!ctx->side) {
