@@ -371,37 +371,53 @@ def main():
             if trainer.comm is not None:
                 extras['rccl_ranks_native_comm'] = trainer.comm.ranks()[1]
         if trainer is not None and not args.no_extras:
+            # Supplementary data-parallel legs.  Every rank issues the SAME sequence of torch collectives whatever happens inside a
+            # leg (a rank that fails locally records the error and still takes part), so a local failure cannot hang the job.
+            if not args.supervision:
+                # configs[4] under data parallelism: per-module losses, contrastive pools of the GLOBAL windows via the class table
+                k_s, err = max(3, args.steps // 2), None
+                try:
+                    dt_s, _ = timed(lambda: run_step(B, True), k_s, 2)
+                except Exception as e:
+                    dt_s, err = float('inf'), '%s: %s' % (type(e).__name__, str(e)[:160])
+                    barrier(); barrier()
+                ts = torch.tensor([dt_s if err is None else 1e30], device=device, dtype=torch.float64)
+                dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+                extras['supervised_step_dp'] = ({'error': err} if err else {
+                    'train_questions_per_s': round(B * k_s * world / float(ts.item()), 1), 'ms_per_step': round(float(ts.item()) / k_s * 1e3, 3),
+                    'classes_in_table': len(class_table),
+                    'note': 'BASELINE configs[4]: gradient all-reduce + one [windows, classes] presence all-reduce on the device per step; '
+                            'no host-side collective'})
             if not args.native_allreduce and backend == 'nccl':
-                # the same step with the collective through the C ABI, and the two all-reduces compared bit for bit on one bucket
+                # the same step with the collective through the C ABI (stair_allreduce_grads), and the two all-reduces compared bit for
+                # bit on one bucket
                 from stair_amd.comm import NativeComm
-                comm = NativeComm(rank, world)
+                comm, err, same_local = None, None, 0.0
                 g = torch.Generator(device=device).manual_seed(77 + rank)
                 a = torch.randn(trainer.bucket.numel(), device=device, generator=g)
                 b = a.clone()
                 dist.all_reduce(a)
-                comm.allreduce_(b)
-                same = torch.tensor([1.0 if torch.equal(a, b) else 0.0], device=device)
+                try:
+                    comm = NativeComm(rank, world)
+                    comm.allreduce_(b)
+                    same_local = 1.0 if torch.equal(a, b) else 0.0
+                except Exception as e:
+                    err = '%s: %s' % (type(e).__name__, str(e)[:160])
+                same = torch.tensor([same_local if err is None else -1.0], device=device)
                 dist.all_reduce(same, op=dist.ReduceOp.MIN)
                 del a, b
-                trainer.comm = comm
-                dt_n, _ = timed(lambda: run_step(B, False), max(3, args.steps // 2), 2)
                 k_n = max(3, args.steps // 2)
-                tn = torch.tensor([dt_n], device=device, dtype=torch.float64)
-                dist.all_reduce(tn, op=dist.ReduceOp.MAX)
-                extras['native_allreduce'] = {'train_questions_per_s': round(B * k_n * world / float(tn.item()), 1),
-                                              'ms_per_step': round(float(tn.item()) / k_n * 1e3, 3), 'rccl_ranks': comm.ranks()[1],
-                                              'bitwise_equal_to_torch_allreduce': bool(same.item() == 1.0)}
-                trainer.comm = None
-            if not args.supervision:
-                # configs[4] under data parallelism: per-module losses, contrastive pools of the GLOBAL windows via the class table
-                k_s = max(3, args.steps // 2)
-                dt_s, _ = timed(lambda: run_step(B, True), k_s, 2)
-                ts = torch.tensor([dt_s], device=device, dtype=torch.float64)
-                dist.all_reduce(ts, op=dist.ReduceOp.MAX)
-                extras['supervised_step_dp'] = {'train_questions_per_s': round(B * k_s * world / float(ts.item()), 1),
-                                                'ms_per_step': round(float(ts.item()) / k_s * 1e3, 3), 'classes_in_table': len(class_table),
-                                                'note': 'BASELINE configs[4]: gradient all-reduce + one [windows, classes] presence all-reduce on the '
-                                                        'device per step; no host-side collective'}
+                if float(same.item()) >= 0.0:            # the native communicator works on every rank: time the step through it
+                    trainer.comm = comm
+                    dt_n, _ = timed(lambda: run_step(B, False), k_n, 2)
+                    trainer.comm = None
+                    tn = torch.tensor([dt_n], device=device, dtype=torch.float64)
+                    dist.all_reduce(tn, op=dist.ReduceOp.MAX)
+                    extras['native_allreduce'] = {'train_questions_per_s': round(B * k_n * world / float(tn.item()), 1),
+                                                  'ms_per_step': round(float(tn.item()) / k_n * 1e3, 3), 'rccl_ranks': comm.ranks()[1],
+                                                  'bitwise_equal_to_torch_allreduce': bool(same.item() == 1.0)}
+                else:
+                    extras['native_allreduce'] = {'error': err or 'the native communicator failed on another rank'}
     if not args.no_extras and world == 1:
         # ---- forward-only rate, shared clips, host-fed pipeline (SURVEY 8d "a second figure including H2D") ----
         dt, r_inf = timed(lambda: model.run_programs(programs, spans, video, question, q_lens), 3, 1)
