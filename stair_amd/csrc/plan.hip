@@ -1164,18 +1164,22 @@ int resolve(const stair_ctx *ctx, Weights &W, bool grads) {
     return 0;
 }
 
-// Where the fused tile operators pay (measured, profiles/r03_*: same box, same build, STAIR_TILE_MLP=0 against 1):
-//   inference          32 / 128 / 512 / 2048 questions per batch: 1.36 / 1.49 / 2.19 / 6.12 ms fused, 1.58 / 1.91 / 2.59 / 6.11 ms sequenced
-//   training step      4.47 / 5.40 / 8.21 / 20.7 ms fused, 4.60 / 5.70 / 8.25 / 18.8 ms sequenced
-// A training tile also WRITES its two saved activations and its backward chain adds dX with atomics; once a bucket holds
-// several rounds of tiles those bytes, not the launches, set the time, and the 128 / 256-row GEMMs (which reuse a weight tile
-// over more rows) win.  Inference plans always run fused; training plans while the largest tile bucket stays within ~1.25
-// rounds of the chip.  STAIR_TILE_TRAIN=1 / 0 forces the choice for training plans.
-bool tile_policy(const stair_plan *pl) {
+// Where the fused tile operators pay (measured on one box per pair, same build, STAIR_TILE_MLP / STAIR_TILE_TRAIN = 0 against 1;
+// profiles/r03_*):
+//   inference       32 / 128 / 512 / 2048 questions per batch: 1.36 / 1.49 / 2.19 / 5.6-6.1 ms fused, 1.58 / 1.91 / 2.59 / 6.1 ms sequenced
+//   training step   32 / 128 / 512 / 1024 / 2048: 4.47 / 5.34 / 8.01 / 12.08 / 18.50 ms fused, 4.60 / 5.71 / 8.33 / 12.18 / 18.85 ms sequenced
+// (the training figures after two fixes that were worth 2.2 ms at 2048 questions: the backward chain's accumulation as
+// 256-byte wave-instructions instead of 16-byte-strided lanes -- float atomics run at full rate only in that shape -- and
+// every mask load / activation save between layers row-wise through the fp32 staging instead of 32-byte pieces from the
+// accumulator layout).  Fused is the default for both kinds of plan; STAIR_TILE_TRAIN=0 / STAIR_TILE_TRAIN_BWD=0 put a
+// training plan's forward / backward back on the GEMM sequences.
+bool tile_policy(const stair_plan *pl, bool backward = false) {
     if (!pl->train) return true;
     static const int force = [] { const char *e = getenv("STAIR_TILE_TRAIN"); return e ? atoi(e) : -1; }();
+    static const int force_bwd = [] { const char *e = getenv("STAIR_TILE_TRAIN_BWD"); return e ? atoi(e) : -1; }();
+    if (backward && force_bwd >= 0) return force_bwd != 0;
     if (force >= 0) return force != 0;
-    return pl->maxI <= 320;
+    return true;
 }
 
 // dense helper: C[g][r] = act(rs * A[g][r] W^T + b)
@@ -1688,7 +1692,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
         RUN(launch_transpose_many(tb, tiles, s));       // one launch for all 31 images
     }
     // ---- backward chains of the fused tile operators (csrc/tile_mlp.hip): dX = (dZ2 W2 * relu'(Z1)) W1 stays on the tile ----
-    const bool fused = pl->o_wfragT > 0 && tile_mlp_usable(H, T) && pl->drop_p <= 0.0f && tile_policy(pl);
+    const bool fused = pl->o_wfragT > 0 && tile_mlp_usable(H, T) && pl->drop_p <= 0.0f && tile_policy(pl, true);
     auto WFT = [&](int slot) { return static_cast<const void *>(ws + pl->o_wfragT + (int64_t)slot * H * H); };
     if (fused) {
         bool need[WF_COUNT] = {};

@@ -9,7 +9,7 @@
 //   Temporal   (:310-327)  ReLU(Lin(r_t feat_t)), then LayerNorm over H
 //   Superlative(:220-248)  Localize's two layers (the scores against Ka = T action rows stay in cosine_attn_grouped_kernel)
 //
-// Mapping to the CU (8 waves, one workgroup per CU, 140 KB of LDS):
+// Mapping to the CU (8 waves, one workgroup per CU, 129 KB of LDS):
 //   * the tile lives in LDS as bf16 hi + lo planes (x = hi + lo), laid out per 32-wide k stage as [64 rows][4 slots of 16 B]
 //     with the slot swizzle of csrc/gemm_planes.hip (conflict-free ds_read_b128 fragment reads);
 //   * a layer is computed TRANSPOSED, Z^T = W . tile^T: the weight rows are the MFMA A operand.  Wave w owns output columns
@@ -18,11 +18,12 @@
 //     its own fragments global -> VGPR with three k steps in flight; the tile (the B operand) is the only thing read from
 //     LDS, 4 KB per wave and k step for 12 v_mfma_f32_32x32x16_bf16 (hi.hi + lo.hi + hi.lo, fp32 accumulate);
 //   * the k loop has NO barrier (the tile is read-only during a layer, W is private to the wave); the workgroup meets only
-//     where the tile is rewritten: in the transposed accumulator layout a lane holds, for its frame t, runs of 4 consecutive
-//     output columns, i.e. 8-byte pieces of the next layer's bf16 operand row -- written back with ds_write_b64;
-//   * the last layer's output is staged once as fp32 [T][H] in LDS (rows 516 floats apart) and every tail -- coalesced row
-//     stores, the sum over frames, cosine / dot products per row, LayerNorm -- reads it from there.
-// Training plans additionally write each activation the backward pass needs ONCE, from registers / the staged rows.
+//     between layers: every layer's output is staged as fp32 [T][H] rows in LDS (rows 516 floats apart, over the dead image),
+//     and everything that touches HBM there is ROW-wise -- a wave per row, a lane per 8 consecutive columns, 2 KB contiguous
+//     per access: the saved activation a backward pass needs, relu'(saved activation) of a backward chain, FilterFrame's
+//     attention -- before the rows are split into the next layer's bf16 image;
+//   * every tail -- coalesced row stores, the sum over frames, cosine / dot products per row, LayerNorm, atomic accumulation
+//     in 256-byte wave-instructions -- reads the staged rows of the last layer.
 #include <algorithm>
 #include <cstdlib>
 
@@ -45,8 +46,7 @@ constexpr int TM_STAGE = 8192;                  // one 32-wide k stage of the ti
 constexpr int TM_IMG = (TM_H / 32) * TM_STAGE;  // 128 KB
 constexpr int TM_FLD = TM_H + 4;                // row stride of the fp32 staging (floats): 16-byte rows, conflict-free float4 writes
 constexpr int TM_F_BYTES = TM_ROWS * TM_FLD * 4;
-constexpr int TM_RED_OFF = TM_F_BYTES;          // cross-wave scratch behind both images: [8 waves][64 rows] floats
-constexpr int TM_LDS = TM_RED_OFF + 8 * 64 * 4;
+constexpr int TM_LDS = TM_F_BYTES;              // 129 KB: the fp32 staging overlays the bf16 image
 static_assert(TM_F_BYTES >= TM_IMG, "the fp32 staging covers the bf16 image");
 
 // slot swizzle of the tile image (as pl_swz of csrc/gemm_planes.hip)
@@ -91,7 +91,6 @@ template <bool NT>
 __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float *F = reinterpret_cast<float *>(lds);
-    float *red = reinterpret_cast<float *>(lds + TM_RED_OFF);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int T = pp.a[0].T;
@@ -211,11 +210,14 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
 #undef TM_LOADZ
 #undef TM_LOADW
             }
-            // ---- bias + activation in the accumulator layout: lane (r, h) holds frame t = 32 tt + r, columns
-            //      n = 64 wave + 32 nt + 8 q + 4 h + i for e = 4 q + i ----------------------------------------------------
+            // ---- bias + ReLU in the accumulator layout: lane (r, h) holds frame t = 32 tt + r, columns
+            //      n = 64 wave + 32 nt + 8 q + 4 h + i for e = 4 q + i -- then the tile goes to LDS as fp32 rows ---------------
             const float *bias = p.bias[ph];
             const int act = p.act[ph];
-            const float *amask = act == 3 ? p.act_mask[ph] + (int64_t)inst * T * TM_H : nullptr;
+            const bool last = ph + 1 == p.n_layers;
+            // between two layers of an inference plan nothing touches HBM: the accumulators go straight into the next image
+            const bool direct = !last && !p.save[ph] && act != 3 && !(p.mid_rowdot && ph == 1);
+            __syncthreads();                      // every wave has finished reading the tile image of this layer
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -223,83 +225,71 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
                     const v4f bv = bias ? *reinterpret_cast<const v4f *>(bias + 64 * wave + 32 * nt + 8 * q + 4 * h) : v4f{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int tt = 0; tt < 2; ++tt) {
-                        v4f mv = {1.f, 1.f, 1.f, 1.f};
-                        if (amask && 32 * tt + r < T) mv = tm_ld<NT>(amask + (int64_t)(32 * tt + r) * TM_H + 64 * wave + 32 * nt + 8 * q + 4 * h);
+                        const int t = 32 * tt + r;
+                        v4f z;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            float v = acc[nt][tt][4 * q + i] + bv[i];
-                            if (act == 1) v = fmaxf(v, 0.0f);
-                            if (act == 3) v = mv[i] > 0.f ? v * p.act_scale : 0.f;     // backward chain: x relu'(saved activation)
-                            acc[nt][tt][4 * q + i] = v;
+                            z[i] = acc[nt][tt][4 * q + i] + bv[i];
+                            if (act == 1) z[i] = fmaxf(z[i], 0.0f);
                         }
-                    }
-                }
-            const bool last = ph + 1 == p.n_layers;
-            __syncthreads();                      // every wave has finished reading the tile image of this layer
-            if (!last) {
-                // the activation the backward pass needs, written once from registers (32-byte pieces, merged in L2)
-                float *sv = p.save[ph];
-                float scale[2] = {1.0f, 1.0f};
-                if (p.mid_rowdot && ph == 1) {
-                    // FilterFrame: a_t = sigmoid(w[:H] . f_t + extra + b) from the registers, then the tile becomes a_t f_t
-                    float part[2] = {0.f, 0.f};
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const v4f wv = *reinterpret_cast<const v4f *>(p.vw + 64 * wave + 32 * nt + 8 * q + 4 * h);
-#pragma unroll
-                            for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) part[tt] += acc[nt][tt][4 * q + i] * wv[i];
-                        }
-#pragma unroll
-                    for (int tt = 0; tt < 2; ++tt) {
-                        part[tt] += __shfl_xor(part[tt], 32, 64);
-                        if (h == 0) red[wave * 64 + 32 * tt + r] = part[tt];
-                    }
-                    __syncthreads();
-                    const float add = p.vb[0] + (p.extra ? p.extra[inst] : 0.f);
-#pragma unroll
-                    for (int tt = 0; tt < 2; ++tt) {
-                        float d = 0.f;
-#pragma unroll
-                        for (int w8 = 0; w8 < 8; ++w8) d += red[w8 * 64 + 32 * tt + r];
-                        scale[tt] = sigmoid_acc(d + add);
-                        if (p.rs_out && wave == 0 && h == 0 && 32 * tt + r < T) p.rs_out[(int64_t)inst * T + 32 * tt + r] = scale[tt];
-                    }
-                }
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                    for (int tt = 0; tt < 2; ++tt) {
-                        const int t = 32 * tt + r;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            v4f z = {acc[nt][tt][4 * q], acc[nt][tt][4 * q + 1], acc[nt][tt][4 * q + 2], acc[nt][tt][4 * q + 3]};
-                            if (sv && t < T) tm_st<NT>(sv + ((int64_t)inst * T + t) * TM_H + 64 * wave + 32 * nt + 8 * q + 4 * h, z);
-                            z *= scale[tt];
+                        if (direct) {             // 4 consecutive columns of frame t = 8 bytes of the next operand row
                             bf16x4 zh4, zl4;
 #pragma unroll
                             for (int i = 0; i < 4; ++i) { zh4[i] = (__bf16)z[i]; zl4[i] = (__bf16)(z[i] - (float)zh4[i]); }
                             const int off = (2 * wave + nt) * TM_STAGE + (t * 4 + (q ^ tm_swz(t))) * 16 + 8 * h;
                             *reinterpret_cast<bf16x4 *>(lds + off) = zh4;
                             *reinterpret_cast<bf16x4 *>(lds + off + 4096) = zl4;
+                        } else {
+                            *reinterpret_cast<v4f *>(F + t * TM_FLD + 64 * wave + 32 * nt + 8 * q + 4 * h) = z;
                         }
                     }
-                __syncthreads();
-            } else {
-                // ---- the last layer's output as fp32 rows in LDS ------------------------------------------------------
+                }
+            __syncthreads();
+            if (!last && !direct) {
+                // ---- between two layers, ROW-wise (a wave per row, a lane per 8 consecutive columns: every global access is a
+                //      contiguous 2 KB row): relu'(saved activation) of a backward chain, the activation a backward pass will
+                //      need, FilterFrame's attention; then the rows become the next layer's bf16 hi / lo operand image.
+                //      The rows are read into registers first: the image overlays the staging. -----------------------------------
+                float *sv = p.save[ph];
+                const float *amask = act == 3 ? p.act_mask[ph] + (int64_t)inst * T * TM_H : nullptr;
+                const bool rowdot = p.mid_rowdot && ph == 1;
+                v4f rowv[8][2];
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
+                for (int j = 0; j < 8; ++j) {
+                    const int t = wave + 8 * j;
+                    v4f a = *reinterpret_cast<const v4f *>(F + t * TM_FLD + 8 * lane), b = *reinterpret_cast<const v4f *>(F + t * TM_FLD + 8 * lane + 4);
+                    if (t < T) {
+                        if (amask) {
+                            const v4f m0 = tm_ld<NT>(amask + (int64_t)t * TM_H + 8 * lane), m1 = tm_ld<NT>(amask + (int64_t)t * TM_H + 8 * lane + 4);
 #pragma unroll
-                    for (int tt = 0; tt < 2; ++tt) {
-                        const int t = 32 * tt + r;
+                            for (int i = 0; i < 4; ++i) { a[i] = m0[i] > 0.f ? a[i] * p.act_scale : 0.f; b[i] = m1[i] > 0.f ? b[i] * p.act_scale : 0.f; }
+                        }
+                        if (sv) {
+                            float *d = sv + ((int64_t)inst * T + t) * TM_H + 8 * lane;
+                            tm_st<NT>(d, a); tm_st<NT>(d + 4, b);
+                        }
+                        if (rowdot) {             // FilterFrame: a_t = sigmoid(w[:H] . f_t + extra + b); the next layer runs on a_t f_t
+                            const v4f w0 = *reinterpret_cast<const v4f *>(p.vw + 8 * lane), w1 = *reinterpret_cast<const v4f *>(p.vw + 8 * lane + 4);
+                            float d = 0.f;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            *reinterpret_cast<v4f *>(F + t * TM_FLD + 64 * wave + 32 * nt + 8 * q + 4 * h) =
-                                v4f{acc[nt][tt][4 * q], acc[nt][tt][4 * q + 1], acc[nt][tt][4 * q + 2], acc[nt][tt][4 * q + 3]};
+                            for (int i = 0; i < 4; ++i) d += a[i] * w0[i] + b[i] * w1[i];
+                            const float at = sigmoid_acc(wave_sum(d) + p.vb[0] + (p.extra ? p.extra[inst] : 0.f));
+                            if (p.rs_out && lane == 0) p.rs_out[(int64_t)inst * T + t] = at;
+                            a *= at; b *= at;
+                        }
                     }
+                    rowv[j][0] = a; rowv[j][1] = b;
+                }
+                __syncthreads();                  // every row is in registers: the staging may be overwritten
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int t = wave + 8 * j;
+                    bf16x8 hi, lo;
+                    tm_split8(rowv[j][0], rowv[j][1], hi, lo);
+                    const int off = (lane >> 2) * TM_STAGE + (t * 4 + ((lane & 3) ^ tm_swz(t))) * 16;
+                    *reinterpret_cast<bf16x8 *>(lds + off) = hi;
+                    *reinterpret_cast<bf16x8 *>(lds + off + 4096) = lo;
+                }
                 __syncthreads();
             }
         }
@@ -322,14 +312,12 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
                 }
                 break;
             case STAIR_TILE_ACCUMULATE:               // backward chains: dX added into a gradient tile several instances may share
+                // one dword per lane, 256 contiguous bytes per wave-instruction: the shape float atomics run at full rate in
+                // (MI355X_MICROARCH.md "Global float atomics"; 16-byte-strided lanes spread an instruction over 1 KB)
                 for (int t = wave; t < T; t += 8) {
                     float *dst = p.out + oslot * p.out_gstride + (int64_t)t * TM_H;
 #pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-                        const v4f v = *reinterpret_cast<const v4f *>(F + t * TM_FLD + 256 * half + 4 * lane);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) unsafeAtomicAdd(dst + 256 * half + 4 * lane + i, v[i]);
-                    }
+                    for (int c = 0; c < TM_H / 64; ++c) unsafeAtomicAdd(dst + 64 * c + lane, F[t * TM_FLD + 64 * c + lane]);
                 }
                 break;
             case STAIR_TILE_SUM_ROWS: {               // Filter: sum over the clip's own frames (modules.py:374,376)
