@@ -74,7 +74,7 @@ class Trainer:
                  module_loss_weight=1.0, contrastive_window=32, no_intermediate=('FilterFrame',),
                  scheduler_start_factor=1.0, scheduler_end_factor=0.1, scheduler_total_iters=200000, world=1,
                  skip_untouched='ever', train_module_before_iters=1e10, train_decoder_after_iters=0, rank=0,
-                 dropout=None, dropout_seed=0, native_allreduce=False, class_table=None):
+                 dropout=None, dropout_seed=0, native_allreduce=False, class_table=None, global_batch=None):
         """skip_untouched: 'ever'   -- a parameter is skipped by Adam until the first window that sends it a gradient
                                       (torch 1.13, which the reference pins: zero_grad() keeps zero tensors afterwards);
                            'window' -- skipped in every window that does not touch it (torch >= 2.0, set_to_none=True)."""
@@ -84,6 +84,10 @@ class Trainer:
         # class_table (losses.ClassTable, the same on every rank): the contrastive pools of a data-parallel step are then
         # exchanged as a [windows, classes] presence matrix summed on the device -- without it every supervised step at
         # world > 1 gathers the ranks' class lists through the host (all_gather_object), a blocking second collective.
+        # global_batch: the window size summed over all ranks when it is the same every step (a data loader with drop_last).
+        # Without it -- here or in step() -- every step at world > 1 agrees on the size with an extra all-reduce and a host
+        # read-back (.item(): the host then waits for the stream, which ends its run-ahead); ragged last windows need that.
+        self.global_batch = global_batch
         self.class_table = class_table
         self.allreduce_events = None                        # set to [] to collect (start, end) events around the step's collective
         self.before_iters, self.after_iters, self.rank = train_module_before_iters, train_decoder_after_iters, rank
@@ -150,6 +154,8 @@ class Trainer:
         Returns (per-question decoder CE of the local shard, BatchResult)."""
         from . import losses as L
         n = len(programs)
+        if global_batch is None:
+            global_batch = self.global_batch
         if global_batch is None and self.world > 1:           # ragged shards: the window is the SUM of the shard sizes
             import torch.distributed as dist
             cnt = torch.tensor([n], dtype=torch.int64, device=self.flat_g.device if dist.get_backend() == 'nccl' else 'cpu')
