@@ -152,6 +152,14 @@ typedef struct stair_gemm_tn_args {
                           row matrix (rows_per_group = 1, no index, no row scale), K % 8 == 0 and a split matmul mode */
 } stair_gemm_tn_args;
 int stair_gemm_tn_f32(const stair_gemm_tn_args *args, stair_stream stream);
+/* The same contraction as one long reduction with a deterministic result (csrc/gemm_tn_x3tr.hip): M is cut into <= 32 slabs, each
+ * slab's partial [N, K] product (and partial column sums) is stored to `scratch`, and a second launch adds the slabs to C / colsum
+ * in slab order -- no atomics, bit-identical from run to run.  This is how stair_plan_backward forms the weight gradient of every
+ * module-level nn.Linear (one call per WEIGHT over all instances that used it; autograd of /root/reference/video_nmn/modules.py's
+ * Linear layers, train_module.py:408).  Split matmul mode only; fp32 operands; N % 256 == 0, K % 128 == 0, ldc == K; M and
+ * rows_per_group multiples of 32; colsum2 unused.  scratch: stair_gemm_tn_slabs_scratch(M, N, K) floats. */
+int64_t stair_gemm_tn_slabs_scratch(int64_t M, int64_t N, int64_t K);
+int stair_gemm_tn_slabs(const stair_gemm_tn_args *args, float *scratch, int64_t scratch_floats, stair_stream stream);
 
 /* ---- pre-split operands: bf16 planes staged by LDS-DMA (csrc/gemm_planes.hip) -----------------------------------
  * x [n] fp32 -> hi[i] = bf16(x[i]) (round to nearest even), lo[i] = bf16(x[i] - hi[i]); x = hi + lo + O(2^-17 |x|).

@@ -122,6 +122,8 @@ SIGNATURES = [
     ('stair_pack_wfrag', C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     ('stair_gemm_f32', C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     ('stair_gemm_tn_f32', C.c_int, [C.POINTER(GemmTnArgs), C.c_void_p]),
+    ('stair_gemm_tn_slabs_scratch', C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),
+    ('stair_gemm_tn_slabs', C.c_int, [C.POINTER(GemmTnArgs), C.c_void_p, C.c_int64, C.c_void_p]),
     ('stair_split_planes', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     ('stair_split_planes_tiled', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     ('stair_gemm_planes', C.c_int, [C.POINTER(GemmPlanesArgs), C.c_void_p]),

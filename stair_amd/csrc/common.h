@@ -78,6 +78,13 @@ struct TransposeBatch {          // up to 32 matrices transposed by one launch (
 };
 int launch_transpose_many(const TransposeBatch &tb, int total_tiles, hipStream_t s);
 int launch_gemm_tn_tr(const stair_gemm_tn_args &a, hipStream_t s);      // -1: not this kernel's shape
+// csrc/gemm_tn_x3tr.hip: slab partials of a weight-gradient product into scratch; tn_x3tr_flush adds every queued product's slabs
+// to its destination in fixed order (one launch), on the same stream and thread
+bool tn_x3tr_takes(const stair_gemm_tn_args &a);
+int tn_x3tr_slabs(int64_t M);
+int64_t tn_x3tr_scratch_floats(int64_t M, int64_t N, int64_t K);
+int launch_gemm_tn_x3tr(const stair_gemm_tn_args &a, float *scratch, hipStream_t s);
+int tn_x3tr_flush(hipStream_t s);
 int launch_lstm_rec_coop(const stair_lstm_args &a, hipStream_t s);
 bool lstm_coop_usable(int Hh);
 int64_t lstm_coop_ws_bytes(int n);

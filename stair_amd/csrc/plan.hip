@@ -353,7 +353,7 @@ struct stair_plan {
     // block of wg_dz[w]; the matching X operand is the input tiles gathered through wg_off_idx[w] (first-layer weights) or the
     // saved first activations, which lie in the same order in wg_sx[w] (second-layer weights).  ONE long-reduction TN GEMM per
     // weight at the end of stair_plan_backward instead of one per bucket.
-    int64_t wg_rows[WF_COUNT] = {}, wg_dz[WF_COUNT] = {}, wg_sx[WF_COUNT] = {}, wg_off_idx[WF_COUNT] = {}, wg_off_rs[WF_COUNT] = {};
+    int64_t wg_rows[WF_COUNT] = {}, wg_dz[WF_COUNT] = {}, wg_sx[WF_COUNT] = {}, wg_off_idx[WF_COUNT] = {}, wg_off_rs[WF_COUNT] = {}, wg_part[WF_COUNT] = {};
     // workspace layout (float offsets)
     int64_t o_idx = 0, o_vec = 0, o_map = 0, o_att = 0, o_tok = 0, o_qfeat = 0, o_vhn = 0, o_xpv = 0, o_xpt = 0,
             o_bias = 0, o_wpack = 0, o_wplanes = 0, o_coop = 0, o_coop2 = 0, o_splitk = 0, o_tmpA = 0, o_tmpB = 0, o_kbuf = 0, o_cat = 0, o_hid = 0, o_rs = 0, o_sup = 0, o_extra = 0,
@@ -925,6 +925,9 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
             pl->wg_rows[w] = rows0[w] + rows3[w];
             if (pl->wg_rows[w]) pl->wg_dz[w] = take(pl->wg_rows[w] * T * H, 64);
             if (rows3[w]) pl->wg_sx[w] = take(rows3[w] * T * H, 64);
+            // slab partials of the weight's one long weight-gradient reduction (csrc/gemm_tn_x3tr.hip: stored, then added in fixed order)
+            if (pl->wg_rows[w] && H % 256 == 0 && T % 32 == 0)
+                pl->wg_part[w] = take(tn_x3tr_scratch_floats(pl->wg_rows[w] * T, H, H), 64);
         }
         int64_t at[WF_COUNT] = {};
         for (Bucket &b : pl->buckets) {
@@ -968,6 +971,11 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
         pl->o_gExtra = take(I, 64);
     }
     pl->total = align_up(o, 64);
+    if (getenv("STAIR_PLAN_DEBUG") && pl->train) {
+        fprintf(stderr, "weight-gradient regions (instances of T rows):");
+        for (int w = 0; w < WF_COUNT; ++w) fprintf(stderr, " %ld", (long)pl->wg_rows[w]);
+        fprintf(stderr, "\n");
+    }
     if (getenv("STAIR_PLAN_DEBUG"))
         fprintf(stderr, "plan build total %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
     *out = plp.release();
@@ -1963,8 +1971,10 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
             t.B = map; t.ldb = H; t.b_gstride = TH; t.b_gidx = didx + pl->wg_off_idx[w];
             if (w == WF_TD) { t.row_scale = att; t.rs_gstride = T; t.rs_gidx = didx + pl->wg_off_rs[w]; }
         }
-        RUN(launch_gemm_tn(t, s_tn));
+        if (pl->wg_part[w] && tn_x3tr_takes(t)) RUN(launch_gemm_tn_x3tr(t, ws + pl->wg_part[w], s_tn));      // deterministic: no atomics
+        else RUN(launch_gemm_tn(t, s_tn));
     }
+    RUN(tn_x3tr_flush(s_tn));                 // dW, db += the slabs of every product above, in slab order: one launch
     if (overlap_tn) STAIR_HIP(hipEventRecord(ctx->ev_join, ctx->side));
 
     // ---- encoders ------------------------------------------------------------------------------------
@@ -2137,8 +2147,10 @@ extern "C" int stair_plan_regions(stair_plan *pl, const stair_ctx *ctx, const ch
             if (b.dzC >= 0) add("dzC", b.dzC, (int64_t)b.cnt * T * H);
             if (b.gRow >= 0) add("gRow", b.gRow, (int64_t)b.cnt * H);
         }
-        for (int w = 0; w < WF_COUNT; ++w)
+        for (int w = 0; w < WF_COUNT; ++w) {
             if (pl->wg_rows[w]) add("wg_dz" + std::to_string(w), pl->wg_dz[w], pl->wg_rows[w] * T * H);
+            if (pl->wg_part[w]) add("wg_part" + std::to_string(w), pl->wg_part[w], tn_x3tr_scratch_floats(pl->wg_rows[w] * T, H, H));
+        }
         add("gV0", pl->o_gV0, Vv * 2 * H);
         add("gV1", pl->o_gV1, Vv * 2 * H);
         add("gCat", pl->o_gCat, Vv * 3 * H);

@@ -132,7 +132,7 @@ def gemm_planes(a_hi, a_lo, w_hi, w_lo, bias=None, act=None, out=None):
 
 
 def gemm_tn(A, B, Cmat, M, N, K, rows_per_group=1, b_gstride=None, b_gidx=None, row_scale=None, rs_gstride=0,
-            rs_gidx=None, colsum=None, colsum2=None, lda=None):
+            rs_gidx=None, colsum=None, colsum2=None, lda=None, deterministic=False):
     """Cmat[N,K] += A[M,N]^T @ (rs * B[M,K]) -- weight gradients (see stair_gemm_tn_args); colsum[N] (and
     colsum2) += column sums of A, the bias gradient of the same layer."""
     a = GemmTnArgs()
@@ -146,6 +146,11 @@ def gemm_tn(A, B, Cmat, M, N, K, rows_per_group=1, b_gstride=None, b_gidx=None, 
     a.M, a.rows_per_group, a.N, a.K = M, rows_per_group, N, K
     a.colsum = colsum.data_ptr() if colsum is not None else None
     a.colsum2 = colsum2.data_ptr() if colsum2 is not None else None
+    if deterministic:           # slab partials + fixed-order reduction (stair_gemm_tn_slabs): bit-identical from run to run
+        n = lib.stair_gemm_tn_slabs_scratch(M, N, K)
+        scratch = torch.empty(n, device=A.device, dtype=torch.float32)
+        check(lib.stair_gemm_tn_slabs(C.byref(a), scratch.data_ptr(), n, _stream()))
+        return
     check(lib.stair_gemm_tn_f32(C.byref(a), _stream()))
 
 
