@@ -249,6 +249,10 @@ typedef struct stair_lstm_bwd_args {
     const int32_t *seq_len; /* optional, as in stair_lstm_args (the gate-gradient rows past a sequence's length are cleared) */
     void *coop_ws; int64_t coop_ws_bytes; /* optional: >= stair_lstm_coop_bwd_ws_bytes(n), 256-byte aligned -> cooperative BPTT (Hh = 256, split mode) */
     uint32_t *status; /* optional sticky timeout word, as in stair_lstm_args */
+    float *tn_ws; int64_t tn_ws_floats; /* optional scratch for the slab-reduced weight-gradient products (stair_gemm_tn_slabs): when it is
+                                           large enough, dW_hh (and dW_ih on fp32 rows) are formed without atomics; their sums reach the
+                                           dw_* / db_* buffers at the END of the stair_plan_backward that passed the scratch (the plan
+                                           runner's use; leave NULL in direct calls) */
 } stair_lstm_bwd_args;
 int64_t stair_lstm_coop_bwd_ws_bytes(int32_t n);
 int stair_lstm_bidir_bwd(const stair_lstm_bwd_args *args, stair_stream stream);

@@ -71,7 +71,7 @@ class LstmBwdArgs(C.Structure):
                 ('whh_pack_ws', C.c_void_p), ('hprev_ws', C.c_void_p),
                 ('dw_ih', C.c_void_p * 2), ('dw_hh', C.c_void_p * 2), ('db_ih', C.c_void_p * 2), ('db_hh', C.c_void_p * 2),
                 ('x_bf16', C.c_void_p), ('seq_len', C.c_void_p), ('coop_ws', C.c_void_p), ('coop_ws_bytes', C.c_int64),
-                ('status', C.c_void_p)]
+                ('status', C.c_void_p), ('tn_ws', C.c_void_p), ('tn_ws_floats', C.c_int64)]
 
 
 class TileMlpArgs(C.Structure):

@@ -58,7 +58,7 @@ __device__ __forceinline__ bf16x8 join8(bf16x4 a, bf16x4 b) { return __builtin_s
 
 }  // namespace
 
-template <bool GIDX, bool RS>
+template <bool GIDX, bool RS, bool KTAIL>
 __global__ __launch_bounds__(512, 1) void gemm_tn_x3tr_kernel(XtParams p) {
     extern __shared__ __attribute__((aligned(16))) char xl[];       // [2 stages][dZ hi | dZ lo | X hi | X lo]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -126,14 +126,18 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x3tr_kernel(XtParams p) {
     }
     const float *a_src = p.A + (m_first + row) * p.lda + n0 + 16 * seg;
     const int64_t a_step = (int64_t)XT_ROWS * p.lda;
-    const int b_off = row * (int)p.ldb + k0 + 8 * seg;
+    // K % 128 != 0 (KTAIL; the text encoder's 300 input columns): the two float4 of a thread that lie past K are read from
+    // column 0 instead and multiplied by zero, and the partial tile's columns past K are not stored
+    const int kc = k0 + 8 * seg;
+    const float bm0 = (!KTAIL || kc < p.K) ? 1.0f : 0.0f, bm1 = (!KTAIL || kc + 4 < p.K) ? 1.0f : 0.0f;
+    const int b_off0 = row * (int)p.ldb + ((!KTAIL || kc < p.K) ? kc : 0), b_off1 = row * (int)p.ldb + ((!KTAIL || kc + 4 < p.K) ? kc + 4 : 0);
     auto load = [&](XtRegs &g) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) g.a[i] = *(const v4f *)(a_src + 4 * i);
         a_src += a_step;
-        const float *bs = p.B + (int64_t)gxs[gl] * p.b_gstride + (int64_t)r0 * p.ldb + b_off;
-        g.b[0] = *(const v4f *)bs;
-        g.b[1] = *(const v4f *)(bs + 4);
+        const float *bs = p.B + (int64_t)gxs[gl] * p.b_gstride + (int64_t)r0 * p.ldb;
+        g.b[0] = *(const v4f *)(bs + b_off0);
+        g.b[1] = *(const v4f *)(bs + b_off1);
         if (RS) g.rs = p.rs[(int64_t)grs[gl] * p.rs_gstride + r0 + row];
         const bool wrap = r0 + XT_ROWS >= p.rpg;
         gl += wrap ? 1 : 0;
@@ -161,7 +165,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x3tr_kernel(XtParams p) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float v = RS ? g.b[i][e] * g.rs : g.b[i][e];
+                float v = RS ? g.b[i][e] * g.rs : g.b[i][e];
+                if (KTAIL) v *= i ? bm1 : bm0;
                 const __bf16 hv = (__bf16)v;
                 bh[4 * i + e] = hv;
                 bl[4 * i + e] = (__bf16)(v - (float)hv);
@@ -203,6 +208,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x3tr_kernel(XtParams p) {
     load(g1);
     write(0, g0);
     int s = 0;
+    // (Tried: the two waves of a SIMD running a stage's two phases in opposite order -- 5 % slower.  Parts compiled out at
+    // M = 109 056: loads + split + writes alone 0.52 of the full time, loads + multiplies alone 0.76: the phases add up.)
     for (; s + 4 <= S; s += 2) {                                     // steady state: both halves have a stage to load, no branches
         __syncthreads();
         load(g0);                                                    // stage s + 2
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x3tr_kernel(XtParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int n = n0 + 64 * wn + 32 * i + 8 * (e >> 2) + 4 * kg + (e & 3);
-                P[(int64_t)n * p.K + k] = acc[i][t][e];
+                if (!KTAIL || k < p.K) P[(int64_t)n * p.K + k] = acc[i][t][e];
             }
         }
     if (cs_on != 0.0f) {                                             // uniform per block
@@ -288,12 +295,17 @@ int64_t tn_x3tr_scratch_floats(int64_t M, int64_t N, int64_t K) { return (int64_
 
 bool tn_x3tr_takes(const stair_gemm_tn_args &a) {
     static const bool on = [] { const char *e = getenv("STAIR_GEMM_TN_X3TR"); return !(e && e[0] == '0'); }();
-    if (!on || a.b_is_bf16 || a.colsum2 || matmul_mode() != STAIR_MATMUL_BF16X3) return false;
-    if (a.N % 256 || a.K % 128 || a.M % XT_ROWS || a.M < 2 * XT_ROWS || a.rows_per_group % XT_ROWS) return false;
+    if (!on || a.b_is_bf16 || matmul_mode() != STAIR_MATMUL_BF16X3) return false;
+    if (a.N % 256 || a.K % 4 || a.K < 4 || a.M % XT_ROWS || a.M < 2 * XT_ROWS || a.rows_per_group < 1) return false;
+    if (a.rows_per_group % XT_ROWS && (a.rows_per_group != 1 || a.b_gidx || a.row_scale || a.b_gstride != a.ldb)) return false;   // groups of whole stages, or a plain row matrix
+    if (a.K % 128 && (a.b_gidx || a.row_scale)) return false;
+    if (a.colsum2 && !a.colsum) return false;
     if (a.lda % 4 || a.ldb % 4 || a.ldc != a.K || a.b_gstride % 4) return false;
-    if (a.M / tn_x3tr_slabs(a.M) / a.rows_per_group + 3 > XT_MAXGRP) return false;       // a slab's gather indices are staged in LDS
+    const int64_t rpg = a.rows_per_group % XT_ROWS ? a.M : a.rows_per_group;
+    if (a.M / tn_x3tr_slabs(a.M) / rpg + 3 > XT_MAXGRP) return false;               // a slab's gather indices are staged in LDS
     if ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.B) | reinterpret_cast<uintptr_t>(a.C)) & 15) return false;
     if (a.colsum && (reinterpret_cast<uintptr_t>(a.colsum) & 15)) return false;
+    if (a.colsum2 && (reinterpret_cast<uintptr_t>(a.colsum2) & 15)) return false;
     return true;
 }
 
@@ -304,26 +316,32 @@ int launch_gemm_tn_x3tr(const stair_gemm_tn_args &a, float *scratch, hipStream_t
     XtParams p;
     p.A = a.A; p.lda = a.lda; p.B = a.B; p.ldb = a.ldb; p.b_gstride = a.b_gstride; p.b_gidx = a.b_gidx;
     p.rs = a.row_scale; p.rs_gstride = a.rs_gstride; p.rs_gidx = a.rs_gidx;
-    p.N = a.N; p.K = a.K; p.rpg = a.rows_per_group; p.stages = a.M / XT_ROWS; p.nslab = tn_x3tr_slabs(a.M);
-    p.tilesK = a.K / 128;
+    p.N = a.N; p.K = a.K; p.rpg = a.rows_per_group % XT_ROWS ? a.M : a.rows_per_group;       // a plain row matrix is one group of M rows
+    if (a.rows_per_group % XT_ROWS) p.b_gstride = 0; p.stages = a.M / XT_ROWS; p.nslab = tn_x3tr_slabs(a.M);
+    p.tilesK = (a.K + 127) / 128;
     p.P = scratch; p.Pc = a.colsum ? scratch + (int64_t)p.nslab * a.N * a.K : nullptr;
     static std::once_flag once;
     std::call_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tn_x3tr_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, XT_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tn_x3tr_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, XT_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tn_x3tr_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, XT_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tn_x3tr_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, XT_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tn_x3tr_kernel<false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, XT_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tn_x3tr_kernel<true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, XT_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tn_x3tr_kernel<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, XT_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tn_x3tr_kernel<true, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, XT_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tn_x3tr_kernel<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, XT_LDS);
     });
+    if (gemm_trace_on())
+        fprintf(stderr, "STAIR_GEMM tn M=%d N=%d K=%d act=0 acc=1 gather=%d scale=%d\n", a.M, a.N, a.K, a.b_gidx ? 1 : 0, a.row_scale ? 1 : 0);
     STAIR_ACCT_MFMA("gemm_tn_x3tr", ((int64_t)a.M * a.N + (int64_t)a.M * a.K + (int64_t)a.N * a.K) * 4, 2ll * a.M * a.N * a.K);
     const dim3 grid(p.nslab * (a.N / 256) * p.tilesK);
-    if (a.b_gidx && a.row_scale) hipLaunchKernelGGL((gemm_tn_x3tr_kernel<true, true>), grid, dim3(512), XT_LDS, s, p);
-    else if (a.b_gidx) hipLaunchKernelGGL((gemm_tn_x3tr_kernel<true, false>), grid, dim3(512), XT_LDS, s, p);
-    else if (a.row_scale) hipLaunchKernelGGL((gemm_tn_x3tr_kernel<false, true>), grid, dim3(512), XT_LDS, s, p);
-    else hipLaunchKernelGGL((gemm_tn_x3tr_kernel<false, false>), grid, dim3(512), XT_LDS, s, p);
+    if (a.K % 128) hipLaunchKernelGGL((gemm_tn_x3tr_kernel<false, false, true>), grid, dim3(512), XT_LDS, s, p);
+    else if (a.b_gidx && a.row_scale) hipLaunchKernelGGL((gemm_tn_x3tr_kernel<true, true, false>), grid, dim3(512), XT_LDS, s, p);
+    else if (a.b_gidx) hipLaunchKernelGGL((gemm_tn_x3tr_kernel<true, false, false>), grid, dim3(512), XT_LDS, s, p);
+    else if (a.row_scale) hipLaunchKernelGGL((gemm_tn_x3tr_kernel<false, true, false>), grid, dim3(512), XT_LDS, s, p);
+    else hipLaunchKernelGGL((gemm_tn_x3tr_kernel<false, false, false>), grid, dim3(512), XT_LDS, s, p);
     STAIR_LAUNCH_CHECK();
-    if (g_pending.n + 2 > 40) STAIR_CHECK(tn_x3tr_flush(s) == 0, "weight-gradient reduction failed");
+    if (g_pending.n + 3 > 40) STAIR_CHECK(tn_x3tr_flush(s) == 0, "weight-gradient reduction failed");
     g_pending.e[g_pending.n++] = {p.P, a.C, p.nslab, (int)((int64_t)a.N * a.K / 4)};
     if (p.Pc) g_pending.e[g_pending.n++] = {p.Pc, a.colsum, p.nslab, a.N / 4};
+    if (p.Pc && a.colsum2) g_pending.e[g_pending.n++] = {p.Pc, a.colsum2, p.nslab, a.N / 4};
     return 0;
 }
 

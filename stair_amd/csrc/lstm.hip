@@ -801,11 +801,31 @@ int launch_lstm_bwd_recur(const stair_lstm_bwd_args &a, hipStream_t s) {
 }
 
 // h(t-1) rows + the four weight-gradient products of a layer whose gate gradients are in a.gates
+// One weight-gradient product of a layer: through the slab-reduced kernel (csrc/gemm_tn_x3tr.hip: no atomics; the sums are added
+// by the caller's tn_x3tr_flush) when the shape is its and the scratch suffices, the < 32 rows past the last whole stage through the
+// atomic kernel (one add per element: still deterministic); otherwise the atomic kernel.
+static int lstm_weight_product(stair_gemm_tn_args g, float *&scr, int64_t &left, hipStream_t s) {
+    stair_gemm_tn_args h = g;
+    h.M = g.M & ~31;
+    if (scr && h.M >= 2048 && tn_x3tr_takes(h)) {
+        const int64_t need = align_up(tn_x3tr_scratch_floats(h.M, h.N, h.K), 64);
+        if (need <= left) {
+            if (int rc = launch_gemm_tn_x3tr(h, scr, s)) return rc;
+            scr += need; left -= need;
+            if (g.M == h.M) return 0;
+            g.A += (int64_t)h.M * g.lda; g.B += (int64_t)h.M * g.ldb; g.M -= h.M;
+        }
+    }
+    return launch_gemm_tn(g, s);
+}
+
 int launch_lstm_bwd_weights(const stair_lstm_bwd_args &a, hipStream_t s) {
     if (a.n == 0 || a.rows == 0) return 0;
     const int Hh = a.Hh;
     hipLaunchKernelGGL(lstm_hprev_kernel, dim3(a.n), dim3(256), 0, s, a.out, a.ldo, a.seq_off, a.seq_len, a.n, Hh, a.hprev_ws, a.gates);
     STAIR_LAUNCH_CHECK();
+    float *scr = a.tn_ws;
+    int64_t left = a.tn_ws ? a.tn_ws_floats : 0;
     // weight gradients: dW_ih = dG^T X, dW_hh = dG^T Hprev, db_ih = db_hh = colsum(dG)
     for (int dir = 0; dir < 2; ++dir) {
         stair_gemm_tn_args g = {};
@@ -813,12 +833,12 @@ int launch_lstm_bwd_weights(const stair_lstm_bwd_args &a, hipStream_t s) {
         g.B = a.x_bf16 ? static_cast<const float *>(a.x_bf16) : a.x; g.b_is_bf16 = a.x_bf16 ? 1 : 0;
         g.ldb = a.ldx; g.b_gstride = a.ldx; g.rows_per_group = 1;
         g.C = a.dw_ih[dir]; g.ldc = a.I; g.M = a.rows; g.N = 4 * Hh; g.K = a.I;
-        if (int rc = launch_gemm_tn(g, s)) return rc;
+        if (int rc = lstm_weight_product(g, scr, left, s)) return rc;
         g.b_is_bf16 = 0;
         g.B = a.hprev_ws + dir * Hh; g.ldb = 2 * (int64_t)Hh; g.b_gstride = 2 * (int64_t)Hh;
         g.C = a.dw_hh[dir]; g.ldc = Hh; g.K = Hh;
         g.colsum = a.db_ih[dir]; g.colsum2 = a.db_hh[dir];     // db_ih = db_hh = colsum(dG), with the smaller of the two products
-        if (int rc = launch_gemm_tn(g, s)) return rc;
+        if (int rc = lstm_weight_product(g, scr, left, s)) return rc;
     }
     return 0;
 }

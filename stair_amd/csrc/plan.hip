@@ -353,6 +353,7 @@ struct stair_plan {
     // block of wg_dz[w]; the matching X operand is the input tiles gathered through wg_off_idx[w] (first-layer weights) or the
     // saved first activations, which lie in the same order in wg_sx[w] (second-layer weights).  ONE long-reduction TN GEMM per
     // weight at the end of stair_plan_backward instead of one per bucket.
+    int64_t o_tnring = 0, tnring_floats = 0, o_tnenc[2] = {0, 0}, tnenc_floats[2] = {0, 0};
     int64_t wg_rows[WF_COUNT] = {}, wg_dz[WF_COUNT] = {}, wg_sx[WF_COUNT] = {}, wg_off_idx[WF_COUNT] = {}, wg_off_rs[WF_COUNT] = {}, wg_part[WF_COUNT] = {};
     // workspace layout (float offsets)
     int64_t o_idx = 0, o_vec = 0, o_map = 0, o_att = 0, o_tok = 0, o_qfeat = 0, o_vhn = 0, o_xpv = 0, o_xpt = 0,
@@ -928,6 +929,21 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
             // slab partials of the weight's one long weight-gradient reduction (csrc/gemm_tn_x3tr.hip: stored, then added in fixed order)
             if (pl->wg_rows[w] && H % 256 == 0 && T % 32 == 0)
                 pl->wg_part[w] = take(tn_x3tr_scratch_floats(pl->wg_rows[w] * T, H, H), 64);
+        }
+        if (H % 256 == 0) {
+            // scratch of the other slab-reduced products: a ring for the map-level layers outside the per-weight regions (two of the
+            // largest in flight), and one piece per encoder weight (dW_ih on fp32 rows, dW_hh; two directions)
+            const int64_t most_rows = std::max<int64_t>((int64_t)std::max(pl->maxI, 1) * T, 64);
+            pl->tnring_floats = 2 * align_up(tn_x3tr_scratch_floats(most_rows & ~31ll, H, 3 * H), 64);
+            pl->o_tnring = take(pl->tnring_floats, 64);
+            const int64_t rv = ((int64_t)pl->n_vid * T) & ~31ll, rq = (int64_t)pl->rows_q & ~31ll;
+            const int E4 = ctx->cfg.text_size, V4 = ctx->cfg.video_size;
+            pl->tnenc_floats[0] = 2 * (align_up(tn_x3tr_scratch_floats(std::max<int64_t>(rv, 64), 2 * H, H / 2), 64) +
+                                       align_up(tn_x3tr_scratch_floats(std::max<int64_t>(rv, 64), 2 * H, V4), 64));
+            pl->tnenc_floats[1] = 2 * (align_up(tn_x3tr_scratch_floats(std::max<int64_t>(rq, 64), 2 * H, H / 2), 64) +
+                                       align_up(tn_x3tr_scratch_floats(std::max<int64_t>(rq, 64), 2 * H, E4), 64));
+            pl->o_tnenc[0] = take(pl->tnenc_floats[0], 64);
+            pl->o_tnenc[1] = take(pl->tnenc_floats[1], 64);
         }
         int64_t at[WF_COUNT] = {};
         for (Bucket &b : pl->buckets) {
@@ -1606,6 +1622,10 @@ struct BwdCtx {
     float *splitk = nullptr;         // split-K scratch (plan workspace): dX products that overwrite their target stage partials there
     std::vector<int64_t> wt_off;     // per weight id
     std::vector<char> deferred;      // per weight id: its weight-gradient product runs once, after all buckets (per-weight regions)
+    // scratch ring of the slab-reduced weight-gradient products of the remaining map-level layers (csrc/gemm_tn_x3tr.hip): a product
+    // takes the next piece; when the ring wraps, the pending sums are added first (tn_x3tr_flush)
+    float *tn_ring = nullptr; int64_t tn_ring_floats = 0;
+    mutable int64_t tn_ring_at = 0;
 };
 
 // Backward of Y = act(rs * X W^T + b) given dZ (already multiplied by act'):
@@ -1620,8 +1640,17 @@ int dense_bwd(const BwdCtx &B, const float *dZ, int groups, int R, int N, int K,
     t.row_scale = rs; t.rs_gstride = rs_gs; t.rs_gidx = rs_gidx;
     t.C = l.dw; t.ldc = K; t.M = M; t.rows_per_group = R; t.N = N; t.K = K;
     t.colsum = l.db;                 // db += colsum(dZ), summed while the TN kernel stages dZ
-    if (!(l.id >= 0 && l.id < (int)B.deferred.size() && B.deferred[l.id]))
-        if (int rc = launch_gemm_tn(t, B.s)) return rc;
+    if (!(l.id >= 0 && l.id < (int)B.deferred.size() && B.deferred[l.id])) {
+        const int64_t need = M >= 4096 && B.tn_ring && tn_x3tr_takes(t) ? align_up(tn_x3tr_scratch_floats(M, N, K), 64) : 0;
+        if (need && need <= B.tn_ring_floats) {
+            if (B.tn_ring_at + need > B.tn_ring_floats) {
+                if (int rc = tn_x3tr_flush(B.s)) return rc;
+                B.tn_ring_at = 0;
+            }
+            if (int rc = launch_gemm_tn_x3tr(t, B.tn_ring + B.tn_ring_at, B.s)) return rc;
+            B.tn_ring_at += need;
+        } else if (int rc = launch_gemm_tn(t, B.s)) return rc;
+    }
     if (dX) {
         stair_gemm_args g = {};
         g.A = dZ; g.lda = N; g.a_gstride = (int64_t)R * N;
@@ -1670,6 +1699,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
     // transposed images of every 2-D weight that needs a dX product
     BwdCtx B;
     B.s = s; B.wt = ws + pl->o_wt; B.splitk = ws + pl->o_splitk;
+    B.tn_ring = pl->o_tnring ? ws + pl->o_tnring : nullptr; B.tn_ring_floats = pl->tnring_floats;
     B.wt_off.assign(ctx->names.size(), 0);
     // weight-gradient products of the tile-level layers run ONCE per weight, after all buckets (FilterFrame's dense layer keeps
     // its per-bucket product: its X operand carries the attention scale only in the tensor-keyword variant)
@@ -1948,6 +1978,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
     static const bool overlap_tn = [] { const char *e = getenv("STAIR_BWD_OVERLAP"); return e && e[0] == '1'; }();
     hipStream_t s_tn = s;
     if (overlap_tn) {
+        RUN(tn_x3tr_flush(s));               // sums queued on `s` by the buckets stay on `s`
         if (!ctx->side) {
             STAIR_HIP(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
             STAIR_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
@@ -1998,6 +2029,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
             a.n = e == 0 ? pl->n_vid : n; a.Hh = Hh; a.ldo = H; a.ldd = H; a.hprev_ws = ws + pl->o_hprev;
             a.coop_ws_bytes = pl->coop_bytes;
             a.status = reinterpret_cast<uint32_t *>(ws + pl->o_status);
+            if (pl->o_tnenc[e]) { a.tn_ws = ws + pl->o_tnenc[e]; a.tn_ws_floats = pl->tnenc_floats[e]; }
             for (int d = 0; d < 2; ++d) {
                 a.w_hh[d] = W.enc[e][4 * d + 1];
                 a.dw_ih[d] = W.denc[e][4 * d]; a.dw_hh[d] = W.denc[e][4 * d + 1];
@@ -2016,6 +2048,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
             RUN(launch_lstm_bwd_weights(enc[0], s));
         }
     }
+    RUN(tn_x3tr_flush(s));                   // the encoders' slab-reduced weight gradients
     if (overlap_tn) STAIR_HIP(hipStreamWaitEvent(s, ctx->ev_join, 0));      // the optimizer (next on `s`) sees every dW
 #undef RUN
     return 0;
