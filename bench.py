@@ -471,6 +471,20 @@ def main():
             fam = gemm_family_rooflines(lambda: run_step(B, False), device)
             if fam:
                 extras['roofline_gemm_families'] = fam
+                t = fam.get('tile_mlp_kernel')
+                if t:       # by SUMMED time per step the fused tile operator (about ten launches) is the largest kernel: its own roofline entry
+                    tile = {'bound': 'mfma', 'kernel': 'tile_mlp_kernel (fused map-level MLP chains, forward and backward, all launches of one step)',
+                            'achieved': t['algorithmic_TFLOPs'], 'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': t['frac_of_bf16_peak'],
+                            'ms_per_step': t['ms_per_step'], 'traffic': None,
+                            'note': 'algorithmic 2MNK of every tile layer of the step / device time of the kernel in the same step (torch.profiler); '
+                                    'three executed bf16 MFMAs per algorithmic product'}
+                    try:
+                        pm = json.load(open(os.path.join(ROOT, 'profiles', 'r03_pmc_tile_summary.json')))
+                        tile['traffic'] = pm['per_tile']
+                        tile['traffic_note'] = 'HBM-side bytes PER TILE of a two-layer launch from separate FETCH_SIZE / WRITE_SIZE passes (profiles/r03_pmc_tile_summary.json; reads doubled per the gfx950 correction): algorithmic 131 072 B in, 256 B out in inference, two 131 072 B saves in training'
+                    except (OSError, ValueError, KeyError):
+                        pass
+                    extras['roofline_tile_operator'] = tile
             # ---- configs[4]: the step with per-module intermediate supervision, next to the decoder-only step ----
             if not args.supervision:
                 dt_s, _ = timed(lambda: run_step(B, True), 6, 3)
