@@ -158,6 +158,9 @@ int stair_gemm_tn_f32(const stair_gemm_tn_args *args, stair_stream stream);
  * module-level nn.Linear (one call per WEIGHT over all instances that used it; autograd of /root/reference/video_nmn/modules.py's
  * Linear layers, train_module.py:408).  Split matmul mode only; fp32 operands; N % 256 == 0, K % 128 == 0, ldc == K; M and
  * rows_per_group multiples of 32; colsum2 unused.  scratch: stair_gemm_tn_slabs_scratch(M, N, K) floats. */
+/* stair_plan_backward sends a per-bucket weight-gradient product of at least this many rows through the slab kernel (default 4096;
+ * the per-weight products and the encoders' always take it).  Tests lower it to exercise that path on small batches. */
+int stair_set_tn_slab_min_rows(int32_t rows);
 int64_t stair_gemm_tn_slabs_scratch(int64_t M, int64_t N, int64_t K);
 int stair_gemm_tn_slabs(const stair_gemm_tn_args *args, float *scratch, int64_t scratch_floats, stair_stream stream);
 
@@ -280,7 +283,8 @@ int stair_lstm_bidir_bwd(const stair_lstm_bwd_args *args, stair_stream stream);
  *     ACCUMULATE      out + o * out_gstride += F (atomic)
  * Rows t >= T of a tile do not exist (nothing is read or written there). */
 enum stair_tile_tail { STAIR_TILE_NONE = 0, STAIR_TILE_STORE = 1, STAIR_TILE_SUM_ROWS = 2, STAIR_TILE_COSINE = 3,
-                       STAIR_TILE_ROWDOT_SIGMOID = 4, STAIR_TILE_LAYERNORM = 5, STAIR_TILE_ACCUMULATE = 6 };
+                       STAIR_TILE_ROWDOT_SIGMOID = 4, STAIR_TILE_LAYERNORM = 5, STAIR_TILE_ACCUMULATE = 6,
+                       STAIR_TILE_STORE_ROWS = 7 };
 typedef struct stair_tile_mlp_args {
     const float *X; int64_t x_gstride; const int32_t *x_idx;
     const float *row_scale; const int32_t *rs_idx;
@@ -303,6 +307,17 @@ typedef struct stair_tile_mlp_args {
     const float *act_mask[3]; float act_scale;
     const float *in_mask; int64_t in_mask_gstride; const int32_t *in_mask_idx; float in_scale; int32_t x_broadcast;
     float *save_in;
+    /* vector-level modules (modules.py:15-37 Compare / Equals, :59-72 Xor, :102-120 ToAction, :141-159 Exists): the "tile" is 64
+     * INSTANCES, one [H] row each, and the first layer runs on a concatenation that is never materialised for the GEMM:
+     *   vec_pack         0 off; 1: [a, b]; 2: [|a - b|, a, b]; 3: [a, b, a * b] with a = pk_a + pk_a_idx[i] * H, b = pk_b + pk_b_idx[i] * H
+     *                    (i = 0 .. vec_cnt - 1; cnt must be (vec_cnt + 63) / 64).  W[0] holds 2 or 3 consecutive [H, H] plane
+     *                    images, one per H-wide column block of the [H, 2H | 3H] weight (stair_pack_wfrag_ld); the layer
+     *                    accumulates over them.  X, x_gstride, x_idx, T are ignored.
+     *   cat_save         optional [vec_cnt, 2H | 3H]: the concatenated rows (what the weight-gradient product needs)
+     *   save[l]          [vec_cnt, H]
+     *   tail STORE_ROWS  row i of the last layer -> out + out_row_idx[i] * out_gstride */
+    int32_t vec_pack; const float *pk_a, *pk_b; const int32_t *pk_a_idx, *pk_b_idx; int32_t vec_cnt;
+    float *cat_save; const int32_t *out_row_idx;
 } stair_tile_mlp_args;
 int stair_tile_mlp_fwd(const stair_tile_mlp_args *args, stair_stream stream);
 /* stair_plan_run uses the fused operators where they apply (hidden_size 512, T <= 64, split matmul mode, no dropout);
@@ -311,6 +326,9 @@ int stair_set_tile_mlp(int32_t on);
 /* W [N, K] fp32 row-major -> planes: [N/32][K/16][hi, lo][64 lanes][8 bf16] (2 * N * K * 2 bytes, 16-byte aligned);
  * N % 32 == 0, K % 16 == 0.  transpose != 0: W is stored [K, N] and the planes are those of W^T (backward chains). */
 int stair_pack_wfrag(const float *W, void *planes, int32_t N, int32_t K, int32_t transpose, stair_stream stream);
+/* The same for a [N, K] column block of a wider row-major matrix (row stride ld floats): the H-wide blocks of a vector-level
+ * module's [H, 2H | 3H] first-layer weight. */
+int stair_pack_wfrag_ld(const float *W, int64_t ld, void *planes, int32_t N, int32_t K, stair_stream stream);
 
 /* att[p][t] = (cos(F[f_idx[p]][t][:], Kmat[k_idx[p]][:]) + 1) * 0.49 -- nn.CosineSimilarity(dim=-1,
  * eps=1e-8) of LocalizeModule / ExistsFrameModule (modules.py:162-217) without materialising the

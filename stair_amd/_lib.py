@@ -88,7 +88,9 @@ class TileMlpArgs(C.Structure):
                 ('cnt', C.c_int32), ('T', C.c_int32), ('H', C.c_int32),
                 ('act_mask', C.c_void_p * 3), ('act_scale', C.c_float),
                 ('in_mask', C.c_void_p), ('in_mask_gstride', C.c_int64), ('in_mask_idx', C.c_void_p), ('in_scale', C.c_float),
-                ('x_broadcast', C.c_int32), ('save_in', C.c_void_p)]
+                ('x_broadcast', C.c_int32), ('save_in', C.c_void_p),
+                ('vec_pack', C.c_int32), ('pk_a', C.c_void_p), ('pk_b', C.c_void_p), ('pk_a_idx', C.c_void_p), ('pk_b_idx', C.c_void_p),
+                ('vec_cnt', C.c_int32), ('cat_save', C.c_void_p), ('out_row_idx', C.c_void_p)]
 
 
 class PlanInfo(C.Structure):
@@ -120,9 +122,11 @@ SIGNATURES = [
     ('stair_set_tile_mlp', C.c_int, [C.c_int32]),
     ('stair_tile_mlp_fwd', C.c_int, [C.POINTER(TileMlpArgs), C.c_void_p]),
     ('stair_pack_wfrag', C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    ('stair_pack_wfrag_ld', C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     ('stair_gemm_f32', C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     ('stair_gemm_tn_f32', C.c_int, [C.POINTER(GemmTnArgs), C.c_void_p]),
     ('stair_gemm_tn_slabs_scratch', C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),
+    ('stair_set_tn_slab_min_rows', C.c_int, [C.c_int32]),
     ('stair_gemm_tn_slabs', C.c_int, [C.POINTER(GemmTnArgs), C.c_void_p, C.c_int64, C.c_void_p]),
     ('stair_split_planes', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     ('stair_split_planes_tiled', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),

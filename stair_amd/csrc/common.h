@@ -108,7 +108,8 @@ int launch_gemm_tn(const stair_gemm_tn_args &a, hipStream_t s);
 int launch_tile_mlp(const stair_tile_mlp_args &a, hipStream_t s);          // csrc/tile_mlp.hip
 int launch_tile_mlp_batch(const stair_tile_mlp_args *args, int n, unsigned *counter, hipStream_t s);   // <= 8 buckets, one launch
 bool tile_mlp_usable(int H, int T);
-int launch_pack_wfrag_many(const float *const *W, void *const *out, int count, int N, int K, hipStream_t s, bool transpose = false);
+int launch_pack_wfrag_many(const float *const *W, void *const *out, int count, int N, int K, hipStream_t s, bool transpose = false,
+                           const int *ld = nullptr);     // ld: row stride per matrix (default: K, or N when transposed)
 int launch_colsum(const float *A, int64_t lda, float *out, int M, int N, hipStream_t s, float *out2 = nullptr);
 int launch_transpose(const float *in, float *out, int rows, int cols, hipStream_t s);
 

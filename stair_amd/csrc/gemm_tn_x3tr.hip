@@ -338,7 +338,12 @@ int launch_gemm_tn_x3tr(const stair_gemm_tn_args &a, float *scratch, hipStream_t
     else if (a.row_scale) hipLaunchKernelGGL((gemm_tn_x3tr_kernel<false, true, false>), grid, dim3(512), XT_LDS, s, p);
     else hipLaunchKernelGGL((gemm_tn_x3tr_kernel<false, false, false>), grid, dim3(512), XT_LDS, s, p);
     STAIR_LAUNCH_CHECK();
-    if (g_pending.n + 3 > 40) STAIR_CHECK(tn_x3tr_flush(s) == 0, "weight-gradient reduction failed");
+    // one reduction launch adds every queued product to its destination in parallel: two products into the SAME buffer (a weight
+    // used by two buckets outside the per-weight regions) must not share it -- the earlier one is added first
+    bool same_dst = false;
+    for (int i = 0; i < g_pending.n; ++i)
+        same_dst |= g_pending.e[i].dst == a.C || (a.colsum && g_pending.e[i].dst == a.colsum) || (a.colsum2 && g_pending.e[i].dst == a.colsum2);
+    if (same_dst || g_pending.n + 3 > 40) STAIR_CHECK(tn_x3tr_flush(s) == 0, "weight-gradient reduction failed");
     g_pending.e[g_pending.n++] = {p.P, a.C, p.nslab, (int)((int64_t)a.N * a.K / 4)};
     if (p.Pc) g_pending.e[g_pending.n++] = {p.Pc, a.colsum, p.nslab, a.N / 4};
     if (p.Pc && a.colsum2) g_pending.e[g_pending.n++] = {p.Pc, a.colsum2, p.nslab, a.N / 4};

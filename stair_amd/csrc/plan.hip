@@ -231,6 +231,8 @@ struct Node {
 // The module-level Linear layers that act on [T, H] tiles, as one table (fused tile operators pack their planes by these
 // ids; the backward pass groups the weight-gradient products by them).
 enum { WF_F0 = 0, WF_F3 = 4, WF_FF0 = 8, WF_FF3 = 11, WF_FFD = 14, WF_HI0 = 15, WF_LV0 = 16, WF_LV3 = 17, WF_TD = 18, WF_COUNT = 19 };
+// plane images of the vector-level modules' weights (forward only): one [H, H] image per H-wide column block of a first layer
+enum { WV_CMP = 19, WV_EQ = 21, WV_XOR = 23, WV_TA0 = 26, WV_TA3 = 28, WV_EX0 = 29, WV_EX3 = 32, WV_END = 33 };
 
 struct Bucket {
     int64_t dzA = -1, dzB = -1;   // training: this bucket's blocks inside the per-WEIGHT dZ regions (first / second layer of its tile MLP)
@@ -874,7 +876,7 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
     pl->o_sup = take((int64_t)std::max(pl->maxSupRows, 1) * T, 64);
     pl->o_extra = take(std::max(pl->maxI, 1), 64);
     pl->o_logits = take((int64_t)n * A, 64);
-    pl->o_wfrag = (H == 512 && T <= 64) ? take(19 * H * H, 64) : 0;     // bf16 hi/lo fragment-order planes of the fused tile operators' weights
+    pl->o_wfrag = (H == 512 && T <= 64) ? take((int64_t)WV_END * H * H, 64) : 0;     // bf16 hi/lo fragment-order planes of the fused tile operators' weights
     pl->o_status = take(128, 64);                // word 0: sticky "a cooperative hand-off timed out" flag of this plan's passes; words 16..63
                                                  // and 64..111: work-queue heads of the fused forward / backward launches
     for (Bucket &b : pl->buckets) {
@@ -1372,6 +1374,36 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
             if (need[i]) { src[cnt_w] = lin_of[i]->w; dst[cnt_w] = const_cast<void *>(WF(i)); ++cnt_w; }
         if (cnt_w) RUN(launch_pack_wfrag_many(src, dst, cnt_w, H, H, s));
     }
+    // vector-level modules on the tile operator (64 instances per tile; STAIR_TILE_VEC=0: the pack -> GEMM -> reduction sequences)
+    static const bool vec_env = [] { const char *e = getenv("STAIR_TILE_VEC"); return !(e && e[0] == '0'); }();
+    const bool fused_vec = fused && vec_env;
+    if (fused_vec) {
+        struct { int slot, nseg; const Lin *l; int op; } vw[7] = {{WV_CMP, 2, &W.compare, STAIR_OP_COMPARE}, {WV_EQ, 2, &W.equals, STAIR_OP_EQUALS},
+            {WV_XOR, 3, &W.xorl, STAIR_OP_XOR}, {WV_TA0, 2, &W.ta0, STAIR_OP_TOACTION}, {WV_TA3, 1, &W.ta3, STAIR_OP_TOACTION},
+            {WV_EX0, 3, &W.exists0, STAIR_OP_EXISTS}, {WV_EX3, 1, &W.exists3, STAIR_OP_EXISTS}};
+        bool has[32] = {};
+        for (const Bucket &b : pl->buckets) if (b.cnt > 0 && b.op >= 0 && b.op < 32) has[b.op] = true;
+        const float *src[16];
+        void *dst[16];
+        int ld[16], cnt_w = 0;
+        for (const auto &v : vw)
+            if (has[v.op])
+                for (int j = 0; j < v.nseg; ++j) { src[cnt_w] = v.l->w + (int64_t)j * H; dst[cnt_w] = const_cast<void *>(WF(v.slot + j)); ld[cnt_w] = v.nseg * H; ++cnt_w; }
+        if (cnt_w) RUN(launch_pack_wfrag_many(src, dst, cnt_w, H, H, s, false, ld));
+    }
+    // a vector-level module as queued tile work: first layer over the never-materialised concatenation of the operand rows
+    // a = vec[ia[i]], b = vec[ib[i]], optional second layer, row i -> vec[io[i]]
+    auto vec_module = [&](const Bucket &b, int pack, const int32_t *ia, const int32_t *ib, const int32_t *io, int slot0, const Lin &l0,
+                          int slot3, const Lin *l3, float *cat_sv, float *hid_sv) {
+        stair_tile_mlp_args a = {};
+        a.vec_pack = pack; a.vec_cnt = b.cnt; a.cnt = (b.cnt + 63) / 64; a.T = 64; a.H = H; a.ln_eps = 1e-5f;
+        a.pk_a = vec; a.pk_a_idx = ia; a.pk_b = vec; a.pk_b_idx = ib;
+        a.W[0] = WF(slot0); a.bias[0] = l0.b; a.act[0] = 1; a.n_layers = 1;
+        if (l3) { a.W[1] = WF(slot3); a.bias[1] = l3->b; a.act[1] = 1; a.n_layers = 2; }
+        if (pl->train) { a.cat_save = cat_sv; if (l3) a.save[0] = hid_sv; }
+        a.tail = STAIR_TILE_STORE_ROWS; a.out = vec; a.out_gstride = H; a.out_row_idx = io;
+        return a;
+    };
     auto tile_args = [&](const int32_t *x_idx, int cnt_) {
         stair_tile_mlp_args a = {};
         a.X = map; a.x_gstride = TH; a.x_idx = x_idx; a.cnt = cnt_; a.T = T; a.H = H; a.ln_eps = 1e-5f;
@@ -1420,22 +1452,39 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
                 break;
             case STAIR_OP_COMPARE:      // modules.py:15-21
             case STAIR_OP_EQUALS: {     // modules.py:24-37
+                if (fused_vec) {
+                    if (phase == 1) tile_queue.push_back(vec_module(b, 1, I0, I1, I2, b.op == STAIR_OP_COMPARE ? WV_CMP : WV_EQ,
+                                                                    b.op == STAIR_OP_COMPARE ? W.compare : W.equals, 0, nullptr, cat, nullptr));
+                    break;
+                }
                 RUN(launch_pack(PACK_CAT2, vec, I0, vec, I1, cat, c, H, s));
                 RUN(dense(s, cat, 2 * H, 2 * H, nullptr, b.op == STAIR_OP_COMPARE ? W.compare : W.equals, 2 * H, vec, H, H,
                           I2, c, 1, H, 2 * H, 1));
                 break;
             }
             case STAIR_OP_XOR:          // modules.py:59-72: cat[|a-b|, a, b]
+                if (fused_vec) {
+                    if (phase == 1) tile_queue.push_back(vec_module(b, 2, I0, I1, I2, WV_XOR, W.xorl, 0, nullptr, cat, nullptr));
+                    break;
+                }
                 RUN(launch_pack(PACK_XOR, vec, I0, vec, I1, cat, c, H, s));
                 RUN(dense(s, cat, 3 * H, 3 * H, nullptr, W.xorl, 3 * H, vec, H, H, I2, c, 1, H, 3 * H, 1));
                 break;
             case STAIR_OP_TOACTION:     // modules.py:102-120: cat[action, keyword]
+                if (fused_vec) {
+                    if (phase == 1) tile_queue.push_back(vec_module(b, 1, I0, I1, I2, WV_TA0, W.ta0, WV_TA3, &W.ta3, cat, hid));
+                    break;
+                }
                 RUN(launch_pack(PACK_CAT2, vec, I0, vec, I1, cat, c, H, s));
                 RUN(dense(s, cat, 2 * H, 2 * H, nullptr, W.ta0, 2 * H, hid, H, H, nullptr, c, 1, H, 2 * H, 1));
                 RUN(drop(hid, H, nullptr, c, H, 0));
                 RUN(dense(s, hid, H, H, nullptr, W.ta3, H, vec, H, H, I2, c, 1, H, H, 1));
                 break;
             case STAIR_OP_EXISTS:       // modules.py:141-159: Exists(keyword, feat) -> cat[feat, keyword, feat*keyword]
+                if (fused_vec) {
+                    if (phase == 1) tile_queue.push_back(vec_module(b, 3, I1, I0, I2, WV_EX0, W.exists0, WV_EX3, &W.exists3, cat, hid));
+                    break;
+                }
                 RUN(launch_pack(PACK_EXISTS, vec, I1, vec, I0, cat, c, H, s));
                 RUN(dense(s, cat, 3 * H, 3 * H, nullptr, W.exists0, 3 * H, hid, H, H, nullptr, c, 1, H, 3 * H, 1));
                 RUN(drop(hid, H, nullptr, c, H, 0));
@@ -1628,6 +1677,10 @@ struct BwdCtx {
     mutable int64_t tn_ring_at = 0;
 };
 
+// rows from which a per-bucket weight-gradient product takes the slab-reduced kernel (below it the atomic kernel's single pass is
+// shorter); stair_set_tn_slab_min_rows lowers it so that small test batches exercise the same path
+int g_tn_slab_min_rows = 4096;
+
 // Backward of Y = act(rs * X W^T + b) given dZ (already multiplied by act'):
 //   dW += dZ^T (rs * X);  db += colsum(dZ);  dX (+)= dZ W      (dX is w.r.t. the scaled input rs*X)
 int dense_bwd(const BwdCtx &B, const float *dZ, int groups, int R, int N, int K, const float *X, int64_t ldx, int64_t x_gs,
@@ -1641,7 +1694,7 @@ int dense_bwd(const BwdCtx &B, const float *dZ, int groups, int R, int N, int K,
     t.C = l.dw; t.ldc = K; t.M = M; t.rows_per_group = R; t.N = N; t.K = K;
     t.colsum = l.db;                 // db += colsum(dZ), summed while the TN kernel stages dZ
     if (!(l.id >= 0 && l.id < (int)B.deferred.size() && B.deferred[l.id])) {
-        const int64_t need = M >= 4096 && B.tn_ring && tn_x3tr_takes(t) ? align_up(tn_x3tr_scratch_floats(M, N, K), 64) : 0;
+        const int64_t need = M >= g_tn_slab_min_rows && B.tn_ring && tn_x3tr_takes(t) ? align_up(tn_x3tr_scratch_floats(M, N, K), 64) : 0;
         if (need && need <= B.tn_ring_floats) {
             if (B.tn_ring_at + need > B.tn_ring_floats) {
                 if (int rc = tn_x3tr_flush(B.s)) return rc;
@@ -1664,6 +1717,12 @@ int dense_bwd(const BwdCtx &B, const float *dZ, int groups, int R, int N, int K,
 }
 
 }  // namespace
+
+extern "C" int stair_set_tn_slab_min_rows(int32_t rows) {
+    STAIR_CHECK(rows >= 64, "rows must be >= 64");
+    g_tn_slab_min_rows = rows;
+    return 0;
+}
 
 extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *video, const float *question,
                                    void *workspace, int64_t workspace_bytes, const int32_t *answers, float loss_scale,

@@ -63,6 +63,8 @@ struct TmParams {
     unsigned *counter;               // work queue head (zeroed before the launch); NULL: tiles are dealt out round robin
 };
 
+static_assert(sizeof(TmParams) <= 4096, "the argument block of a launch must stay under the 4 KB kernarg limit");
+
 }  // namespace
 
 // hi = bf16(x), lo = bf16(x - hi) of 8 consecutive floats
@@ -93,7 +95,6 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
     float *F = reinterpret_cast<float *>(lds);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int T = pp.a[0].T;
     const int total = pp.first[pp.nb];
     __shared__ int next_work;
     // B-operand fragment offsets (bytes inside a stage plane, chunk 0) of this lane's two frame tiles
@@ -123,11 +124,52 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
         for (int j = 1; j < TM_MAXB; ++j) bsel += (j < pp.nb && w >= pp.first[j]) ? 1 : 0;
         const stair_tile_mlp_args &p = pp.a[bsel];
         const int inst = w - pp.first[bsel];
+        // rows of this tile: the T frames of a module instance, or (vector-level modules) up to 64 INSTANCES of one row each
+        const int vpack = p.vec_pack;
+        const int T = vpack ? min(TM_ROWS, p.vec_cnt - TM_ROWS * inst) : p.T;
+        const int Ts = vpack ? TM_ROWS : p.T;            // rows between two tiles in the [cnt, T, H] save / mask buffers
+        const int nseg = vpack == 0 ? 1 : (vpack == 1 ? 2 : 3);
         // ---- the input tile: fp32 rows -> (row scale) -> bf16 hi / lo image ------------------------------------------
         const float *x = p.X + (int64_t)(p.x_idx ? p.x_idx[inst] : inst) * p.x_gstride;
         const float *rsrow = p.row_scale ? p.row_scale + (int64_t)(p.rs_idx ? p.rs_idx[inst] : inst) * T : nullptr;
         const float *imask = p.in_mask ? p.in_mask + (int64_t)(p.in_mask_idx ? p.in_mask_idx[inst] : inst) * p.in_mask_gstride : nullptr;
         const int Lrows = p.x_broadcast ? (p.len ? p.len[inst] : T) : T;     // a broadcast row fills the clip's own frames only
+        // vector-level modules: row t of the tile is H-wide block `seg` of the concatenation built from the two operand rows
+        // of instance 64 inst + t (never materialised for the GEMM; cat_save keeps it for the weight gradient)
+        auto build_vec_image = [&](const int seg) {
+            for (int u = tid; u < TM_ROWS * 64; u += 512) {
+                const int t = u >> 6, c8 = u & 63;
+                v4f a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+                if (t < T) {
+                    const int64_t i = (int64_t)TM_ROWS * inst + t;
+                    const float *ar = p.pk_a + (int64_t)(p.pk_a_idx ? p.pk_a_idx[i] : i) * TM_H + 8 * c8;
+                    const float *br = p.pk_b + (int64_t)(p.pk_b_idx ? p.pk_b_idx[i] : i) * TM_H + 8 * c8;
+                    const v4f a0 = *reinterpret_cast<const v4f *>(ar), a1 = *reinterpret_cast<const v4f *>(ar + 4);
+                    const v4f b0 = *reinterpret_cast<const v4f *>(br), b1 = *reinterpret_cast<const v4f *>(br + 4);
+                    if (vpack == 1) { a = seg == 0 ? a0 : b0; b = seg == 0 ? a1 : b1; }
+                    else if (vpack == 2) {
+                        if (seg == 0) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) { a[j] = fabsf(a0[j] - b0[j]); b[j] = fabsf(a1[j] - b1[j]); }
+                        } else { a = seg == 1 ? a0 : b0; b = seg == 1 ? a1 : b1; }
+                    } else {
+                        if (seg == 2) { a = a0 * b0; b = a1 * b1; }
+                        else { a = seg == 0 ? a0 : b0; b = seg == 0 ? a1 : b1; }
+                    }
+                    if (p.cat_save) {
+                        float *d = p.cat_save + (i * nseg + seg) * TM_H + 8 * c8;
+                        *reinterpret_cast<v4f *>(d) = a; *reinterpret_cast<v4f *>(d + 4) = b;
+                    }
+                }
+                bf16x8 hi, lo;
+                tm_split8(a, b, hi, lo);
+                const int off = (c8 >> 2) * TM_STAGE + (t * 4 + ((c8 & 3) ^ tm_swz(t))) * 16;
+                *reinterpret_cast<bf16x8 *>(lds + off) = hi;
+                *reinterpret_cast<bf16x8 *>(lds + off + 4096) = lo;
+            }
+        };
+        if (vpack) build_vec_image(0);
+        else
         for (int u = tid; u < TM_ROWS * 64; u += 512) {
             const int t = u >> 6, c8 = u & 63;
             v4f a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
@@ -143,7 +185,7 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
                 }
             }
             if (p.save_in && t < T) {
-                float *d = p.save_in + ((int64_t)inst * T + t) * TM_H + 8 * c8;
+                float *d = p.save_in + ((int64_t)inst * Ts + t) * TM_H + 8 * c8;
                 tm_st<NT>(d, a); tm_st<NT>(d + 4, b);
             }
             bf16x8 hi, lo;
@@ -163,8 +205,14 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
             // ---- Z^T[n][t] += W[n][k] tile[t][k]: this wave's 64 weight rows straight from HBM / L2 in fragment order ----
-            {
-                const bf16x8 *wq = static_cast<const bf16x8 *>(p.W[ph]) + (int64_t)(2 * wave) * TM_KS * 2 * 64 + lane;
+            // (a vector-level module's first layer: once per H-wide block of the concatenated input, into the same accumulators)
+            for (int seg = 0; seg < (ph == 0 ? nseg : 1); ++seg) {
+                if (seg > 0) {
+                    __syncthreads();              // every wave has finished reading the previous block's image
+                    build_vec_image(seg);
+                    __syncthreads();
+                }
+                const bf16x8 *wq = static_cast<const bf16x8 *>(p.W[ph]) + (int64_t)seg * (TM_H * TM_H * 2 / 8) + (int64_t)(2 * wave) * TM_KS * 2 * 64 + lane;
                 bf16x8 wf[4][2][2];
 #define TM_LOADW(slot_, ks_)                                                                                  \
     _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_)                                                       \
@@ -251,7 +299,7 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
                 //      need, FilterFrame's attention; then the rows become the next layer's bf16 hi / lo operand image.
                 //      The rows are read into registers first: the image overlays the staging. -----------------------------------
                 float *sv = p.save[ph];
-                const float *amask = act == 3 ? p.act_mask[ph] + (int64_t)inst * T * TM_H : nullptr;
+                const float *amask = act == 3 ? p.act_mask[ph] + (int64_t)inst * Ts * TM_H : nullptr;
                 const bool rowdot = p.mid_rowdot && ph == 1;
                 v4f rowv[8][2];
 #pragma unroll
@@ -265,7 +313,7 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
                             for (int i = 0; i < 4; ++i) { a[i] = m0[i] > 0.f ? a[i] * p.act_scale : 0.f; b[i] = m1[i] > 0.f ? b[i] * p.act_scale : 0.f; }
                         }
                         if (sv) {
-                            float *d = sv + ((int64_t)inst * T + t) * TM_H + 8 * lane;
+                            float *d = sv + ((int64_t)inst * Ts + t) * TM_H + 8 * lane;
                             tm_st<NT>(d, a); tm_st<NT>(d + 4, b);
                         }
                         if (rowdot) {             // FilterFrame: a_t = sigmoid(w[:H] . f_t + extra + b); the next layer runs on a_t f_t
@@ -298,7 +346,7 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
         float *svl = p.save[p.n_layers - 1];
         if (svl)                                      // the last layer's rows for the backward pass (coalesced 2 KB rows)
             for (int t = wave; t < T; t += 8) {
-                float *dst = svl + ((int64_t)inst * T + t) * TM_H;
+                float *dst = svl + ((int64_t)inst * Ts + t) * TM_H;
                 tm_st<NT>(dst + 4 * lane, *reinterpret_cast<const v4f *>(F + t * TM_FLD + 4 * lane));
                 tm_st<NT>(dst + 256 + 4 * lane, *reinterpret_cast<const v4f *>(F + t * TM_FLD + 256 + 4 * lane));
             }
@@ -309,6 +357,13 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
                     float *dst = p.out + oslot * p.out_gstride + (int64_t)t * TM_H;
                     tm_st<NT>(dst + 4 * lane, *reinterpret_cast<const v4f *>(F + t * TM_FLD + 4 * lane));
                     tm_st<NT>(dst + 256 + 4 * lane, *reinterpret_cast<const v4f *>(F + t * TM_FLD + 256 + 4 * lane));
+                }
+                break;
+            case STAIR_TILE_STORE_ROWS:               // vector-level modules: row t = instance 64 inst + t goes to its own slot
+                for (int t = wave; t < T; t += 8) {
+                    float *dst = p.out + (int64_t)p.out_row_idx[(int64_t)TM_ROWS * inst + t] * p.out_gstride;
+                    *reinterpret_cast<v4f *>(dst + 4 * lane) = *reinterpret_cast<const v4f *>(F + t * TM_FLD + 4 * lane);
+                    *reinterpret_cast<v4f *>(dst + 256 + 4 * lane) = *reinterpret_cast<const v4f *>(F + t * TM_FLD + 256 + 4 * lane);
                 }
                 break;
             case STAIR_TILE_ACCUMULATE:               // backward chains: dX added into a gradient tile several instances may share
@@ -390,7 +445,7 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
 // W [N, K] fp32 row-major -> bf16 hi / lo planes in MFMA fragment order: the A operand of v_mfma_f32_32x32x16_bf16 for the
 // 32-row tile nt and the 16-wide k step ks is 64 lanes x 8 bf16, lane (r, h) = W[32 nt + r][16 ks + 8 h + 0..7]; the image is
 // [N/32][K/16][hi, lo][64 lanes][8].  One thread per (row, 8 columns).
-struct WfragBatch { const float *w[32]; __bf16 *o[32]; int count, blocks_per; };
+struct WfragBatch { const float *w[32]; __bf16 *o[32]; int ld[32]; int count, blocks_per; };     // ld: row stride of matrix m (floats)
 // TRANSPOSE: the planes of W^T (the "weight" of a backward chain, dX = dZ W): image row n <-> column n of the stored W [K, N]
 template <bool TRANSPOSE>
 __global__ void pack_wfrag_kernel(WfragBatch tb, int N, int K) {
@@ -402,13 +457,15 @@ __global__ void pack_wfrag_kernel(WfragBatch tb, int N, int K) {
     v4f a, b;
     if (!TRANSPOSE) {
         n = (int)(i / k8n); k8 = (int)(i - (int64_t)n * k8n);
-        const float *src = tb.w[m] + (int64_t)n * K + 8 * k8;
+        const float *src = tb.w[m] + (int64_t)n * tb.ld[m] + 8 * k8;
         a = *reinterpret_cast<const v4f *>(src); b = *reinterpret_cast<const v4f *>(src + 4);
     } else {                            // consecutive threads walk n: the strided reads of a column run coalesce across the wave
         k8 = (int)(i / N); n = (int)(i - (int64_t)k8 * N);
-        const float *src = tb.w[m] + (int64_t)(8 * k8) * N + n;      // stored matrix is [K, N] row-major
+        const float *src = tb.w[m] + (int64_t)(8 * k8) * tb.ld[m] + n;      // stored matrix is [K, N] row-major
+#define TM_TLD tb.ld[m]
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { a[j] = src[(int64_t)j * N]; b[j] = src[(int64_t)(4 + j) * N]; }
+        for (int j = 0; j < 4; ++j) { a[j] = src[(int64_t)j * TM_TLD]; b[j] = src[(int64_t)(4 + j) * TM_TLD]; }
+#undef TM_TLD
     }
     bf16x8 hi, lo;
     tm_split8(a, b, hi, lo);
@@ -419,7 +476,7 @@ __global__ void pack_wfrag_kernel(WfragBatch tb, int N, int K) {
 }
 
 // up to 32 matrices of one shape in ONE launch (the tables travel as kernel arguments: no copy, no host wait)
-int launch_pack_wfrag_many(const float *const *W, void *const *out, int count, int N, int K, hipStream_t s, bool transpose) {
+int launch_pack_wfrag_many(const float *const *W, void *const *out, int count, int N, int K, hipStream_t s, bool transpose, const int *ld) {
     STAIR_CHECK(count >= 1 && count <= 32, "1..32 matrices per launch");
     STAIR_CHECK(N % 32 == 0 && K % 16 == 0, "N % 32 == 0 and K % 16 == 0");
     WfragBatch t;
@@ -428,6 +485,8 @@ int launch_pack_wfrag_many(const float *const *W, void *const *out, int count, i
     for (int m = 0; m < 32; ++m) {
         t.w[m] = m < count ? W[m] : nullptr;
         t.o[m] = m < count ? static_cast<__bf16 *>(out[m]) : nullptr;
+        t.ld[m] = (ld && m < count) ? ld[m] : (transpose ? N : K);
+        STAIR_CHECK(t.ld[m] % 4 == 0 && t.ld[m] >= (transpose ? N : K), "row stride");
         STAIR_CHECK(m >= count || (t.w[m] && t.o[m] && ((reinterpret_cast<uintptr_t>(t.w[m]) | reinterpret_cast<uintptr_t>(t.o[m])) & 15) == 0),
                     "null or unaligned matrix");
     }
@@ -446,21 +505,32 @@ bool tile_mlp_usable(int H, int T) {
 
 static int tile_mlp_check(const stair_tile_mlp_args &a) {
     STAIR_CHECK(a.H == TM_H, "the fused tile operators are built for hidden_size 512");
-    STAIR_CHECK(a.T >= 1 && a.T <= TM_ROWS, "a tile holds 1..64 frames");
     STAIR_CHECK(a.n_layers >= 1 && a.n_layers <= 3, "1..3 layers");
-    STAIR_CHECK(a.X && a.cnt >= 0, "null input");
+    if (a.vec_pack) {                     // vector-level modules: 64 instances per tile
+        STAIR_CHECK(a.vec_pack >= 1 && a.vec_pack <= 3, "vec_pack: 1 [a, b], 2 [|a - b|, a, b], 3 [a, b, a * b]");
+        STAIR_CHECK(a.pk_a && a.pk_b && a.vec_cnt >= 0 && a.cnt == (a.vec_cnt + TM_ROWS - 1) / TM_ROWS, "vector operands / cnt = ceil(vec_cnt / 64)");
+        STAIR_CHECK(((reinterpret_cast<uintptr_t>(a.pk_a) | reinterpret_cast<uintptr_t>(a.pk_b) | reinterpret_cast<uintptr_t>(a.cat_save)) & 15) == 0, "vector operands must be 16-byte aligned");
+        STAIR_CHECK(!a.row_scale && !a.in_mask && !a.x_broadcast && !a.save_in && !a.mid_rowdot, "vector-level tiles take no map-level input options");
+        STAIR_CHECK(a.tail == STAIR_TILE_STORE_ROWS || a.tail == STAIR_TILE_NONE, "vector-level tiles end in STORE_ROWS");
+        for (int l = 0; l < a.n_layers; ++l) STAIR_CHECK(a.act[l] != 3, "no backward chains on vector-level tiles");
+    } else {
+        STAIR_CHECK(a.T >= 1 && a.T <= TM_ROWS, "a tile holds 1..64 frames");
+        STAIR_CHECK(a.X && a.cnt >= 0, "null input");
+        STAIR_CHECK(a.tail != STAIR_TILE_STORE_ROWS, "STORE_ROWS is the vector-level tail");
+    }
     for (int l = 0; l < a.n_layers; ++l)
         STAIR_CHECK(a.W[l] && (reinterpret_cast<uintptr_t>(a.W[l]) & 15) == 0, "weight planes (stair_pack_wfrag) missing or unaligned");
     for (int l = 0; l < a.n_layers; ++l) STAIR_CHECK(a.act[l] != 3 || a.act_mask[l], "act 3 multiplies by relu'(act_mask[l])");
     STAIR_CHECK(!a.x_broadcast || a.x_gstride == a.H, "a broadcast input is one [H] row per instance");
     STAIR_CHECK(!a.mid_rowdot || (a.n_layers == 3 && a.vw && a.vb), "mid_rowdot is FilterFrame's attention between layers 2 and 3");
-    STAIR_CHECK(a.x_gstride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.X) & 15) == 0, "input tiles must be 16-byte aligned");
+    STAIR_CHECK(a.vec_pack || (a.x_gstride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.X) & 15) == 0), "input tiles must be 16-byte aligned");
     switch (a.tail) {
         case STAIR_TILE_STORE: case STAIR_TILE_SUM_ROWS: case STAIR_TILE_ACCUMULATE:
             STAIR_CHECK(a.out && a.out_gstride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0, "out missing or unaligned"); break;
         case STAIR_TILE_COSINE: STAIR_CHECK(a.kb && a.pair_first && a.pair_cnt && a.att_idx && a.att, "cosine tail: keyword rows / pair tables / att"); break;
         case STAIR_TILE_ROWDOT_SIGMOID: STAIR_CHECK(a.vw && a.vb && a.out, "row-dot tail: vw, vb, out"); break;
         case STAIR_TILE_LAYERNORM: STAIR_CHECK(a.gamma && a.beta && a.out && a.out_gstride % 4 == 0, "LayerNorm tail: gamma, beta, out"); break;
+        case STAIR_TILE_STORE_ROWS: STAIR_CHECK(a.out && a.out_row_idx && a.out_gstride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0, "row-scatter tail: out, out_row_idx"); break;
         case STAIR_TILE_NONE: break;
         default: STAIR_FAIL("unknown tail");
     }
@@ -481,17 +551,18 @@ int launch_tile_mlp_batch(const stair_tile_mlp_args *args, int n, unsigned *coun
     int order[TM_MAXB], m = 0;
     for (int i = 0; i < n; ++i) {
         if (int rc = tile_mlp_check(args[i])) return rc;
-        STAIR_CHECK(args[i].T == args[0].T, "the buckets of one launch share T");
         if (args[i].cnt > 0) order[m++] = i;
     }
     if (m == 0) return 0;
-    std::stable_sort(order, order + m, [&](int x, int y) { return args[x].n_layers > args[y].n_layers; });    // long tiles first
+    auto rounds = [&](int x) { return args[x].n_layers + (args[x].vec_pack ? (args[x].vec_pack == 1 ? 1 : 2) : 0); };   // k loops per tile
+    std::stable_sort(order, order + m, [&](int x, int y) { return rounds(x) > rounds(y); });    // long tiles first
     for (int j = 0; j < m; ++j) {
         const stair_tile_mlp_args &a = args[order[j]];
         pp.a[j] = a;
         pp.first[j + 1] = pp.first[j] + a.cnt;
-        const int64_t M = (int64_t)a.cnt * a.T;
-        STAIR_ACCT_MFMA("tile_mlp", (M * TM_H * 2 + (int64_t)a.n_layers * TM_H * TM_H) * 4, 2 * M * TM_H * TM_H * a.n_layers);
+        const int64_t M = a.vec_pack ? a.vec_cnt : (int64_t)a.cnt * a.T;
+        const int kl = rounds(order[j]);
+        STAIR_ACCT_MFMA("tile_mlp", (M * TM_H * 2 + (int64_t)kl * TM_H * TM_H) * 4, 2 * M * TM_H * TM_H * kl);
     }
     for (int j = m; j < TM_MAXB; ++j) { pp.a[j] = pp.a[0]; pp.first[j + 1] = pp.first[m]; }
     pp.nb = m;
@@ -537,4 +608,15 @@ extern "C" int stair_pack_wfrag(const float *W, void *planes, int32_t N, int32_t
     const float *w[1] = {W};
     void *o[1] = {planes};
     return stair::launch_pack_wfrag_many(w, o, 1, N, K, static_cast<hipStream_t>(stream), transpose != 0);
+}
+
+extern "C" int stair_pack_wfrag_ld(const float *W, int64_t ld, void *planes, int32_t N, int32_t K, stair_stream stream) {
+    if (!W || !planes) {
+        stair::set_error("stair_pack_wfrag_ld: null argument");
+        return 1;
+    }
+    const float *w[1] = {W};
+    void *o[1] = {planes};
+    const int l[1] = {(int)ld};
+    return stair::launch_pack_wfrag_many(w, o, 1, N, K, static_cast<hipStream_t>(stream), false, l);
 }

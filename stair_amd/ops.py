@@ -372,3 +372,49 @@ def tile_mlp(x, layers, tail, x_idx=None, row_scale=None, rs_idx=None, save=Fals
     a.cnt, a.T, a.H = cnt, T, H
     check(lib.stair_tile_mlp_fwd(C.byref(a), _stream()))
     return saves, rs_out
+
+
+VEC_PACKS = {'cat2': 1, 'xor': 2, 'exists': 3}
+
+
+def vec_mlp(kind, a_rows, a_idx, b_rows, b_idx, layers, out, out_row_idx, save=False):
+    """A vector-level module as ONE launch of the fused tile operator (stair_tile_mlp_args.vec_pack): 64 instances per tile, the
+    first layer over the concatenation [a, b] ('cat2': Compare / Equals / ToAction), [|a - b|, a, b] ('xor') or [a, b, a * b]
+    ('exists') of the rows a = a_rows[a_idx[i]], b = b_rows[b_idx[i]] -- never materialised for the GEMM --, an optional second
+    layer, and row i of the result stored at out[out_row_idx[i]].  layers = [(weight [512, 2H | 3H], bias, act), (weight [512, 512],
+    bias, act)?].  Returns (cat [n, 2H | 3H], [saved activation per layer]) when save=True, else (None, [])."""
+    _req(a_rows, 'a_rows'); _req(b_rows, 'b_rows'); _req(out, 'out')
+    _req(a_idx, 'a_idx', torch.int32); _req(b_idx, 'b_idx', torch.int32); _req(out_row_idx, 'out_row_idx', torch.int32)
+    H = a_rows.shape[-1]
+    n = int(a_idx.numel())
+    nseg = 2 if kind == 'cat2' else 3
+    a = TileMlpArgs()
+    a.vec_pack, a.vec_cnt = VEC_PACKS[kind], n
+    a.pk_a, a.pk_b, a.pk_a_idx, a.pk_b_idx = a_rows.data_ptr(), b_rows.data_ptr(), a_idx.data_ptr(), b_idx.data_ptr()
+    keep = []
+    for l, (w, b, act) in enumerate(layers):
+        _req(w, 'weight')
+        if l == 0:
+            assert w.shape == (H, nseg * H), w.shape
+            planes = torch.empty(nseg * 2 * H * H, dtype=torch.bfloat16, device=w.device)
+            for j in range(nseg):
+                check(lib.stair_pack_wfrag_ld(w.data_ptr() + 4 * j * H, nseg * H, planes.data_ptr() + 2 * j * 2 * H * H, H, H, _stream()))
+        else:
+            planes = pack_wfrag(w)
+        keep.append(planes)
+        a.W[l], a.bias[l], a.act[l] = planes.data_ptr(), (b.data_ptr() if b is not None else None), ACT[act]
+    a.n_layers = len(layers)
+    cat, saves = None, []
+    if save:
+        cat = torch.empty(n, nseg * H, device=out.device)
+        a.cat_save = cat.data_ptr()
+        for l in range(len(layers)):
+            sv = torch.empty(n, H, device=out.device)
+            saves.append(sv)
+            a.save[l] = sv.data_ptr()
+    a.tail = 7
+    a.out, a.out_gstride, a.out_row_idx = out.data_ptr(), H, out_row_idx.data_ptr()
+    a.cnt, a.T, a.H = (n + 63) // 64, 64, H
+    check(lib.stair_tile_mlp_fwd(C.byref(a), _stream()))
+    return cat, saves
+

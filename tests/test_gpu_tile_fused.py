@@ -99,3 +99,42 @@ def test_ragged_batch_through_the_fused_operators():
     for i, q in enumerate(qs):
         solo = model.forward_batch([q]).logits.cpu()
         assert float((batch[i] - solo[0]).abs().max()) < 2e-5, (q['form'], lens[i])
+
+
+@pytest.mark.parametrize('kind', ['cat2', 'xor', 'exists'])
+@pytest.mark.parametrize('n,two_layers', [(1, True), (63, False), (64, True), (65, True), (200, False), (1044, True)])
+def test_vector_level_module_as_one_tile_launch(kind, n, two_layers):
+    """Compare / Equals / ToAction ('cat2'), Xor, Exists (/root/reference/video_nmn/modules.py:15-37,59-72,102-120,141-159):
+    pack + Linear + ReLU (+ Linear + ReLU) on 64 instances per tile, the concatenation never materialised for the GEMM; against
+    fp64 of the same formula.  Rows of `out` that no instance writes stay untouched; the saved concatenation and activations are
+    what the backward pass reads."""
+    from stair_amd import ops
+    H = 512
+    g = torch.Generator().manual_seed(n * 7 + len(kind))
+    slots = n + 9
+    vec = torch.randn(slots, H, generator=g)
+    ia = torch.randint(0, slots, (n,), generator=g, dtype=torch.int32)
+    ib = torch.randint(0, slots, (n,), generator=g, dtype=torch.int32)
+    io = torch.randperm(slots, generator=g)[:n].to(torch.int32)
+    nseg = 2 if kind == 'cat2' else 3
+    w1 = torch.randn(H, nseg * H, generator=g) / (nseg * H) ** 0.5; b1 = torch.randn(H, generator=g) * 0.1
+    w2 = torch.randn(H, H, generator=g) / H ** 0.5; b2 = torch.randn(H, generator=g) * 0.1
+    d = lambda t: t.to(DEV)
+    out0 = torch.randn(slots, H, generator=g)
+    out = d(out0.clone())
+    layers = [(d(w1), d(b1), 'relu')] + ([(d(w2), d(b2), 'relu')] if two_layers else [])
+    cat, saves = ops.vec_mlp(kind, d(vec), d(ia), d(vec), d(ib), layers, out, d(io), save=True)
+    a, b = vec[ia.long()].double(), vec[ib.long()].double()
+    ref_cat = {'cat2': torch.cat([a, b], 1), 'xor': torch.cat([(a - b).abs(), a, b], 1), 'exists': torch.cat([a, b, a * b], 1)}[kind]
+    h1 = torch.relu(ref_cat @ w1.double().t() + b1.double())
+    ref = torch.relu(h1 @ w2.double().t() + b2.double()) if two_layers else h1
+    assert float((cat.cpu().double() - ref_cat).abs().max()) == 0.0 or kind != 'cat2'
+    assert float((cat.cpu().double() - ref_cat).abs().max()) < 1e-6
+    assert float((saves[0].cpu().double() - h1).abs().max()) < 3e-5
+    got = out.cpu().double()
+    assert float((got[io.long()] - ref).abs().max()) < 3e-5
+    untouched = torch.ones(slots, dtype=torch.bool); untouched[io.long()] = False
+    assert torch.equal(out.cpu()[untouched], out0[untouched])
+    out2 = d(out0.clone())
+    ops.vec_mlp(kind, d(vec), d(ia), d(vec), d(ib), layers, out2, d(io), save=False)      # inference form: no saves, direct layer boundary
+    assert float((out2.cpu().double()[io.long()] - ref).abs().max()) < 3e-5

@@ -24,7 +24,7 @@ def _case(M, N, K, R, seed, gather=True, scale=True):
 
 @pytest.mark.parametrize('M,N,K,R', [(64, 256, 128, 32), (64 * 13, 512, 512, 64), (64 * 273, 512, 512, 64), (32 * 1001, 256, 384, 32),
                                      (64 * 1704, 512, 512, 64), (96 * 40, 512, 256, 96)])
-@pytest.mark.parametrize('gather,scale', [(True, True), (True, False), (False, False)])
+@pytest.mark.parametrize('gather,scale', [(True, True), (True, False), (False, False), (False, True)])
 def test_slab_product_matches_fp64(M, N, K, R, gather, scale):
     from stair_amd import ops
     X, idx, dZ, rs, C0, b0 = _case(M, N, K, R, M + N + K, gather, scale)
@@ -67,3 +67,16 @@ def test_unsupported_shapes_are_refused():
     A = torch.zeros(64, 100, device=DEV); B = torch.zeros(64, 128, device=DEV); Cm = torch.zeros(100, 128, device=DEV)
     with pytest.raises(RuntimeError, match='shape not supported'):
         ops.gemm_tn(A, B, Cm, 64, 100, 128, rows_per_group=32, deterministic=True)
+
+
+def test_step_gradients_with_every_map_level_product_on_the_slab_kernel():
+    """The per-bucket products of stair_plan_backward (FilterFrame's dense layer is used by up to three buckets of a step) take the
+    slab kernel from 4096 rows on; lowered to 64 rows, the six-question full-size gradient check runs every one of them through it:
+    several products into ONE weight are queued before the single reduction launch, which must add them one after the other."""
+    from stair_amd._lib import lib, check
+    import test_gpu_train
+    check(lib.stair_set_tn_slab_min_rows(64))
+    try:
+        test_gpu_train.test_full_size_backward_sample('bf16x3')
+    finally:
+        check(lib.stair_set_tn_slab_min_rows(4096))
