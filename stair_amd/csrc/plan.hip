@@ -1375,14 +1375,19 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
         if (cnt_w) RUN(launch_pack_wfrag_many(src, dst, cnt_w, H, H, s));
     }
     // vector-level modules on the tile operator (64 instances per tile; STAIR_TILE_VEC=0: the pack -> GEMM -> reduction sequences)
-    static const bool vec_env = [] { const char *e = getenv("STAIR_TILE_VEC"); return !(e && e[0] == '0'); }();
-    const bool fused_vec = fused && vec_env;
+    // Policy (measured, ms per batch, fused / unfused): 2048 questions, buckets of 205..1044 instances: training 17.91 / 17.96,
+    // inference 5.61 / 5.73; 128 questions, 13..66 instances: training 5.06 / 5.01 -- one workgroup carries a tile's whole
+    // [64 x 1536 x 512] first layer (3 x 17 us) where the split-K GEMM spreads it over 64 workgroups (13 us), so the tile form
+    // pays only when a bucket fills several tiles.  STAIR_TILE_VEC = minimum instances per bucket (0: never).
+    const int vec_min = [] { const char *e = getenv("STAIR_TILE_VEC"); return e ? atoi(e) : 128; }();      // read per pass: tests switch it
+    auto fused_vec_for = [&](const Bucket &b) { return fused && vec_min > 0 && b.cnt >= vec_min; };
+    const bool fused_vec = fused && vec_min > 0;
     if (fused_vec) {
         struct { int slot, nseg; const Lin *l; int op; } vw[7] = {{WV_CMP, 2, &W.compare, STAIR_OP_COMPARE}, {WV_EQ, 2, &W.equals, STAIR_OP_EQUALS},
             {WV_XOR, 3, &W.xorl, STAIR_OP_XOR}, {WV_TA0, 2, &W.ta0, STAIR_OP_TOACTION}, {WV_TA3, 1, &W.ta3, STAIR_OP_TOACTION},
             {WV_EX0, 3, &W.exists0, STAIR_OP_EXISTS}, {WV_EX3, 1, &W.exists3, STAIR_OP_EXISTS}};
         bool has[32] = {};
-        for (const Bucket &b : pl->buckets) if (b.cnt > 0 && b.op >= 0 && b.op < 32) has[b.op] = true;
+        for (const Bucket &b : pl->buckets) if (fused_vec_for(b) && b.op >= 0 && b.op < 32) has[b.op] = true;
         const float *src[16];
         void *dst[16];
         int ld[16], cnt_w = 0;
@@ -1452,7 +1457,7 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
                 break;
             case STAIR_OP_COMPARE:      // modules.py:15-21
             case STAIR_OP_EQUALS: {     // modules.py:24-37
-                if (fused_vec) {
+                if (fused_vec_for(b)) {
                     if (phase == 1) tile_queue.push_back(vec_module(b, 1, I0, I1, I2, b.op == STAIR_OP_COMPARE ? WV_CMP : WV_EQ,
                                                                     b.op == STAIR_OP_COMPARE ? W.compare : W.equals, 0, nullptr, cat, nullptr));
                     break;
@@ -1463,7 +1468,7 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
                 break;
             }
             case STAIR_OP_XOR:          // modules.py:59-72: cat[|a-b|, a, b]
-                if (fused_vec) {
+                if (fused_vec_for(b)) {
                     if (phase == 1) tile_queue.push_back(vec_module(b, 2, I0, I1, I2, WV_XOR, W.xorl, 0, nullptr, cat, nullptr));
                     break;
                 }
@@ -1471,7 +1476,7 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
                 RUN(dense(s, cat, 3 * H, 3 * H, nullptr, W.xorl, 3 * H, vec, H, H, I2, c, 1, H, 3 * H, 1));
                 break;
             case STAIR_OP_TOACTION:     // modules.py:102-120: cat[action, keyword]
-                if (fused_vec) {
+                if (fused_vec_for(b)) {
                     if (phase == 1) tile_queue.push_back(vec_module(b, 1, I0, I1, I2, WV_TA0, W.ta0, WV_TA3, &W.ta3, cat, hid));
                     break;
                 }
@@ -1481,7 +1486,7 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
                 RUN(dense(s, hid, H, H, nullptr, W.ta3, H, vec, H, H, I2, c, 1, H, H, 1));
                 break;
             case STAIR_OP_EXISTS:       // modules.py:141-159: Exists(keyword, feat) -> cat[feat, keyword, feat*keyword]
-                if (fused_vec) {
+                if (fused_vec_for(b)) {
                     if (phase == 1) tile_queue.push_back(vec_module(b, 3, I1, I0, I2, WV_EX0, W.exists0, WV_EX3, &W.exists3, cat, hid));
                     break;
                 }

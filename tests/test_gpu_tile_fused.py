@@ -32,8 +32,21 @@ def unfused():
     lib.stair_set_tile_mlp(-1)
 
 
+@pytest.fixture
+def vec_tiles():
+    """vector-level modules on the tile operator whatever the bucket size (the default policy wants 128 instances per bucket)"""
+    import os
+    old = os.environ.get('STAIR_TILE_VEC')
+    os.environ['STAIR_TILE_VEC'] = '1'
+    yield
+    if old is None:
+        del os.environ['STAIR_TILE_VEC']
+    else:
+        os.environ['STAIR_TILE_VEC'] = old
+
+
 @pytest.mark.parametrize('T', [64, 40])
-def test_every_node_at_full_width_matches_the_oracle(T):
+def test_every_node_at_full_width_matches_the_oracle(T, vec_tiles):
     """Every intermediate value of all 12 program forms at H = 512 (the tiny-config node tests never reach the fused
     operators): vec / map / attention values against the oracle's interpreter, 2e-5 relative to the value's scale."""
     from stair_amd import ops
@@ -59,7 +72,7 @@ def test_every_node_at_full_width_matches_the_oracle(T):
     assert checked > 100
 
 
-def test_fused_and_sequenced_paths_agree_forward_and_backward(unfused):
+def test_fused_and_sequenced_paths_agree_forward_and_backward(unfused, vec_tiles):
     """Same batch through both runners: logits, every node, per-question loss and every parameter gradient.  The two compute the
     same split-bf16 products in another order, so only rounding separates them."""
     config = dict(spec.DEFAULT_CONFIG)
