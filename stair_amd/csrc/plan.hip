@@ -1645,9 +1645,9 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
             static const bool use_queue = [] { const char *e = getenv("STAIR_TILE_QUEUE"); return !(e && e[0] == '0'); }();
             for (size_t q0 = 0; q0 < tile_queue.size(); q0 += merge_max) {
                 const int nq = (int)std::min<size_t>(merge_max, tile_queue.size() - q0);
-                STAIR_CHECK(tile_launches < 48, "internal: more fused launches than work-queue heads");
+                STAIR_CHECK(tile_launches + 1 < 48, "internal: more fused launches than work-queue heads");
                 RUN(launch_tile_mlp_batch(tile_queue.data() + q0, nq, use_queue ? tile_ctr + tile_launches : nullptr, s));
-                ++tile_launches;
+                tile_launches += 2;           // map-level and vector-level tiles of a batch are two kernels, each with its own queue head
             }
             for (size_t k = lo_; k < hi_; ++k) RUN(run_bucket(pl->buckets[k], (int)k, 2));
             lo_ = hi_;

@@ -89,32 +89,45 @@ __device__ __forceinline__ void tm_st(float *p, const v4f v) {
     else *reinterpret_cast<v4f *>(p) = v;
 }
 
-template <bool NT>
+// a stage boundary: the workgroup barrier, and nothing scheduled across it (hipcc otherwise hoists the next stage's loads over the
+// barrier into the previous stage, where the accumulators are still live: spills)
+// hide a uniform pointer's provenance from the optimiser: what is derived from the result cannot be hoisted above this point
+// (row addresses precomputed outside the tile / layer loops are what ran the kernel out of registers)
+template <typename P>
+__device__ __forceinline__ P *tm_fresh(P *p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+__device__ __forceinline__ int tm_fresh_v(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+#define TM_SYNC() do { __builtin_amdgcn_sched_barrier(0); __syncthreads(); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+template <bool NT, bool VEC>
 __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float *F = reinterpret_cast<float *>(lds);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
+    const int tid = threadIdx.x, lane0 = tid & 63;
+    // the wave index is uniform over the wave: in an SGPR every row address (row = wave + 8 j) is scalar arithmetic and the row-wise
+    // accesses take the base-in-SGPR + one shared lane offset form -- as a VGPR it made every row of every array a 64-bit VGPR
+    // pointer of its own (hoisted out of the loops: 150 spilled registers once the loads were batched)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int total = pp.first[pp.nb];
     __shared__ int next_work;
-    // B-operand fragment offsets (bytes inside a stage plane, chunk 0) of this lane's two frame tiles
-    int offT[2];
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-        const int R = 32 * tt + r;
-        offT[tt] = (R * 4 + tm_swz(R)) * 16;
-    }
-
     // Work items = tiles of all buckets of the launch, handed out through one atomic counter: a workgroup that finishes a
     // one-layer tile takes the next item while another is still in a three-layer one, and the last partial round of one
     // bucket is filled with the next bucket's tiles (the buckets are listed by decreasing layer count).
     for (int it = 0;; ++it) {
         int w;
-        __syncthreads();                          // the previous tile's tail has finished reading the staging (and next_work)
+        TM_SYNC();                          // the previous tile's tail has finished reading the staging (and next_work)
         if (pp.counter) {
             if (tid == 0) next_work = (int)atomicAdd(pp.counter, 1u);
-            __syncthreads();
-            w = next_work;
+            TM_SYNC();
+            w = __builtin_amdgcn_readfirstlane(next_work);       // uniform BY CONSTRUCTION: says so, so that everything derived from it
+                                                                 // (argument block, tile pointers) lives in SGPRs, not in 64-bit VGPR pairs
         } else {
             w = blockIdx.x + it * gridDim.x;
         }
@@ -124,77 +137,126 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
         for (int j = 1; j < TM_MAXB; ++j) bsel += (j < pp.nb && w >= pp.first[j]) ? 1 : 0;
         const stair_tile_mlp_args &p = pp.a[bsel];
         const int inst = w - pp.first[bsel];
+        // the lane id, re-derived per tile from an opaque copy: the dozens of lane-dependent LDS / row offsets below are then computed
+        // where they are used instead of being hoisted out of this (persistent) loop and kept alive -- or spilled -- across it
+        const int lane = tm_fresh_v(lane0);
+        const int r = lane & 31, h = lane >> 5;
+        // B-operand fragment offsets (bytes inside a stage plane, chunk 0) of this lane's two frame tiles
+        int offT[2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int R = 32 * tt + r;
+            offT[tt] = (R * 4 + tm_swz(R)) * 16;
+        }
+
+
         // rows of this tile: the T frames of a module instance, or (vector-level modules) up to 64 INSTANCES of one row each
-        const int vpack = p.vec_pack;
+        const int vpack = VEC ? p.vec_pack : 0;          // the vector-level form is a kernel of its own (registers)
         const int T = vpack ? min(TM_ROWS, p.vec_cnt - TM_ROWS * inst) : p.T;
         const int Ts = vpack ? TM_ROWS : p.T;            // rows between two tiles in the [cnt, T, H] save / mask buffers
         const int nseg = vpack == 0 ? 1 : (vpack == 1 ? 2 : 3);
         // ---- the input tile: fp32 rows -> (row scale) -> bf16 hi / lo image ------------------------------------------
-        const float *x = p.X + (int64_t)(p.x_idx ? p.x_idx[inst] : inst) * p.x_gstride;
-        const float *rsrow = p.row_scale ? p.row_scale + (int64_t)(p.rs_idx ? p.rs_idx[inst] : inst) * T : nullptr;
-        const float *imask = p.in_mask ? p.in_mask + (int64_t)(p.in_mask_idx ? p.in_mask_idx[inst] : inst) * p.in_mask_gstride : nullptr;
-        const int Lrows = p.x_broadcast ? (p.len ? p.len[inst] : T) : T;     // a broadcast row fills the clip's own frames only
+        const float *x = tm_fresh(p.X + (int64_t)(p.x_idx ? __builtin_amdgcn_readfirstlane(p.x_idx[inst]) : inst) * p.x_gstride);
+        const float *rsrow = p.row_scale ? p.row_scale + (int64_t)(p.rs_idx ? __builtin_amdgcn_readfirstlane(p.rs_idx[inst]) : inst) * T : nullptr;
+        const float *imask = tm_fresh(p.in_mask ? p.in_mask + (int64_t)(p.in_mask_idx ? __builtin_amdgcn_readfirstlane(p.in_mask_idx[inst]) : inst) * p.in_mask_gstride : nullptr);
+        const int Lrows = p.x_broadcast ? (p.len ? __builtin_amdgcn_readfirstlane(p.len[inst]) : T) : T;     // a broadcast row fills the clip's own frames only
         // vector-level modules: row t of the tile is H-wide block `seg` of the concatenation built from the two operand rows
         // of instance 64 inst + t (never materialised for the GEMM; cat_save keeps it for the weight gradient)
         auto build_vec_image = [&](const int seg) {
-            for (int u = tid; u < TM_ROWS * 64; u += 512) {
-                const int t = u >> 6, c8 = u & 63;
-                v4f a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-                if (t < T) {
-                    const int64_t i = (int64_t)TM_ROWS * inst + t;
-                    const float *ar = p.pk_a + (int64_t)(p.pk_a_idx ? p.pk_a_idx[i] : i) * TM_H + 8 * c8;
-                    const float *br = p.pk_b + (int64_t)(p.pk_b_idx ? p.pk_b_idx[i] : i) * TM_H + 8 * c8;
-                    const v4f a0 = *reinterpret_cast<const v4f *>(ar), a1 = *reinterpret_cast<const v4f *>(ar + 4);
-                    const v4f b0 = *reinterpret_cast<const v4f *>(br), b1 = *reinterpret_cast<const v4f *>(br + 4);
-                    if (vpack == 1) { a = seg == 0 ? a0 : b0; b = seg == 0 ? a1 : b1; }
-                    else if (vpack == 2) {
-                        if (seg == 0) {
+            const int c8 = tm_fresh_v(lane);          // (row wave + 8 j, columns 8 c8 .. +7); offsets computed here, see above
+#pragma unroll 1
+            for (int half = 0; half < 2; ++half) {
+                v4f a0[4], a1[4], b0[4], b1[4];
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) { a[j] = fabsf(a0[j] - b0[j]); b[j] = fabsf(a1[j] - b1[j]); }
-                        } else { a = seg == 1 ? a0 : b0; b = seg == 1 ? a1 : b1; }
-                    } else {
-                        if (seg == 2) { a = a0 * b0; b = a1 * b1; }
-                        else { a = seg == 0 ? a0 : b0; b = seg == 0 ? a1 : b1; }
-                    }
-                    if (p.cat_save) {
-                        float *d = p.cat_save + (i * nseg + seg) * TM_H + 8 * c8;
-                        *reinterpret_cast<v4f *>(d) = a; *reinterpret_cast<v4f *>(d + 4) = b;
-                    }
+                for (int j = 0; j < 4; ++j) {         // all operand rows of four instances first, then the arithmetic
+                    const int t = wave + 8 * (4 * half + j);
+                    const int64_t i = (int64_t)TM_ROWS * inst + (t < T ? t : 0);
+                    const float *ar = p.pk_a + (int64_t)(p.pk_a_idx ? __builtin_amdgcn_readfirstlane(p.pk_a_idx[i]) : i) * TM_H + 8 * c8;
+                    const float *br = p.pk_b + (int64_t)(p.pk_b_idx ? __builtin_amdgcn_readfirstlane(p.pk_b_idx[i]) : i) * TM_H + 8 * c8;
+                    a0[j] = *reinterpret_cast<const v4f *>(ar); a1[j] = *reinterpret_cast<const v4f *>(ar + 4);
+                    b0[j] = *reinterpret_cast<const v4f *>(br); b1[j] = *reinterpret_cast<const v4f *>(br + 4);
                 }
-                bf16x8 hi, lo;
-                tm_split8(a, b, hi, lo);
-                const int off = (c8 >> 2) * TM_STAGE + (t * 4 + ((c8 & 3) ^ tm_swz(t))) * 16;
-                *reinterpret_cast<bf16x8 *>(lds + off) = hi;
-                *reinterpret_cast<bf16x8 *>(lds + off + 4096) = lo;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int t = wave + 8 * (4 * half + j);
+                    v4f a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+                    if (t < T) {
+                        if (vpack == 1) { a = seg == 0 ? a0[j] : b0[j]; b = seg == 0 ? a1[j] : b1[j]; }
+                        else if (vpack == 2) {
+                            if (seg == 0) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { a[e] = fabsf(a0[j][e] - b0[j][e]); b[e] = fabsf(a1[j][e] - b1[j][e]); }
+                            } else { a = seg == 1 ? a0[j] : b0[j]; b = seg == 1 ? a1[j] : b1[j]; }
+                        } else {
+                            if (seg == 2) { a = a0[j] * b0[j]; b = a1[j] * b1[j]; }
+                            else { a = seg == 0 ? a0[j] : b0[j]; b = seg == 0 ? a1[j] : b1[j]; }
+                        }
+                        if (p.cat_save) {
+                            float *d = p.cat_save + (((int64_t)TM_ROWS * inst + t) * nseg + seg) * TM_H + 8 * c8;
+                            *reinterpret_cast<v4f *>(d) = a; *reinterpret_cast<v4f *>(d + 4) = b;
+                        }
+                    }
+                    bf16x8 hi, lo;
+                    tm_split8(a, b, hi, lo);
+                    const int off = (c8 >> 2) * TM_STAGE + (t * 4 + ((c8 & 3) ^ tm_swz(t))) * 16;
+                    *reinterpret_cast<bf16x8 *>(lds + off) = hi;
+                    *reinterpret_cast<bf16x8 *>(lds + off + 4096) = lo;
+                }
             }
         };
         if (vpack) build_vec_image(0);
-        else
-        for (int u = tid; u < TM_ROWS * 64; u += 512) {
-            const int t = u >> 6, c8 = u & 63;
-            v4f a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-            if (t < Lrows) {
-                const float *xr = x + (p.x_broadcast ? 0 : (int64_t)t * TM_H) + 8 * c8;
-                a = tm_ld<NT>(xr);
-                b = tm_ld<NT>(xr + 4);
-                if (rsrow) { const float s = rsrow[t]; a *= s; b *= s; }
-                if (imask) {                  // backward chains: the incoming gradient times relu'(saved activation) (x in_scale)
-                    const v4f m0 = tm_ld<NT>(imask + (int64_t)t * TM_H + 8 * c8), m1 = tm_ld<NT>(imask + (int64_t)t * TM_H + 8 * c8 + 4);
+        else {
+            // thread (wave, lane) carries columns 8 lane .. +7 of rows wave + 8 j.  All global loads of four rows are issued before
+            // anything uses them (a load -> use -> store -> load loop runs one memory round trip per row: 8 x ~2 us per tile);
+            // rows past the tile's length read row 0 and are zeroed afterwards, so that no load hides behind a branch.
+            const int c8 = lane;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) { a[i] = m0[i] > 0.f ? a[i] * p.in_scale : 0.f; b[i] = m1[i] > 0.f ? b[i] * p.in_scale : 0.f; }
+            for (int half = 0; half < 2; ++half) {
+                v4f xa[4], xb[4], ma[4], mb[4];
+                float sc[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int t = wave + 8 * (4 * half + j);
+                    const int ts = t < Lrows ? t : 0;
+                    const float *xr = x + (p.x_broadcast ? 0 : (int64_t)ts * TM_H) + 8 * c8;
+                    xa[j] = tm_ld<NT>(xr);
+                    xb[j] = tm_ld<NT>(xr + 4);
+                    sc[j] = rsrow ? rsrow[ts] : 1.0f;
+                    if (imask) {
+                        ma[j] = tm_ld<NT>(imask + (int64_t)ts * TM_H + 8 * c8);
+                        mb[j] = tm_ld<NT>(imask + (int64_t)ts * TM_H + 8 * c8 + 4);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int t = wave + 8 * (4 * half + j);
+                    v4f a = xa[j], b = xb[j];
+                    if (rsrow) { a *= sc[j]; b *= sc[j]; }
+                    if (imask) {              // backward chains: the incoming gradient times relu'(saved activation) (x in_scale)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { a[i] = ma[j][i] > 0.f ? a[i] * p.in_scale : 0.f; b[i] = mb[j][i] > 0.f ? b[i] * p.in_scale : 0.f; }
+                    }
+                    if (t >= Lrows) { a = v4f{0.f, 0.f, 0.f, 0.f}; b = a; }
+                    xa[j] = a; xb[j] = b;
+                    bf16x8 hi, lo;
+                    tm_split8(a, b, hi, lo);
+                    const int off = (c8 >> 2) * TM_STAGE + (t * 4 + ((c8 & 3) ^ tm_swz(t))) * 16;
+                    *reinterpret_cast<bf16x8 *>(lds + off) = hi;
+                    *reinterpret_cast<bf16x8 *>(lds + off + 4096) = lo;
+                }
+                if (p.save_in) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int t = wave + 8 * (4 * half + j);
+                        if (t < T) {
+                            float *d = p.save_in + ((int64_t)inst * Ts + t) * TM_H + 8 * c8;
+                            tm_st<NT>(d, xa[j]); tm_st<NT>(d + 4, xb[j]);
+                        }
+                    }
                 }
             }
-            if (p.save_in && t < T) {
-                float *d = p.save_in + ((int64_t)inst * Ts + t) * TM_H + 8 * c8;
-                tm_st<NT>(d, a); tm_st<NT>(d + 4, b);
-            }
-            bf16x8 hi, lo;
-            tm_split8(a, b, hi, lo);
-            const int off = (c8 >> 2) * TM_STAGE + (t * 4 + ((c8 & 3) ^ tm_swz(t))) * 16;
-            *reinterpret_cast<bf16x8 *>(lds + off) = hi;
-            *reinterpret_cast<bf16x8 *>(lds + off + 4096) = lo;
         }
-        __syncthreads();
+        TM_SYNC();
 
         f32x16 acc[2][2];
         for (int ph = 0; ph < p.n_layers; ++ph) {
@@ -208,9 +270,9 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
             // (a vector-level module's first layer: once per H-wide block of the concatenated input, into the same accumulators)
             for (int seg = 0; seg < (ph == 0 ? nseg : 1); ++seg) {
                 if (seg > 0) {
-                    __syncthreads();              // every wave has finished reading the previous block's image
+                    TM_SYNC();              // every wave has finished reading the previous block's image
                     build_vec_image(seg);
-                    __syncthreads();
+                    TM_SYNC();
                 }
                 const bf16x8 *wq = static_cast<const bf16x8 *>(p.W[ph]) + (int64_t)seg * (TM_H * TM_H * 2 / 8) + (int64_t)(2 * wave) * TM_KS * 2 * 64 + lane;
                 bf16x8 wf[4][2][2];
@@ -237,6 +299,9 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
                         const int ks = ks0 + u;
                         if (ks + 3 < TM_KS) { TM_LOADW((u + 3) & 3, ks + 3) }
                         if (ks + 1 < TM_KS) { TM_LOADZ((u + 1) & 1, ks + 1) }
+                        // the loads stay ABOVE this step's MFMAs: hipcc otherwise sinks each weight load to just before its use three
+                        // steps later (fewer live registers), and every k step then waits out an L2 round trip
+                        __builtin_amdgcn_sched_barrier(0);
                         // product-major order: four independent accumulators between two MFMAs on the same one
 #pragma unroll
                         for (int nt = 0; nt < 2; ++nt)
@@ -260,20 +325,28 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
             }
             // ---- bias + ReLU in the accumulator layout: lane (r, h) holds frame t = 32 tt + r, columns
             //      n = 64 wave + 32 nt + 8 q + 4 h + i for e = 4 q + i -- then the tile goes to LDS as fp32 rows ---------------
+            const int lane_e = tm_fresh_v(lane), r_e = lane_e & 31, h_e = lane_e >> 5;     // offsets of this stage are computed HERE, not before the k loop
             const float *bias = p.bias[ph];
             const int act = p.act[ph];
             const bool last = ph + 1 == p.n_layers;
             // between two layers of an inference plan nothing touches HBM: the accumulators go straight into the next image
             const bool direct = !last && !p.save[ph] && act != 3 && !(p.mid_rowdot && ph == 1);
-            __syncthreads();                      // every wave has finished reading the tile image of this layer
+            v4f bvs[2][4];                        // the lane's 32 bias values, loaded together (one round trip, behind the barrier)
+            __builtin_amdgcn_sched_barrier(0);    // ... and not earlier: inside the k loop they would cost 32 registers
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    bvs[nt][q] = bias ? *reinterpret_cast<const v4f *>(bias + 64 * wave + 32 * nt + 8 * q + 4 * h_e) : v4f{0.f, 0.f, 0.f, 0.f};
+            TM_SYNC();                      // every wave has finished reading the tile image of this layer
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const v4f bv = bias ? *reinterpret_cast<const v4f *>(bias + 64 * wave + 32 * nt + 8 * q + 4 * h) : v4f{0.f, 0.f, 0.f, 0.f};
+                    const v4f bv = bvs[nt][q];
 #pragma unroll
                     for (int tt = 0; tt < 2; ++tt) {
-                        const int t = 32 * tt + r;
+                        const int t = 32 * tt + r_e;
                         v4f z;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
@@ -284,61 +357,80 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
                             bf16x4 zh4, zl4;
 #pragma unroll
                             for (int i = 0; i < 4; ++i) { zh4[i] = (__bf16)z[i]; zl4[i] = (__bf16)(z[i] - (float)zh4[i]); }
-                            const int off = (2 * wave + nt) * TM_STAGE + (t * 4 + (q ^ tm_swz(t))) * 16 + 8 * h;
+                            const int off = (2 * wave + nt) * TM_STAGE + (t * 4 + (q ^ tm_swz(t))) * 16 + 8 * h_e;
                             *reinterpret_cast<bf16x4 *>(lds + off) = zh4;
                             *reinterpret_cast<bf16x4 *>(lds + off + 4096) = zl4;
                         } else {
-                            *reinterpret_cast<v4f *>(F + t * TM_FLD + 64 * wave + 32 * nt + 8 * q + 4 * h) = z;
+                            *reinterpret_cast<v4f *>(F + t * TM_FLD + 64 * wave + 32 * nt + 8 * q + 4 * h_e) = z;
                         }
                     }
                 }
-            __syncthreads();
+            TM_SYNC();
             if (!last && !direct) {
-                // ---- between two layers, ROW-wise (a wave per row, a lane per 8 consecutive columns: every global access is a
+                // ---- between two layers, ROW-wise (a wave per row, a lane_e per 8 consecutive columns: every global access is a
                 //      contiguous 2 KB row): relu'(saved activation) of a backward chain, the activation a backward pass will
                 //      need, FilterFrame's attention; then the rows become the next layer's bf16 hi / lo operand image.
                 //      The rows are read into registers first: the image overlays the staging. -----------------------------------
-                float *sv = p.save[ph];
-                const float *amask = act == 3 ? p.act_mask[ph] + (int64_t)inst * Ts * TM_H : nullptr;
+                float *sv = tm_fresh(p.save[ph]);
+                const float *amask = tm_fresh(act == 3 ? p.act_mask[ph] + (int64_t)inst * Ts * TM_H : nullptr);
                 const bool rowdot = p.mid_rowdot && ph == 1;
                 v4f rowv[8][2];
+                // every global load of the stage first (the relu' masks of all eight rows, the row-dot weights): interleaved with
+                // the saves they ran one memory round trip per row
+                v4f w0 = {0.f, 0.f, 0.f, 0.f}, w1 = w0;
+                float rd_b = 0.f;
+                if (rowdot) {
+                    w0 = *reinterpret_cast<const v4f *>(p.vw + 8 * lane_e); w1 = *reinterpret_cast<const v4f *>(p.vw + 8 * lane_e + 4);
+                    rd_b = p.vb[0] + (p.extra ? p.extra[inst] : 0.f);
+                }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int t = wave + 8 * j;
-                    v4f a = *reinterpret_cast<const v4f *>(F + t * TM_FLD + 8 * lane), b = *reinterpret_cast<const v4f *>(F + t * TM_FLD + 8 * lane + 4);
-                    if (t < T) {
-                        if (amask) {
-                            const v4f m0 = tm_ld<NT>(amask + (int64_t)t * TM_H + 8 * lane), m1 = tm_ld<NT>(amask + (int64_t)t * TM_H + 8 * lane + 4);
+                for (int half = 0; half < 2; ++half) {
+                    v4f mk[4][2];
+                    __builtin_amdgcn_sched_barrier(0);            // the loads stay here: hoisted above the epilogue they cost registers there
+                    if (amask) {
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) { a[i] = m0[i] > 0.f ? a[i] * p.act_scale : 0.f; b[i] = m1[i] > 0.f ? b[i] * p.act_scale : 0.f; }
-                        }
-                        if (sv) {
-                            float *d = sv + ((int64_t)inst * Ts + t) * TM_H + 8 * lane;
-                            tm_st<NT>(d, a); tm_st<NT>(d + 4, b);
-                        }
-                        if (rowdot) {             // FilterFrame: a_t = sigmoid(w[:H] . f_t + extra + b); the next layer runs on a_t f_t
-                            const v4f w0 = *reinterpret_cast<const v4f *>(p.vw + 8 * lane), w1 = *reinterpret_cast<const v4f *>(p.vw + 8 * lane + 4);
-                            float d = 0.f;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) d += a[i] * w0[i] + b[i] * w1[i];
-                            const float at = sigmoid_acc(wave_sum(d) + p.vb[0] + (p.extra ? p.extra[inst] : 0.f));
-                            if (p.rs_out && lane == 0) p.rs_out[(int64_t)inst * T + t] = at;
-                            a *= at; b *= at;
+                        for (int jj = 0; jj < 4; ++jj) {
+                            const int t = wave + 8 * (4 * half + jj), ts = t < T ? t : 0;
+                            mk[jj][0] = tm_ld<NT>(amask + (int64_t)ts * TM_H + 8 * lane_e);
+                            mk[jj][1] = tm_ld<NT>(amask + (int64_t)ts * TM_H + 8 * lane_e + 4);
                         }
                     }
-                    rowv[j][0] = a; rowv[j][1] = b;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int j = 4 * half + jj, t = wave + 8 * j;
+                        v4f a = *reinterpret_cast<const v4f *>(F + t * TM_FLD + 8 * lane_e), b = *reinterpret_cast<const v4f *>(F + t * TM_FLD + 8 * lane_e + 4);
+                        if (t < T) {
+                            if (amask) {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) { a[i] = mk[jj][0][i] > 0.f ? a[i] * p.act_scale : 0.f; b[i] = mk[jj][1][i] > 0.f ? b[i] * p.act_scale : 0.f; }
+                            }
+                            if (sv) {
+                                float *d = sv + ((int64_t)inst * Ts + t) * TM_H + 8 * lane_e;
+                                tm_st<NT>(d, a); tm_st<NT>(d + 4, b);
+                            }
+                            if (rowdot) {         // FilterFrame: a_t = sigmoid(w[:H] . f_t + extra + b); the next layer runs on a_t f_t
+                                float d = 0.f;
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) d += a[i] * w0[i] + b[i] * w1[i];
+                                const float at = sigmoid_acc(wave_sum(d) + rd_b);
+                                if (p.rs_out && lane_e == 0) p.rs_out[(int64_t)inst * T + t] = at;
+                                a *= at; b *= at;
+                            }
+                        }
+                        rowv[j][0] = a; rowv[j][1] = b;
+                    }
                 }
-                __syncthreads();                  // every row is in registers: the staging may be overwritten
+                TM_SYNC();                  // every row is in registers: the staging may be overwritten
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int t = wave + 8 * j;
                     bf16x8 hi, lo;
                     tm_split8(rowv[j][0], rowv[j][1], hi, lo);
-                    const int off = (lane >> 2) * TM_STAGE + (t * 4 + ((lane & 3) ^ tm_swz(t))) * 16;
+                    const int off = (lane_e >> 2) * TM_STAGE + (t * 4 + ((lane_e & 3) ^ tm_swz(t))) * 16;
                     *reinterpret_cast<bf16x8 *>(lds + off) = hi;
                     *reinterpret_cast<bf16x8 *>(lds + off + 4096) = lo;
                 }
-                __syncthreads();
+                TM_SYNC();
             }
         }
 
@@ -350,7 +442,7 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
                 tm_st<NT>(dst + 4 * lane, *reinterpret_cast<const v4f *>(F + t * TM_FLD + 4 * lane));
                 tm_st<NT>(dst + 256 + 4 * lane, *reinterpret_cast<const v4f *>(F + t * TM_FLD + 256 + 4 * lane));
             }
-        const int64_t oslot = p.out_idx ? p.out_idx[inst] : inst;
+        const int64_t oslot = p.out_idx ? __builtin_amdgcn_readfirstlane(p.out_idx[inst]) : inst;
         switch (p.tail) {
             case STAIR_TILE_STORE:
                 for (int t = wave; t < T; t += 8) {
@@ -376,48 +468,54 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
                 }
                 break;
             case STAIR_TILE_SUM_ROWS: {               // Filter: sum over the clip's own frames (modules.py:374,376)
-                const int L = p.len ? p.len[inst] : T;
+                const int L = p.len ? __builtin_amdgcn_readfirstlane(p.len[inst]) : T;
                 float s = 0.f;
                 for (int t = 0; t < L; ++t) s += F[t * TM_FLD + tid];
                 p.out[oslot * p.out_gstride + tid] = s;
                 break;
             }
             case STAIR_TILE_COSINE: {                 // Localize: (cos(f_t, k_j) + 1) * 0.49, nn.CosineSimilarity eps 1e-8
-                const int first = p.pair_first[inst], cn = p.pair_cnt[inst];
-                for (int t = wave; t < T; t += 8) {
-                    const v4f f0 = *reinterpret_cast<const v4f *>(F + t * TM_FLD + 4 * lane), f1 = *reinterpret_cast<const v4f *>(F + t * TM_FLD + 256 + 4 * lane);
-                    float nf = 0.f;
+                const int first = __builtin_amdgcn_readfirstlane(p.pair_first[inst]), cn = __builtin_amdgcn_readfirstlane(p.pair_cnt[inst]);
+                // pair-major: a keyword row (and its norm, and its attention slot) is fetched once, not once per frame
+                for (int j = 0; j < cn; ++j) {
+                    const float *k = p.kb + (int64_t)(first + j) * TM_H;
+                    const v4f k0 = *reinterpret_cast<const v4f *>(k + 4 * lane), k1 = *reinterpret_cast<const v4f *>(k + 256 + 4 * lane);
+                    float *arow = p.att + (int64_t)p.att_idx[first + j] * T;
+                    float nk = 0.f;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) nf += f0[i] * f0[i] + f1[i] * f1[i];
-                    nf = wave_sum(nf);
-                    for (int j = 0; j < cn; ++j) {
-                        const float *k = p.kb + (int64_t)(first + j) * TM_H;
-                        const v4f k0 = *reinterpret_cast<const v4f *>(k + 4 * lane), k1 = *reinterpret_cast<const v4f *>(k + 256 + 4 * lane);
-                        float d = 0.f, nk = 0.f;
+                    for (int i = 0; i < 4; ++i) nk += k0[i] * k0[i] + k1[i] * k1[i];
+                    nk = wave_sum(nk);
+                    for (int t = wave; t < T; t += 8) {
+                        const v4f f0 = *reinterpret_cast<const v4f *>(F + t * TM_FLD + 4 * lane), f1 = *reinterpret_cast<const v4f *>(F + t * TM_FLD + 256 + 4 * lane);
+                        float nf = 0.f, d = 0.f;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) { d += f0[i] * k0[i] + f1[i] * k1[i]; nk += k0[i] * k0[i] + k1[i] * k1[i]; }
-                        d = wave_sum(d); nk = wave_sum(nk);
+                        for (int i = 0; i < 4; ++i) { nf += f0[i] * f0[i] + f1[i] * f1[i]; d += f0[i] * k0[i] + f1[i] * k1[i]; }
+                        nf = wave_sum(nf); d = wave_sum(d);
                         if (lane == 0) {
                             const float eps = 1e-8f;
                             const float c = d / (fmaxf(sqrtf(nf), eps) * fmaxf(sqrtf(nk), eps));
-                            p.att[(int64_t)p.att_idx[first + j] * T + t] = (c + 1.0f) * 0.49f;
+                            arow[t] = (c + 1.0f) * 0.49f;
                         }
                     }
                 }
                 break;
             }
-            case STAIR_TILE_ROWDOT_SIGMOID:           // HasItem: sigmoid(w . row + b) (modules.py:131-137)
+            case STAIR_TILE_ROWDOT_SIGMOID: {         // HasItem: sigmoid(w . row + b) (modules.py:131-137)
+                const v4f w0 = *reinterpret_cast<const v4f *>(p.vw + 4 * lane), w1 = *reinterpret_cast<const v4f *>(p.vw + 256 + 4 * lane);
+                const float off = p.vb[0] + (p.extra ? p.extra[inst] : 0.f);
                 for (int t = wave; t < T; t += 8) {
                     const v4f f0 = *reinterpret_cast<const v4f *>(F + t * TM_FLD + 4 * lane), f1 = *reinterpret_cast<const v4f *>(F + t * TM_FLD + 256 + 4 * lane);
-                    const v4f w0 = *reinterpret_cast<const v4f *>(p.vw + 4 * lane), w1 = *reinterpret_cast<const v4f *>(p.vw + 256 + 4 * lane);
                     float d = 0.f;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) d += f0[i] * w0[i] + f1[i] * w1[i];
                     d = wave_sum(d);
-                    if (lane == 0) p.out[oslot * p.out_gstride + t] = sigmoid_acc(d + p.vb[0] + (p.extra ? p.extra[inst] : 0.f));
+                    if (lane == 0) p.out[oslot * p.out_gstride + t] = sigmoid_acc(d + off);
                 }
                 break;
-            case STAIR_TILE_LAYERNORM:                // Temporal: LayerNorm over H, eps 1e-5, biased variance (modules.py:283,327)
+            }
+            case STAIR_TILE_LAYERNORM: {              // Temporal: LayerNorm over H, eps 1e-5, biased variance (modules.py:283,327)
+                const v4f g0 = *reinterpret_cast<const v4f *>(p.gamma + 4 * lane), g1 = *reinterpret_cast<const v4f *>(p.gamma + 256 + 4 * lane);
+                const v4f b0 = *reinterpret_cast<const v4f *>(p.beta + 4 * lane), b1 = *reinterpret_cast<const v4f *>(p.beta + 256 + 4 * lane);
                 for (int t = wave; t < T; t += 8) {
                     v4f f0 = *reinterpret_cast<const v4f *>(F + t * TM_FLD + 4 * lane), f1 = *reinterpret_cast<const v4f *>(F + t * TM_FLD + 256 + 4 * lane);
                     float sum = 0.f;
@@ -428,8 +526,6 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { const float a = f0[i] - mean, b = f1[i] - mean; sq += a * a + b * b; }
                     const float rstd = rsqrtf(wave_sum(sq) / (float)TM_H + p.ln_eps);
-                    const v4f g0 = *reinterpret_cast<const v4f *>(p.gamma + 4 * lane), g1 = *reinterpret_cast<const v4f *>(p.gamma + 256 + 4 * lane);
-                    const v4f b0 = *reinterpret_cast<const v4f *>(p.beta + 4 * lane), b1 = *reinterpret_cast<const v4f *>(p.beta + 256 + 4 * lane);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { f0[i] = (f0[i] - mean) * rstd * g0[i] + b0[i]; f1[i] = (f1[i] - mean) * rstd * g1[i] + b1[i]; }
                     float *dst = p.out + oslot * p.out_gstride + (int64_t)t * TM_H;
@@ -437,6 +533,7 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
                     *reinterpret_cast<v4f *>(dst + 256 + 4 * lane) = f1;
                 }
                 break;
+            }
             default: break;
         }
     }
@@ -546,43 +643,49 @@ int launch_tile_mlp_batch(const stair_tile_mlp_args *args, int n, unsigned *coun
     // memset + atomic pattern replays correctly, tools/scratch/graph_memset.hip), and a replayed batch has fixed shapes anyway.
     hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
     if (counter && hipStreamIsCapturing(s, &cap_status) == hipSuccess && cap_status != hipStreamCaptureStatusNone) counter = nullptr;
-    TmParams pp;
-    pp.nb = 0; pp.counter = counter; pp.first[0] = 0;
-    int order[TM_MAXB], m = 0;
-    for (int i = 0; i < n; ++i) {
+    for (int i = 0; i < n; ++i)
         if (int rc = tile_mlp_check(args[i])) return rc;
-        if (args[i].cnt > 0) order[m++] = i;
-    }
-    if (m == 0) return 0;
-    auto rounds = [&](int x) { return args[x].n_layers + (args[x].vec_pack ? (args[x].vec_pack == 1 ? 1 : 2) : 0); };   // k loops per tile
-    std::stable_sort(order, order + m, [&](int x, int y) { return rounds(x) > rounds(y); });    // long tiles first
-    for (int j = 0; j < m; ++j) {
-        const stair_tile_mlp_args &a = args[order[j]];
-        pp.a[j] = a;
-        pp.first[j + 1] = pp.first[j] + a.cnt;
-        const int64_t M = a.vec_pack ? a.vec_cnt : (int64_t)a.cnt * a.T;
-        const int kl = rounds(order[j]);
-        STAIR_ACCT_MFMA("tile_mlp", (M * TM_H * 2 + (int64_t)kl * TM_H * TM_H) * 4, 2 * M * TM_H * TM_H * kl);
-    }
-    for (int j = m; j < TM_MAXB; ++j) { pp.a[j] = pp.a[0]; pp.first[j + 1] = pp.first[m]; }
-    pp.nb = m;
     static bool attr_set[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     static int cus[64] = {};
     if (!attr_set[dev]) {
-        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_mlp_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, TM_LDS));
-        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_mlp_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, TM_LDS));
+        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_mlp_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, TM_LDS));
+        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_mlp_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, TM_LDS));
+        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_mlp_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, TM_LDS));
         int v = 256;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
         cus[dev] = v;
         attr_set[dev] = true;
     }
-    const int grid = std::min(pp.first[m], cus[dev]);
     static const bool nt = [] { const char *e = getenv("STAIR_TILE_NT"); return e && e[0] == '1'; }();     // measured: plain stores are faster (profiles/r03_e_*)
-    if (nt) hipLaunchKernelGGL(tile_mlp_kernel<true>, dim3(grid), dim3(512), TM_LDS, s, pp);
-    else hipLaunchKernelGGL(tile_mlp_kernel<false>, dim3(grid), dim3(512), TM_LDS, s, pp);
-    STAIR_LAUNCH_CHECK();
+    auto rounds = [&](int x) { return args[x].n_layers + (args[x].vec_pack ? (args[x].vec_pack == 1 ? 1 : 2) : 0); };   // k loops per tile
+    // map-level tiles and vector-level tiles are two kernels (the vector form's segment loop costs the other one registers):
+    // two launches when a level has both; the second queue head is the word after the first
+    for (int vec = 0; vec < 2; ++vec) {
+        TmParams pp;
+        pp.nb = 0; pp.counter = counter ? counter + vec : nullptr; pp.first[0] = 0;
+        int order[TM_MAXB], m = 0;
+        for (int i = 0; i < n; ++i)
+            if (args[i].cnt > 0 && (args[i].vec_pack != 0) == (vec != 0)) order[m++] = i;
+        if (m == 0) continue;
+        std::stable_sort(order, order + m, [&](int x, int y) { return rounds(x) > rounds(y); });    // long tiles first
+        for (int j = 0; j < m; ++j) {
+            const stair_tile_mlp_args &a = args[order[j]];
+            pp.a[j] = a;
+            pp.first[j + 1] = pp.first[j] + a.cnt;
+            const int64_t M = a.vec_pack ? a.vec_cnt : (int64_t)a.cnt * a.T;
+            const int kl = rounds(order[j]);
+            STAIR_ACCT_MFMA("tile_mlp", (M * TM_H * 2 + (int64_t)kl * TM_H * TM_H) * 4, 2 * M * TM_H * TM_H * kl);
+        }
+        for (int j = m; j < TM_MAXB; ++j) { pp.a[j] = pp.a[0]; pp.first[j + 1] = pp.first[m]; }
+        pp.nb = m;
+        const int grid = std::min(pp.first[m], cus[dev]);
+        if (vec) hipLaunchKernelGGL((tile_mlp_kernel<false, true>), dim3(grid), dim3(512), TM_LDS, s, pp);
+        else if (nt) hipLaunchKernelGGL((tile_mlp_kernel<true, false>), dim3(grid), dim3(512), TM_LDS, s, pp);
+        else hipLaunchKernelGGL((tile_mlp_kernel<false, false>), dim3(grid), dim3(512), TM_LDS, s, pp);
+        STAIR_LAUNCH_CHECK();
+    }
     return 0;
 }
 
