@@ -353,14 +353,14 @@ def match_spans(program_list, question, normaliser=None):
 # ----------------------------------------------------------------------------------------------
 class CompiledProgram:
     """int32 token codes (enum stair_token) and the [lo, hi) question-word span of every span token."""
-    __slots__ = ('codes', 'lo', 'hi', 'n_tokens')
+    __slots__ = ('codes', 'lo', 'hi', 'n_tokens', 'packed')
 
     def __init__(self, program_list, spans, _shape=None):
         codes, pos = _shape if _shape is not None else _encode(program_list)
-        self.codes = codes
         self.n_tokens = int(codes.shape[0])
-        self.lo = np.zeros(self.n_tokens, dtype=np.int32)
-        self.hi = np.zeros(self.n_tokens, dtype=np.int32)
+        self.packed = np.zeros((3, self.n_tokens), dtype=np.int32)     # rows: codes, lo, hi -- one concatenation per batch (pack_batch)
+        self.packed[0] = codes
+        self.codes, self.lo, self.hi = self.packed[0], self.packed[1], self.packed[2]
         for i in pos:
             s, e = _span(spans, i)
             self.lo[i], self.hi[i] = s, e
@@ -420,9 +420,8 @@ def pack_batch(compiled, q_lens):
     n = len(compiled)
     prog_off = np.zeros(n + 1, dtype=np.int32)
     np.cumsum([c.n_tokens for c in compiled], out=prog_off[1:])
-    tokens = np.concatenate([c.codes for c in compiled])
-    lo = np.concatenate([c.lo for c in compiled])
-    hi = np.concatenate([c.hi for c in compiled])
+    allp = np.concatenate([c.packed for c in compiled], axis=1) if n else np.zeros((3, 0), dtype=np.int32)
+    tokens, lo, hi = allp[0], allp[1], allp[2]          # rows of a C-contiguous [3, total] array: each contiguous
     q_off = np.zeros(n + 1, dtype=np.int32)
     np.cumsum(np.asarray(q_lens, dtype=np.int64), out=q_off[1:])
     return prog_off, tokens, lo, hi, q_off
