@@ -237,6 +237,7 @@ enum { WV_CMP = 19, WV_EQ = 21, WV_XOR = 23, WV_TA0 = 26, WV_TA3 = 28, WV_EX0 = 
 struct Bucket {
     int64_t dzA = -1, dzB = -1;   // training: this bucket's blocks inside the per-WEIGHT dZ regions (first / second layer of its tile MLP)
     int64_t dzC = -1, gRow = -1;  // training, fused backward: FilterFrame's third dZ tile set; Filter's per-instance gradient row [c, H]
+    int64_t dzV0 = -1, dzV3 = -1; // training: this bucket's rows inside the per-weight dZ regions of its vector-level weights
     int level, op, variant, sub;
     int cnt = 0;        // instances
     int nrows = 0;      // secondary count (Localize pairs / Superlative action rows)
@@ -246,6 +247,24 @@ struct Bucket {
     // training: private regions, kept until stair_plan_backward has consumed them.
     int64_t svA = 0, svB = 0, svK = 0, svCat = 0, svHid = 0, svRs = 0, svSup = 0, svExtra = 0;
 };
+
+// Vector-level weights whose gradient is ONE product per weight over all buckets that use it (training plans): the dZ rows
+// and the saved inputs of every bucket lie back to back in per-weight regions, like the map level's.  K = columns of the input.
+enum { VD_CMP = 0, VD_EQ, VD_XOR, VD_TA0, VD_TA3, VD_EX0, VD_EX3, VD_FD, VD_COUNT };
+inline int vd_cols(int w, int H) { return (w == VD_XOR || w == VD_EX0) ? 3 * H : (w == VD_CMP || w == VD_EQ || w == VD_TA0) ? 2 * H : H; }
+// first-layer (reads the packed operands; Filter: the pooled rows) and second-layer (reads the saved hidden rows) weight of a bucket
+inline void bucket_vec_weights(int op, int &v0, int &v3) {
+    v0 = v3 = -1;
+    switch (op) {
+        case STAIR_OP_COMPARE: v0 = VD_CMP; break;
+        case STAIR_OP_EQUALS: v0 = VD_EQ; break;
+        case STAIR_OP_XOR: v0 = VD_XOR; break;
+        case STAIR_OP_TOACTION: v0 = VD_TA0; v3 = VD_TA3; break;
+        case STAIR_OP_EXISTS: v0 = VD_EX0; v3 = VD_EX3; break;
+        case STAIR_OP_FILTER: v0 = VD_FD; break;
+        default: break;
+    }
+}
 
 // first-layer weight (reads the module's input tile) and second-layer weight (reads the saved first activation) of a bucket's
 // tile MLP, as WF_* ids; -1 = none
@@ -355,6 +374,7 @@ struct stair_plan {
     // block of wg_dz[w]; the matching X operand is the input tiles gathered through wg_off_idx[w] (first-layer weights) or the
     // saved first activations, which lie in the same order in wg_sx[w] (second-layer weights).  ONE long-reduction TN GEMM per
     // weight at the end of stair_plan_backward instead of one per bucket.
+    int64_t vd_rows[VD_COUNT] = {}, vd_dz[VD_COUNT] = {}, vd_x[VD_COUNT] = {};
     int64_t o_tnring = 0, tnring_floats = 0, o_tnenc[2] = {0, 0}, tnenc_floats[2] = {0, 0};
     int64_t wg_rows[WF_COUNT] = {}, wg_dz[WF_COUNT] = {}, wg_sx[WF_COUNT] = {}, wg_off_idx[WF_COUNT] = {}, wg_off_rs[WF_COUNT] = {}, wg_part[WF_COUNT] = {};
     // workspace layout (float offsets)
@@ -894,8 +914,8 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
         const int64_t c = b.cnt;
         switch (b.op) {
             // (svA of Filter / FilterFrame / Localize / Superlative lives in the per-weight region wg_sx, assigned below)
-            case STAIR_OP_FILTER:
-                b.svB = take(c * T * H, 64); b.svCat = take(c * H, 64); break;
+            case STAIR_OP_FILTER:            // (svCat, the pooled rows = the dense layer's input, lives in the per-weight region vd_x)
+                b.svB = take(c * T * H, 64); break;
             case STAIR_OP_FILTERFRAME:
                 b.svB = take(c * T * H, 64); b.svRs = take(c * T, 64); b.svExtra = take(c, 64); break;
             case STAIR_OP_HASITEM:
@@ -906,11 +926,7 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
             case STAIR_OP_SUPERLATIVE:
                 b.svB = take(c * T * H, 64); b.svK = take((int64_t)b.nrows * H, 64);
                 b.svSup = take((int64_t)b.nrows * T, 64); b.svCat = take(c * H, 64); break;
-            case STAIR_OP_COMPARE: case STAIR_OP_EQUALS: case STAIR_OP_XOR:
-                b.svCat = take(c * 3 * H, 64); break;
-            case STAIR_OP_TOACTION: case STAIR_OP_EXISTS:
-                b.svCat = take(c * 3 * H, 64); b.svHid = take(c * H, 64); break;
-            default: break;
+            default: break;                  // (the vector-level modules' packed inputs and hidden rows: per-weight regions vd_x)
         }
     }
     if (pl->train) {
@@ -946,6 +962,23 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
                                        align_up(tn_x3tr_scratch_floats(std::max<int64_t>(rq, 64), 2 * H, E4), 64));
             pl->o_tnenc[0] = take(pl->tnenc_floats[0], 64);
             pl->o_tnenc[1] = take(pl->tnenc_floats[1], 64);
+        }
+        {   // vector-level weights: per-weight dZ and input regions, the buckets' rows back to back in bucket order
+            for (const Bucket &b : pl->buckets) {
+                int v0, v3;
+                bucket_vec_weights(b.op, v0, v3);
+                if (v0 >= 0) pl->vd_rows[v0] += b.cnt;
+                if (v3 >= 0) pl->vd_rows[v3] += b.cnt;
+            }
+            for (int w = 0; w < VD_COUNT; ++w)
+                if (pl->vd_rows[w]) { pl->vd_dz[w] = take(pl->vd_rows[w] * H, 64); pl->vd_x[w] = take(pl->vd_rows[w] * vd_cols(w, H), 64); }
+            int64_t vat[VD_COUNT] = {};
+            for (Bucket &b : pl->buckets) {
+                int v0, v3;
+                bucket_vec_weights(b.op, v0, v3);
+                if (v0 >= 0) { b.dzV0 = pl->vd_dz[v0] + vat[v0] * H; b.svCat = pl->vd_x[v0] + vat[v0] * vd_cols(v0, H); vat[v0] += b.cnt; }
+                if (v3 >= 0) { b.dzV3 = pl->vd_dz[v3] + vat[v3] * H; b.svHid = pl->vd_x[v3] + vat[v3] * H; vat[v3] += b.cnt; }
+            }
         }
         int64_t at[WF_COUNT] = {};
         for (Bucket &b : pl->buckets) {
@@ -1772,6 +1805,8 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
     B.deferred.assign(ctx->names.size(), 0);
     for (int w = 0; w < WF_COUNT; ++w)
         if (w != WF_FFD) B.deferred[lin_of[w]->id] = 1;
+    const Lin *vlin_of[VD_COUNT] = {&W.compare, &W.equals, &W.xorl, &W.ta0, &W.ta3, &W.exists0, &W.exists3, &W.fdense};
+    for (int w = 0; w < VD_COUNT; ++w) B.deferred[vlin_of[w]->id] = 1;
     {
         int64_t o = 0;
         for (size_t i = 0; i < ctx->names.size(); ++i) { B.wt_off[i] = o; o += align_up(ctx->numel[i], 64); }
@@ -1892,8 +1927,9 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
                 const bool isx = b.op == STAIR_OP_XOR;
                 const int K = isx ? 3 * H : 2 * H;
                 const Lin &l = isx ? W.xorl : (b.op == STAIR_OP_COMPARE ? W.compare : W.equals);
-                RUN(launch_mask_relu(gV0, g_vec, H, I2, vec, H, I2, c, H, s));
-                RUN(dense_bwd(B, gV0, c, 1, H, K, svCat, K, K, nullptr, l, gCat, K, K, nullptr, 0));
+                float *dz0 = ws + b.dzV0;                 // this bucket's rows of the weight's dZ region (its product runs once, at the end)
+                RUN(launch_mask_relu(dz0, g_vec, H, I2, vec, H, I2, c, H, s));
+                RUN(dense_bwd(B, dz0, c, 1, H, K, svCat, K, K, nullptr, l, gCat, K, K, nullptr, 0));
                 RUN(launch_pack_bwd(isx ? PACK_XOR : PACK_CAT2, vec, I0, vec, I1, gCat, g_vec, g_vec, c, H, s));
                 break;
             }
@@ -1901,10 +1937,11 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
             case STAIR_OP_EXISTS: {
                 const bool ex = b.op == STAIR_OP_EXISTS;
                 const int K = ex ? 3 * H : 2 * H;
-                RUN(launch_mask_relu(gV0, g_vec, H, I2, vec, H, I2, c, H, s, ex ? inv_keep : 1.0f));     // only Exists ends in ReLU . Dropout
-                RUN(dense_bwd(B, gV0, c, 1, H, H, svHid, H, H, nullptr, ex ? W.exists3 : W.ta3, gV1, H, H, nullptr, 0));
-                RUN(launch_mask_relu(gV1, gV1, H, nullptr, svHid, H, nullptr, c, H, s, inv_keep));
-                RUN(dense_bwd(B, gV1, c, 1, H, K, svCat, K, K, nullptr, ex ? W.exists0 : W.ta0, gCat, K, K, nullptr, 0));
+                float *dz3 = ws + b.dzV3, *dz0 = ws + b.dzV0;
+                RUN(launch_mask_relu(dz3, g_vec, H, I2, vec, H, I2, c, H, s, ex ? inv_keep : 1.0f));     // only Exists ends in ReLU . Dropout
+                RUN(dense_bwd(B, dz3, c, 1, H, H, svHid, H, H, nullptr, ex ? W.exists3 : W.ta3, gV1, H, H, nullptr, 0));
+                RUN(launch_mask_relu(dz0, gV1, H, nullptr, svHid, H, nullptr, c, H, s, inv_keep));
+                RUN(dense_bwd(B, dz0, c, 1, H, K, svCat, K, K, nullptr, ex ? W.exists0 : W.ta0, gCat, K, K, nullptr, 0));
                 if (ex) RUN(launch_pack_bwd(PACK_EXISTS, vec, I1, vec, I0, gCat, g_vec, g_vec, c, H, s));
                 else RUN(launch_pack_bwd(PACK_CAT2, vec, I0, vec, I1, gCat, g_vec, g_vec, c, H, s));
                 break;
@@ -1916,8 +1953,9 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
                 const int v = b.variant;
                 if (phase == 2) break;
                 float *grow = fused ? ws + b.gRow : gV1;          // the gradient of the sum over frames: one row per instance
-                RUN(launch_mask_relu(gV0, g_vec, H, I1, vec, H, I1, c, H, s));
-                RUN(dense_bwd(B, gV0, c, 1, H, H, svCat, H, H, nullptr, W.fdense, grow, H, H, nullptr, 0));
+                float *dzf = ws + b.dzV0;
+                RUN(launch_mask_relu(dzf, g_vec, H, I1, vec, H, I1, c, H, s));
+                RUN(dense_bwd(B, dzf, c, 1, H, H, svCat, H, H, nullptr, W.fdense, grow, H, H, nullptr, 0));
                 if (fused) { RUN(mlp_tail_fused(W.f3[v], W.f0[v], WF_F3 + v, WF_F0 + v, false, grow)); break; }
                 RUN(launch_bcast_mask_relu(gB, gV1, svB, c, T, H, s, inv_keep, LEN));
                 RUN(mlp_tail(W.f3[v], W.f0[v], false));
@@ -2068,6 +2106,30 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
         }
         if (pl->wg_part[w] && tn_x3tr_takes(t)) RUN(launch_gemm_tn_x3tr(t, ws + pl->wg_part[w], s_tn));      // deterministic: no atomics
         else RUN(launch_gemm_tn(t, s_tn));
+    }
+    // the vector-level weights (and Filter's dense layer on the pooled rows): one product per weight over the rows of all its
+    // buckets; from 2048 rows on through the slab kernel (whole 32-row stages; the < 32 rows left over by the atomic kernel, one
+    // add per element), below that the atomic kernel's single pass is shorter
+    for (int w = 0; w < VD_COUNT; ++w) {
+        if (pl->vd_rows[w] == 0) continue;
+        const Lin &l = *vlin_of[w];
+        const int Kw = vd_cols(w, H);
+        stair_gemm_tn_args t = {};
+        t.A = ws + pl->vd_dz[w]; t.lda = H;
+        t.B = ws + pl->vd_x[w]; t.ldb = Kw; t.b_gstride = Kw; t.rows_per_group = 1;
+        t.C = l.dw; t.ldc = Kw; t.colsum = l.db;
+        t.M = (int)pl->vd_rows[w]; t.N = H; t.K = Kw;
+        stair_gemm_tn_args h = t;
+        h.M = t.M & ~31;
+        const int64_t need = h.M >= 2048 && B.tn_ring && tn_x3tr_takes(h) ? align_up(tn_x3tr_scratch_floats(h.M, H, Kw), 64) : 0;
+        if (need && need <= B.tn_ring_floats) {
+            if (B.tn_ring_at + need > B.tn_ring_floats) { RUN(tn_x3tr_flush(s_tn)); B.tn_ring_at = 0; }
+            RUN(launch_gemm_tn_x3tr(h, B.tn_ring + B.tn_ring_at, s_tn));
+            B.tn_ring_at += need;
+            if (t.M == h.M) continue;
+            t.A += (int64_t)h.M * t.lda; t.B += (int64_t)h.M * t.ldb; t.M -= h.M;
+        }
+        RUN(launch_gemm_tn(t, s_tn));
     }
     RUN(tn_x3tr_flush(s_tn));                 // dW, db += the slabs of every product above, in slab order: one launch
     if (overlap_tn) STAIR_HIP(hipEventRecord(ctx->ev_join, ctx->side));
@@ -2226,7 +2288,11 @@ extern "C" int stair_plan_regions(stair_plan *pl, const stair_ctx *ctx, const ch
             if (b.svA != pl->o_tmpA) add(p + "svA", b.svA, c * T * H);
             if (b.svB != pl->o_tmpB) add(p + "svB", b.svB, c * T * H);
             if (b.svK != pl->o_kbuf) add(p + "svK", b.svK, (int64_t)b.nrows * H);
-            if (b.svCat != pl->o_cat) add(p + "svCat", b.svCat, (b.op == STAIR_OP_FILTER || b.op == STAIR_OP_SUPERLATIVE) ? c * H : c * 3 * H);
+            int v0, v3;
+            bucket_vec_weights(b.op, v0, v3);
+            if (b.svCat != pl->o_cat) add(p + "svCat", b.svCat, v0 >= 0 ? c * vd_cols(v0, H) : c * H);
+            if (b.dzV0 >= 0) add(p + "dzV0", b.dzV0, c * H);
+            if (b.dzV3 >= 0) add(p + "dzV3", b.dzV3, c * H);
             if (b.svHid != pl->o_hid) add(p + "svHid", b.svHid, c * H);
             if (b.svRs != pl->o_rs) add(p + "svRs", b.svRs, c * T);
             if (b.svSup != pl->o_sup) add(p + "svSup", b.svSup, (int64_t)b.nrows * T);
