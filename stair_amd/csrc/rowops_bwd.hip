@@ -412,11 +412,21 @@ int launch_cosine_attn_bwd_grouped(const float *F, const float *Kmat, const floa
 // ---------------------------------------------------------------------------------------------
 // Temporal relate nets backward (recomputes the three layers in LDS).  dw[6] accumulate with atomics.
 struct RelateWB { const float *w[6]; float *dw[6]; };
+constexpr int kRelateTapStride = 72;      // LDS floats per staged Conv1d filter: up to 71 taps (2 k + 1 with k <= 35) + the bias
 __global__ void temporal_relate_bwd_kernel(const float *att, const int32_t *att_idx, const int32_t *att_k,
                                            const float *drel, const int32_t *rel_idx, float *datt, int n, int T, int mode,
                                            int conv, int ksize, RelateWB W, const int32_t *len) {
-    extern __shared__ float sm[];   // x0, y1, y2, y3 (post-activation), g (ping), g2 (pong): 6 rows of T
+    extern __shared__ float sm[];   // x0, y1, y2, y3 (post-activation), g (ping), g2 (pong): 6 rows of T; then the conv filters
     float *x0 = sm, *y1 = sm + T, *y2 = sm + 2 * T, *y3 = sm + 3 * T, *ga = sm + 4 * T, *gb = sm + 5 * T;
+    // Conv1d nets: the three filters (k, k, 2k + 1 taps) and biases staged in LDS once -- read from global memory inside the tap
+    // loops below, every tap was a dependent scalar load (31 us per block whatever it computed)
+    float *wl = sm + 6 * T;         // [3][kRelateTapStride]: taps, then the bias at [kRelateTapStride - 1]
+    if (mode != 0 && conv)
+        for (int e = threadIdx.x; e < 3 * kRelateTapStride; e += blockDim.x) {
+            const int layer = e / kRelateTapStride, j = e - layer * kRelateTapStride;
+            const int k = layer < 2 ? ksize : 2 * ksize + 1;
+            wl[e] = j < k ? W.w[2 * layer][j] : (j == kRelateTapStride - 1 ? W.w[2 * layer + 1][0] : 0.f);
+        }
     const int i = blockIdx.x;
     const int K = att_k[i];
     const int L = len ? len[i] : T;                 // the clip's own frame count (see temporal_relate_kernel); Linear nets: L == T
@@ -435,14 +445,15 @@ __global__ void temporal_relate_bwd_kernel(const float *att, const int32_t *att_
         float *yout[3] = {y1, y2, y3};
         for (int layer = 0; layer < 3; ++layer) {           // forward recompute
             const float *w = W.w[2 * layer], *b = W.w[2 * layer + 1];
+            const float *wc = wl + layer * kRelateTapStride;
             const float *x = xin[layer];
             float *y = yout[layer];
             const int k = layer < 2 ? ksize : 2 * ksize + 1, left = (k - 1) / 2;
             for (int t = threadIdx.x; t < L; t += blockDim.x) {
                 float acc;
                 if (conv) {
-                    acc = b[0];
-                    for (int j = 0; j < k; ++j) { const int u = t + j - left; if (u >= 0 && u < L) acc += w[j] * x[u]; }
+                    acc = wc[kRelateTapStride - 1];
+                    for (int j = 0; j < k; ++j) { const int u = t + j - left; if (u >= 0 && u < L) acc += wc[j] * x[u]; }
                 } else {
                     acc = b[t];
                     for (int u = 0; u < T; ++u) acc += w[(int64_t)t * T + u] * x[u];
@@ -454,6 +465,7 @@ __global__ void temporal_relate_bwd_kernel(const float *att, const int32_t *att_
         float *gin = ga, *gout = gb;
         for (int layer = 2; layer >= 0; --layer) {          // backward
             const float *w = W.w[2 * layer];
+            const float *wc = wl + layer * kRelateTapStride;
             const float *x = xin[layer], *y = yout[layer];
             const int k = layer < 2 ? ksize : 2 * ksize + 1, left = (k - 1) / 2;
             for (int t = threadIdx.x; t < L; t += blockDim.x)      // through the activation
@@ -472,7 +484,7 @@ __global__ void temporal_relate_bwd_kernel(const float *att, const int32_t *att_
                 }
                 for (int u = threadIdx.x; u < L; u += blockDim.x) {       // dx[u] = sum_j w[j] dz[u-j+left]
                     float acc = 0.f;
-                    for (int j = 0; j < k; ++j) { const int t = u - j + left; if (t >= 0 && t < L) acc += w[j] * gin[t]; }
+                    for (int j = 0; j < k; ++j) { const int t = u - j + left; if (t >= 0 && t < L) acc += wc[j] * gin[t]; }
                     gout[u] = acc;
                 }
             } else {
@@ -507,7 +519,8 @@ int launch_temporal_relate_bwd(const float *att, const int32_t *att_idx, const i
     STAIR_ACCT("temporal_relate_bwd_kernel", (int64_t)n * T * 4 * (2 + 1 + 2));
     RelateWB W;
     for (int i = 0; i < 6; ++i) { W.w[i] = (mode && w) ? w[i] : nullptr; W.dw[i] = (mode && dw) ? dw[i] : nullptr; }
-    hipLaunchKernelGGL(temporal_relate_bwd_kernel, dim3(n), dim3(64), 6 * T * sizeof(float), s, att, att_idx, att_k, drel,
+    STAIR_CHECK(!(mode && conv) || 2 * ksize + 1 < kRelateTapStride, "Conv1d relate nets: kernel size <= 35");
+    hipLaunchKernelGGL(temporal_relate_bwd_kernel, dim3(n), dim3(64), (6 * T + 3 * kRelateTapStride) * sizeof(float), s, att, att_idx, att_k, drel,
                        rel_idx, datt, n, T, mode, conv, ksize, W, len);
     STAIR_LAUNCH_CHECK();
     return 0;
