@@ -329,6 +329,11 @@ int stair_pack_wfrag(const float *W, void *planes, int32_t N, int32_t K, int32_t
 /* The same for a [N, K] column block of a wider row-major matrix (row stride ld floats): the H-wide blocks of a vector-level
  * module's [H, 2H | 3H] first-layer weight. */
 int stair_pack_wfrag_ld(const float *W, int64_t ld, void *planes, int32_t N, int32_t K, stair_stream stream);
+/* Measurement aid: while on, every tile-operator launch is bracketed by HIP events on its stream; stair_tile_timing_read waits for
+ * them and returns the summed device time (ms) and the number of launches since stair_tile_timing(1) (bench.py's
+ * roofline_tile_operator: the kernel's live time without a profiler).  Not thread-safe; off by default. */
+int stair_tile_timing(int32_t on);
+int stair_tile_timing_read(double *ms, int32_t *launches);
 
 /* att[p][t] = (cos(F[f_idx[p]][t][:], Kmat[k_idx[p]][:]) + 1) * 0.49 -- nn.CosineSimilarity(dim=-1,
  * eps=1e-8) of LocalizeModule / ExistsFrameModule (modules.py:162-217) without materialising the

@@ -123,6 +123,8 @@ SIGNATURES = [
     ('stair_tile_mlp_fwd', C.c_int, [C.POINTER(TileMlpArgs), C.c_void_p]),
     ('stair_pack_wfrag', C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     ('stair_pack_wfrag_ld', C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    ('stair_tile_timing', C.c_int, [C.c_int32]),
+    ('stair_tile_timing_read', C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     ('stair_gemm_f32', C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     ('stair_gemm_tn_f32', C.c_int, [C.POINTER(GemmTnArgs), C.c_void_p]),
     ('stair_gemm_tn_slabs_scratch', C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),

@@ -26,6 +26,8 @@
 //     in 256-byte wave-instructions -- reads the staged rows of the last layer.
 #include <algorithm>
 #include <cstdlib>
+#include <utility>
+#include <vector>
 
 #include "common.h"
 #include "ops.h"
@@ -593,6 +595,11 @@ int launch_pack_wfrag_many(const float *const *W, void *const *out, int count, i
     return 0;
 }
 
+// Measurement aid (bench.py's roofline_tile_operator): HIP events around every tile launch while switched on; the sum of the
+// elapsed times is the kernel's device time on its own stream, without a profiler.
+static bool g_tile_timing = false;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_tile_events;
+
 static int g_tile_on = -1;          // stair_set_tile_mlp; -1 = the environment's STAIR_TILE_MLP (default on)
 bool tile_mlp_usable(int H, int T) {
     static const bool env_on = [] { const char *e = getenv("STAIR_TILE_MLP"); return !(e && e[0] == '0'); }();
@@ -681,10 +688,19 @@ int launch_tile_mlp_batch(const stair_tile_mlp_args *args, int n, unsigned *coun
         for (int j = m; j < TM_MAXB; ++j) { pp.a[j] = pp.a[0]; pp.first[j + 1] = pp.first[m]; }
         pp.nb = m;
         const int grid = std::min(pp.first[m], cus[dev]);
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (g_tile_timing) {
+            STAIR_HIP(hipEventCreate(&e0)); STAIR_HIP(hipEventCreate(&e1));
+            STAIR_HIP(hipEventRecord(e0, s));
+        }
         if (vec) hipLaunchKernelGGL((tile_mlp_kernel<false, true>), dim3(grid), dim3(512), TM_LDS, s, pp);
         else if (nt) hipLaunchKernelGGL((tile_mlp_kernel<true, false>), dim3(grid), dim3(512), TM_LDS, s, pp);
         else hipLaunchKernelGGL((tile_mlp_kernel<false, false>), dim3(grid), dim3(512), TM_LDS, s, pp);
         STAIR_LAUNCH_CHECK();
+        if (g_tile_timing) {
+            STAIR_HIP(hipEventRecord(e1, s));
+            g_tile_events.emplace_back(e0, e1);
+        }
     }
     return 0;
 }
@@ -723,3 +739,24 @@ extern "C" int stair_pack_wfrag_ld(const float *W, int64_t ld, void *planes, int
     const int l[1] = {(int)ld};
     return stair::launch_pack_wfrag_many(w, o, 1, N, K, static_cast<hipStream_t>(stream), false, l);
 }
+
+extern "C" int stair_tile_timing(int32_t on) {
+    for (auto &e : stair::g_tile_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    stair::g_tile_events.clear();
+    stair::g_tile_timing = on != 0;
+    return 0;
+}
+
+extern "C" int stair_tile_timing_read(double *ms, int32_t *launches) {
+    double total = 0.0;
+    for (auto &e : stair::g_tile_events) {
+        STAIR_HIP(hipEventSynchronize(e.second));
+        float t = 0.0f;
+        STAIR_HIP(hipEventElapsedTime(&t, e.first, e.second));
+        total += t;
+    }
+    if (ms) *ms = total;
+    if (launches) *launches = (int32_t)stair::g_tile_events.size();
+    return 0;
+}
+
