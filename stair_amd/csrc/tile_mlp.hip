@@ -665,7 +665,11 @@ int launch_tile_mlp_batch(const stair_tile_mlp_args *args, int n, unsigned *coun
         cus[dev] = v;
         attr_set[dev] = true;
     }
-    static const bool nt = [] { const char *e = getenv("STAIR_TILE_NT"); return e && e[0] == '1'; }();     // measured: plain stores are faster (profiles/r03_e_*)
+    // non-temporal hints on the tile's own traffic (inputs, masks, saves): with the first version of the kernel plain accesses were
+    // faster (saves 273 -> 290 us per 1024 tiles); now that a layer is bound by the weight stream from L2, keeping the streamed
+    // tiles from displacing the weight planes pays: 17.02 -> 16.89 ms per 2048-question step (three A/B pairs on one box),
+    // neutral at 128 questions and in inference.  STAIR_TILE_NT=0 switches them off.
+    static const bool nt = [] { const char *e = getenv("STAIR_TILE_NT"); return !(e && e[0] == '0'); }();
     auto rounds = [&](int x) { return args[x].n_layers + (args[x].vec_pack ? (args[x].vec_pack == 1 ? 1 : 2) : 0); };   // k loops per tile
     // map-level tiles and vector-level tiles are two kernels (the vector form's segment loop costs the other one registers):
     // two launches when a level has both; the second queue head is the word after the first
