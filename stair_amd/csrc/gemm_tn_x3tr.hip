@@ -15,7 +15,6 @@
 // per-row scale (Temporal's r_t); the bias gradient rides along in the staging of dZ.
 #include <algorithm>
 #include <cstdlib>
-#include <mutex>
 
 #include "common.h"
 
@@ -320,14 +319,18 @@ int launch_gemm_tn_x3tr(const stair_gemm_tn_args &a, float *scratch, hipStream_t
     if (a.rows_per_group % XT_ROWS) p.b_gstride = 0; p.stages = a.M / XT_ROWS; p.nslab = tn_x3tr_slabs(a.M);
     p.tilesK = (a.K + 127) / 128;
     p.P = scratch; p.Pc = a.colsum ? scratch + (int64_t)p.nslab * a.N * a.K : nullptr;
-    static std::once_flag once;
-    std::call_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tn_x3tr_kernel<false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, XT_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tn_x3tr_kernel<true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, XT_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tn_x3tr_kernel<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, XT_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tn_x3tr_kernel<true, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, XT_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tn_x3tr_kernel<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, XT_LDS);
-    });
+    // the dynamic-LDS limit is an attribute per function AND device: set once for each device this process launches on
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev]) {
+        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tn_x3tr_kernel<false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, XT_LDS));
+        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tn_x3tr_kernel<true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, XT_LDS));
+        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tn_x3tr_kernel<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, XT_LDS));
+        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tn_x3tr_kernel<true, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, XT_LDS));
+        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tn_x3tr_kernel<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, XT_LDS));
+        attr_set[dev] = true;
+    }
     if (gemm_trace_on())
         fprintf(stderr, "STAIR_GEMM tn M=%d N=%d K=%d act=0 acc=1 gather=%d scale=%d\n", a.M, a.N, a.K, a.b_gidx ? 1 : 0, a.row_scale ? 1 : 0);
     STAIR_ACCT_MFMA("gemm_tn_x3tr", ((int64_t)a.M * a.N + (int64_t)a.M * a.K + (int64_t)a.N * a.K) * 4, 2ll * a.M * a.N * a.K);
