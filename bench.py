@@ -47,7 +47,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA" 
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md, "HBM3E peak BW" (spec)
 ALGO_BYTES_PER_QUESTION = 1.93e6   # SURVEY.md section 8(d), mean over the 8 forms, fp32, weights/128
 ALGO_FLOP_PER_QUESTION = 0.86e9
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r02_pmc_dominant.json')     # written by tools/summarize_prof.py from the PMC passes
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r03_pmc_dominant.json')     # written by tools/summarize_prof.py from the PMC passes
 
 
 def make_batch(config, B, T, seed, device, features):
@@ -67,7 +67,7 @@ def pmc_traffic(M, N, K):
     try:
         rows = json.load(open(PMC_FILE))
     except Exception:
-        return None, 'profiles/r02_pmc_dominant.json missing'
+        return None, 'profiles/r03_pmc_dominant.json missing'
     vals = {}
     for r in rows:
         if 'gemm_planes' in r['kernel'] and r.get('shape') == [M, N, K]:
@@ -78,7 +78,7 @@ def pmc_traffic(M, N, K):
     # memory-side counter tallies at their true size: FETCH is NOT doubled here (the 2x correction of MI355X_MICROARCH.md applies
     # to 128-byte requests); calibration: FETCH_SIZE = 1.00x the bf16 A panel + W planes of the launch.
     return int((vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024), \
-        'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (profiles/r02_pmc_dominant.json); 64-byte requests, no 2x correction'
+        'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (profiles/r03_pmc_dominant.json, tools/collect_pmc_planes.sh); 64-byte requests, no 2x correction'
 
 
 def time_dominant_kernel(model, B, T, device, features, iters=10):
