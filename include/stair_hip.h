@@ -323,6 +323,10 @@ int stair_tile_mlp_fwd(const stair_tile_mlp_args *args, stair_stream stream);
 /* stair_plan_run uses the fused operators where they apply (hidden_size 512, T <= 64, split matmul mode, no dropout);
  * on = 0 keeps the GEMM / row-kernel sequences everywhere, on < 0 restores the default (env STAIR_TILE_MLP, default on). */
 int stair_set_tile_mlp(int32_t on);
+/* Tiles of a fused launch are dealt out through a self-resetting atomic work queue in the plan workspace (on != 0, default; two
+ * words that every launch leaves at zero, so eager runs and hipGraph replays need no reset between launches) or by a static round
+ * robin (on = 0); on < 0 restores the default (env STAIR_TILE_QUEUE).  Results are bit-identical either way. */
+int stair_set_tile_queue(int32_t on);
 /* W [N, K] fp32 row-major -> planes: [N/32][K/16][hi, lo][64 lanes][8 bf16] (2 * N * K * 2 bytes, 16-byte aligned);
  * N % 32 == 0, K % 16 == 0.  transpose != 0: W is stored [K, N] and the planes are those of W^T (backward chains). */
 int stair_pack_wfrag(const float *W, void *planes, int32_t N, int32_t K, int32_t transpose, stair_stream stream);
@@ -458,6 +462,16 @@ int stair_plan_get_info(const stair_plan *plan, stair_plan_info *info);
  * not want the synchronisation passes the word's device address (workspace + status_off floats) to stair_adam_step as
  * `guard` and checks later. */
 int stair_plan_status(const stair_plan *plan, const void *workspace, stair_stream stream);
+
+/* Diagnostics (tools/queue_probe.py; DESIGN.md section 2, "the replay abort"): enqueues on `stream` -- which may be capturing -- the
+ * reset and `launches` work-queue kernels laid out as stair_plan_run lays out its fused tile launches, with a kernel that RECORDS the
+ * tickets it draws instead of using them (no tile work, safe whatever the words hold).  words: >= 64 uint32, queue words from
+ * word 16 on; seen: [launches][grid][2] uint32 = (first ticket, tiles taken) per workgroup; reset_mode 0: hipMemsetAsync of the
+ * 256 bytes (round 3), 1: a zeroing kernel (now), 2: none; per_launch_heads != 0: launch l draws from words 16 + 2 l (round 3),
+ * else all launches share words 16, 17; self_reset != 0: the last workgroup to leave zeroes the pair (now). */
+int stair_debug_memset(void *ptr, int64_t bytes, int32_t mode, stair_stream stream); /* mode 0: hipMemsetAsync(ptr, 0, bytes); 1: the library's zero-fill kernel */
+int stair_debug_queue_probe(void *words, uint32_t *seen, int32_t launches, int32_t grid, int32_t total, int32_t reset_mode,
+                            int32_t per_launch_heads, int32_t self_reset, stair_stream stream);
 
 /* kind/slot/aux of program token `tok` (global index into `tokens`); level as stat_module_levels;
  * rel_slot = att-arena row of Temporal's related_attn (-1 otherwise). */

@@ -120,6 +120,7 @@ SIGNATURES = [
     ('stair_set_split_min_rows', C.c_int, [C.c_int32]),
     ('stair_lstm_coop_limit', C.c_int, [C.c_int32]),
     ('stair_set_tile_mlp', C.c_int, [C.c_int32]),
+    ('stair_set_tile_queue', C.c_int, [C.c_int32]),
     ('stair_tile_mlp_fwd', C.c_int, [C.POINTER(TileMlpArgs), C.c_void_p]),
     ('stair_pack_wfrag', C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     ('stair_pack_wfrag_ld', C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
@@ -185,6 +186,8 @@ SIGNATURES = [
     ('stair_plan_destroy', None, [C.c_void_p]),
     ('stair_plan_get_info', C.c_int, [C.c_void_p, C.POINTER(PlanInfo)]),
     ('stair_plan_status', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    ('stair_debug_memset', C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
+    ('stair_debug_queue_probe', C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     ('stair_plan_node', C.c_int, [C.c_void_p, C.c_int32, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p]),
     ('stair_plan_saved_offset', C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]),
     ('stair_plan_nodes', C.c_int, [C.c_void_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p, C.c_int32]),

@@ -112,5 +112,7 @@ int launch_pack_wfrag_many(const float *const *W, void *const *out, int count, i
                            const int *ld = nullptr);     // ld: row stride per matrix (default: K, or N when transposed)
 int launch_colsum(const float *A, int64_t lda, float *out, int M, int N, hipStream_t s, float *out2 = nullptr);
 int launch_transpose(const float *in, float *out, int rows, int cols, hipStream_t s);
+// bytes % 4 == 0 zero bytes at a 4-byte aligned address, as a kernel (never a memset node of a captured graph; csrc/rowops.hip)
+int launch_zero(void *ptr, int64_t bytes, hipStream_t s);
 
 }  // namespace stair

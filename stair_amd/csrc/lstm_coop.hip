@@ -426,9 +426,9 @@ static int coop_prepare(const stair_lstm_args &a, hipStream_t s, CoopParams &p, 
     p.flags = reinterpret_cast<unsigned *>(base + slab_bytes);
     p.err = p.flags + G * nt * CP * FLAG_STRIDE;
     // flags and the error word are one block, zeroed before every launch (epochs restart at 1)
-    STAIR_HIP(hipMemsetAsync(p.flags, 0, (size_t)flag_words * 4, s));
+    if (int rcz_ = launch_zero(p.flags, (size_t)flag_words * 4, s)) return rcz_;
     // h_n of empty sequences is zero and the kernel only writes it at a sequence's last step
-    STAIR_HIP(hipMemsetAsync(a.h_n, 0, (size_t)a.n * 2 * CH * sizeof(float), s));
+    if (int rcz_ = launch_zero(a.h_n, (size_t)a.n * 2 * CH * sizeof(float), s)) return rcz_;
     blocks = coop_blocks(p.gpd);
     return 0;
 }
@@ -780,7 +780,7 @@ static int coop_bwd_prepare(const stair_lstm_bwd_args &a, hipStream_t s, CoopBwd
     p.xh = base;
     p.flags = reinterpret_cast<unsigned *>(base + slab_bytes);
     p.err = p.flags + G * nt * CP * FLAG_STRIDE;
-    STAIR_HIP(hipMemsetAsync(p.flags, 0, (size_t)flag_words * 4, s));
+    if (int rcz_ = launch_zero(p.flags, (size_t)flag_words * 4, s)) return rcz_;
     blocks = coop_blocks(p.gpd);
     return 0;
 }

@@ -216,6 +216,34 @@ namespace {
 
 constexpr int64_t kSplitKFloats = 16ll * 64 * 128 * 128;     // split-K scratch: 16 K pieces x 64 output tiles of 128 x 128
 
+// how a fused tile launch deals its tiles out: the self-resetting atomic queue (default) or a static round robin
+// (stair_set_tile_queue(0) / STAIR_TILE_QUEUE=0); both run eagerly and inside a stream capture
+int g_tile_queue = -1;
+bool tile_queue_on() {
+    static const bool env_on = [] { const char *e = getenv("STAIR_TILE_QUEUE"); return !(e && e[0] == '0'); }();
+    return g_tile_queue >= 0 ? g_tile_queue != 0 : env_on;
+}
+
+// Diagnostic twin of the tile operator's work queue (stair_debug_queue_probe): the same ticket protocol, no tile work, every
+// ticket a workgroup sees is RECORDED instead of used as an index -- safe whatever the words hold.
+__global__ void queue_probe_kernel(unsigned *counter, unsigned *seen, int total, int self_reset) {
+    unsigned first = 0xffffffffu, taken = 0;
+    if (threadIdx.x == 0) {
+        for (;;) {
+            const unsigned w = atomicAdd(counter, 1u);
+            if (first == 0xffffffffu) first = w;
+            if (w >= (unsigned)total) break;
+            ++taken;
+        }
+        seen[2 * blockIdx.x] = first;
+        seen[2 * blockIdx.x + 1] = taken;
+        if (self_reset && atomicAdd(counter + 1, 1u) == gridDim.x - 1) {
+            atomicExch(counter, 0u);
+            atomicExch(counter + 1, 0u);
+        }
+    }
+}
+
 
 constexpr int OP_SPAN = 50;      // pseudo op: span mean (level 0)
 const int kArity[STAIR_OP_COUNT] = {2, 2, 3, 2, 2, 2, 2, 2, 2, 1, 2, 2, 3, 3, 2, 2, 2, 2};
@@ -897,8 +925,8 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
     pl->o_extra = take(std::max(pl->maxI, 1), 64);
     pl->o_logits = take((int64_t)n * A, 64);
     pl->o_wfrag = (H == 512 && T <= 64) ? take((int64_t)WV_END * H * H, 64) : 0;     // bf16 hi/lo fragment-order planes of the fused tile operators' weights
-    pl->o_status = take(128, 64);                // word 0: sticky "a cooperative hand-off timed out" flag of this plan's passes; words 16..63
-                                                 // and 64..111: work-queue heads of the fused forward / backward launches
+    pl->o_status = take(128, 64);                // word 0: sticky "a cooperative hand-off timed out" flag of this plan's passes; words 16, 17
+                                                 // and 18, 19: the self-resetting work queues of the fused forward / backward tile launches
     for (Bucket &b : pl->buckets) {
         b.svA = pl->o_tmpA; b.svB = pl->o_tmpB; b.svK = pl->o_kbuf; b.svCat = pl->o_cat; b.svHid = pl->o_hid;
         b.svRs = pl->o_rs; b.svSup = pl->o_sup; b.svExtra = pl->o_extra;
@@ -1324,8 +1352,12 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
 
     if (!(flags & STAIR_RUN_INDEX_RESIDENT))
         if (int rc_ = upload_index_image(pl, didx, s)) return rc_;
+    // A new run of this plan starts clean (the backward pass keeps the word): status word + the work-queue words of the fused tile
+    // launches.  By a KERNEL, not hipMemsetAsync: inside a stream capture this becomes an ordinary kernel node of the chain like
+    // every other launch of the pass ("the replay abort").  The queue words reset themselves after every launch
+    // (csrc/tile_mlp.hip); zeroing them here only covers a workspace that has never been used.
     uint32_t *status = reinterpret_cast<uint32_t *>(ws + pl->o_status);
-    STAIR_HIP(hipMemsetAsync(status, 0, 64 * sizeof(float), s));      // a new run of this plan starts clean; the backward pass keeps it
+    if (int rcz_ = launch_zero(status, 64 * sizeof(uint32_t), s)) return rcz_;
 
     struct SplitKScope {            // forward products of this call may stage split-K partials in the workspace
         explicit SplitKScope(float *p) { g_splitk_ws = p; }
@@ -1459,7 +1491,6 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
     // bucket it belongs to, so a bucket's last partial round is filled by its neighbours); phase 2 = what follows the tile
     // operator (Filter's dense layer, Superlative's scores and pooling).
     std::vector<stair_tile_mlp_args> tile_queue;
-    int tile_launches = 0;
     auto run_bucket = [&](const Bucket &b, const int bno, const int phase) -> int {
         bucket_no = bno;
         if (b.cnt == 0) return 0;
@@ -1668,19 +1699,20 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
         int bno = 0;
         for (const Bucket &b : pl->buckets) RUN(run_bucket(b, bno++, 0));
     } else {
-        unsigned *tile_ctr = reinterpret_cast<unsigned *>(ws + pl->o_status) + 16;      // 48 work-queue heads, zeroed with the status word
+        // the work queue of the forward tile launches: (head, sign-off count) at status words 16, 17.  Every launch leaves both at
+        // zero and the launches of a pass follow each other on one stream, so ONE pair serves them all: no per-launch heads, no limit
+        // on the number of fused launches of a plan (deep programs, levels with many buckets)
+        unsigned *tile_ctr = reinterpret_cast<unsigned *>(ws + pl->o_status) + 16;
         for (size_t lo_ = 0; lo_ < pl->buckets.size();) {
             size_t hi_ = lo_;
             while (hi_ < pl->buckets.size() && pl->buckets[hi_].level == pl->buckets[lo_].level) ++hi_;
             tile_queue.clear();
             for (size_t k = lo_; k < hi_; ++k) RUN(run_bucket(pl->buckets[k], (int)k, 1));
             static const int merge_max = [] { const char *e = getenv("STAIR_TILE_MERGE"); return e ? std::max(1, std::min(8, atoi(e))) : 8; }();
-            static const bool use_queue = [] { const char *e = getenv("STAIR_TILE_QUEUE"); return !(e && e[0] == '0'); }();
+            const bool use_queue = tile_queue_on();
             for (size_t q0 = 0; q0 < tile_queue.size(); q0 += merge_max) {
                 const int nq = (int)std::min<size_t>(merge_max, tile_queue.size() - q0);
-                STAIR_CHECK(tile_launches + 1 < 48, "internal: more fused launches than work-queue heads");
-                RUN(launch_tile_mlp_batch(tile_queue.data() + q0, nq, use_queue ? tile_ctr + tile_launches : nullptr, s));
-                tile_launches += 2;           // map-level and vector-level tiles of a batch are two kernels, each with its own queue head
+                RUN(launch_tile_mlp_batch(tile_queue.data() + q0, nq, use_queue ? tile_ctr : nullptr, s));
             }
             for (size_t k = lo_; k < hi_; ++k) RUN(run_bucket(pl->buckets[k], (int)k, 2));
             lo_ = hi_;
@@ -1791,7 +1823,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
 
 #define RUN(x) do { if (int rc_ = (x)) return rc_; } while (0)
     if (!(flags & STAIR_BWD_KEEP_ARENAS))
-        STAIR_HIP(hipMemsetAsync(ws + pl->o_zero_beg, 0, (pl->o_zero_end - pl->o_zero_beg) * sizeof(float), s));
+        if (int rcz_ = launch_zero(ws + pl->o_zero_beg, (pl->o_zero_end - pl->o_zero_beg) * sizeof(float), s)) return rcz_;
 
     // transposed images of every 2-D weight that needs a dX product
     BwdCtx B;
@@ -1865,7 +1897,6 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
     // phase 0: a bucket's whole adjoint.  With the fused chains a level runs as: phase 1 = everything up to the tile chain (its
     // arguments are queued), ONE launch for the chains of all buckets of the level, phase 2 = what needs the chain's outputs.
     std::vector<stair_tile_mlp_args> chain_queue;
-    int chain_launches = 0;
     auto bwd_bucket = [&](const Bucket &b, const int phase) -> int {
         if (b.cnt == 0) return 0;
         const int c = b.cnt;
@@ -1985,8 +2016,8 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
                 if (v == 0) {
                     // dense input is a_t * f_t: weight grads see the scaled input, G = dZ.W is d(a*f)
                     RUN(dense_bwd(B, gA, c, T, H, H, svB, H, TH, nullptr, W.ffdense, gB, H, TH, nullptr, 0, svRs, T, nullptr));
-                    STAIR_HIP(hipMemsetAsync(gRs, 0, (size_t)c * T * sizeof(float), s));
-                    STAIR_HIP(hipMemsetAsync(gExtra, 0, (size_t)c * sizeof(float), s));
+                    if (int rcz_ = launch_zero(gRs, (size_t)c * T * sizeof(float), s)) return rcz_;
+                    if (int rcz_ = launch_zero(gExtra, (size_t)c * sizeof(float), s)) return rcz_;
                     RUN(launch_rowscale_bwd(gB, svB, TH, nullptr, svRs, T, nullptr, nullptr, gRs, c, T, H, s));   // da_t = G_t . f_t
                     RUN(launch_scale_rows(gB, svRs, (int64_t)c * T, H, s));                                        // df  = a_t * G_t
                     RUN(launch_rowdot_sigmoid_bwd(gRs, T, nullptr, svRs, T, nullptr, W.ffatt.w, gB, 1, gRs2, gExtra, c, T, H, s));
@@ -2054,8 +2085,9 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
     if (!fused) {
         for (auto it = pl->buckets.rbegin(); it != pl->buckets.rend(); ++it) RUN(bwd_bucket(*it, 0));
     } else {
-        unsigned *chain_ctr = reinterpret_cast<unsigned *>(ws + pl->o_status) + 64;      // a second block of 48 work-queue heads
-        STAIR_HIP(hipMemsetAsync(chain_ctr, 0, 48 * sizeof(unsigned), s));
+        // queue words of the backward chains: status words 18, 19 (zeroed by the forward run, left at zero by every launch)
+        unsigned *chain_ctr = reinterpret_cast<unsigned *>(ws + pl->o_status) + 18;
+        const bool use_queue = tile_queue_on();
         for (int64_t hi_ = (int64_t)pl->buckets.size(); hi_ > 0;) {
             int64_t lo_ = hi_;
             while (lo_ > 0 && pl->buckets[lo_ - 1].level == pl->buckets[hi_ - 1].level) --lo_;
@@ -2063,9 +2095,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
             for (int64_t k = hi_ - 1; k >= lo_; --k) RUN(bwd_bucket(pl->buckets[k], 1));
             for (size_t q0 = 0; q0 < chain_queue.size(); q0 += 8) {
                 const int nq = (int)std::min<size_t>(8, chain_queue.size() - q0);
-                STAIR_CHECK(chain_launches < 48, "internal: more fused launches than work-queue heads");
-                RUN(launch_tile_mlp_batch(chain_queue.data() + q0, nq, chain_ctr + chain_launches, s));
-                ++chain_launches;
+                RUN(launch_tile_mlp_batch(chain_queue.data() + q0, nq, use_queue ? chain_ctr : nullptr, s));
             }
             for (int64_t k = hi_ - 1; k >= lo_; --k) RUN(bwd_bucket(pl->buckets[k], 2));
             hi_ = lo_;
@@ -2344,6 +2374,36 @@ extern "C" int stair_plan_zero_grads(stair_plan *pl, void *workspace, stair_stre
     STAIR_CHECK(pl && workspace, "null argument");
     STAIR_CHECK(pl->train, "plan was not built with STAIR_PLAN_TRAIN");
     float *ws = static_cast<float *>(workspace);
-    STAIR_HIP(hipMemsetAsync(ws + pl->o_zero_beg, 0, (pl->o_zero_end - pl->o_zero_beg) * sizeof(float), static_cast<hipStream_t>(stream)));
+    if (int rcz_ = launch_zero(ws + pl->o_zero_beg, (pl->o_zero_end - pl->o_zero_beg) * sizeof(float), static_cast<hipStream_t>(stream))) return rcz_;
+    return 0;
+}
+
+// Diagnostics for the hipGraph question of DESIGN.md section 2: enqueue, on `stream` (which may be capturing), the reset + `launches`
+// queue kernels exactly as stair_plan_run lays them out -- reset_mode 0: hipMemsetAsync of 256 bytes (round 3's reset), 1: the
+// zeroing kernel, 2: no reset at all (self-resetting queue only) -- each launch on its own head (per_launch_heads = 1, round 3) or
+// all on one (0).  seen [launches][grid][2] receives (first ticket, tiles taken) of every workgroup.  No tile work: safe to replay.
+extern "C" int stair_debug_queue_probe(void *words, uint32_t *seen, int32_t launches, int32_t grid, int32_t total, int32_t reset_mode,
+                                       int32_t per_launch_heads, int32_t self_reset, stair_stream stream) {
+    STAIR_CHECK(words && seen && launches >= 1 && launches <= 24 && grid >= 1 && total >= 0, "bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    uint32_t *w = static_cast<uint32_t *>(words);
+    if (reset_mode == 0) STAIR_HIP(hipMemsetAsync(w, 0, 64 * sizeof(float), s));
+    else if (reset_mode == 1) { if (int rcz_ = launch_zero(w, 64 * sizeof(uint32_t), s)) return rcz_; }
+    for (int l = 0; l < launches; ++l)
+        hipLaunchKernelGGL(queue_probe_kernel, dim3(grid), dim3(64), 0, s, w + 16 + (per_launch_heads ? 2 * l : 0), seen + (int64_t)l * grid * 2,
+                           total, self_reset);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int stair_set_tile_queue(int32_t on) { g_tile_queue = on; return 0; }
+
+// reset_mode 0 of the probe on its own: a hipMemsetAsync of `bytes` zero bytes on `stream` (which may be capturing) -- which sizes
+// of a captured memset survive a replay?  mode 1: the library's zero-fill kernel instead.
+extern "C" int stair_debug_memset(void *ptr, int64_t bytes, int32_t mode, stair_stream stream) {
+    STAIR_CHECK(ptr && bytes > 0, "bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (mode == 0) STAIR_HIP(hipMemsetAsync(ptr, 0, (size_t)bytes, s));
+    else if (int rcz_ = launch_zero(ptr, bytes, s)) return rcz_;
     return 0;
 }

@@ -1,6 +1,7 @@
 // HBM-bound row kernels of the NMN path: cosine attention, temporal relate nets, LayerNorm,
 // reductions over frames, concatenations, softmaxes.  One wave (64 lanes) per row wherever a row
 // reduction is needed, float4 loads along H, __shfl_xor wave reductions, no LDS unless stated.
+#include <algorithm>
 #include "ops.h"
 
 namespace stair {
@@ -618,6 +619,32 @@ int launch_dropout_rows(float *X, int64_t gstride, const int32_t *gidx, int grou
     const uint32_t thresh = (uint32_t)(p * 16777216.0f);         // drop when the 24-bit hash is below p * 2^24
     hipLaunchKernelGGL(dropout_rows_kernel, dim3((unsigned)std::min<int64_t>((total + kBlock - 1) / kBlock, 8192)), dim3(kBlock), 0,
                        s, X, gstride, gidx, groups, rowlen, thresh, 1.0f / (1.0f - p), seed, site);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- zero fill ------------------------------------------------------------------------------------------------------------
+// Every "start from zero" of the library (status / queue words, hand-off flags of the cooperative recurrences, gradient arenas)
+// is THIS kernel, never hipMemsetAsync: a memset recorded into a torch-captured hipGraph was observed to fill its target with
+// stale kernel-argument bytes instead of zeros from the second replay on (profiles/r04_queue_probe.json);
+// a kernel node replays like every other launch of the pass.  16-byte stores over the aligned body, words at both ends.
+__global__ void zero_fill_kernel(uint32_t *p, int64_t head, int64_t body16, int64_t tail) {
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, step = (int64_t)gridDim.x * blockDim.x;
+    uint4 *b = reinterpret_cast<uint4 *>(p + head);
+    for (int64_t i = i0; i < body16; i += step) b[i] = uint4{0u, 0u, 0u, 0u};
+    if (i0 < head) p[i0] = 0u;
+    if (i0 < tail) p[head + 4 * body16 + i0] = 0u;
+}
+
+int launch_zero(void *ptr, int64_t bytes, hipStream_t s) {
+    if (bytes <= 0) return 0;
+    STAIR_CHECK(ptr && bytes % 4 == 0 && (reinterpret_cast<uintptr_t>(ptr) & 3) == 0, "zero fill: 4-byte aligned words");
+    const int64_t n = bytes / 4;
+    const int64_t head = std::min<int64_t>(n, ((16 - (int64_t)(reinterpret_cast<uintptr_t>(ptr) & 15)) & 15) / 4);
+    const int64_t body16 = (n - head) / 4, tail = n - head - 4 * body16;
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((body16 + 255) / 256, 4096));
+    STAIR_ACCT("zero_fill", bytes);
+    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<uint32_t *>(ptr), head, body16, tail);
     STAIR_LAUNCH_CHECK();
     return 0;
 }

@@ -62,7 +62,8 @@ struct TmParams {
     stair_tile_mlp_args a[TM_MAXB];  // the buckets of one program level: independent of each other, so their tiles share one launch
     int first[TM_MAXB + 1];          // work item w belongs to bucket b with first[b] <= w < first[b + 1]; its tile is w - first[b]
     int nb;
-    unsigned *counter;               // work queue head (zeroed before the launch); NULL: tiles are dealt out round robin
+    unsigned *counter;               // work queue: counter[0] = head, counter[1] = workgroups that have left the queue.  Both words are
+                                     // zero between launches (the last workgroup to leave puts them back); NULL: tiles are dealt out round robin
 };
 
 static_assert(sizeof(TmParams) <= 4096, "the argument block of a launch must stay under the 4 KB kernarg limit");
@@ -133,7 +134,9 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
         } else {
             w = blockIdx.x + it * gridDim.x;
         }
-        if (w >= total) break;
+        // UNSIGNED: whatever the head word held (a ticket >= 2^31 read as a negative int passed the signed test and indexed the
+        // bucket table and the tile pointers out of bounds), a workgroup only ever touches tiles 0 .. total - 1
+        if ((unsigned)w >= (unsigned)total) break;
         int bsel = 0;
 #pragma unroll
         for (int j = 1; j < TM_MAXB; ++j) bsel += (j < pp.nb && w >= pp.first[j]) ? 1 : 0;
@@ -539,6 +542,16 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
             default: break;
         }
     }
+    // The queue resets ITSELF: every workgroup takes exactly one ticket >= total (the one that made it leave) and then signs off;
+    // the last one to sign off knows that nobody will touch the head again and zeroes both words, so the next launch on the stream
+    // -- eager, or the same kernel node of a replayed hipGraph -- finds them at 0 without any memset in between.
+    // (thread 0's last head ticket has RETURNED before it signs off -- it branched on the value -- so no fence is needed between the two)
+    if (pp.counter && tid == 0) {
+        if (atomicAdd(pp.counter + 1, 1u) == gridDim.x - 1) {
+            atomicExch(pp.counter, 0u);
+            atomicExch(pp.counter + 1, 0u);
+        }
+    }
 }
 
 // W [N, K] fp32 row-major -> bf16 hi / lo planes in MFMA fragment order: the A operand of v_mfma_f32_32x32x16_bf16 for the
@@ -641,15 +654,11 @@ static int tile_mlp_check(const stair_tile_mlp_args &a) {
     return 0;
 }
 
-// n buckets (same T) in one launch; counter: a zeroed device word (the dynamic work queue) or NULL
+// n buckets (same T) in one launch; counter: TWO zeroed device words (the dynamic work queue: head, sign-off count; the kernel
+// leaves them zeroed, so launches that follow each other on one stream may share them) or NULL (static round robin)
 int launch_tile_mlp_batch(const stair_tile_mlp_args *args, int n, unsigned *counter, hipStream_t s) {
     STAIR_CHECK(n >= 0 && n <= TM_MAXB, "at most 8 buckets per launch");
     STAIR_CHECK(matmul_mode() == STAIR_MATMUL_BF16X3, "the fused tile operators compute split-bf16 products (STAIR_MATMUL_BF16X3)");
-    // Inside a stream capture the tiles are dealt out round robin: under torch's hipGraph replays the queue form faulted on
-    // the second replay (the ticket word is reset by a captured memset; cause not established -- a raw HIP graph with the same
-    // memset + atomic pattern replays correctly, tools/scratch/graph_memset.hip), and a replayed batch has fixed shapes anyway.
-    hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
-    if (counter && hipStreamIsCapturing(s, &cap_status) == hipSuccess && cap_status != hipStreamCaptureStatusNone) counter = nullptr;
     for (int i = 0; i < n; ++i)
         if (int rc = tile_mlp_check(args[i])) return rc;
     static bool attr_set[64] = {};
@@ -672,10 +681,10 @@ int launch_tile_mlp_batch(const stair_tile_mlp_args *args, int n, unsigned *coun
     static const bool nt = [] { const char *e = getenv("STAIR_TILE_NT"); return !(e && e[0] == '0'); }();
     auto rounds = [&](int x) { return args[x].n_layers + (args[x].vec_pack ? (args[x].vec_pack == 1 ? 1 : 2) : 0); };   // k loops per tile
     // map-level tiles and vector-level tiles are two kernels (the vector form's segment loop costs the other one registers):
-    // two launches when a level has both; the second queue head is the word after the first
+    // two launches when a level has both; stream-ordered, so they share the (self-resetting) queue words
     for (int vec = 0; vec < 2; ++vec) {
         TmParams pp;
-        pp.nb = 0; pp.counter = counter ? counter + vec : nullptr; pp.first[0] = 0;
+        pp.nb = 0; pp.counter = counter; pp.first[0] = 0;
         int order[TM_MAXB], m = 0;
         for (int i = 0; i < n; ++i)
             if (args[i].cnt > 0 && (args[i].vec_pack != 0) == (vec != 0)) order[m++] = i;

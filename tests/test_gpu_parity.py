@@ -504,40 +504,80 @@ def test_on_disk_dataset_to_logits():
     assert acc == E.accuracy(preds, [int(it['answer']) for it in items], vocab['word2id']['<UNK>'])
 
 
-def test_captured_plan_replays_bit_exactly(matmul):
+@pytest.mark.parametrize('queue', [1, 0])
+def test_captured_plan_replays_bit_exactly(matmul, queue):
     """BASELINE configs[3]: a plan's forward pass recorded into a hipGraph.  Replay == eager run, bit for bit; new
-    inputs written into the static tensors (same programs and lengths) give the eager result for those inputs."""
+    inputs written into the static tensors (same programs and lengths) give the eager result for those inputs -- on the
+    third and fourth replay too, with other batches run eagerly in between.  Both tile schedules: the self-resetting work
+    queue (default; round 3 fell back to the static schedule under capture) and the static round robin."""
+    from stair_amd._lib import lib
     config = dict(spec.DEFAULT_CONFIG)
     model = _model(config, 4)
     qs = synth.make_questions(config, 31, 24, forms=synth.ALL_FORMS)
-    eager = model.forward_batch(qs)
-    want = eager.logits.clone()
-    cap = model.forward_batch(qs).capture_graph()
-    cap.logits.zero_()
-    logits, pred = cap.replay()
-    torch.cuda.synchronize()
-    if not torch.equal(logits, want):      # say where: a replay that differs is a determinism bug somewhere in the forward pass
-        d = (logits - want).abs().amax(1)
-        rows = d.nonzero().flatten().tolist()
-        raise AssertionError('replay differs from the eager run in %d rows (max %.3g): %s' % (
-            len(rows), float(d.max()), [(i, qs[i]['nmn_program_list'][0]) for i in rows[:8]]))
-    assert torch.equal(pred, eager.pred)
-    # other clips and word embeddings under the same programs, spans and lengths (= the same plan)
-    g = torch.Generator().manual_seed(5)
-    other = []
+    lib.stair_set_tile_queue(queue)
+    try:
+        eager = model.forward_batch(qs)
+        want = eager.logits.clone()
+        cap = model.forward_batch(qs).capture_graph()
+        cap.logits.zero_()
+        logits, pred = cap.replay()
+        torch.cuda.synchronize()
+        if not torch.equal(logits, want):      # say where: a replay that differs is a determinism bug somewhere in the forward pass
+            d = (logits - want).abs().amax(1)
+            rows = d.nonzero().flatten().tolist()
+            raise AssertionError('replay differs from the eager run in %d rows (max %.3g): %s' % (
+                len(rows), float(d.max()), [(i, qs[i]['nmn_program_list'][0]) for i in rows[:8]]))
+        assert torch.equal(pred, eager.pred)
+        # other clips and word embeddings under the same programs, spans and lengths (= the same plan)
+        for rep in range(3):
+            g = torch.Generator().manual_seed(5 + rep)
+            other = []
+            for q in qs:
+                o = dict(q)
+                o['video_features'] = torch.randn(q['video_features'].shape, generator=g)
+                o['question'] = torch.randn(q['question'].shape, generator=g)
+                other.append(o)
+            fresh = model.forward_batch(other).logits.clone()
+            cap.result._video.copy_(torch.stack([torch.as_tensor(q['video_features']) for q in other]).to(DEV))
+            cap.result._question.copy_(torch.cat([torch.as_tensor(q['question']) for q in other]).to(DEV))
+            cap.logits.zero_()
+            logits, _ = cap.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(logits, fresh), rep
+            # the queue words are back at zero after every pass
+            off = cap.result.info.status_off
+            assert int(cap._ws[off + 16: off + 20].view(torch.int32).abs().sum()) == 0
+        with pytest.raises(Exception):
+            model.forward_batch(qs, train=True).capture_graph()
+    finally:
+        lib.stair_set_tile_queue(-1)
+
+
+def test_program_deeper_than_the_old_queue_head_block(matmul):
+    """A program nested 40 levels deep (round 3 reserved one queue head per fused launch, 24 forward launches at most, and
+    refused deeper plans): forward against the oracle, and a training step runs through its 40 backward chain launches."""
+    config = dict(spec.DEFAULT_CONFIG)
+    model = _model(config, 3)
+    w = oracle_weights(config, 3)
+    depth = 39
+    qs = synth.make_questions(config, 13, 6, forms=['P1'])
     for q in qs:
-        o = dict(q)
-        o['video_features'] = torch.randn(q['video_features'].shape, generator=g)
-        o['question'] = torch.randn(q['question'].shape, generator=g)
-        other.append(o)
-    fresh = model.forward_batch(other).logits.clone()
-    cap.result._video.copy_(torch.stack([torch.as_tensor(q['video_features']) for q in other]).to(DEV))
-    cap.result._question.copy_(torch.cat([torch.as_tensor(q['question']) for q in other]).to(DEV))
-    logits, _ = cap.replay()
+        q['nmn_program_list'] = ['Exists', 'dish', 'Filter'] + ['FilterFrame'] * depth + ['video'] + ['holding'] * depth + ['objects']
+        q['nmn_program_idx'] = list(range(len(q['nmn_program_list'])))
+        Q = q['question'].shape[0]
+        q['prog_str_to_question_tokens'] = {i: (1 + i % (Q - 2), 2 + i % (Q - 2)) for i in range(len(q['nmn_program_list']))}
+    res = model.forward_batch(qs)
+    assert res.info.n_levels >= depth + 2
+    for qi in (0, 5):
+        r = O.forward(w, config, qs[qi])
+        assert _maxerr(res.logits[qi], r['logits']) < 1e-4
+    for p in model.parameters():
+        p.grad = torch.zeros_like(p)
+    tr = model.forward_batch(qs, train=True)
+    loss = tr.backward(torch.tensor([q['answer'] for q in qs], dtype=torch.int32, device=DEV))
     torch.cuda.synchronize()
-    assert torch.equal(logits, fresh)
-    with pytest.raises(Exception):
-        model.forward_batch(qs, train=True).capture_graph()
+    assert torch.isfinite(loss).all()
+    tr.check()
 
 
 def test_forward_pass_is_bit_reproducible(matmul):
