@@ -248,9 +248,10 @@ def main():
 
     from stair_amd import launch
     if args.gpus > 1 and not launch.launched_as_rank():
-        # `python bench.py --gpus N` on its own: start the N ranks (fresh processes; this one has not touched the GPU --
-        # torch.cuda.device_count() does not initialise HIP) and relay rank 0's line.  Never run fewer ranks than asked for.
-        ndev = torch.cuda.device_count()
+        # `python bench.py --gpus N` on its own: start the N ranks (fresh processes; this one has not touched the GPU -- the
+        # count comes from the kfd topology and the *_VISIBLE_DEVICES lists, no HIP call) and relay rank 0's line.  Never run
+        # fewer ranks than asked for.
+        ndev = launch.visible_gpu_count()
         if ndev < args.gpus and os.environ.get('STAIR_DIST_BACKEND', 'nccl') == 'nccl':      # (a gloo rehearsal wraps the ranks around the visible cards)
             print('bench.py: --gpus %d but only %d GPU(s) visible' % (args.gpus, ndev), file=sys.stderr)
             sys.exit(2)
@@ -346,6 +347,7 @@ def main():
 
     if trainer is not None and world > 1:
         trainer.allreduce_events = []
+        trainer.allreduce_late_events = []
     elapsed, res = timed(lambda: run_step(B, args.supervision), args.steps, args.warmup)
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -358,7 +360,9 @@ def main():
         # how many ranks the collective really spans: a sum of ones through the communicator (and ncclCommCount on the native one)
         probe = torch.ones(1, device=device)
         dist.all_reduce(probe)
-        extras['rccl_ranks'] = int(probe.item())
+        extras['collective_ranks'] = int(probe.item())
+        if backend == 'nccl':
+            extras['rccl_ranks'] = extras['collective_ranks']
         extras['collective_backend'] = ('stair_allreduce_grads (RCCL from libstair_hip.so)' if args.native_allreduce else
                                         'torch.distributed %s' % backend)
         if trainer is not None:
@@ -368,8 +372,40 @@ def main():
             dist.all_reduce(ar, op=dist.ReduceOp.MAX)
             extras['allreduce_ms_per_step'] = round(float(ar.item()), 4)
             extras['allreduce_bytes_per_step'] = int(trainer.bucket.numel() * 4)
+
+            def exposed_ms(events):
+                """what the main stream sits through after its backward pass: from the start of the late collective
+                ([encoder gradients | mask | status]) to the point where both pieces have arrived; max over ranks"""
+                x = torch.tensor([sum(a.elapsed_time(b) for a, b in events) / max(1, len(events))], device=device, dtype=torch.float64)
+                dist.all_reduce(x, op=dist.ReduceOp.MAX)
+                return round(float(x.item()), 4)
+            torch.cuda.synchronize()
+            extras['allreduce_exposed_ms_per_step'] = exposed_ms(trainer.allreduce_late_events[-args.steps:])
+            extras['allreduce_overlap'] = ('two pieces: [module + decoder gradients] (%d bytes) on a side stream from the backward pass\'s '
+                                           '"module gradients final" event on, beside BPTT and the encoders\' dW products; [encoder gradients | '
+                                           'touched mask | status] (%d bytes) after the pass' % (trainer.split * 4, (trainer.bucket.numel() - trainer.split) * 4)
+                                           if trainer._side is not None else 'off: one collective after the backward pass')
+            trainer.allreduce_late_events = None
             if trainer.comm is not None:
                 extras['rccl_ranks_native_comm'] = trainer.comm.ranks()[1]
+        if trainer is not None:
+            # BASELINE configs[2]: "AGQA2 train DP=8 over xGMI, RCCL grad all-reduce, global batch 1024" = 1024 / N questions per GPU
+            # per step (128 at N = 8), the latency-bound regime; same step, same collectives, smaller window
+            nq2 = max(1, min(B, 1024 // world))
+            k2 = max(10, args.steps)
+            trainer.allreduce_events, trainer.allreduce_late_events = [], []
+            dt2, _ = timed(lambda: run_step(nq2, args.supervision), k2, 3)
+            t2 = torch.tensor([dt2], device=device, dtype=torch.float64)
+            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+            ar2 = torch.tensor([sum(a.elapsed_time(b) for a, b in trainer.allreduce_events[-k2:]) / k2], device=device, dtype=torch.float64)
+            dist.all_reduce(ar2, op=dist.ReduceOp.MAX)
+            extras['configs2_global_1024'] = {
+                'questions_per_gpu_per_step': nq2, 'global_batch': nq2 * world, 'collective_ranks': extras['collective_ranks'],
+                'train_ms_per_step': round(float(t2.item()) / k2 * 1e3, 3), 'train_questions_per_s': round(nq2 * world * k2 / float(t2.item()), 1),
+                'allreduce_ms_per_step': round(float(ar2.item()), 4),
+                'allreduce_exposed_ms_per_step': exposed_ms(trainer.allreduce_late_events[-k2:]),
+                'note': 'BASELINE configs[2] (global batch 1024 over N GPUs); the headline `value` is configs[1]\'s 2048 questions per GPU per step'}
+            trainer.allreduce_events = trainer.allreduce_late_events = None
         if trainer is not None and not args.no_extras:
             # Supplementary data-parallel legs.  Every rank issues the SAME sequence of torch collectives whatever happens inside a
             # leg (a rank that fails locally records the error and still takes part), so a local failure cannot hang the job.

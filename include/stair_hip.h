@@ -254,8 +254,8 @@ typedef struct stair_lstm_bwd_args {
     uint32_t *status; /* optional sticky timeout word, as in stair_lstm_args */
     float *tn_ws; int64_t tn_ws_floats; /* optional scratch for the slab-reduced weight-gradient products (stair_gemm_tn_slabs): when it is
                                            large enough, dW_hh (and dW_ih on fp32 rows) are formed without atomics; their sums reach the
-                                           dw_* / db_* buffers at the END of the stair_plan_backward that passed the scratch (the plan
-                                           runner's use; leave NULL in direct calls) */
+                                           dw_* / db_* buffers at the END of the stair_plan_backward that passed the scratch, or before
+                                           stair_lstm_bidir_bwd returns in a direct call */
 } stair_lstm_bwd_args;
 int64_t stair_lstm_coop_bwd_ws_bytes(int32_t n);
 int stair_lstm_bidir_bwd(const stair_lstm_bwd_args *args, stair_stream stream);
@@ -501,8 +501,15 @@ int stair_plan_run(stair_ctx *ctx, stair_plan *plan, const float *video, const f
  * Exists / HasItem / ToAction / the decoder, after the dense layers of FilterFrame and Temporal, after HasItem's
  * sigmoid).  Call on a STAIR_PLAN_TRAIN plan before stair_plan_run; p = 0 switches it off again.  The masks are a
  * counter-based hash of (seed, position, element) -- torch's Philox stream cannot be reproduced -- so a step is
- * replayable and stair_plan_backward needs no stored masks.  Inference plans never drop. */
+ * replayable and stair_plan_backward needs no stored masks.  Inference plans never drop.  A plan with
+ * shared subexpressions (n_aliased > 0) is refused: the reference draws an independent mask per question and occurrence
+ * (module_net.py:100-106 under model.train()), so build dropout plans with STAIR_PLAN_NO_CSE. */
 int stair_plan_set_dropout(stair_plan *plan, float p, uint64_t seed);
+/* Data-parallel training: `event` (a hipEvent_t the caller owns; NULL switches it off) is recorded on stair_plan_backward's stream at
+ * the point where every gradient EXCEPT the two encoders' is final -- decoder, all program levels and their weight-gradient products
+ * -- i.e. before BPTT and the encoders' dW_ih / dW_hh.  A trainer lets a side stream wait for it and reduces that part of its
+ * gradient bucket beside the rest of the pass (stair_amd/train.py; the reference is single-process, train_module.py:408). */
+int stair_plan_set_backward_event(stair_plan *plan, void *event);
 /* The mask generator on its own (building block / test hook): in place on `groups` rows of `rowlen` floats, row g at
  * x + (gidx ? gidx[g] : g) * gstride; element e of the launch is kept iff hash24(seed, site, e) >= p * 2^24 and then
  * divided by (1 - p). */

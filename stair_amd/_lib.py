@@ -196,6 +196,7 @@ SIGNATURES = [
     ('stair_dropout_fwd', C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_uint32,
                                    C.c_void_p]),
     ('stair_plan_set_dropout', C.c_int, [C.c_void_p, C.c_float, C.c_uint64]),
+    ('stair_plan_set_backward_event', C.c_int, [C.c_void_p, C.c_void_p]),
     ('stair_plan_upload', C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     ('stair_plan_run_flags', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                        C.c_void_p, C.c_int32, C.c_void_p]),

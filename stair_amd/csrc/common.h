@@ -85,6 +85,7 @@ int tn_x3tr_slabs(int64_t M);
 int64_t tn_x3tr_scratch_floats(int64_t M, int64_t N, int64_t K);
 int launch_gemm_tn_x3tr(const stair_gemm_tn_args &a, float *scratch, hipStream_t s);
 int tn_x3tr_flush(hipStream_t s);
+void tn_x3tr_discard();          // forget queued sums (a pass that failed half-way must not leak them into the next one)
 int launch_lstm_rec_coop(const stair_lstm_args &a, hipStream_t s);
 bool lstm_coop_usable(int Hh);
 int64_t lstm_coop_ws_bytes(int n);

@@ -353,6 +353,8 @@ int launch_gemm_tn_x3tr(const stair_gemm_tn_args &a, float *scratch, hipStream_t
     return 0;
 }
 
+void tn_x3tr_discard() { g_pending.n = 0; }
+
 int tn_x3tr_flush(hipStream_t s) {
     if (g_pending.n == 0) return 0;
     XtReduceBatch b = g_pending;

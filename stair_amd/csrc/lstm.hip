@@ -975,5 +975,11 @@ extern "C" int stair_lstm_bidir_bwd(const stair_lstm_bwd_args *args, stair_strea
         stair::set_error("stair_lstm_bidir_bwd: null args");
         return 1;
     }
-    return stair::launch_lstm_bwd(*args, static_cast<hipStream_t>(stream));
+    // with tn_ws the slab-reduced weight gradients are queued by the launcher: added here, before returning (inside
+    // stair_plan_backward the plan does that once for both encoders)
+    stair::tn_x3tr_discard();
+    int rc = stair::launch_lstm_bwd(*args, static_cast<hipStream_t>(stream));
+    if (rc == 0) rc = stair::tn_x3tr_flush(static_cast<hipStream_t>(stream));
+    else stair::tn_x3tr_discard();
+    return rc;
 }

@@ -411,6 +411,7 @@ struct stair_plan {
             o_logits = 0, o_status = 0, o_wfrag = 0, total = 0;
     // training only
     bool train = false;
+    void *bwd_event = nullptr;      // stair_plan_set_backward_event
     float drop_p = 0.0f;            // training-mode dropout (stair_plan_set_dropout); 0 = off
     uint64_t drop_seed = 0;
     int64_t o_cv = 0, o_ct = 0, o_hprev = 0, o_gblock = 0, o_gatt = 0, o_gtok = 0, o_gqfeat = 0, o_gA = 0, o_gB = 0,
@@ -1296,8 +1297,18 @@ extern "C" int stair_plan_set_dropout(stair_plan *pl, float p, uint64_t seed) {
     STAIR_CHECK(pl, "null plan");
     STAIR_CHECK(p >= 0.0f && p < 1.0f, "dropout probability must be in [0, 1)");
     STAIR_CHECK(p == 0.0f || pl->train, "dropout needs a STAIR_PLAN_TRAIN plan (model.eval() has none, modules.py)");
+    // module_net.py:100-106 evaluates every node of every question, so under model.train() every occurrence draws its OWN mask;
+    // a node shared by several questions would be dropped once for all of them
+    STAIR_CHECK(p == 0.0f || pl->n_aliased == 0, "dropout needs a plan without shared subexpressions: build it with STAIR_PLAN_NO_CSE");
     pl->drop_p = p;
     pl->drop_seed = seed;
+    return 0;
+}
+
+extern "C" int stair_plan_set_backward_event(stair_plan *pl, void *event) {
+    STAIR_CHECK(pl, "null plan");
+    STAIR_CHECK(!event || pl->train, "the backward event belongs to a STAIR_PLAN_TRAIN plan");
+    pl->bwd_event = event;
     return 0;
 }
 
@@ -1799,6 +1810,9 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
                                    float *loss_out, int32_t flags, stair_stream stream) {
     STAIR_CHECK(ctx && pl && video && question && workspace && answers, "null argument");
     STAIR_CHECK(pl->train, "plan was not built with STAIR_PLAN_TRAIN");
+    // slab products queued by a pass that failed half-way must not be added into THIS pass's buffers: the queue starts empty and
+    // is emptied again however this function returns
+    struct PendingScope { PendingScope() { tn_x3tr_discard(); } ~PendingScope() { tn_x3tr_discard(); } } pending_scope;
     STAIR_CHECK(workspace_bytes >= pl->total * (int64_t)sizeof(float), "workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
     Weights W;
@@ -2163,6 +2177,12 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
     }
     RUN(tn_x3tr_flush(s_tn));                 // dW, db += the slabs of every product above, in slab order: one launch
     if (overlap_tn) STAIR_HIP(hipEventRecord(ctx->ev_join, ctx->side));
+    // Every gradient except the two encoders' is final here (decoder, all module levels, their weight-gradient products): a
+    // data-parallel trainer starts reducing that part of its bucket now, beside the BPTT below (stair_plan_set_backward_event)
+    if (pl->bwd_event) {
+        if (overlap_tn) STAIR_HIP(hipStreamWaitEvent(s, ctx->ev_join, 0));
+        STAIR_HIP(hipEventRecord(static_cast<hipEvent_t>(pl->bwd_event), s));
+    }
 
     // ---- encoders ------------------------------------------------------------------------------------
     {

@@ -20,6 +20,30 @@ def launched_as_rank(env=None):
     return 'WORLD_SIZE' in env and 'RANK' in env
 
 
+def visible_gpu_count(env=None, topology='/sys/class/kfd/kfd/topology/nodes'):
+    """GPUs this process could use, WITHOUT a HIP / HSA call (a parent that is about to spawn ranks must stay clean):
+    the kfd topology lists every node; GPU nodes have simd_count > 0.  HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES /
+    CUDA_VISIBLE_DEVICES restrict the set (a comma list; an empty string hides every GPU)."""
+    env = os.environ if env is None else env
+    n = 0
+    try:
+        for node in sorted(os.listdir(topology)):
+            try:
+                with open(os.path.join(topology, node, 'properties')) as f:
+                    props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            except OSError:
+                continue
+            if int(props.get('simd_count', '0')) > 0:
+                n += 1
+    except OSError:
+        n = 0
+    for key in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        if key in env:
+            listed = [x for x in env[key].split(',') if x.strip() != '']
+            n = min(n, len(listed))
+    return n
+
+
 def free_port():
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
         s.bind(('127.0.0.1', 0))

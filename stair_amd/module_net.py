@@ -120,15 +120,18 @@ class BatchResult:
             return self._ws[inf.gmap_off: inf.gmap_off + inf.n_map * T * H].view(inf.n_map, T, H)
         return self._ws[inf.gatt_off: inf.gatt_off + inf.n_att * T].view(inf.n_att, T)
 
-    def backward(self, answers, loss_scale=1.0, keep_arenas=False):
+    def backward(self, answers, loss_scale=1.0, keep_arenas=False, ready_event=None):
         """Reverse pass of a train=True run: decoder cross entropy against `answers` (int32 [n] on the GPU),
         gradients of loss_scale * sum_i CE_i accumulated into the model's gradient buffers.
         keep_arenas: the gradient arenas were zeroed by zero_grad_arenas() and hold injected loss gradients.
+        ready_event: a torch.cuda.Event that has been recorded once (so that its hipEvent_t exists); the pass records it on the
+        current stream when every gradient except the two encoders' is final (stair_plan_set_backward_event).
         Returns the unscaled per-question losses [n]."""
         ops._req(answers, 'answers', torch.int32)
         loss = torch.empty(self.info.n_questions, dtype=torch.float32, device=answers.device)
         self._model._bind_grads()
         flags = (1 if keep_arenas else 0) | (RUN_VIDEO_BF16 if self._video.dtype == torch.bfloat16 else 0)
+        check(lib.stair_plan_set_backward_event(self._plan, C.c_void_p(ready_event.cuda_event if ready_event is not None else None)))
         check(lib.stair_plan_backward(self._model._ctx, self._plan, C.c_void_p(self._video.data_ptr()),
                                       C.c_void_p(self._question.data_ptr()), C.c_void_p(self._ws.data_ptr()),
                                       self._ws.numel() * 4, C.c_void_p(answers.data_ptr()), C.c_float(loss_scale),
@@ -367,7 +370,8 @@ class VideoNMN(nn.Module):
         question is computed as the reference computes a clip of its own length (stair_plan_build_ragged).
         cse: share common subexpressions across the batch (include/stair_hip.h STAIR_PLAN_NO_CSE): a node that depends only on
         the clip, keyword strings and identical question spans is computed once and aliased by every other occurrence; the
-        values are those of the expanded computation (module_net.py:100-106), gradients of all users accumulate.
+        values are those of the expanded computation (module_net.py:100-106), gradients of all users accumulate.  Ignored when
+        dropout is active: the reference draws one mask per question and occurrence, a shared node would be dropped once for all.
         before_run (optional): called with the BatchResult after the plan is built (node table, slots and offsets are
         known) and BEFORE the pass is enqueued -- host work that only needs the plan (the loss driver's index arrays)
         then overlaps the previous step's GPU work instead of sitting between this step's forward and backward."""
@@ -397,6 +401,8 @@ class VideoNMN(nn.Module):
         def ip(a):
             return a.ctypes.data_as(C.POINTER(C.c_int32))
         plan = C.c_void_p()
+        # under dropout every occurrence of a node draws its own mask (module_net.py:100-106 in model.train()): nothing is shared
+        drop_on = dropout is not None and dropout[0] > 0
         if video_len is not None:
             video_len = np.ascontiguousarray(np.asarray(video_len, dtype=np.int32))
             if video_len.shape != (video.shape[0],):
@@ -405,7 +411,7 @@ class VideoNMN(nn.Module):
                 video_len = None
         check(lib.stair_plan_build_ragged(self._ctx, n, ip(prog_off), ip(tokens), ip(lo), ip(hi), ip(q_off), video.shape[0],
                                           ip(video_index) if video_index is not None else None,
-                                          ip(video_len) if video_len is not None else None, T, (1 if train else 0) | (0 if cse else 2),
+                                          ip(video_len) if video_len is not None else None, T, (1 if train else 0) | (0 if cse and not drop_on else 2),
                                           C.byref(plan)))
         try:
             info = PlanInfo()

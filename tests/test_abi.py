@@ -222,6 +222,18 @@ def test_common_subexpressions_are_aliased_not_recomputed():
         check(lib.stair_plan_build_shared(h, n, ip(prog_off), ip(tokens), ip(lo), ip(hi), ip(q_off), 3, ip(clip), 40, flag, C.byref(plan)))
         inf = PlanInfo()
         check(lib.stair_plan_get_info(plan, C.byref(inf)))
+        if flag == 2:
+            # dropout on a TRAINING plan: every occurrence draws its own mask in the reference (module_net.py:100-106 under
+            # model.train()), so a plan that shares nodes refuses p > 0 and an unshared one takes it
+            for fl, ok in ((1, False), (1 | 2, True)):
+                tplan = C.c_void_p()
+                check(lib.stair_plan_build_shared(h, n, ip(prog_off), ip(tokens), ip(lo), ip(hi), ip(q_off), 3, ip(clip), 40, fl, C.byref(tplan)))
+                rc = lib.stair_plan_set_dropout(tplan, C.c_float(0.25), C.c_uint64(7))
+                assert (rc == 0) == ok, (fl, rc)
+                if not ok:
+                    assert b'STAIR_PLAN_NO_CSE' in lib.stair_last_error()
+                    assert lib.stair_plan_set_dropout(tplan, C.c_float(0.0), C.c_uint64(0)) == 0
+                lib.stair_plan_destroy(tplan)
         info[flag] = inf
         tab = [np.empty(inf.n_nodes, np.int32) for _ in range(5)]
         check(lib.stair_plan_nodes(plan, *[ip(t) for t in tab], inf.n_nodes))

@@ -52,7 +52,7 @@ def _pack(qs, dev, bf16):
             [q['question'].shape[0] for q in qs], answers)
 
 
-def _run(rank, world, supervised, bf16, out, table=False):
+def _run(rank, world, supervised, bf16, out, table=False, overlap=None, fail_rank=None):
     from stair_amd import losses as L
     from stair_amd.train import Trainer
     dev = torch.device('cuda', 0)
@@ -62,12 +62,25 @@ def _run(rank, world, supervised, bf16, out, table=False):
     # table: the contrastive pools travel as a presence matrix summed on the device (losses.ClassTable), built from each
     # rank's OWN shard and merged once -- instead of the per-step all_gather_object of the class lists
     class_table = L.ClassTable.from_questions(mine, world) if table else None
-    tr = Trainer(model, world=world, rank=rank, dropout=0.0, contrastive_window=WINDOW, lr=1e-3, class_table=class_table)
+    tr = Trainer(model, world=world, rank=rank, dropout=0.0, contrastive_window=WINDOW, lr=1e-3, class_table=class_table,
+                 overlap_allreduce=overlap)
     state = {}
     for it in range(2):                                        # the second step exercises 'ever'-touched bookkeeping
         progs, spans, video, question, q_lens, answers = _pack(mine, dev, bf16)
+        if fail_rank is not None and it == 1:                  # the second step's pass "fails" on ONE rank
+            before = (tr.flat_p.clone(), tr.exp_avg.clone(), tr.steps.clone(), tr.touched.clone())
+            tr.inject_failure = rank == fail_rank
         loss, _ = tr.step(progs, spans, video, question, q_lens, answers, questions=mine if supervised else None)
         torch.cuda.synchronize()
+        if fail_rank is not None and it == 1:
+            from stair_amd._lib import StairError
+            state['unchanged'] = all(torch.equal(a, b) for a, b in zip(before, (tr.flat_p, tr.exp_avg, tr.steps, tr.touched)))
+            state['guard'] = int(tr.guard[0])
+            try:
+                tr.check()
+                state['raised'] = False
+            except StairError:
+                state['raised'] = True
         state['grad%d' % it] = tr.flat_g.cpu().clone()
         state['loss%d' % it] = loss.cpu().clone()
     state.update(params=tr.flat_p.cpu().clone(), touched=tr.touched.cpu().clone(), steps=tr.steps.cpu().clone(),
@@ -75,12 +88,12 @@ def _run(rank, world, supervised, bf16, out, table=False):
     torch.save(state, out)
 
 
-def _worker(rank, world, port, supervised, bf16, out_dir, table=False):
+def _worker(rank, world, port, supervised, bf16, out_dir, table=False, overlap=None, fail_rank=None, tag='rank'):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        _run(rank, world, supervised, bf16, os.path.join(out_dir, 'rank%d.pt' % rank), table)
+        _run(rank, world, supervised, bf16, os.path.join(out_dir, '%s%d.pt' % (tag, rank)), table, overlap, fail_rank)
     finally:
         dist.destroy_process_group()
 
@@ -115,6 +128,49 @@ def test_two_rank_trainer_step_equals_single_process_step(supervised, bf16, tabl
     dp = (solo['params'] - ranks[0]['params']).abs()
     # Adam divides by sqrt(v): where a gradient is ~0 the step direction is ill-conditioned; lr = 1e-3, two steps
     assert float((dp > 2e-5).float().mean()) < 2e-3 and float(dp.max()) <= 2.1e-3
+
+
+def test_two_piece_exchange_equals_one_piece_bit_for_bit():
+    """Trainer(overlap_allreduce=True): [module + decoder gradients] reduced on a side stream from the backward pass's
+    "module gradients are final" event on, [encoder gradients | mask | status] after the pass -- against the whole bucket in one
+    collective after the pass, two supervised steps each.  The exchange itself is bit-identical either way (a + b; pinned on CPU
+    tensors in tests/test_sharding_gloo.py); two RUNS of the backward pass are not (fp32 atomics in the dX fan-in), so the two
+    jobs are compared as two runs of one job are: masks, step counts and losses exactly, gradients to 2e-5 of their largest
+    entry -- a piece reduced before it was final, or a zero_grad overtaking the side stream, is wrong by whole terms."""
+    import torch.multiprocessing as mp
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(2, _free_port(), True, True, d, True, False, None, 'one'), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, _free_port(), True, True, d, True, True, None, 'two'), nprocs=2, join=True)
+        one = [torch.load(os.path.join(d, 'one%d.pt' % r)) for r in range(2)]
+        two = [torch.load(os.path.join(d, 'two%d.pt' % r)) for r in range(2)]
+    for r in range(2):
+        for key in ('touched', 'steps'):
+            assert torch.equal(one[r][key], two[r][key]), (r, key)
+        for key in ('loss0', 'loss1'):
+            assert torch.allclose(one[r][key], two[r][key], rtol=1e-5, atol=1e-6), (r, key)
+        for key in ('grad0', 'grad1'):
+            a, b = one[r][key], two[r][key]
+            assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()), (r, key)
+        dp = (one[r]['params'] - two[r]['params']).abs()
+        assert float((dp > 2e-5).float().mean()) < 2e-3 and float(dp.max()) <= 2.1e-3
+    for key in ('params', 'grad0', 'grad1', 'touched', 'steps'):
+        assert torch.equal(two[0][key], two[1][key]), key       # both ranks of the overlapped job hold the same state, bit for bit
+
+
+@pytest.mark.parametrize('overlap', [False, True])
+def test_a_pass_that_fails_on_one_rank_is_refused_by_every_rank(overlap):
+    """The status word of a step travels in the gradient bucket: when ONE rank's pass reports a failure (here injected after
+    the backward pass of rank 1's second step) the reduced word is set on BOTH ranks, both Adam kernels refuse the update --
+    weights, moments, per-tensor step counts and the 'ever touched' mask stay those of the first step -- and both ranks'
+    Trainer.check() raise for that step (round 3 read the local word only: the healthy rank applied the NaN sum and hung in
+    the next collective)."""
+    import torch.multiprocessing as mp
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(2, _free_port(), False, True, d, False, overlap, 1, 'f'), nprocs=2, join=True)
+        ranks = [torch.load(os.path.join(d, 'f%d.pt' % r)) for r in range(2)]
+    for r in ranks:
+        assert r['guard'] == 1 and r['unchanged'] and r['raised']
+    assert torch.equal(ranks[0]['params'], ranks[1]['params'])
 
 
 def test_native_allreduce_entry_point_single_rank():

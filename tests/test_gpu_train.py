@@ -386,6 +386,25 @@ def test_dropout_mask_generator():
     assert torch.equal(g[untouched], x[untouched]) and float((g[[5, 299, 17]] == 0).float().mean()) > 0.4
 
 
+def test_dropout_draws_one_mask_per_question_even_when_questions_share_everything():
+    """module_net.py:100-106 evaluates every node of every question, so under model.train() two questions with the same
+    program about the same clip still see different dropout masks.  A plan that shared their nodes (the default for
+    dropout-free plans) would drop them identically: with dropout on, the plan is built without sharing."""
+    config = dict(spec.DEFAULT_CONFIG, hidden_size=64, video_size=128, answer_vocab_length=16, max_video_length=40, object_types=10)
+    model = _model(config, 2)
+    base = synth.make_question(config, 3, 0, form='P3')          # Superlative(max, FilterFrame(video, actions), video): clip-only
+    qs = [dict(base, qa_id='a'), dict(base, qa_id='b')]
+    for q in qs:
+        q['video_features'] = base['video_features']             # the same clip object: one encoder pass
+    plain = model.forward_batch(qs, train=True)
+    assert plain.info.n_aliased > 0 and torch.equal(plain.logits[0], plain.logits[1])
+    dropped = model.forward_batch(qs, train=True, dropout=(0.25, 11))
+    assert dropped.info.n_aliased == 0
+    assert not torch.equal(dropped.logits[0], dropped.logits[1])
+    again = model.forward_batch(qs, train=True, dropout=(0.25, 11))
+    assert torch.equal(again.logits, dropped.logits)
+
+
 def test_dropout_training_forward_and_gradients():
     """Training-mode dropout at the reference's `D` positions (stair_plan_set_dropout).  torch's masks cannot be matched,
     so what is checked: (a) p = 0 and inference are the pinned arithmetic, bit for bit; (b) a seed fixes the step

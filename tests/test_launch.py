@@ -23,6 +23,22 @@ def test_rank_detection_and_command_line():
     assert launch.last_json_line('nothing here') is None
 
 
+def test_gpu_count_without_touching_the_gpu(tmp_path):
+    """The pre-spawn probe reads the kfd topology (GPU nodes have simd_count > 0) and the *_VISIBLE_DEVICES lists; it makes no
+    HIP call, so the parent stays clean for the ranks it starts."""
+    for i, simd in enumerate([0, 0, 256, 256, 256]):          # two CPU nodes, three GPUs
+        d = tmp_path / str(i)
+        d.mkdir()
+        (d / 'properties').write_text('cpu_cores_count %d\nsimd_count %d\nmem_banks_count 1\n' % (0 if simd else 64, simd))
+    top = str(tmp_path)
+    assert launch.visible_gpu_count({}, top) == 3
+    assert launch.visible_gpu_count({'HIP_VISIBLE_DEVICES': '0,2'}, top) == 2
+    assert launch.visible_gpu_count({'ROCR_VISIBLE_DEVICES': ''}, top) == 0
+    assert launch.visible_gpu_count({}, str(tmp_path / 'missing')) == 0
+    import inspect
+    assert 'torch' not in inspect.getsource(launch.visible_gpu_count)
+
+
 def test_two_ranks_are_started_and_the_line_is_relayed():
     env = dict(os.environ, RANK='5', WORLD_SIZE='9')             # stale rank variables of the caller must not leak into the children
     code, line, out = launch.spawn_ranks(PROBE, [], 2, env=env, timeout=300)

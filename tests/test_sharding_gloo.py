@@ -167,10 +167,25 @@ def _worker_exchange(rank, world, port, out_dir):
     flat_g.copy_(torch.arange(total, dtype=torch.float32) * (rank + 1))
     touched = torch.tensor([1, 0, 0, 1, 0] if rank == 0 else [0, 0, 1, 1, 0], dtype=torch.int32)
     reduce_gradients(flat_g, touched, world, bucket)
+    # the same exchange in two pieces (module + decoder gradients first, [encoder gradients | mask | status] second) with the
+    # status word of ONE rank set: bit-identical sums, the union mask, and the failure visible on BOTH ranks
+    g = torch.Generator().manual_seed(100 + rank)
+    vals = torch.randn(total, generator=g) * 1e3
+    outs = {}
+    for mode, split in (('one', None), ('two', 256)):
+        b2 = torch.zeros(total + 256)
+        b2[:total].copy_(vals)
+        t2 = torch.tensor([1, 0, 0, 1, 0] if rank == 0 else [0, 0, 1, 1, 0], dtype=torch.int32)
+        st = torch.tensor([1 if rank == 1 else 0], dtype=torch.int32)
+        reduce_gradients(b2[:total], t2, world, b2, status=st, split=split)
+        outs[mode] = (b2[:total].clone(), t2.clone(), int(st[0]))
+    ok = torch.tensor([0], dtype=torch.int32)
+    b3 = torch.zeros(total + 256)
+    reduce_gradients(b3[:total], torch.zeros(ntensor, dtype=torch.int32), world, b3, status=ok, split=256)
     # rank r holds the contrastive golds of global positions r, r + 2, ...: classes chosen so that windows overlap
     entries = [(g, 'class_%d' % (g % 5), np.full((1 + g % 3, 4), float(g % 5), dtype=np.float32)) for g in range(rank, 21, world)]
     names, embs, rows, win_range, slot_of = L.contrastive_windows(entries, 8, world)
-    torch.save({'g': flat_g.clone(), 'touched': touched, 'names': names, 'rows': rows.tolist(), 'win_range': win_range,
+    torch.save({'one': outs['one'], 'two': outs['two'], 'ok_status': int(ok[0]), 'g': flat_g.clone(), 'touched': touched, 'names': names, 'rows': rows.tolist(), 'win_range': win_range,
                 'slot_of': {'%d/%s' % k: v for k, v in slot_of.items()}, 'emb0': [e.tolist() for e in embs]}, os.path.join(out_dir, 'x%d.pt' % rank))
     dist.barrier()
     dist.destroy_process_group()
@@ -185,6 +200,11 @@ def test_two_rank_gradient_bucket_and_global_contrastive_windows(tmp_path):
     # ONE all-reduce: gradients summed, touched mask = union over ranks
     assert torch.equal(r0['g'], torch.arange(512, dtype=torch.float32) * 3) and torch.equal(r0['g'], r1['g'])
     assert r0['touched'].tolist() == r1['touched'].tolist() == [1, 0, 1, 1, 0]
+    # two collectives == one collective, bit for bit; one rank's failure reaches every rank; no failure -> no flag
+    for r in (r0, r1):
+        assert torch.equal(r['one'][0], r['two'][0]) and torch.equal(r['one'][0], r0['one'][0])
+        assert r['one'][1].tolist() == r['two'][1].tolist() == [1, 0, 1, 1, 0]
+        assert r['one'][2] == r['two'][2] == 1 and r['ok_status'] == 0
     # every rank built the tables of the whole window, i.e. the single-process tables
     sys.path.insert(0, ROOT)
     from stair_amd import losses as L
