@@ -47,7 +47,15 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA" 
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md, "HBM3E peak BW" (spec)
 ALGO_BYTES_PER_QUESTION = 1.93e6   # SURVEY.md section 8(d), mean over the 8 forms, fp32, weights/128
 ALGO_FLOP_PER_QUESTION = 0.86e9
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r03_pmc_dominant.json')     # written by tools/summarize_prof.py from the PMC passes
+def _newest(*names):
+    for n in names:
+        if os.path.exists(os.path.join(ROOT, 'profiles', n)):
+            return os.path.join(ROOT, 'profiles', n)
+    return os.path.join(ROOT, 'profiles', names[-1])
+
+
+PMC_FILE = _newest('r04_pmc_dominant.json', 'r03_pmc_dominant.json')     # written by tools/summarize_prof.py from the PMC passes
+PMC_STEP_FILE = _newest('r04_pmc_whole_step.json')                        # tools/collect_pmc_step.sh: both counters over whole training steps
 
 
 def make_batch(config, B, T, seed, device, features):
@@ -74,11 +82,31 @@ def pmc_traffic(M, N, K):
             vals[r['counter']] = r['mean_per_dispatch']
     if 'FETCH_SIZE' not in vals or 'WRITE_SIZE' not in vals:
         return None, 'shape not profiled'
-    # rocprofv3 reports KiB.  The LDS-DMA reads of this kernel are 64-byte half lines (16 rows x 64 B per instruction), which the
-    # memory-side counter tallies at their true size: FETCH is NOT doubled here (the 2x correction of MI355X_MICROARCH.md applies
-    # to 128-byte requests); calibration: FETCH_SIZE = 1.00x the bf16 A panel + W planes of the launch.
-    return int((vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024), \
-        'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (profiles/r03_pmc_dominant.json, tools/collect_pmc_planes.sh); 64-byte requests, no 2x correction'
+    # rocprofv3 reports KiB.  FETCH_SIZE is DOUBLED: on gfx950 a 16-byte-per-lane streaming read (this kernel's LDS-DMA loads) is
+    # tallied at half its bytes (MI355X_MICROARCH.md, HBM section) -- calibrated on this kernel with an N = 256 launch, where every A
+    # panel has ONE column tile and is read exactly once: FETCH_SIZE 285 MB against 537 MB of A + 2 MB of W
+    # (profiles/r04_pmc_planes_calibration.json).  WRITE_SIZE is exact.  The counter includes Infinity-Cache hits: at N = 2048 the
+    # corrected 2.69 GB are A once (0.54 GB) + the 16.8 MB of W planes re-fetched by each XCD once per group of 4 row panels
+    # (8 column tiles x 2 MB of planes exceed the 4 MB L2: 512 / 4 x 16.8 MB = 2.15 GB, served on-die, not from HBM).
+    return int((2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024), \
+        ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (%s, tools/collect_pmc_planes.sh); FETCH_SIZE x 2 per the gfx950 '
+         'correction, calibrated in profiles/r04_pmc_planes_calibration.json; memory-side requests incl. Infinity-Cache hits: A once + W planes '
+         're-fetched per 4 row panels and XCD' % os.path.relpath(PMC_FILE, ROOT))
+
+
+def whole_step_traffic():
+    """memory-side bytes per question of a whole training step (FETCH_SIZE + WRITE_SIZE summed over every kernel of 4 steps)"""
+    try:
+        d = json.load(open(PMC_STEP_FILE))
+        return {'fetch_bytes_per_step_as_reported': d['fetch_bytes_per_step'], 'write_bytes_per_step': d['write_bytes_per_step'],
+                'bytes_per_question_as_reported': d['bytes_per_question'],
+                'bytes_per_question_reads_doubled': int((2 * d['fetch_bytes_per_step'] + d['write_bytes_per_step']) / d['questions_per_step']),
+                'source': os.path.relpath(PMC_STEP_FILE, ROOT) + ' (tools/collect_pmc_step.sh; training step, 2048 questions)',
+                'note': 'against 1.93 MB algorithmic for the FORWARD pass alone: saved activations, gate matrices, dZ regions and gradient '
+                        'arenas of the training step make up the difference; wide reads are tallied at half their bytes on gfx950, so the '
+                        'truth lies between the two figures'}
+    except Exception:
+        return None
 
 
 def time_dominant_kernel(model, B, T, device, features, iters=10):
@@ -623,7 +651,8 @@ def main():
                                  'algorithmic product by design (executed %.0f TFLOP/s = %.3f of peak)' % (nprod, nprod * achieved, nprod * achieved / BF16_MFMA_PEAK_TFLOPS)},
             'roofline_hbm': {'bound': 'hbm', 'scope': 'whole path, algorithmic bytes x q/s (per GPU)',
                              'achieved': round(ALGO_BYTES_PER_QUESTION * qps / world / 1e9, 2), 'peak': HBM_PEAK_GBS,
-                             'unit': 'GB/s', 'frac': round(ALGO_BYTES_PER_QUESTION * qps / world / 1e9 / HBM_PEAK_GBS, 5)},
+                             'unit': 'GB/s', 'frac': round(ALGO_BYTES_PER_QUESTION * qps / world / 1e9 / HBM_PEAK_GBS, 5),
+                             'traffic': whole_step_traffic() if args.mode == 'train' else None},
             'path_tflops': round(ALGO_FLOP_PER_QUESTION * (3.0 if args.mode == 'train' else 1.0) * qps / world / 1e12, 2),
         }
         line.update(extras)

@@ -7,7 +7,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stair_amd import ops
 
-B, T, V, N = 2048, 64, 2048, 2048          # N = 8 * Hh: both directions of the bi-LSTM in one launch
+B, T, V = 2048, 64, 2048
+N = int(os.environ.get('STAIR_PLANES_N', '2048'))          # 2048 = 8 * Hh: both directions of the bi-LSTM in one launch; 256: ONE column
+                                                            # tile per A panel, so A is read exactly once (the FETCH_SIZE calibration)
 M = B * T
 dev = 'cuda:0'
 x = torch.randn(M, V, device=dev).to(torch.bfloat16)
