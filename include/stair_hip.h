@@ -320,6 +320,36 @@ typedef struct stair_tile_mlp_args {
     float *cat_save; const int32_t *out_row_idx;
 } stair_tile_mlp_args;
 int stair_tile_mlp_fwd(const stair_tile_mlp_args *args, stair_stream stream);
+/* ---- grouped vector-level products (csrc/vec_group.hip) ------------------------------------------------------------------
+ * Every Linear layer that acts on ONE [H] row per instance -- Compare / Equals / Xor / ToAction / Exists (modules.py:15-37, 59-72,
+ * 102-120, 141-159), Filter's dense layer (:376-378), Localize's keyword projection (:199-203), the decoder (module_net.py:49-53)
+ * -- as a list of problems carried by ONE launch: work items are (problem, 64-row tile, 64-column block), the reduction dimension
+ * is never split across workgroups (no scratch, no reduction launch, deterministic, a row's result is independent of the other rows).
+ * H = 512 (the reference's hidden size), split matmul mode.
+ *   kind FWD   out[io[i]] (+)= act(in(i) W^T + bias), W [N, nseg * 512 (ldw)] row-major fp32
+ *   kind ADJ   the backward of such a layer THROUGH its concatenation: in(i) (a gradient row, optionally masked) times
+ *              W = the transposed weight image [nseg * 512, 512 (ldw)] gives the nseg H-wide blocks of d(concatenation), and the
+ *              epilogue adds the adjoint of the concatenation into the operands' gradient rows ga[fia[i]], gb[fib[i]]
+ *              (N = nseg * 512; adj = the forward layer's input form; fa / fb = its operand rows, read by EXISTS and XOR)
+ *   input form in(i), from the operand rows a_i = a + (ia ? ia[i] : i) * lda, b_i likewise:
+ *     IN_A [a_i] (kred <= 512 columns);  IN_CAT2 [a_i, b_i];  IN_XOR [|a_i - b_i|, a_i, b_i];  IN_EXISTS [a_i, b_i, a_i * b_i];
+ *     IN_MASK [a_i * in_scale where b_i > 0, else 0] (relu' of a saved output applied to an incoming gradient)
+ *   in_save    optional [rows, ld_save]: the formed input rows (the operand a weight-gradient product needs)
+ *   act        0 none, 1 ReLU, 2: times escale where emask[i * ldm + n] > 0, else 0;  accumulate != 0: float atomics instead of stores */
+enum { STAIR_VEC_FWD = 0, STAIR_VEC_ADJ = 1 };
+enum { STAIR_VEC_IN_A = 0, STAIR_VEC_IN_CAT2 = 1, STAIR_VEC_IN_XOR = 2, STAIR_VEC_IN_EXISTS = 3, STAIR_VEC_IN_MASK = 4 };
+typedef struct stair_vec_problem {
+    int32_t kind, rows;
+    const float *a, *b; const int32_t *ia, *ib; int64_t lda, ldb;
+    int32_t pack; float in_scale; int32_t kred;
+    const float *W; int64_t ldw; const float *bias; int32_t N, act;
+    const float *emask; int64_t ldm; float escale;
+    float *out; const int32_t *io; int64_t ldo; int32_t accumulate;
+    float *in_save; int64_t ld_save;
+    int32_t adj; const float *fa, *fb; const int32_t *fia, *fib; int64_t ldfa, ldfb; float *ga, *gb;
+} stair_vec_problem;
+int stair_vec_group(const stair_vec_problem *problems, int32_t count, stair_stream stream);
+
 /* stair_plan_run uses the fused operators where they apply (hidden_size 512, T <= 64, split matmul mode, no dropout);
  * on = 0 keeps the GEMM / row-kernel sequences everywhere, on < 0 restores the default (env STAIR_TILE_MLP, default on). */
 int stair_set_tile_mlp(int32_t on);

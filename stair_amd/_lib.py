@@ -93,6 +93,18 @@ class TileMlpArgs(C.Structure):
                 ('vec_cnt', C.c_int32), ('cat_save', C.c_void_p), ('out_row_idx', C.c_void_p)]
 
 
+class VecProblem(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('rows', C.c_int32),
+                ('a', C.c_void_p), ('b', C.c_void_p), ('ia', C.c_void_p), ('ib', C.c_void_p), ('lda', C.c_int64), ('ldb', C.c_int64),
+                ('pack', C.c_int32), ('in_scale', C.c_float), ('kred', C.c_int32),
+                ('W', C.c_void_p), ('ldw', C.c_int64), ('bias', C.c_void_p), ('N', C.c_int32), ('act', C.c_int32),
+                ('emask', C.c_void_p), ('ldm', C.c_int64), ('escale', C.c_float),
+                ('out', C.c_void_p), ('io', C.c_void_p), ('ldo', C.c_int64), ('accumulate', C.c_int32),
+                ('in_save', C.c_void_p), ('ld_save', C.c_int64),
+                ('adj', C.c_int32), ('fa', C.c_void_p), ('fb', C.c_void_p), ('fia', C.c_void_p), ('fib', C.c_void_p),
+                ('ldfa', C.c_int64), ('ldfb', C.c_int64), ('ga', C.c_void_p), ('gb', C.c_void_p)]
+
+
 class PlanInfo(C.Structure):
     _fields_ = [('workspace_bytes', C.c_int64), ('vec_off', C.c_int64), ('map_off', C.c_int64), ('att_off', C.c_int64),
                 ('tok_off', C.c_int64), ('qfeat_off', C.c_int64), ('logits_off', C.c_int64),
@@ -119,6 +131,7 @@ SIGNATURES = [
     ('stair_get_matmul_mode', C.c_int, []),
     ('stair_set_split_min_rows', C.c_int, [C.c_int32]),
     ('stair_lstm_coop_limit', C.c_int, [C.c_int32]),
+    ('stair_vec_group', C.c_int, [C.POINTER(VecProblem), C.c_int32, C.c_void_p]),
     ('stair_set_tile_mlp', C.c_int, [C.c_int32]),
     ('stair_set_tile_queue', C.c_int, [C.c_int32]),
     ('stair_tile_mlp_fwd', C.c_int, [C.POINTER(TileMlpArgs), C.c_void_p]),

@@ -109,6 +109,13 @@ int launch_gemm_tn(const stair_gemm_tn_args &a, hipStream_t s);
 int launch_tile_mlp(const stair_tile_mlp_args &a, hipStream_t s);          // csrc/tile_mlp.hip
 int launch_tile_mlp_batch(const stair_tile_mlp_args *args, int n, unsigned *counter, hipStream_t s);   // <= 8 buckets, one launch
 bool tile_mlp_usable(int H, int T);
+// csrc/vec_group.hip: the row-wise Linear layers of a program level as one launch
+using VgProblem = stair_vec_problem;
+constexpr int VG_FWD = STAIR_VEC_FWD, VG_ADJ = STAIR_VEC_ADJ;
+constexpr int VG_IN_A = STAIR_VEC_IN_A, VG_IN_CAT2 = STAIR_VEC_IN_CAT2, VG_IN_XOR = STAIR_VEC_IN_XOR, VG_IN_EXISTS = STAIR_VEC_IN_EXISTS,
+              VG_IN_MASK = STAIR_VEC_IN_MASK;
+int launch_vec_group(const VgProblem *probs, int n, hipStream_t s);
+bool vec_group_usable(int H);
 int launch_pack_wfrag_many(const float *const *W, void *const *out, int count, int N, int K, hipStream_t s, bool transpose = false,
                            const int *ld = nullptr);     // ld: row stride per matrix (default: K, or N when transposed)
 int launch_colsum(const float *A, int64_t lda, float *out, int M, int N, hipStream_t s, float *out2 = nullptr);

@@ -374,6 +374,44 @@ def tile_mlp(x, layers, tail, x_idx=None, row_scale=None, rs_idx=None, save=Fals
     return saves, rs_out
 
 
+VEC_IN = {'a': 0, 'cat2': 1, 'xor': 2, 'exists': 3, 'mask': 4}
+
+
+def vec_group(problems):
+    """The row-wise Linear layers of a program level as ONE launch (stair_vec_group, csrc/vec_group.hip).  problems: dicts with
+      kind 'fwd' | 'adj', rows, a, b, ia, ib (operand rows [*, lda] / int32 index tensors or None), pack in VEC_IN, in_scale,
+      kred (default 512), W [N, ldw], bias, N, act (None | 'relu' | ('mask', emask, escale)), out, io, accumulate, in_save;
+      adjoint problems: adj (the forward layer's input form), fa, fb, fia, fib, ga, gb.
+    Every tensor is a contiguous float32 / int32 GPU tensor; row strides are taken from the tensors' last-but-one stride."""
+    from ._lib import VecProblem
+    arr = (VecProblem * len(problems))()
+
+    def ptr(t):
+        return t.data_ptr() if t is not None else None
+
+    def ld(t, default=0):
+        return int(t.stride(-2)) if t is not None and t.dim() >= 2 else default
+    for q, d in zip(arr, problems):
+        q.kind = 0 if d['kind'] == 'fwd' else 1
+        q.rows = int(d['rows'])
+        q.a, q.b, q.ia, q.ib = ptr(d['a']), ptr(d.get('b')), ptr(d.get('ia')), ptr(d.get('ib'))
+        q.lda, q.ldb = int(d.get('lda', ld(d['a']))), int(d.get('ldb', ld(d.get('b'))))
+        q.pack, q.in_scale, q.kred = VEC_IN[d.get('pack', 'a')], float(d.get('in_scale', 1.0)), int(d.get('kred', 512))
+        q.W, q.ldw, q.bias, q.N = ptr(d['W']), int(d.get('ldw', ld(d['W']))), ptr(d.get('bias')), int(d['N'])
+        act = d.get('act')
+        if isinstance(act, tuple):
+            q.act, q.emask, q.ldm, q.escale = 2, ptr(act[1]), ld(act[1]), float(act[2])
+        else:
+            q.act = {None: 0, 'relu': 1}[act]
+        q.out, q.io, q.ldo, q.accumulate = ptr(d.get('out')), ptr(d.get('io')), int(d.get('ldo', ld(d.get('out')))), int(bool(d.get('accumulate')))
+        q.in_save, q.ld_save = ptr(d.get('in_save')), ld(d.get('in_save'))
+        q.adj = VEC_IN[d['adj']] if d.get('adj') else 0
+        q.fa, q.fb, q.fia, q.fib = ptr(d.get('fa')), ptr(d.get('fb')), ptr(d.get('fia')), ptr(d.get('fib'))
+        q.ldfa, q.ldfb = int(d.get('ldfa', ld(d.get('ga'), 512))), int(d.get('ldfb', ld(d.get('gb'), 512)))
+        q.ga, q.gb = ptr(d.get('ga')), ptr(d.get('gb'))
+    check(lib.stair_vec_group(arr, len(problems), _stream()))
+
+
 VEC_PACKS = {'cat2': 1, 'xor': 2, 'exists': 3}
 
 
