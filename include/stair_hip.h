@@ -323,7 +323,7 @@ int stair_tile_mlp_fwd(const stair_tile_mlp_args *args, stair_stream stream);
 /* ---- grouped vector-level products (csrc/vec_group.hip) ------------------------------------------------------------------
  * Every Linear layer that acts on ONE [H] row per instance -- Compare / Equals / Xor / ToAction / Exists (modules.py:15-37, 59-72,
  * 102-120, 141-159), Filter's dense layer (:376-378), Localize's keyword projection (:199-203), the decoder (module_net.py:49-53)
- * -- as a list of problems carried by ONE launch: work items are (problem, 64-row tile, 64-column block), the reduction dimension
+ * -- as a list of problems carried by ONE launch: work items are (problem, 32-row tile, 32-column block), the reduction dimension
  * is never split across workgroups (no scratch, no reduction launch, deterministic, a row's result is independent of the other rows).
  * H = 512 (the reference's hidden size), split matmul mode.
  *   kind FWD   out[io[i]] (+)= act(in(i) W^T + bias), W [N, nseg * 512 (ldw)] row-major fp32
@@ -343,6 +343,10 @@ typedef struct stair_vec_problem {
     const float *a, *b; const int32_t *ia, *ib; int64_t lda, ldb;
     int32_t pack; float in_scale; int32_t kred;
     const float *W; int64_t ldw; const float *bias; int32_t N, act;
+    const void *wplanes; /* optional: the weight as bf16 hi / lo fragment-order planes (stair_pack_wfrag), one [512 x 512] image per
+                            (block b of 512 output columns, input segment s) at wplanes + (b * nseg + s) * 512 * 512 * 4 bytes;
+                            NULL: the fp32 rows of W are read and split (plain and two-segment forward problems only;
+                            needed when N % 32 or kred != 512) */
     const float *emask; int64_t ldm; float escale;
     float *out; const int32_t *io; int64_t ldo; int32_t accumulate;
     float *in_save; int64_t ld_save;

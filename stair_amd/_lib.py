@@ -97,7 +97,7 @@ class VecProblem(C.Structure):
     _fields_ = [('kind', C.c_int32), ('rows', C.c_int32),
                 ('a', C.c_void_p), ('b', C.c_void_p), ('ia', C.c_void_p), ('ib', C.c_void_p), ('lda', C.c_int64), ('ldb', C.c_int64),
                 ('pack', C.c_int32), ('in_scale', C.c_float), ('kred', C.c_int32),
-                ('W', C.c_void_p), ('ldw', C.c_int64), ('bias', C.c_void_p), ('N', C.c_int32), ('act', C.c_int32),
+                ('W', C.c_void_p), ('ldw', C.c_int64), ('bias', C.c_void_p), ('N', C.c_int32), ('act', C.c_int32), ('wplanes', C.c_void_p),
                 ('emask', C.c_void_p), ('ldm', C.c_int64), ('escale', C.c_float),
                 ('out', C.c_void_p), ('io', C.c_void_p), ('ldo', C.c_int64), ('accumulate', C.c_int32),
                 ('in_save', C.c_void_p), ('ld_save', C.c_int64),

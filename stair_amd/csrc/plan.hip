@@ -260,7 +260,8 @@ struct Node {
 // ids; the backward pass groups the weight-gradient products by them).
 enum { WF_F0 = 0, WF_F3 = 4, WF_FF0 = 8, WF_FF3 = 11, WF_FFD = 14, WF_HI0 = 15, WF_LV0 = 16, WF_LV3 = 17, WF_TD = 18, WF_COUNT = 19 };
 // plane images of the vector-level modules' weights (forward only): one [H, H] image per H-wide column block of a first layer
-enum { WV_CMP = 19, WV_EQ = 21, WV_XOR = 23, WV_TA0 = 26, WV_TA3 = 28, WV_EX0 = 29, WV_EX3 = 32, WV_END = 33 };
+enum { WV_CMP = 19, WV_EQ = 21, WV_XOR = 23, WV_TA0 = 26, WV_TA3 = 28, WV_EX0 = 29, WV_EX3 = 32,
+       WV_FD = 33, WV_LK = 34, WV_DEC0 = 35 /* four [512 x 512] blocks: (output block, input segment) */, WV_END = 39 };
 
 struct Bucket {
     int64_t dzA = -1, dzB = -1;   // training: this bucket's blocks inside the per-WEIGHT dZ regions (first / second layer of its tile MLP)
@@ -937,6 +938,8 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
             if (pl->o_wfrag > 0 && b.cnt > 0) {
                 if (b.op == STAIR_OP_FILTER) b.svCat = take((int64_t)b.cnt * H, 64);
                 if (b.op == STAIR_OP_SUPERLATIVE) b.svB = take((int64_t)b.cnt * T * H, 64);
+                // the grouped vector-level launches: a two-layer module's hidden rows live from the level's first launch to its second
+                if (b.op == STAIR_OP_EXISTS || b.op == STAIR_OP_TOACTION) b.svHid = take((int64_t)b.cnt * H, 64);
             }
             continue;
         }
@@ -1027,7 +1030,8 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
         pl->o_wt = take(ctx_weight_floats(ctx), 64);
         pl->o_gA = take(I * T * H, 64);
         pl->o_gB = take(I * T * H, 64);
-        if (pl->o_wfrag > 0) pl->o_wfragT = take(19 * H * H, 64);     // backward chains of the fused tile operators: planes of the transposed weights
+        if (pl->o_wfrag > 0) pl->o_wfragT = take((int64_t)WV_END * H * H, 64);     // backward chains of the fused tile operators and the grouped
+                                                                                   // vector-level launches: planes of the transposed weights
         pl->o_gV0 = take(Vv * 2 * H, 64);
         pl->o_gV1 = take(Vv * 2 * H, 64);
         pl->o_gCat = take(Vv * 3 * H, 64);
@@ -1286,6 +1290,20 @@ int dense(hipStream_t s, const float *A, int64_t lda, int64_t a_gs, const int32_
     return launch_gemm(g, s);
 }
 
+// a forward-shaped problem of the grouped vector-level launch (csrc/vec_group.hip): out[io[i]] = act(in(a_i, b_i) W^T + bias)
+VgProblem vg_fwd(int rows, const float *a, const int32_t *ia, int64_t lda, const float *b, const int32_t *ib, int64_t ldb, int pack,
+                 const float *Wm, int64_t ldw, const float *bias, int N, int act, float *out, const int32_t *io, int64_t ldo) {
+    VgProblem p = {};
+    p.kind = VG_FWD; p.rows = rows; p.a = a; p.ia = ia; p.lda = lda; p.b = b; p.ib = ib; p.ldb = ldb; p.pack = pack; p.in_scale = 1.0f;
+    p.kred = 512; p.W = Wm; p.ldw = ldw; p.bias = bias; p.N = N; p.act = act; p.out = out; p.io = io; p.ldo = ldo;
+    return p;
+}
+// STAIR_VEC_GROUP=0 keeps the per-module pack -> GEMM -> reduction sequences (and the tile form for large buckets)
+bool vec_group_on() {
+    static const bool on = [] { const char *e = getenv("STAIR_VEC_GROUP"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 struct Ptrs {     // workspace views shared by forward and backward
     float *ws, *vec, *map, *att, *tok, *qfeat;
     int32_t *didx;
@@ -1456,8 +1474,34 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
     // [64 x 1536 x 512] first layer (3 x 17 us) where the split-K GEMM spreads it over 64 workgroups (13 us), so the tile form
     // pays only when a bucket fills several tiles.  STAIR_TILE_VEC = minimum instances per bucket (0: never).
     const int vec_min = [] { const char *e = getenv("STAIR_TILE_VEC"); return e ? atoi(e) : 128; }();      // read per pass: tests switch it
-    auto fused_vec_for = [&](const Bucket &b) { return fused && vec_min > 0 && b.cnt >= vec_min; };
-    const bool fused_vec = fused && vec_min > 0;
+    // The row-wise Linear layers of a level -- vector-level modules, Filter's dense layer, Localize's keyword rows, the decoder -- as
+    // problems of ONE launch before the level's tile operators (first layers, keyword rows) and ONE after them (second layers, the
+    // dense layers on the pooled rows): csrc/vec_group.hip.  Takes precedence over the tile form of the vector-level modules.
+    const bool grouped = fused && vec_group_usable(H) && vec_group_on();
+    std::vector<VgProblem> vg1, vg2;
+    // [512 x 512] blocks of a row-wise weight as planes: slot + (output block) * nseg + (input segment); blocks of a [N, nseg * 512] matrix
+    struct VgW { int slot, nblk, nseg; const Lin *l; int op; };
+    const VgW vgw[10] = {{WV_CMP, 1, 2, &W.compare, STAIR_OP_COMPARE}, {WV_EQ, 1, 2, &W.equals, STAIR_OP_EQUALS}, {WV_XOR, 1, 3, &W.xorl, STAIR_OP_XOR},
+                         {WV_TA0, 1, 2, &W.ta0, STAIR_OP_TOACTION}, {WV_TA3, 1, 1, &W.ta3, STAIR_OP_TOACTION}, {WV_EX0, 1, 3, &W.exists0, STAIR_OP_EXISTS},
+                         {WV_EX3, 1, 1, &W.exists3, STAIR_OP_EXISTS}, {WV_FD, 1, 1, &W.fdense, STAIR_OP_FILTER}, {WV_LK, 1, 1, &W.lk, STAIR_OP_LOCALIZE},
+                         {WV_DEC0, 2, 2, &W.dec0, -1}};
+    if (grouped) {
+        bool has[32] = {};
+        for (const Bucket &b : pl->buckets) if (b.cnt > 0 && b.op >= 0 && b.op < 32) has[b.op] = true;
+        const float *src[32];
+        void *dst[32];
+        int ld[32], cnt_w = 0;
+        for (const VgW &v : vgw)
+            if (v.op < 0 || has[v.op])
+                for (int jb = 0; jb < v.nblk; ++jb)
+                    for (int sg = 0; sg < v.nseg; ++sg) {
+                        src[cnt_w] = v.l->w + ((int64_t)jb * H * v.nseg + sg) * H; dst[cnt_w] = const_cast<void *>(WF(v.slot + jb * v.nseg + sg));
+                        ld[cnt_w] = v.nseg * H; ++cnt_w;
+                    }
+        if (cnt_w) RUN(launch_pack_wfrag_many(src, dst, cnt_w, H, H, s, false, ld));
+    }
+    auto fused_vec_for = [&](const Bucket &b) { return !grouped && fused && vec_min > 0 && b.cnt >= vec_min; };
+    const bool fused_vec = !grouped && fused && vec_min > 0;
     if (fused_vec) {
         struct { int slot, nseg; const Lin *l; int op; } vw[7] = {{WV_CMP, 2, &W.compare, STAIR_OP_COMPARE}, {WV_EQ, 2, &W.equals, STAIR_OP_EQUALS},
             {WV_XOR, 3, &W.xorl, STAIR_OP_XOR}, {WV_TA0, 2, &W.ta0, STAIR_OP_TOACTION}, {WV_TA3, 1, &W.ta3, STAIR_OP_TOACTION},
@@ -1532,6 +1576,15 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
                 break;
             case STAIR_OP_COMPARE:      // modules.py:15-21
             case STAIR_OP_EQUALS: {     // modules.py:24-37
+                if (grouped) {
+                    if (phase != 1) break;
+                    const Lin &l = b.op == STAIR_OP_COMPARE ? W.compare : W.equals;
+                    VgProblem q = vg_fwd(c, vec, I0, H, vec, I1, H, VG_IN_CAT2, l.w, 2 * H, l.b, H, 1, vec, I2, H);
+                    q.wplanes = WF(b.op == STAIR_OP_COMPARE ? WV_CMP : WV_EQ);
+                    if (pl->train) { q.in_save = cat; q.ld_save = 2 * H; }
+                    vg1.push_back(q);
+                    break;
+                }
                 if (fused_vec_for(b)) {
                     if (phase == 1) tile_queue.push_back(vec_module(b, 1, I0, I1, I2, b.op == STAIR_OP_COMPARE ? WV_CMP : WV_EQ,
                                                                     b.op == STAIR_OP_COMPARE ? W.compare : W.equals, 0, nullptr, cat, nullptr));
@@ -1543,6 +1596,14 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
                 break;
             }
             case STAIR_OP_XOR:          // modules.py:59-72: cat[|a-b|, a, b]
+                if (grouped) {
+                    if (phase != 1) break;
+                    VgProblem q = vg_fwd(c, vec, I0, H, vec, I1, H, VG_IN_XOR, W.xorl.w, 3 * H, W.xorl.b, H, 1, vec, I2, H);
+                    q.wplanes = WF(WV_XOR);
+                    if (pl->train) { q.in_save = cat; q.ld_save = 3 * H; }
+                    vg1.push_back(q);
+                    break;
+                }
                 if (fused_vec_for(b)) {
                     if (phase == 1) tile_queue.push_back(vec_module(b, 2, I0, I1, I2, WV_XOR, W.xorl, 0, nullptr, cat, nullptr));
                     break;
@@ -1551,6 +1612,16 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
                 RUN(dense(s, cat, 3 * H, 3 * H, nullptr, W.xorl, 3 * H, vec, H, H, I2, c, 1, H, 3 * H, 1));
                 break;
             case STAIR_OP_TOACTION:     // modules.py:102-120: cat[action, keyword]
+                if (grouped) {              // first layer before the level's tile operators, second layer after them
+                    if (phase != 1) break;
+                    VgProblem q = vg_fwd(c, vec, I0, H, vec, I1, H, VG_IN_CAT2, W.ta0.w, 2 * H, W.ta0.b, H, 1, hid, nullptr, H);
+                    q.wplanes = WF(WV_TA0);
+                    if (pl->train) { q.in_save = cat; q.ld_save = 2 * H; }
+                    vg1.push_back(q);
+                    vg2.push_back(vg_fwd(c, hid, nullptr, H, nullptr, nullptr, 0, VG_IN_A, W.ta3.w, H, W.ta3.b, H, 1, vec, I2, H));
+                    vg2.back().wplanes = WF(WV_TA3);
+                    break;
+                }
                 if (fused_vec_for(b)) {
                     if (phase == 1) tile_queue.push_back(vec_module(b, 1, I0, I1, I2, WV_TA0, W.ta0, WV_TA3, &W.ta3, cat, hid));
                     break;
@@ -1561,6 +1632,16 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
                 RUN(dense(s, hid, H, H, nullptr, W.ta3, H, vec, H, H, I2, c, 1, H, H, 1));
                 break;
             case STAIR_OP_EXISTS:       // modules.py:141-159: Exists(keyword, feat) -> cat[feat, keyword, feat*keyword]
+                if (grouped) {
+                    if (phase != 1) break;
+                    VgProblem q = vg_fwd(c, vec, I1, H, vec, I0, H, VG_IN_EXISTS, W.exists0.w, 3 * H, W.exists0.b, H, 1, hid, nullptr, H);
+                    q.wplanes = WF(WV_EX0);
+                    if (pl->train) { q.in_save = cat; q.ld_save = 3 * H; }
+                    vg1.push_back(q);
+                    vg2.push_back(vg_fwd(c, hid, nullptr, H, nullptr, nullptr, 0, VG_IN_A, W.exists3.w, H, W.exists3.b, H, 1, vec, I2, H));
+                    vg2.back().wplanes = WF(WV_EX3);
+                    break;
+                }
                 if (fused_vec_for(b)) {
                     if (phase == 1) tile_queue.push_back(vec_module(b, 3, I1, I0, I2, WV_EX0, W.exists0, WV_EX3, &W.exists3, cat, hid));
                     break;
@@ -1583,7 +1664,11 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
                         tile_layer(a, WF_F3 + v, W.f3[v], 1, tmpB);
                         a.tail = STAIR_TILE_SUM_ROWS; a.out = cat; a.out_gstride = H; a.len = LEN;
                         tile_queue.push_back(a);
-                    } else {
+                        if (grouped) {
+                            vg2.push_back(vg_fwd(c, cat, nullptr, H, nullptr, nullptr, 0, VG_IN_A, W.fdense.w, H, W.fdense.b, H, 1, vec, I1, H));
+                            vg2.back().wplanes = WF(WV_FD);
+                        }
+                    } else if (!grouped) {
                         RUN(dense(s, cat, H, H, nullptr, W.fdense, H, vec, H, H, I1, c, 1, H, H, 1));
                     }
                     break;
@@ -1642,7 +1727,10 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
             case STAIR_OP_LOCALIZE:     // modules.py:181-217
                 if (fused) {            // keyword rows first (a vector-level product), then both layers + the cosine on the tile
                     if (phase != 1) break;
-                    RUN(dense(s, vec, H, H, I2, W.lk, H, kbuf, H, H, nullptr, b.nrows, 1, H, H, 0));
+                    if (grouped) {
+                        vg1.push_back(vg_fwd(b.nrows, vec, I2, H, nullptr, nullptr, 0, VG_IN_A, W.lk.w, H, W.lk.b, H, 0, kbuf, nullptr, H));
+                        vg1.back().wplanes = WF(WV_LK);
+                    } else RUN(dense(s, vec, H, H, I2, W.lk, H, kbuf, H, H, nullptr, b.nrows, 1, H, H, 0));
                     stair_tile_mlp_args a = tile_args(I0, c);
                     tile_layer(a, WF_LV0, W.lv0, 1, tmpA);
                     tile_layer(a, WF_LV3, W.lv3, 0, tmpB);
@@ -1718,13 +1806,16 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
             size_t hi_ = lo_;
             while (hi_ < pl->buckets.size() && pl->buckets[hi_].level == pl->buckets[lo_].level) ++hi_;
             tile_queue.clear();
+            vg1.clear(); vg2.clear();
             for (size_t k = lo_; k < hi_; ++k) RUN(run_bucket(pl->buckets[k], (int)k, 1));
+            if (!vg1.empty()) RUN(launch_vec_group(vg1.data(), (int)vg1.size(), s));
             static const int merge_max = [] { const char *e = getenv("STAIR_TILE_MERGE"); return e ? std::max(1, std::min(8, atoi(e))) : 8; }();
             const bool use_queue = tile_queue_on();
             for (size_t q0 = 0; q0 < tile_queue.size(); q0 += merge_max) {
                 const int nq = (int)std::min<size_t>(merge_max, tile_queue.size() - q0);
                 RUN(launch_tile_mlp_batch(tile_queue.data() + q0, nq, use_queue ? tile_ctr : nullptr, s));
             }
+            if (!vg2.empty()) RUN(launch_vec_group(vg2.data(), (int)vg2.size(), s));
             for (size_t k = lo_; k < hi_; ++k) RUN(run_bucket(pl->buckets[k], (int)k, 2));
             lo_ = hi_;
         }
@@ -1732,6 +1823,16 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
 
     // ---- decoder (module_net.py:136-138) -----------------------------------------------------
     float *cat = ws + pl->o_cat, *hid = ws + pl->o_hid;
+    if (grouped) {          // cat[root, question] never materialised for the product (kept for the weight gradient in training)
+        VgProblem q = vg_fwd(n, vec, didx + pl->off_roots, H, qfeat, nullptr, H, VG_IN_CAT2, W.dec0.w, 2 * H, W.dec0.b, 2 * H, 1, hid, nullptr, 2 * H);
+        q.wplanes = WF(WV_DEC0);
+        if (pl->train) { q.in_save = cat; q.ld_save = 2 * H; }
+        RUN(launch_vec_group(&q, 1, s));
+        VgProblem q3 = vg_fwd(n, hid, nullptr, 2 * H, hid + H, nullptr, 2 * H, VG_IN_CAT2, W.dec3.w, 2 * H, W.dec3.b, A, 0, logits, nullptr, A);
+        RUN(launch_vec_group(&q3, 1, s));
+        if (argmax) RUN(launch_argmax(logits, argmax, n, A, s));
+        return 0;
+    }
     RUN(launch_pack(PACK_CAT2, vec, didx + pl->off_roots, qfeat, nullptr, cat, n, H, s));
     RUN(dense(s, cat, 2 * H, 2 * H, nullptr, W.dec0, 2 * H, hid, 2 * H, 2 * H, nullptr, n, 1, 2 * H, 2 * H, 1));
     bucket_no = 0x1fff;
@@ -1877,6 +1978,45 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
     // ---- backward chains of the fused tile operators (csrc/tile_mlp.hip): dX = (dZ2 W2 * relu'(Z1)) W1 stays on the tile ----
     const bool fused = pl->o_wfragT > 0 && tile_mlp_usable(H, T) && pl->drop_p <= 0.0f && tile_policy(pl, true);
     auto WFT = [&](int slot) { return static_cast<const void *>(ws + pl->o_wfragT + (int64_t)slot * H * H); };
+    // the row-wise layers' backward as grouped launches (csrc/vec_group.hip): per level one launch for everything that starts from a
+    // gradient row of the arena (relu' on load, kept as dZ), one for the second stage of the two-layer modules
+    const bool grouped = fused && vec_group_usable(H) && vec_group_on();
+    std::vector<VgProblem> bvg1, bvg2;
+    if (grouped) {      // planes of the transposed images (already there as fp32): block (j, s) of W^T = slot + j * nin + s
+        struct VgWT { int slot, nblk, nin; const Lin *l; int op; };        // W^T is [nblk * 512, nin * 512]
+        const VgWT vgw[10] = {{WV_CMP, 2, 1, &W.compare, STAIR_OP_COMPARE}, {WV_EQ, 2, 1, &W.equals, STAIR_OP_EQUALS}, {WV_XOR, 3, 1, &W.xorl, STAIR_OP_XOR},
+                              {WV_TA0, 2, 1, &W.ta0, STAIR_OP_TOACTION}, {WV_TA3, 1, 1, &W.ta3, STAIR_OP_TOACTION}, {WV_EX0, 3, 1, &W.exists0, STAIR_OP_EXISTS},
+                              {WV_EX3, 1, 1, &W.exists3, STAIR_OP_EXISTS}, {WV_FD, 1, 1, &W.fdense, STAIR_OP_FILTER}, {WV_LK, 1, 1, &W.lk, STAIR_OP_LOCALIZE},
+                              {WV_DEC0, 2, 2, &W.dec0, -1}};
+        bool has[32] = {};
+        for (const Bucket &b : pl->buckets) if (b.cnt > 0 && b.op >= 0 && b.op < 32) has[b.op] = true;
+        const float *src[32];
+        void *dst[32];
+        int ld[32], cnt_w = 0;
+        for (const VgWT &v : vgw)
+            if (v.op < 0 || has[v.op])
+                for (int jb = 0; jb < v.nblk; ++jb)
+                    for (int sg = 0; sg < v.nin; ++sg) {
+                        src[cnt_w] = B.wt + B.wt_off[v.l->id] + ((int64_t)jb * H * v.nin + sg) * H; dst[cnt_w] = const_cast<void *>(WFT(v.slot + jb * v.nin + sg));
+                        ld[cnt_w] = v.nin * H; ++cnt_w;
+                    }
+        if (cnt_w) RUN(launch_pack_wfrag_many(src, dst, cnt_w, H, H, s, false, ld));
+    }
+    auto vslot = [&](const Lin &l) {
+        const Lin *ls[10] = {&W.compare, &W.equals, &W.xorl, &W.ta0, &W.ta3, &W.exists0, &W.exists3, &W.fdense, &W.lk, &W.dec0};
+        const int slots[10] = {WV_CMP, WV_EQ, WV_XOR, WV_TA0, WV_TA3, WV_EX0, WV_EX3, WV_FD, WV_LK, WV_DEC0};
+        for (int i = 0; i < 10; ++i) if (ls[i]->id == l.id) return WFT(slots[i]);
+        return static_cast<const void *>(nullptr);
+    };
+    auto vg_adj = [&](int rows, const float *a, const int32_t *ia, const float *bmask, int pack, float in_scale, float *in_save, const Lin &l, int nseg,
+                      int adj, const int32_t *fia, const int32_t *fib) {
+        VgProblem q = {};
+        q.kind = VG_ADJ; q.rows = rows; q.a = a; q.ia = ia; q.lda = H; q.b = bmask; q.ib = ia; q.ldb = H; q.pack = pack; q.in_scale = in_scale; q.kred = 512;
+        q.in_save = in_save; q.ld_save = H;
+        q.W = B.wt + B.wt_off[l.id]; q.ldw = H; q.N = nseg * H; q.adj = adj; q.wplanes = vslot(l);
+        q.fa = vec; q.fb = vec; q.fia = fia; q.fib = fib; q.ldfa = H; q.ldfb = H; q.ga = g_vec; q.gb = g_vec;
+        return q;
+    };
     if (fused) {
         bool need[WF_COUNT] = {};
         for (const Bucket &b : pl->buckets) {
@@ -1901,10 +2041,25 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
     RUN(launch_ce_loss(logits, answers, loss_scale, loss, dlogits, n, A, s));
     {
         const float *cat = ws + pl->o_cat, *hid = ws + pl->o_hid;     // decoder buffers are never reused by buckets in training
+        if (grouped) {
+            // d(hidden) = (dlogits W3) * relu'(hidden) in one launch, d(cat[root, question]) = d(hidden) W0 with the adjoint of the
+            // concatenation in the epilogue in a second one; the two weight gradients stay reductions over the batch (TN products)
+            RUN(dense_bwd(B, dlogits, n, 1, A, 2 * H, hid, 2 * H, 2 * H, nullptr, W.dec3, nullptr, 2 * H, 2 * H, nullptr, 0));
+            VgProblem q3 = vg_fwd(n, dlogits, nullptr, A, nullptr, nullptr, 0, VG_IN_A, B.wt + B.wt_off[W.dec3.id], A, nullptr, 2 * H, 2, gV0, nullptr, 2 * H);
+            q3.kred = A; q3.emask = hid; q3.ldm = 2 * H; q3.escale = inv_keep;
+            RUN(launch_vec_group(&q3, 1, s));
+            RUN(dense_bwd(B, gV0, n, 1, 2 * H, 2 * H, cat, 2 * H, 2 * H, nullptr, W.dec0, nullptr, 2 * H, 2 * H, nullptr, 0));
+            VgProblem q0 = {};
+            q0.kind = VG_ADJ; q0.rows = n; q0.a = gV0; q0.lda = 2 * H; q0.b = gV0 + H; q0.ldb = 2 * H; q0.pack = VG_IN_CAT2; q0.in_scale = 1.0f; q0.kred = 512;
+            q0.W = B.wt + B.wt_off[W.dec0.id]; q0.ldw = 2 * H; q0.N = 2 * H; q0.adj = VG_IN_CAT2; q0.wplanes = WFT(WV_DEC0);
+            q0.fia = didx + pl->off_roots; q0.ldfa = H; q0.ldfb = H; q0.ga = g_vec; q0.gb = g_qfeat;
+            RUN(launch_vec_group(&q0, 1, s));
+        } else {
         RUN(dense_bwd(B, dlogits, n, 1, A, 2 * H, hid, 2 * H, 2 * H, nullptr, W.dec3, gV0, 2 * H, 2 * H, nullptr, 0));
         RUN(launch_mask_relu(gV0, gV0, 2 * H, nullptr, hid, 2 * H, nullptr, n, 2 * H, s, inv_keep));
         RUN(dense_bwd(B, gV0, n, 1, 2 * H, 2 * H, cat, 2 * H, 2 * H, nullptr, W.dec0, gCat, 2 * H, 2 * H, nullptr, 0));
         RUN(launch_pack_bwd(PACK_CAT2, vec, didx + pl->off_roots, qfeat, nullptr, gCat, g_vec, g_qfeat, n, H, s));
+        }
     }
 
     // ---- program levels in reverse ---------------------------------------------------------------
@@ -1973,6 +2128,10 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
                 const int K = isx ? 3 * H : 2 * H;
                 const Lin &l = isx ? W.xorl : (b.op == STAIR_OP_COMPARE ? W.compare : W.equals);
                 float *dz0 = ws + b.dzV0;                 // this bucket's rows of the weight's dZ region (its product runs once, at the end)
+                if (grouped) {          // dZ = g[out] * relu'(out) on load (kept), dZ W, the concatenation's adjoint: one work list entry
+                    if (phase == 1) bvg1.push_back(vg_adj(c, g_vec, I2, vec, VG_IN_MASK, 1.0f, dz0, l, isx ? 3 : 2, isx ? VG_IN_XOR : VG_IN_CAT2, I0, I1));
+                    break;
+                }
                 RUN(launch_mask_relu(dz0, g_vec, H, I2, vec, H, I2, c, H, s));
                 RUN(dense_bwd(B, dz0, c, 1, H, K, svCat, K, K, nullptr, l, gCat, K, K, nullptr, 0));
                 RUN(launch_pack_bwd(isx ? PACK_XOR : PACK_CAT2, vec, I0, vec, I1, gCat, g_vec, g_vec, c, H, s));
@@ -1983,6 +2142,18 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
                 const bool ex = b.op == STAIR_OP_EXISTS;
                 const int K = ex ? 3 * H : 2 * H;
                 float *dz3 = ws + b.dzV3, *dz0 = ws + b.dzV0;
+                if (grouped) {
+                    if (phase != 1) break;
+                    // stage 1: dZ3 = g[out] * relu'(out) (kept), dZ0 = (dZ3 W3) * relu'(hidden) written to the first layer's dZ region
+                    VgProblem q = vg_fwd(c, g_vec, I2, H, vec, I2, H, VG_IN_MASK, B.wt + B.wt_off[(ex ? W.exists3 : W.ta3).id], H, nullptr, H, 2, dz0, nullptr, H);
+                    q.in_scale = ex ? inv_keep : 1.0f; q.in_save = dz3; q.ld_save = H; q.emask = svHid; q.ldm = H; q.escale = inv_keep;
+                    q.wplanes = vslot(ex ? W.exists3 : W.ta3);
+                    bvg1.push_back(q);
+                    // stage 2: dZ0 W0 and the concatenation's adjoint (Exists packs [feat, keyword, feat * keyword] = rows I1, I0)
+                    bvg2.push_back(vg_adj(c, dz0, nullptr, nullptr, VG_IN_A, 1.0f, nullptr, ex ? W.exists0 : W.ta0, ex ? 3 : 2, ex ? VG_IN_EXISTS : VG_IN_CAT2,
+                                          ex ? I1 : I0, ex ? I0 : I1));
+                    break;
+                }
                 RUN(launch_mask_relu(dz3, g_vec, H, I2, vec, H, I2, c, H, s, ex ? inv_keep : 1.0f));     // only Exists ends in ReLU . Dropout
                 RUN(dense_bwd(B, dz3, c, 1, H, H, svHid, H, H, nullptr, ex ? W.exists3 : W.ta3, gV1, H, H, nullptr, 0));
                 RUN(launch_mask_relu(dz0, gV1, H, nullptr, svHid, H, nullptr, c, H, s, inv_keep));
@@ -1999,8 +2170,14 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
                 if (phase == 2) break;
                 float *grow = fused ? ws + b.gRow : gV1;          // the gradient of the sum over frames: one row per instance
                 float *dzf = ws + b.dzV0;
+                if (grouped) {          // (grouped implies fused: the chain below reads `grow` after the level's grouped launch)
+                    VgProblem q = vg_fwd(c, g_vec, I1, H, vec, I1, H, VG_IN_MASK, B.wt + B.wt_off[W.fdense.id], H, nullptr, H, 0, grow, nullptr, H);
+                    q.in_save = dzf; q.ld_save = H; q.wplanes = vslot(W.fdense);
+                    bvg1.push_back(q);
+                } else {
                 RUN(launch_mask_relu(dzf, g_vec, H, I1, vec, H, I1, c, H, s));
                 RUN(dense_bwd(B, dzf, c, 1, H, H, svCat, H, H, nullptr, W.fdense, grow, H, H, nullptr, 0));
+                }
                 if (fused) { RUN(mlp_tail_fused(W.f3[v], W.f0[v], WF_F3 + v, WF_F0 + v, false, grow)); break; }
                 RUN(launch_bcast_mask_relu(gB, gV1, svB, c, T, H, s, inv_keep, LEN));
                 RUN(mlp_tail(W.f3[v], W.f0[v], false));
@@ -2065,6 +2242,12 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
             case STAIR_OP_LOCALIZE:
                 if (phase == 2) break;
                 RUN(launch_cosine_attn_bwd_grouped(svB, svK, att, I3, g_att, I3, I4, I5, gB, gK, gRs2, gStats, c, b.nrows, T, H, 2, s));
+                if (grouped) {          // dW_lk stays a reduction over the keyword rows; d(keyword rows) joins the level's grouped launch
+                    RUN(dense_bwd(B, gK, b.nrows, 1, H, H, vec, H, H, I2, W.lk, nullptr, H, H, I2, 1));
+                    VgProblem q = vg_fwd(b.nrows, gK, nullptr, H, nullptr, nullptr, 0, VG_IN_A, B.wt + B.wt_off[W.lk.id], H, nullptr, H, 0, g_vec, I2, H);
+                    q.accumulate = 1; q.wplanes = vslot(W.lk);
+                    bvg1.push_back(q);
+                } else
                 RUN(dense_bwd(B, gK, b.nrows, 1, H, H, vec, H, H, I2, W.lk, g_vec, H, H, I2, 1));
                 if (fused) RUN(mlp_tail_fused(W.lv3, W.lv0, WF_LV3, WF_LV0, false, nullptr));
                 else RUN(mlp_tail(W.lv3, W.lv0, false));
@@ -2106,7 +2289,10 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
             int64_t lo_ = hi_;
             while (lo_ > 0 && pl->buckets[lo_ - 1].level == pl->buckets[hi_ - 1].level) --lo_;
             chain_queue.clear();
+            bvg1.clear(); bvg2.clear();
             for (int64_t k = hi_ - 1; k >= lo_; --k) RUN(bwd_bucket(pl->buckets[k], 1));
+            if (!bvg1.empty()) RUN(launch_vec_group(bvg1.data(), (int)bvg1.size(), s));
+            if (!bvg2.empty()) RUN(launch_vec_group(bvg2.data(), (int)bvg2.size(), s));
             for (size_t q0 = 0; q0 < chain_queue.size(); q0 += 8) {
                 const int nq = (int)std::min<size_t>(8, chain_queue.size() - q0);
                 RUN(launch_tile_mlp_batch(chain_queue.data() + q0, nq, use_queue ? chain_ctr : nullptr, s));
@@ -2355,7 +2541,7 @@ extern "C" int stair_plan_regions(stair_plan *pl, const stair_ctx *ctx, const ch
         add("wt", pl->o_wt, ctx_weight_floats(ctx));
         add("gA", pl->o_gA, I * T * H);
         add("gB", pl->o_gB, I * T * H);
-        if (pl->o_wfragT > 0) add("wfragT", pl->o_wfragT, 19 * H * H);
+        if (pl->o_wfragT > 0) add("wfragT", pl->o_wfragT, (int64_t)WV_END * H * H);
         for (const Bucket &b : pl->buckets) {
             if (b.dzC >= 0) add("dzC", b.dzC, (int64_t)b.cnt * T * H);
             if (b.gRow >= 0) add("gRow", b.gRow, (int64_t)b.cnt * H);

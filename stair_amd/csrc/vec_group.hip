@@ -4,19 +4,19 @@
 // (:102-120), Exists (:141-159) -- Filter's dense layer on the pooled rows (:376-378), Localize's keyword projection (:199-203) and
 // the decoder (module_net.py:49-53, 136-138) are Linear layers on ONE [H] row per instance.  A level of a 128-question batch holds a
 // handful of such products of 13 .. 130 rows each; as separate launches (pack -> split-K GEMM -> reduction, per module) a training
-// step spent ~150 of its ~290 launches on them.  Here a launch carries a list of PROBLEMS; its work items are (problem, 64-row tile,
-// 64-column block) and a workgroup computes its [64 x 64] output block over the FULL reduction length (<= 1536), so there is no
+// step spent ~150 of its ~290 launches on them.  Here a launch carries a list of PROBLEMS; its work items are (problem, 32-row tile,
+// 32-column block) and a workgroup computes its [32 x 32] output block over the FULL reduction length (<= 1536), so there is no
 // split-K scratch and no reduction launch:
-//   * 8 waves = 2 row halves x 4 quarters of the reduction dimension; operands go global -> registers -> MFMA directly (the A / B
-//     fragment of v_mfma_f32_32x32x16_bf16 for lane (r, h) is 8 consecutive floats of row r: both the instance rows and the
-//     row-major weight rows have that shape), split into bf16 hi / lo on the way (three products, fp32 accumulate: the arithmetic
-//     of csrc/gemm_bf16x3.hip);
+//   * 8 waves = 8 slices of the reduction dimension (64 columns of every input segment each).  A wave requests ALL its weight
+//     fragments first (fragment-order bf16 hi / lo planes, 1 KB per fragment: stair_pack_wfrag), stages its slice of the operand rows
+//     through a private LDS area with row-contiguous loads, and multiplies (hi.hi + lo.hi + hi.lo on v_mfma_f32_32x32x16_bf16, fp32
+//     accumulate: the arithmetic of csrc/gemm_bf16x3.hip);
 //   * the concatenated inputs of the modules ([a, b], [|a - b|, a, b], [a, b, a * b]) are formed in registers from the two operand
 //     rows -- never materialised for the product; a training plan keeps them (in_save) as the weight-gradient operand;
-//   * the four quarters meet in LDS (fixed order: deterministic, and a row's result does not depend on the other rows of the
-//     launch); bias / ReLU / relu' mask, then 256-byte row segments go out: plain stores, or float atomics (gradient rows that
+//   * the eight slices meet in LDS (fixed order: deterministic, and a row's result does not depend on the other rows of the
+//     launch); bias / ReLU / relu' mask, then 128-byte row segments go out: plain stores, or float atomics (gradient rows that
 //     several instances share);
-//   * backward (kind ADJ): dX = dZ W through the transposed weight image, all 2 - 3 H-wide blocks of dX for one 64-column slice in
+//   * backward (kind ADJ): dX = dZ W through the transposed weight image, all 2 - 3 H-wide blocks of dX for one 32-column slice in
 //     one work item, so that the adjoint of the concatenation (CAT2 / EXISTS / XOR, rowops_bwd.hip pack_bwd_kernel) is applied in
 //     the epilogue and added straight into the operands' gradient rows; the relu' mask of the incoming gradient is applied on load
 //     (IN_MASK) and the masked rows are kept (in_save) as the dZ operand of the weight-gradient product.
@@ -35,8 +35,12 @@ using v4f = __attribute__((ext_vector_type(4))) float;
 namespace {
 
 constexpr int VG_SEG = 512;                  // width of one input segment / one adjoint output block (the reference's hidden size)
-constexpr int VG_PLD = 68;                   // row stride (floats) of the partial tiles in LDS
-constexpr int VG_LDS = 4 * 64 * VG_PLD * 4;  // four reduction quarters x [64 x 64] partial tile
+constexpr int VG_PLD = 36;                   // row stride (floats) of the [64 x 32] partial tiles in LDS
+constexpr int VG_ROWS = 32;                  // rows per work item
+constexpr int VG_XLD = 68;                   // row stride (floats) of a wave's operand staging
+constexpr int VG_LDS = 8 * 2 * 32 * VG_XLD * 4;      // eight waves x (a, b) x [32 rows x 64 columns] staging; the eight [32 x 32] partial
+                                                     // tiles of the reduction slices (8 * 32 * VG_PLD floats) overlay it afterwards
+static_assert(VG_LDS >= 8 * 32 * VG_PLD * 4, "the partial tiles fit over the staging");
 constexpr int VG_MAXP = 12;                  // problems per launch (kernel-argument block < 4 KB)
 
 struct VgParams {
@@ -54,9 +58,10 @@ __device__ __forceinline__ void vg_split8(const v4f a, const v4f b, bf16x8 &hi, 
     }
 }
 
-// 8 consecutive floats at p[k .. k + 7], zero beyond `lim` (the reduction tail of a row shorter than a whole step)
+// 8 consecutive floats at p[k .. k + 7]; TAIL: zero beyond `lim` (the reduction tail of a row shorter than a whole step)
+template <bool TAIL>
 __device__ __forceinline__ void vg_load8(const float *p, int k, int lim, v4f &x0, v4f &x1) {
-    if (k + 8 <= lim) {
+    if (!TAIL || k + 8 <= lim) {
         x0 = *reinterpret_cast<const v4f *>(p + k);
         x1 = *reinterpret_cast<const v4f *>(p + k + 4);
     } else {
@@ -87,109 +92,151 @@ __device__ __forceinline__ void vg_form(int pack, int s, float in_scale, const v
     }
 }
 
-// One [64 x 64] output block of a work item: this wave's quarter of the reduction for its 32 rows x 64 columns.
-// Micro-step m = (16-wide step ks, input segment s): the weight pieces of micro-step m + 1 and the row pieces of step ks + 1 are in
-// flight while m's MFMAs run (two register buffers each; the loops are unrolled so that the buffers are registers).
-template <int NIN>
-__device__ __forceinline__ void vg_tile(const VgProblem &p, const float *ap, const float *bp, const float *w0, const float *w1, const int kq,
-                                        const int h, float *save_row, f32x16 (&acc)[2]) {
-    const int kred = p.kred;
-    const bool two = p.pack != VG_IN_A;
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
-    const int nsteps = min(8, max(0, (kred - 128 * kq + 15) / 16));       // kred = 512: 8 steps per quarter
-    if (nsteps == 0) return;
-    v4f xa[2][2], xb[2][2], wv[2][2][2];
-    auto load_x = [&](const int buf, const int ks) {
-        const int k = 128 * kq + 16 * ks + 8 * h;
-        vg_load8(ap, k, kred, xa[buf][0], xa[buf][1]);
-        if (two) vg_load8(bp, k, kred, xb[buf][0], xb[buf][1]);
-    };
-    auto load_w = [&](const int buf, const int ks, const int s) {
-        const int k = 128 * kq + 16 * ks + 8 * h;
-        vg_load8(w0 + s * VG_SEG, k, kred, wv[buf][0][0], wv[buf][0][1]);
-        vg_load8(w1 + s * VG_SEG, k, kred, wv[buf][1][0], wv[buf][1][1]);
-    };
-    load_x(0, 0);
-    load_w(0, 0, 0);
-#pragma unroll
-    for (int m = 0; m < 8 * NIN; ++m) {
-        const int ks = m / NIN, s = m - ks * NIN;
-        if (ks >= nsteps) break;
-        if (s == 0 && ks + 1 < nsteps) load_x((ks + 1) & 1, ks + 1);
-        if (s + 1 < NIN) load_w((m + 1) & 1, ks, s + 1);
-        else if (ks + 1 < nsteps) load_w((m + 1) & 1, ks + 1, 0);
-        __builtin_amdgcn_sched_barrier(0);          // the prefetches stay above this micro-step's MFMAs
-        v4f x0, x1;
-        vg_form(p.pack, s, p.in_scale, xa[ks & 1][0], xa[ks & 1][1], xb[ks & 1][0], xb[ks & 1][1], x0, x1);
-        const int k = 128 * kq + 16 * ks + 8 * h;
-        if (save_row && k + 8 <= kred) {
-            float *d = save_row + s * VG_SEG + k;
-            *reinterpret_cast<v4f *>(d) = x0; *reinterpret_cast<v4f *>(d + 4) = x1;
-        }
-        bf16x8 xh, xl;
-        vg_split8(x0, x1, xh, xl);
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            bf16x8 wh, wl;
-            vg_split8(wv[m & 1][nt][0], wv[m & 1][nt][1], wh, wl);
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, acc[nt], 0, 0, 0);
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc[nt], 0, 0, 0);
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc[nt], 0, 0, 0);
-        }
-    }
-}
-
-// One work item: rows [64 rt, 64 rt + 64) x output columns of block cb.  NIN input segments; NOUT output blocks (1: a forward-shaped
-// product; 2 / 3: the H-wide blocks of a concatenation's gradient at the same 64 columns, combined by the adjoint epilogue).
-template <int NIN, int NOUT>
+// One work item: rows [32 rt, 32 rt + 32) x the 32 output columns of block cb (x NOUT H-wide blocks for an adjoint problem).
+// Wave w owns columns [64 w, 64 w + 64) of EVERY input segment (an eighth of the reduction).  A work item is a short chain of memory
+// round trips, so everything is requested as early as it can be:
+//   * weights: the wave's fragments of every output block -- NOUT x NIN segments x 4 steps x (hi, lo), 1 KB each, fragment-order
+//     planes (stair_pack_wfrag; one [512 x 512] image per (block of 512 output columns, input segment)) -- are ALL requested first: the
+//     whole weight stream of the item is one L2 round trip.  (A ring of a few steps made a launch take 9 us per 512 of reduction
+//     length whatever it computed.)  wplanes == NULL: fp32 rows, split on the way (column / reduction tails);
+//   * operand rows: the wave fetches its [32 rows x 64 columns] pieces of a and b with ROW-CONTIGUOUS 16-byte loads (16 lanes per row)
+//     into a wave-private LDS staging area, once, and reads the MFMA fragments back from there -- the fragment shape itself (lane (r, h)
+//     = 8 floats of row r) touches 32 cache lines per load instruction, and the first version of this kernel was bound by the L1's
+//     line rate.  The formed, split fragments stay in registers for all output blocks.
+template <int NIN, int NOUT, bool TAIL, bool PLANES>
 __device__ __forceinline__ void vg_item(const VgProblem &p, const int rt, const int cb, float *P) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int tt = wave >> 2, kq = wave & 3;
-    const int rows = p.rows;
-    const int row = rt * 64 + 32 * tt + r, rowc = min(row, rows - 1);
-    const float *ap = p.a + (int64_t)(p.ia ? p.ia[rowc] : rowc) * p.lda;
-    const float *bp = p.pack != VG_IN_A ? p.b + (int64_t)(p.ib ? p.ib[rowc] : rowc) * p.ldb : ap;
-    float *save_row = p.in_save != nullptr && cb == 0 && row < rows ? p.in_save + (int64_t)row * p.ld_save : nullptr;
+    const int rows = p.rows, kred = p.kred;
+    const bool two = p.pack != VG_IN_A;
+    const int k0 = 64 * wave;
+    const int nsteps = min(4, max(0, (kred - k0 + 15) / 16));             // kred = 512: 4 steps per wave and segment
+    const int blk0 = p.kind == VG_ADJ ? 0 : cb / 16, nt = cb % 16;
 
-    // ---- per output block: the product, then the four quarters meet in LDS; thread (wave, lane) owns column `lane` of rows
-    //      wave, wave + 8, ... of the block ----
-    float d[NOUT][8];
+    // ---- 1. every weight fragment of the item ----
+    bf16x8 wpl[PLANES ? NOUT : 1][PLANES ? NIN : 1][4][2];
+    v4f wv[PLANES ? 1 : NIN][4][2];                                        // (fp32 rows: forward-shaped problems only, NOUT = 1)
+    if (PLANES) {
+        const bf16x8 *wq = static_cast<const bf16x8 *>(p.wplanes);
 #pragma unroll
-    for (int j = 0; j < NOUT; ++j) {
-        const int n0 = (p.kind == VG_ADJ ? j * VG_SEG : 0) + cb * 64 + r;
-        f32x16 acc[2];
-        vg_tile<NIN>(p, ap, bp, p.W + (int64_t)min(n0, p.N - 1) * p.ldw, p.W + (int64_t)min(n0 + 32, p.N - 1) * p.ldw, kq, h,
-                     j == 0 ? save_row : nullptr, acc);
-        if (j > 0) __syncthreads();               // the previous block's partials have been read
-        // lane (r, h) holds row t = 32 tt + r, columns 32 nt + 8 q + 4 h + i for e = 4 q + i
+        for (int j = 0; j < NOUT; ++j)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+            for (int s = 0; s < NIN; ++s) {
+                const bf16x8 *img = wq + (int64_t)((blk0 + j) * NIN + s) * (VG_SEG * VG_SEG * 2 / 8) + lane;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                v4f z;
+                for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) z[i] = acc[nt][4 * q + i];
-                *reinterpret_cast<v4f *>(P + (kq * 64 + 32 * tt + r) * VG_PLD + 32 * nt + 8 * q + 4 * h) = z;
+                    for (int pl = 0; pl < 2; ++pl) wpl[PLANES ? j : 0][PLANES ? s : 0][ks][pl] = img[((nt * (VG_SEG / 16) + 4 * wave + ks) * 2 + pl) * 64];
             }
-        __syncthreads();
+    } else {
+        const float *wrow = p.W + (int64_t)min(cb * 32 + r, p.N - 1) * p.ldw;
+#pragma unroll
+        for (int s = 0; s < NIN; ++s)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                if (ks < nsteps) vg_load8<TAIL>(wrow + s * VG_SEG, k0 + 16 * ks + 8 * h, kred, wv[PLANES ? 0 : s][ks][0], wv[PLANES ? 0 : s][ks][1]);
+    }
+
+    // ---- 2. the wave's [32 rows x 64 columns] of a and b: row-contiguous loads -> wave-private LDS -> fragments in registers ----
+    float *Xa = P + wave * (2 * 32 * VG_XLD), *Xb = Xa + 32 * VG_XLD;
+    bf16x8 xh[NIN][4], xl[NIN][4];
+    if (nsteps > 0) {
+        const int rsub = lane >> 4, c4 = (lane & 15) * 4;    // lane = (row 4 i + rsub, columns c4 .. c4 + 3 of the slice)
+        const int kc = k0 + c4;
+        const bool live = !TAIL || kc < kred;
+        float *save_base = p.in_save != nullptr && cb == 0 ? p.in_save : nullptr;
+        int aoff[8], boff[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int t = wave + 8 * i;
-            d[j][i] = ((P[(0 * 64 + t) * VG_PLD + lane] + P[(1 * 64 + t) * VG_PLD + lane]) + P[(2 * 64 + t) * VG_PLD + lane]) + P[(3 * 64 + t) * VG_PLD + lane];
+            const int rowc = min(rt * 32 + 4 * i + rsub, rows - 1);
+            aoff[i] = (int)((p.ia ? p.ia[rowc] : rowc) * p.lda);
+            boff[i] = two ? (int)((p.ib ? p.ib[rowc] : rowc) * p.ldb) : aoff[i];
+        }
+        v4f va[8], vb[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            va[i] = live ? *reinterpret_cast<const v4f *>(p.a + aoff[i] + kc) : v4f{0.f, 0.f, 0.f, 0.f};
+            if (two) vb[i] = live ? *reinterpret_cast<const v4f *>(p.b + boff[i] + kc) : v4f{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = 4 * i + rsub;
+            *reinterpret_cast<v4f *>(Xa + row * VG_XLD + c4) = va[i];
+            if (two) *reinterpret_cast<v4f *>(Xb + row * VG_XLD + c4) = vb[i];
+            if (save_base && rt * 32 + row < rows && live) {       // the formed input rows (the weight-gradient operand), 256 contiguous bytes per 16 lanes
+#pragma unroll
+                for (int s = 0; s < NIN; ++s) {
+                    v4f x0, x1;
+                    vg_form(p.pack, s, p.in_scale, va[i], va[i], two ? vb[i] : va[i], two ? vb[i] : va[i], x0, x1);
+                    *reinterpret_cast<v4f *>(save_base + (int64_t)(rt * 32 + row) * p.ld_save + s * VG_SEG + kc) = x0;
+                }
+            }
+        }
+        // (wave-private staging: the wave's own LDS accesses complete in order, no workgroup barrier)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const float *xr = Xa + r * VG_XLD + 16 * ks + 8 * h, *yr = Xb + r * VG_XLD + 16 * ks + 8 * h;
+            const v4f a0 = *reinterpret_cast<const v4f *>(xr), a1 = *reinterpret_cast<const v4f *>(xr + 4);
+            v4f b0 = a0, b1 = a1;
+            if (two) { b0 = *reinterpret_cast<const v4f *>(yr); b1 = *reinterpret_cast<const v4f *>(yr + 4); }
+#pragma unroll
+            for (int s = 0; s < NIN; ++s) {
+                v4f x0, x1;
+                vg_form(p.pack, s, p.in_scale, a0, a1, b0, b1, x0, x1);
+                vg_split8(x0, x1, xh[s][ks], xl[s][ks]);
+            }
         }
     }
 
-    const int col = cb * 64 + lane;
+    // ---- 3. per output block: the products, then the eight slices of the reduction meet in LDS (over the staging); thread (wave, lane)
+    //         owns column lane % 32 of rows g and g + 16, g = 2 wave + lane / 32 ----
+    float d[NOUT][2];
+    const int ecol = lane & 31, erow = 2 * wave + (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j) {
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks >= nsteps) break;
+#pragma unroll
+            for (int s = 0; s < NIN; ++s) {
+                bf16x8 wh, wl;
+                if (PLANES) { wh = wpl[PLANES ? j : 0][PLANES ? s : 0][ks][0]; wl = wpl[PLANES ? j : 0][PLANES ? s : 0][ks][1]; }
+                else vg_split8(wv[PLANES ? 0 : s][ks][0], wv[PLANES ? 0 : s][ks][1], wh, wl);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh[s][ks], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl[s][ks], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh[s][ks], acc, 0, 0, 0);
+            }
+        }
+        __syncthreads();                          // every wave has its fragments in registers (j = 0) / has read the previous block's partials
+        // lane (r, h) holds row r, columns 8 q + 4 h + i for e = 4 q + i
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            v4f z;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) z[i] = acc[4 * q + i];
+            *reinterpret_cast<v4f *>(P + (wave * 32 + r) * VG_PLD + 8 * q + 4 * h) = z;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int t = erow + 16 * i;
+            float v = 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) v += P[(w8 * 32 + t) * VG_PLD + ecol];        // fixed order: deterministic
+            d[j][i] = v;
+        }
+    }
+
+    const int col = cb * 32 + ecol;
     if (p.kind == VG_FWD) {
         if (col >= p.N) return;
         const float bias = p.bias ? p.bias[col] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int rw = rt * 64 + wave + 8 * i;
+        for (int i = 0; i < 2; ++i) {
+            const int rw = rt * 32 + erow + 16 * i;
             if (rw >= rows) break;
             float v = d[0][i] + bias;
             if (p.act == 1) v = fmaxf(v, 0.f);
@@ -202,8 +249,8 @@ __device__ __forceinline__ void vg_item(const VgProblem &p, const int rt, const 
         // adjoint of the concatenation: d[0], d[1] (, d[2]) are the gradient blocks at column `col` of the H-wide operand rows
         constexpr int J1 = NOUT > 1 ? 1 : 0, J2 = NOUT > 2 ? 2 : 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int rw = rt * 64 + wave + 8 * i;
+        for (int i = 0; i < 2; ++i) {
+            const int rw = rt * 32 + erow + 16 * i;
             if (rw >= rows) break;
             const int64_t ra = (int64_t)(p.fia ? p.fia[rw] : rw) * p.ldfa + col, rb = (int64_t)(p.fib ? p.fib[rw] : rw) * p.ldfb + col;
             float da, db;
@@ -229,20 +276,27 @@ __global__ __launch_bounds__(512, 1) void vec_group_kernel(VgParams pp) {
     int sel = 0;
 #pragma unroll
     for (int j = 1; j < VG_MAXP; ++j) sel += (j < pp.np && w >= pp.first[j]) ? 1 : 0;
-    const VgProblem &p = pp.p[sel];
+    const VgProblem p = pp.p[sel];            // a copy in scalar registers: a reference into the argument block made the compiler
+                                              // copy the whole block to scratch
     const int item = w - pp.first[sel];
-    const int nblk = p.kind == VG_ADJ ? VG_SEG / 64 : (p.N + 63) / 64;
+    const int nblk = p.kind == VG_ADJ ? VG_SEG / 32 : (p.N + 31) / 32;
     const int rt = item / nblk, cb = item - rt * nblk;
     const int nin = p.pack == VG_IN_A || p.pack == VG_IN_MASK ? 1 : (p.pack == VG_IN_CAT2 ? 2 : 3);
+    // Variants: weights as fragment-order planes for every form; fp32 weight rows only where planes cannot be (a reduction tail: the
+    // decoder's last layer seen from behind; a column tail: that layer itself) -- each variant is unrolled code of its own, and a
+    // dispatcher holding all combinations spilled although no single variant does
+    const bool planes = p.wplanes != nullptr;
     if (p.kind == VG_FWD) {
-        if (nin == 1) vg_item<1, 1>(p, rt, cb, P);
-        else if (nin == 2) vg_item<2, 1>(p, rt, cb, P);
-        else vg_item<3, 1>(p, rt, cb, P);
+        if (nin == 1 && !planes) vg_item<1, 1, true, false>(p, rt, cb, P);
+        else if (nin == 2 && !planes) vg_item<2, 1, false, false>(p, rt, cb, P);
+        else if (nin == 1) vg_item<1, 1, false, true>(p, rt, cb, P);
+        else if (nin == 2) vg_item<2, 1, false, true>(p, rt, cb, P);
+        else vg_item<3, 1, false, true>(p, rt, cb, P);
     } else {
         const int nout = p.N / VG_SEG;
-        if (nin == 2) vg_item<2, 2>(p, rt, cb, P);
-        else if (nout == 2) vg_item<1, 2>(p, rt, cb, P);
-        else vg_item<1, 3>(p, rt, cb, P);
+        if (nin == 2) vg_item<2, 2, false, true>(p, rt, cb, P);
+        else if (nout == 2) vg_item<1, 2, false, true>(p, rt, cb, P);
+        else vg_item<1, 3, false, true>(p, rt, cb, P);
     }
 }
 
@@ -251,6 +305,11 @@ int vg_check(const VgProblem &p) {
     STAIR_CHECK(p.pack >= VG_IN_A && p.pack <= VG_IN_MASK, "unknown input form");
     STAIR_CHECK(p.pack == VG_IN_A || p.b, "the input form needs a second operand row");
     STAIR_CHECK(p.kred >= 1 && p.kred <= VG_SEG && (p.kred == VG_SEG || p.pack == VG_IN_A), "reduction length per segment: 512, or shorter for a plain row");
+    STAIR_CHECK(p.kred % 4 == 0, "reduction length must be a multiple of 4");
+    STAIR_CHECK(p.wplanes || (p.kind == VG_FWD && (p.pack == VG_IN_A || p.pack == VG_IN_CAT2)),
+                "fp32 weight rows are read for plain and two-segment forward problems only; every other form needs weight planes");
+    STAIR_CHECK(!p.wplanes || (p.kred == VG_SEG && (p.kind == VG_ADJ || p.N % 32 == 0) && (reinterpret_cast<uintptr_t>(p.wplanes) & 15) == 0),
+                "weight planes need whole 32-column blocks and 512-wide segments");
     STAIR_CHECK(p.lda % 4 == 0 && p.ldb % 4 == 0 && p.ldw % 4 == 0 && p.ld_save % 4 == 0, "row strides must be multiples of 4 floats");
     STAIR_CHECK(((reinterpret_cast<uintptr_t>(p.a) | reinterpret_cast<uintptr_t>(p.b) | reinterpret_cast<uintptr_t>(p.W) | reinterpret_cast<uintptr_t>(p.in_save)) & 15) == 0,
                 "operands must be 16-byte aligned");
@@ -287,10 +346,10 @@ int launch_vec_group(const VgProblem *probs, int n, hipStream_t s) {
             const VgProblem &p = probs[at++];
             if (p.rows == 0) continue;
             if (int rc = vg_check(p)) return rc;
-            const int nblk = p.kind == VG_ADJ ? VG_SEG / 64 : (p.N + 63) / 64;
+            const int nblk = p.kind == VG_ADJ ? VG_SEG / 32 : (p.N + 31) / 32;
             const int nin = p.pack == VG_IN_A || p.pack == VG_IN_MASK ? 1 : (p.pack == VG_IN_CAT2 ? 2 : 3);
             pp.p[pp.np] = p;
-            pp.first[pp.np + 1] = pp.first[pp.np] + ((p.rows + 63) / 64) * nblk;
+            pp.first[pp.np + 1] = pp.first[pp.np] + ((p.rows + VG_ROWS - 1) / VG_ROWS) * nblk;
             ++pp.np;
             const int64_t K = (int64_t)nin * p.kred;
             STAIR_ACCT_MFMA("vec_group", ((int64_t)p.rows * (K + p.N) + (int64_t)p.N * K) * 4, 2 * (int64_t)p.rows * p.N * K);

@@ -398,6 +398,7 @@ def vec_group(problems):
         q.lda, q.ldb = int(d.get('lda', ld(d['a']))), int(d.get('ldb', ld(d.get('b'))))
         q.pack, q.in_scale, q.kred = VEC_IN[d.get('pack', 'a')], float(d.get('in_scale', 1.0)), int(d.get('kred', 512))
         q.W, q.ldw, q.bias, q.N = ptr(d['W']), int(d.get('ldw', ld(d['W']))), ptr(d.get('bias')), int(d['N'])
+        q.wplanes = ptr(d.get('planes'))
         act = d.get('act')
         if isinstance(act, tuple):
             q.act, q.emask, q.ldm, q.escale = 2, ptr(act[1]), ld(act[1]), float(act[2])

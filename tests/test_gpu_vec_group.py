@@ -11,6 +11,14 @@ DEV = 'cuda:0'
 H = 512
 
 
+def _planes(W, nin):
+    """[N, nin * 512] fp32 -> fragment-order planes, one [512 x 512] image per (block of 512 output rows, input segment)"""
+    from stair_amd import ops
+    N = W.shape[0]
+    imgs = [ops.pack_wfrag(W[jb * 512:(jb + 1) * 512, s * 512:(s + 1) * 512].contiguous()) for jb in range(N // 512) for s in range(nin)]
+    return torch.cat([i.reshape(-1) for i in imgs])
+
+
 def _cat(kind, a, b):
     return {'a': a, 'cat2': torch.cat([a, b], 1), 'xor': torch.cat([(a - b).abs(), a, b], 1), 'exists': torch.cat([a, b, a * b], 1)}[kind]
 
@@ -27,12 +35,14 @@ def test_forward_forms_match_fp64_in_one_launch(rows):
     A, IA, IB, IO = d(arena), d(ia), d(ib), d(io)
     probs, want = [], []
     for kind, nseg, N, act in (('cat2', 2, 512, 'relu'), ('xor', 3, 512, 'relu'), ('exists', 3, 512, 'relu'), ('a', 1, 512, None),
-                               ('cat2', 2, 1024, 'relu'), ('cat2', 2, 172, None)):
+                               ('cat2', 2, 1024, 'relu'), ('cat2', 2, 172, None), ('a', 1, 172, 'relu')):
         W = torch.randn(N, nseg * H, generator=g) / (nseg * H) ** 0.5
         bias = torch.randn(N, generator=g)
         out = torch.full((300, N), -7.0, device=DEV)
         save = torch.zeros(rows, nseg * H, device=DEV)
-        probs.append(dict(kind='fwd', rows=rows, a=A, b=A, ia=IA, ib=IB, pack=kind, W=d(W), bias=d(bias), N=N, act=act, out=out, io=IO, in_save=save))
+        planes = _planes(d(W), nseg) if N % 512 == 0 else None         # (the fp32-row path serves the column tail: N = 172)
+        probs.append(dict(kind='fwd', rows=rows, a=A, b=A, ia=IA, ib=IB, pack=kind, W=d(W), planes=planes, bias=d(bias), N=N, act=act, out=out, io=IO,
+                          in_save=save))
         x = _cat(kind, arena[ia.long()].double(), arena[ib.long()].double())
         y = x @ W.double().t() + bias.double()
         want.append((x, y.relu() if act else y, out, save))
@@ -91,7 +101,8 @@ def test_adjoint_forms_match_autograd(kind, nseg):
     garena = torch.zeros(40, H, device=DEV)
     dz = torch.zeros(rows, H, device=DEV)
     A = d(arena.detach())
-    ops.vec_group([dict(kind='adj', rows=rows, a=d(gy), b=d(y.detach()), pack='mask', in_scale=1.0, in_save=dz, W=d(W.t().contiguous()), N=nseg * H,
+    Wt = d(W.t().contiguous())
+    ops.vec_group([dict(kind='adj', rows=rows, a=d(gy), b=d(y.detach()), pack='mask', in_scale=1.0, in_save=dz, W=Wt, planes=_planes(Wt, 1), N=nseg * H,
                         adj=kind, fa=A, fb=A, fia=ia.to(torch.int32).to(DEV), fib=ib.to(torch.int32).to(DEV), ga=garena, gb=garena)])
     assert float((dz.cpu().double() - gy * (y.detach() > 0)).abs().max()) < 1e-6
     ref = arena.grad
@@ -111,7 +122,8 @@ def test_decoder_shaped_adjoint_with_two_input_segments():
     gq = torch.zeros(n, H, device=DEV)
     d = lambda t: t.to(DEV)
     GH = d(gh)
-    ops.vec_group([dict(kind='adj', rows=n, a=GH, b=GH[:, 512:], lda=1024, ldb=1024, pack='cat2', W=d(W0.t().contiguous()), N=1024, adj='cat2',
+    W0t = d(W0.t().contiguous())
+    ops.vec_group([dict(kind='adj', rows=n, a=GH, b=GH[:, 512:], lda=1024, ldb=1024, pack='cat2', W=W0t, planes=_planes(W0t, 2), N=1024, adj='cat2',
                         fia=d(roots), ga=gvec, gb=gq)])
     want = gh.double() @ W0.double()
     assert float((gvec.cpu().double()[roots.long()] - want[:, :512]).abs().max()) < 2e-4
