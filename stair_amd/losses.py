@@ -161,6 +161,77 @@ def compile_gold(question, pretrain_modules=CRITERION_MODULES, no_intermediate=(
     return pack
 
 
+class GoldBatch:
+    """The gold intermediates of a BATCH as flat arrays -- what a data loader's collate step hands to the training loop (the
+    reference's loader hands batch-1 dicts, dataset.py:463-464; its per-question bookkeeping, train_module.py:351-406, then runs in
+    the stepping process).  With a GoldBatch, prepare_module_losses is a handful of numpy operations whatever the batch size;
+    from a list of question dicts it walks the questions in Python (6.7 ms per 2048 questions on the bench host).
+      att_q / att_pos / att_kind / att_iv      attention criteria: question index, token position, kind, gold intervals [n, 2, 2]
+      head[module] = (q, pos, label)            Exists / Xor / Equals
+      cg_q / cg_pos / cg_name (/ cg_cls)       one entry per (contrastive node, gold class): names, and their ClassTable rows
+      cg_emb                                   the embeddings of those entries (list mode only)
+      ff = [(q, pos, gold dict)]               FilterFrame (off by default)"""
+
+    def __init__(self, questions, pretrain_modules=CRITERION_MODULES, no_intermediate=('FilterFrame',), class_table=None):
+        packs = [compile_gold(q, pretrain_modules, no_intermediate) for q in questions]
+        self.n = len(packs)
+        self.key = (frozenset(pretrain_modules), tuple(no_intermediate))
+        cat = lambda parts, dt, shape=None: (np.concatenate(parts).astype(dt, copy=False) if parts else np.zeros((0,) + (shape or ()), dtype=dt))
+        sel = [qi for qi, p in enumerate(packs) if p.att_pos.size]
+        self.att_q = cat([np.full(packs[qi].att_pos.size, qi, dtype=np.int64) for qi in sel], np.int64)
+        self.att_pos = cat([packs[qi].att_pos for qi in sel], np.int64)
+        self.att_kind = cat([packs[qi].att_kind for qi in sel], np.int64)
+        self.att_iv = cat([packs[qi].att_iv for qi in sel], np.float64, (2, 2))
+        self.head = {}
+        for module in ('Exists', 'Xor', 'Equals'):
+            sel = [qi for qi, p in enumerate(packs) if module in p.head]
+            if sel:
+                self.head[module] = (cat([np.full(packs[qi].head[module][0].size, qi, dtype=np.int64) for qi in sel], np.int64),
+                                     cat([packs[qi].head[module][0] for qi in sel], np.int64),
+                                     cat([packs[qi].head[module][1] for qi in sel], np.int32))
+        cq, cp, cn, ce = [], [], [], []
+        for qi, p in enumerate(packs):
+            for pos, module, gold in p.cont:
+                for class_name, emb in gold:
+                    cq.append(qi); cp.append(pos); cn.append(class_name); ce.append(emb)
+        self.cg_q, self.cg_pos = np.asarray(cq, dtype=np.int64), np.asarray(cp, dtype=np.int64)
+        self.cg_name, self.cg_emb = cn, ce
+        self.class_table = class_table
+        self.cg_cls = None
+        if class_table is not None:
+            try:
+                self.cg_cls = np.asarray([class_table.index[n] for n in cn], dtype=np.int64)
+            except KeyError as e:
+                raise KeyError('class %s is not in the ClassTable (build it from the whole dataset: ClassTable.from_questions)' % e)
+        self.ff = [(qi, pos, gold) for qi, p in enumerate(packs) for pos, gold in p.ff]
+
+    def select(self, keep):
+        """The batch with the gold of the questions where keep[q] is False removed (train_module.py:350: no intermediate losses
+        once global_steps >= train_module_before_iters)."""
+        keep = np.asarray(keep, dtype=bool)
+        out = object.__new__(GoldBatch)
+        out.n, out.key, out.class_table = self.n, self.key, self.class_table
+        m = keep[self.att_q]
+        out.att_q, out.att_pos, out.att_kind, out.att_iv = self.att_q[m], self.att_pos[m], self.att_kind[m], self.att_iv[m]
+        out.head = {}
+        for module, (q, pos, lab) in self.head.items():
+            m = keep[q]
+            if m.any():
+                out.head[module] = (q[m], pos[m], lab[m])
+        m = keep[self.cg_q] if self.cg_q.size else np.zeros(0, dtype=bool)
+        idx = np.nonzero(m)[0]
+        out.cg_q, out.cg_pos = self.cg_q[m], self.cg_pos[m]
+        out.cg_name, out.cg_emb = [self.cg_name[i] for i in idx], [self.cg_emb[i] for i in idx]
+        out.cg_cls = self.cg_cls[m] if self.cg_cls is not None else None
+        out.ff = [t for t in self.ff if keep[t[0]]]
+        return out
+
+
+def collate_gold(questions, pretrain_modules=CRITERION_MODULES, no_intermediate=('FilterFrame',), class_table=None):
+    """GoldBatch of a list of question dicts (the data loader's collate step)."""
+    return GoldBatch(questions, pretrain_modules, no_intermediate, class_table)
+
+
 def contrastive_windows(entries, window, world=1):
     """The class pools of train_module.py:386-402 over the GLOBAL accumulation window.
     entries: [(global question position, class_name, embedding)] of this rank's contrastive golds; with world > 1 every
@@ -243,35 +314,40 @@ class ClassTable:
 
 
 class _Staging:
-    """One pinned host buffer + one device buffer per model: every index / label / interval array of a step's loss launches
-    goes to the GPU in ONE asynchronous copy (a pageable `.to(device)` per array blocks the host on the stream each time)."""
+    """A ring of pinned host buffers + device buffers per model: every index / label / interval array of a step's loss launches
+    goes to the GPU in ONE asynchronous copy (a pageable `.to(device)` per array blocks the host on the stream each time).
+    A single buffer makes the host wait until the GPU has executed the PREVIOUS step's copy -- i.e. it cannot run ahead of the
+    GPU by more than one step; with `depth` slots a slot is waited for only when it comes round again."""
 
-    def __init__(self):
-        self.host = self.dev = None
+    def __init__(self, depth=4):
+        self.slots = [dict(host=None, dev=None, event=None) for _ in range(depth)]
+        self.at = 0
 
     def upload(self, arrays, device):
-        """arrays: list of contiguous numpy arrays (int32 / float64).  Returns device views in the same order."""
+        """arrays: list of contiguous numpy arrays (int32 / float32 / float64).  Returns device views in the same order, valid until
+        the slot is reused `depth` uploads later."""
         offs, total = [], 0
         for a in arrays:
             total = (total + 15) // 16 * 16               # kernels want 16-byte aligned operands
             offs.append(total)
             total += a.nbytes
         total = max(16, (total + 15) // 16 * 16)
-        if self.host is None or self.host.numel() < total or self.dev.device != device:
+        sl = self.slots[self.at]
+        self.at = (self.at + 1) % len(self.slots)
+        if sl['event'] is not None:
+            sl['event'].synchronize()                     # the copy issued `depth` uploads ago has left this slot's pinned buffer
+        if sl['host'] is None or sl['host'].numel() < total or sl['dev'].device != device:
             cap = max(total * 2, 1 << 16)
-            self.host = torch.empty(cap, dtype=torch.uint8).pin_memory()
-            self.dev = torch.empty(cap, dtype=torch.uint8, device=device)
-            self.event = None
-        if self.event is not None:
-            self.event.synchronize()                      # the previous step's copy has left the pinned buffer
-        hv = self.host.numpy()
+            sl['host'] = torch.empty(cap, dtype=torch.uint8).pin_memory()
+            sl['dev'] = torch.empty(cap, dtype=torch.uint8, device=device)
+        hv = sl['host'].numpy()
         for a, o in zip(arrays, offs):
             hv[o: o + a.nbytes] = a.view(np.uint8).reshape(-1)
-        self.dev[:total].copy_(self.host[:total], non_blocking=True)
-        self.event = torch.cuda.Event()
-        self.event.record()
+        sl['dev'][:total].copy_(sl['host'][:total], non_blocking=True)
+        sl['event'] = torch.cuda.Event()
+        sl['event'].record()
         tdt = {np.dtype(np.float64): torch.float64, np.dtype(np.float32): torch.float32, np.dtype(np.int32): torch.int32}
-        return [self.dev[o: o + a.nbytes].view(tdt[a.dtype]) for a, o in zip(arrays, offs)]
+        return [sl['dev'][o: o + a.nbytes].view(tdt[a.dtype]) for a, o in zip(arrays, offs)]
 
 
 def prepare_module_losses(model, res, questions, pretrain_modules=CRITERION_MODULES, no_intermediate=('FilterFrame',), window=32,
@@ -287,7 +363,10 @@ def prepare_module_losses(model, res, questions, pretrain_modules=CRITERION_MODU
     H, T = model.config['hidden_size'], res.info.T
     _, slot_t, aux_t, _, rel_t = res.node_table()
     base = np.asarray(res._prog_off, dtype=np.int64)
-    packs = [compile_gold(q, pretrain_modules, no_intermediate) for q in questions]
+    # a GoldBatch (the loader's collate output) or a list of question dicts, collated here
+    gb = questions if isinstance(questions, GoldBatch) else GoldBatch(questions, pretrain_modules, no_intermediate, class_table)
+    if gb.n != res.info.n_questions:
+        raise ValueError('gold batch of %d questions for a plan of %d' % (gb.n, res.info.n_questions))
     i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
     up, plan = [], {}                                    # arrays to upload, and where each launch finds its own
 
@@ -296,60 +375,56 @@ def prepare_module_losses(model, res, questions, pretrain_modules=CRITERION_MODU
         up.extend(arrays)
 
     # ---- attention criteria (Localize / Temporal / ExistsFrame) ----
-    sel = [qi for qi, p in enumerate(packs) if p.att_pos.size]
-    n_att = 0
-    if sel:
-        tok = np.concatenate([packs[qi].att_pos + base[qi] for qi in sel])
-        kind = np.concatenate([packs[qi].att_kind for qi in sel])
-        iv = np.concatenate([packs[qi].att_iv for qi in sel])                    # [n, 2, 2]
+    n_att = int(gb.att_q.size)
+    if n_att:
+        tok = gb.att_pos + base[gb.att_q]
+        kind, iv = gb.att_kind, gb.att_iv                                        # iv [n, 2, 2]
         slot = np.where(kind == 1, rel_t[tok], slot_t[tok])
         K = np.where(kind == 0, aux_t[tok], 1).astype(np.int64)
         keep = np.arange(2)[None, :] < K[:, None]
-        n_att = len(tok)
         qf = res.question_frames
-        att_len = i32(np.concatenate([np.full(packs[qi].att_pos.size, qf[qi]) for qi in sel])) if qf is not None else np.zeros(0, np.int32)
+        att_len = i32(np.asarray(qf)[gb.att_q]) if qf is not None else np.zeros(0, np.int32)
         stage('att', i32(slot), i32(K), i32(np.concatenate([[0], np.cumsum(K)])), np.ascontiguousarray(iv[keep], dtype=np.float64), att_len)
     # ---- linear heads (Exists / Xor / Equals) ----
     n_head = {}
     for module in ('Exists', 'Xor', 'Equals'):
-        sel = [qi for qi, p in enumerate(packs) if module in p.head]
-        if not sel:
+        if module not in gb.head:
             continue
         if not model.config['have_pretrain_head']:
             raise RuntimeError('%s loss needs have_pretrain_head (modules.py)' % module)
         if model.submodules[module].pretrain_head.weight.grad is None:
             raise RuntimeError('pretrain head of %s has no .grad buffer (use stair_amd.train.Trainer)' % module)
-        tok = np.concatenate([packs[qi].head[module][0] + base[qi] for qi in sel])
+        hq, hpos, hlab = gb.head[module]
+        tok = hpos + base[hq]
         n_head[module] = len(tok)
-        stage(module, i32(slot_t[tok]), i32(np.concatenate([packs[qi].head[module][1] for qi in sel])))
+        stage(module, i32(slot_t[tok]), i32(hlab))
     # ---- contrastive (Filter / ToAction / Superlative) ----
-    c_slot, c_wid, c_name, entries = [], [], [], []
-    for qi, p in enumerate(packs):
-        if not p.cont:
-            continue
-        gpos = window_base + rank + qi * world
-        wid = gpos // window if window else 0
-        for pos, module, gold in p.cont:
-            s_ = int(slot_t[base[qi] + pos])
-            for class_name, emb in gold:
-                c_slot.append(s_); c_wid.append(wid); c_name.append(class_name)
-                entries.append((gpos, class_name, emb))
+    n_cg = int(gb.cg_q.size)
+    c_slot = slot_t[base[gb.cg_q] + gb.cg_pos] if n_cg else np.zeros(0, dtype=np.int64)
+    c_gpos = window_base + rank + gb.cg_q * world
+    c_wid = (c_gpos // window if window else np.zeros_like(c_gpos))
+    c_name = gb.cg_name
     table_mode = class_table is not None
     if table_mode:
-        G_ = int(global_batch if global_batch is not None else len(questions) * world)
+        G_ = int(global_batch if global_batch is not None else gb.n * world)
         wid0 = window_base // window if window else 0
         n_win = ((window_base + G_ - 1) // window if window else 0) - wid0 + 1
         presence = np.zeros((n_win, len(class_table)), dtype=np.float32)
-        try:
-            c_cls = [class_table.index[n] for n in c_name]
-        except KeyError as e:
-            raise KeyError('class %s is not in the ClassTable (build it from the whole dataset: ClassTable.from_questions)' % e)
-        if c_slot:
-            presence[np.asarray(c_wid) - wid0, np.asarray(c_cls)] = 1.0
-        stage('cont', i32(c_slot), i32(c_cls), i32(np.asarray(c_wid, dtype=np.int64) - wid0), presence.reshape(-1))
-    cw = contrastive_windows(entries, window, world) if ((c_slot or world > 1) and not table_mode) else None
+        if gb.cg_cls is not None and gb.class_table is class_table:
+            c_cls = gb.cg_cls
+        else:
+            try:
+                c_cls = np.asarray([class_table.index[n] for n in c_name], dtype=np.int64)
+            except KeyError as e:
+                raise KeyError('class %s is not in the ClassTable (build it from the whole dataset: ClassTable.from_questions)' % e)
+        if n_cg:
+            presence[c_wid - wid0, c_cls] = 1.0
+        stage('cont', i32(c_slot), i32(c_cls), i32(c_wid - wid0), presence.reshape(-1))
+    entries = [] if table_mode else [(int(g), n, e) for g, n, e in zip(c_gpos, c_name, gb.cg_emb)]
+    c_slot, c_wid = (c_slot, c_wid) if table_mode else (c_slot.tolist(), c_wid.tolist())
+    cw = contrastive_windows(entries, window, world) if ((n_cg or world > 1) and not table_mode) else None
     lens, max_classes = [], 0
-    if c_slot and not table_mode:
+    if n_cg and not table_mode:
         names, embs, rows, win_range, slot_of = cw
         embs = [np.asarray(e, dtype=np.float32).reshape(-1, model.config['text_size']) for e in embs]
         lens = [int(e.shape[0]) for e in embs]
@@ -358,23 +433,23 @@ def prepare_module_losses(model, res, questions, pretrain_modules=CRITERION_MODU
               i32([win_range[w][0] for w in c_wid]), i32([win_range[w][1] for w in c_wid]), rows,
               i32(np.concatenate([[0], np.cumsum(lens)])), np.ascontiguousarray(np.concatenate(embs)))
     qf_ = res.question_frames
-    ff_items = [(int(slot_t[base[qi] + pos]), gold, int(qf_[qi]) if qf_ is not None else T) for qi, p in enumerate(packs) for pos, gold in p.ff]
+    ff_items = [(int(slot_t[base[qi] + pos]), gold, int(qf_[qi]) if qf_ is not None else T) for qi, pos, gold in gb.ff]
     # ---- ONE upload ----
     staging = model.__dict__.setdefault('_loss_staging', _Staging())
     d = staging.upload(up, dev) if up else []
     got = lambda key: d[plan[key][0]: plan[key][0] + plan[key][1]]
-    prep = {'n_att': n_att, 'n_head': n_head, 'n_cont': len(c_slot), 'ff_items': ff_items, 'max_classes': max_classes,
+    prep = {'n_att': n_att, 'n_head': n_head, 'n_cont': n_cg, 'ff_items': ff_items, 'max_classes': max_classes,
             'att': got('att') if n_att else None, 'head': {m: got(m) for m in n_head}}
     if table_mode:
         slot_d, cls_d, win_d, pres_d = got('cont')
         if world > 1:                       # the pools of the GLOBAL windows: one small device all-reduce, no host round trip
             import torch.distributed as dist
             dist.all_reduce(pres_d, op=dist.ReduceOp.SUM)
-        if c_slot:
+        if n_cg:
             x, seq_off, max_len = class_table.device_rows(dev, model.config['text_size'])
             _, h_n = ops.lstm_bidir(x, seq_off, max_len, [w.detach() for w in model._lstm_weights('text_encoder')])
             prep['cont_table'] = (slot_d, cls_d, win_d, pres_d, ops.l2normalize(h_n), len(class_table))
-    elif c_slot:
+    elif n_cg:
         # class representations: text encoder without gradient + L2Normalize (module_net.py:78-89); they depend on the weights
         # only, so they are encoded here, ahead of the forward pass, on the same stream
         slot_d, pos_d, ws_d, wc_d, rows_d, seq_off, x = got('cont')

@@ -215,8 +215,9 @@ class Trainer:
 
     def step(self, programs, spans, video, question, q_lens, answers, global_batch=None, questions=None, video_index=None,
              video_len=None):
-        """One optimizer step over this rank's shard of a window.  `questions` (the dicts, with
-        'sg_res_by_step') switches the per-module intermediate losses on (train_module.py:351-373, 388-406).
+        """One optimizer step over this rank's shard of a window.  `questions` -- the dicts, with 'sg_res_by_step', or their
+        losses.GoldBatch (losses.collate_gold: the data loader's collate step; the per-question bookkeeping then costs the stepping
+        process nothing) -- switches the per-module intermediate losses on (train_module.py:351-373, 388-406).
         video_index: questions that share a clip (see VideoNMN.run_programs).
         Returns (per-question decoder CE of the local shard, BatchResult)."""
         from . import losses as L
@@ -237,7 +238,10 @@ class Trainer:
             answers = torch.where(torch.tensor([g > self.after_iters for g in gstep], device=answers.device), answers,
                                   torch.full_like(answers, -1))
         if questions is not None and gstep[-1] >= self.before_iters:
-            questions = [q if g < self.before_iters else dict(q, sg_res_by_step={}) for q, g in zip(questions, gstep)]
+            if isinstance(questions, L.GoldBatch):
+                questions = questions.select([g < self.before_iters for g in gstep])
+            else:
+                questions = [q if g < self.before_iters else dict(q, sg_res_by_step={}) for q, g in zip(questions, gstep)]
         drop = (self.dropout, self.dropout_seed + self.iters * self.world + self.rank) if self.dropout > 0 else None
         supervised = questions is not None and self.module_loss_weight != 0
         prep = {}

@@ -745,6 +745,46 @@ def test_contrastive_pools_from_a_class_table_equal_the_pooled_lists(matmul):
         assert float((g - out['table'][1][n]).abs().max()) <= 2e-5 * max(float(g.abs().max()), 1e-3), n
 
 
+def test_collated_gold_batch_gives_the_step_of_the_question_dicts():
+    """losses.collate_gold (the loader's collate step: the batch's gold intermediates as flat arrays) against the list of question
+    dicts: the same index / target arrays reach the same loss kernels -- every criterion value and every parameter gradient bit for
+    bit --, with pooled class lists and with a class table; GoldBatch.select drops the gold of the masked questions."""
+    from stair_amd import losses as L
+    z, meta = load_golden('tiny_conv')
+    config, T = meta['config'], meta['T']
+    qs = _with_gold(config, 3, [question_for(meta, q) for q in meta['questions']] +
+                    [synth.make_question(config, 8, 50 + i, form=f, T=T) for i, f in enumerate(synth.ALL_FORMS)], T)
+    table = L.ClassTable.from_questions(qs)
+    for tab in (None, table):
+        out = {}
+        for mode in ('dicts', 'collated'):
+            model = _model(config, meta['seed'])
+            model.pretrain_modules = set(L.CRITERION_MODULES)
+            for p in model.parameters():
+                p.grad = torch.zeros_like(p)
+            progs, spans, video, question, q_lens, answers = _pack(model, qs)
+            res = model.run_programs(progs, spans, video, question, q_lens, train=True)
+            res.zero_grad_arenas()
+            gold = qs if mode == 'dicts' else L.collate_gold(qs, class_table=tab)
+            losses, _ = L.apply_module_losses(model, res, gold, 1.0 / len(qs), window=7, class_table=tab)
+            out[mode] = ({k: v.cpu().clone() for k, v in losses.items()},
+                         [res.grad_arena(k).clone() for k in ('vec', 'att')])
+        assert set(out['dicts'][0]) == set(out['collated'][0]) and len(out['dicts'][0]) >= 3
+        for k, v in out['dicts'][0].items():
+            assert torch.equal(v, out['collated'][0][k]), k
+        # (the loss kernels add into the arenas with float atomics: equal up to the order of the sums)
+        for a, b in zip(out['dicts'][1], out['collated'][1]):
+            assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(a.abs().max()))
+    gb = L.collate_gold(qs, class_table=table)
+    keep = [i % 2 == 0 for i in range(len(qs))]
+    half = gb.select(keep)
+    ref = L.collate_gold([q if k else dict(q, sg_res_by_step={}) for q, k in zip(qs, keep)], class_table=table)
+    assert np.array_equal(half.att_q, ref.att_q) and np.array_equal(half.att_pos, ref.att_pos) and np.array_equal(half.att_iv, ref.att_iv)
+    assert half.cg_name == ref.cg_name and np.array_equal(half.cg_cls, ref.cg_cls) and set(half.head) == set(ref.head)
+    for m in half.head:
+        assert all(np.array_equal(a, b) for a, b in zip(half.head[m], ref.head[m]))
+
+
 @pytest.mark.parametrize('name', ['tiny_conv', 'full'])
 def test_common_subexpression_sharing_keeps_values_and_gradients(name, matmul):
     """Clip-level common subexpressions computed once (stair_plan_build: a node of clip-only operands is aliased by every later

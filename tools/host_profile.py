@@ -23,15 +23,17 @@ q_lens = [q['question'].shape[0] for q in qs]
 question = torch.randn(sum(q_lens), 300, device=dev)
 answers = torch.tensor([q['answer'] for q in qs], dtype=torch.int32, device=dev)
 progs = [q['nmn_program_list'] for q in qs]; spans = [q['prog_str_to_question_tokens'] for q in qs]
-tr = Trainer(m, dropout=0.0)
+tr = Trainer(m, dropout=0.0, class_table=L.ClassTable.from_questions(qs))
+gold = L.collate_gold(qs, class_table=tr.class_table)          # the loader's collate step
+import gc; gc.freeze()
 for sup in (False, True):
     for _ in range(2):
-        tr.step(progs, spans, video, question, q_lens, answers, questions=qs if sup else None)
+        tr.step(progs, spans, video, question, q_lens, answers, questions=gold if sup else None)
     torch.cuda.synchronize()
     pr = cProfile.Profile(); pr.enable()
     for _ in range(3):
-        tr.step(progs, spans, video, question, q_lens, answers, questions=qs if sup else None)
+        tr.step(progs, spans, video, question, q_lens, answers, questions=gold if sup else None)
     torch.cuda.synchronize()
     pr.disable()
-    s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(22)
-    print('==== supervised =', sup, ' (3 steps)'); print('\n'.join(s.getvalue().splitlines()[:45]))
+    s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(40)
+    print('==== supervised =', sup, ' (3 steps)'); print('\n'.join(s.getvalue().splitlines()[:64]))

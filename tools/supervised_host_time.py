@@ -1,5 +1,5 @@
 import sys, time, os
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from stair_amd import spec, synth, losses as L
 from stair_amd.module_net import VideoNMN
@@ -22,14 +22,15 @@ question = torch.randn(sum(q_lens), 300, device=dev)
 answers = torch.tensor([q['answer'] for q in qs], dtype=torch.int32, device=dev)
 progs = [q['nmn_program_list'] for q in qs]; spans = [q['prog_str_to_question_tokens'] for q in qs]
 import gc; gc.freeze()
-tr = Trainer(m, dropout=0.0)
-for sup in (False, True):
+tr = Trainer(m, dropout=0.0, class_table=L.ClassTable.from_questions(qs))
+gold = {'dicts': qs, 'collated': L.collate_gold(qs, class_table=tr.class_table)}
+for sup in (False, 'dicts', 'collated'):
     for _ in range(3):
-        tr.step(progs, spans, video, question, q_lens, answers, questions=qs if sup else None)
+        tr.step(progs, spans, video, question, q_lens, answers, questions=gold[sup] if sup else None)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(10):
-        tr.step(progs, spans, video, question, q_lens, answers, questions=qs if sup else None)
+        tr.step(progs, spans, video, question, q_lens, answers, questions=gold[sup] if sup else None)
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
