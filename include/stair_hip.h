@@ -351,6 +351,9 @@ typedef struct stair_vec_problem {
     float *out; const int32_t *io; int64_t ldo; int32_t accumulate;
     float *in_save; int64_t ld_save;
     int32_t adj; const float *fa, *fb; const int32_t *fia, *fib; int64_t ldfa, ldfb; float *ga, *gb;
+    const int32_t *gia, *gib; /* optional: the gradient rows ga + gia[i] * ldfa, gb + gib[i] * ldfb when they are not the rows fia / fib
+                                 (a plan sends all but one same-level reader of a shared operand to private staging rows, so that every
+                                 address receives at most one atomic add per launch: stair_plan_backward's deterministic fan-in) */
 } stair_vec_problem;
 int stair_vec_group(const stair_vec_problem *problems, int32_t count, stair_stream stream);
 
@@ -487,6 +490,10 @@ typedef struct stair_plan_info {
     int32_t n_vec, n_map, n_att, n_tok_rows;
     int32_t n_nodes, n_launches, n_levels, n_questions, T;
     int32_t n_aliased; /* program nodes that alias another node's value (common subexpressions, see STAIR_PLAN_NO_CSE) */
+    int32_t n_vec_stage, n_map_stage, n_att_stage; /* STAIR_PLAN_TRAIN: staging rows / tiles / rows behind the gradient arenas.  A value that
+                           several nodes of ONE level read gets one staging slot per extra reader; stair_plan_backward adds them to the
+                           value's gradient slot in a fixed order before it walks the level that produced the value, so that no address
+                           receives two atomic adds from one launch (run-to-run reproducible sums) */
 } stair_plan_info;
 int stair_plan_get_info(const stair_plan *plan, stair_plan_info *info);
 

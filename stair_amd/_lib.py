@@ -102,7 +102,7 @@ class VecProblem(C.Structure):
                 ('out', C.c_void_p), ('io', C.c_void_p), ('ldo', C.c_int64), ('accumulate', C.c_int32),
                 ('in_save', C.c_void_p), ('ld_save', C.c_int64),
                 ('adj', C.c_int32), ('fa', C.c_void_p), ('fb', C.c_void_p), ('fia', C.c_void_p), ('fib', C.c_void_p),
-                ('ldfa', C.c_int64), ('ldfb', C.c_int64), ('ga', C.c_void_p), ('gb', C.c_void_p)]
+                ('ldfa', C.c_int64), ('ldfb', C.c_int64), ('ga', C.c_void_p), ('gb', C.c_void_p), ('gia', C.c_void_p), ('gib', C.c_void_p)]
 
 
 class PlanInfo(C.Structure):
@@ -111,7 +111,7 @@ class PlanInfo(C.Structure):
                 ('gvec_off', C.c_int64), ('gmap_off', C.c_int64), ('gatt_off', C.c_int64), ('status_off', C.c_int64),
                 ('n_vec', C.c_int32), ('n_map', C.c_int32), ('n_att', C.c_int32), ('n_tok_rows', C.c_int32),
                 ('n_nodes', C.c_int32), ('n_launches', C.c_int32), ('n_levels', C.c_int32), ('n_questions', C.c_int32),
-                ('T', C.c_int32), ('n_aliased', C.c_int32)]
+                ('T', C.c_int32), ('n_aliased', C.c_int32), ('n_vec_stage', C.c_int32), ('n_map_stage', C.c_int32), ('n_att_stage', C.c_int32)]
 
 
 # every symbol include/stair_hip.h declares: (name, restype, argtypes)

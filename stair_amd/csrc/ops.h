@@ -66,6 +66,7 @@ int launch_mask_relu(float *dst, const float *G, int64_t g_gs, const int32_t *g_
                      const int32_t *y_idx, int groups, int rowlen, hipStream_t s, float scale = 1.0f);
 int launch_bcast_mask_relu(float *dst, const float *dsum, const float *Y, int groups, int T, int H, hipStream_t s,
                            float scale = 1.0f, const int32_t *len = nullptr);
+int launch_grad_fanin(const int32_t *tab, int n, float *gvec, float *gmap, float *gatt, int H, int T, hipStream_t s);
 int launch_scatter_add_rows(float *dst, const int32_t *dst_idx, const float *src, int n, int len, float scale, hipStream_t s);
 int launch_pack_bwd(int mode, const float *A, const int32_t *ia, const float *B, const int32_t *ib, const float *g,
                     float *dA, float *dB, int n, int H, hipStream_t s);
@@ -73,19 +74,20 @@ int launch_span_mean_bwd(float *dtok, int64_t ld, const int32_t *start, const in
                          const int32_t *out_idx, int n, int H, hipStream_t s);
 int launch_cosine_attn_bwd(const float *F, int64_t f_gs, const int32_t *f_idx, const float *Kmat, const int32_t *k_idx,
                            const float *datt, const int32_t *out_idx, float *dF, float *dK, int npairs, int T, int H,
-                           hipStream_t s);
+                           hipStream_t s, const int32_t *gf_idx = nullptr, const int32_t *gk_idx = nullptr);
 int launch_cosine_attn_bwd_grouped(const float *F, const float *Kmat, const float *score, const int32_t *score_idx,
                                    const float *dscore, const int32_t *dscore_idx, const int32_t *pair_start,
                                    const int32_t *pair_cnt, float *dF, float *dK, float *nf_ws, float *nk_ws, int n, int npairs,
                                    int T, int H, int ka_max, hipStream_t s);
 int launch_temporal_relate_bwd(const float *att, const int32_t *att_idx, const int32_t *att_k, const float *drel,
                                const int32_t *rel_idx, float *datt, int n, int T, int mode, int conv, int ksize,
-                               const float *const w[6], float *const dw[6], hipStream_t s, const int32_t *len = nullptr);
+                               const float *const w[6], float *const dw[6], hipStream_t s, const int32_t *len = nullptr,
+                               const int32_t *gatt_idx = nullptr);
 int launch_layernorm_bwd(const float *dOut, int64_t g_gs, const int32_t *g_idx, const float *Y, int n, int T, int H,
                          const float *gamma, float eps, float *dZ, float *stats, float *dgamma, float *dbeta, hipStream_t s,
                          float scale = 1.0f);
 int launch_rowscale_bwd(const float *G, const float *X, int64_t x_gs, const int32_t *x_idx, const float *rs, int64_t rs_gs,
-                        const int32_t *rs_idx, float *dX, float *drs, int n, int T, int H, hipStream_t s);
+                        const int32_t *rs_idx, float *dX, float *drs, int n, int T, int H, hipStream_t s, const int32_t *gx_idx = nullptr);
 int launch_rowdot_sigmoid_bwd(const float *dOut, int64_t o_gs, const int32_t *o_idx, const float *A, int64_t a_gs,
                               const int32_t *a_idx, const float *w, float *dXdst, int add_mode, float *dpre_out,
                               float *dextra, int n, int T, int H, hipStream_t s, float keep = 1.0f);
@@ -98,16 +100,17 @@ int launch_weighted_colsum(const float *X, int64_t ld, const int32_t *x_idx, con
 int launch_axpy_rows(float *dV, const int32_t *idx, const float *scale, const float *w, int n, int H, hipStream_t s);
 int launch_sum_all(const float *x, float *out, int n, hipStream_t s);
 int launch_relate_softmax_bwd(const float *att, float *datt, const int32_t *in_idx, const int32_t *out_idx, float *dbeta,
-                              float sign, int n, int T, hipStream_t s, const int32_t *len = nullptr);
+                              float sign, int n, int T, hipStream_t s, const int32_t *len = nullptr, const int32_t *gin_idx = nullptr);
 int launch_eltwise_bwd(int mode, const float *base, float *dbase, const int32_t *ia, const int32_t *ib, const int32_t *io,
-                       int n, int len, hipStream_t s);
+                       int n, int len, hipStream_t s, const int32_t *gia = nullptr, const int32_t *gib = nullptr);
 int launch_attnvideo_bwd(const float *map, float *dmap, const float *att, float *datt, const int32_t *in_idx,
-                         const int32_t *att_idx, const int32_t *out_idx, int n, int T, int H, hipStream_t s);
+                         const int32_t *att_idx, const int32_t *out_idx, int n, int T, int H, hipStream_t s,
+                         const int32_t *gin_idx = nullptr, const int32_t *gatt_idx = nullptr);
 int launch_choose_bwd(const float *vec, float *dvec, const int32_t *k1, const int32_t *k2, const int32_t *q,
-                      const int32_t *out, int n, int H, hipStream_t s);
+                      const int32_t *out, int n, int H, hipStream_t s, const int32_t *gk1 = nullptr, const int32_t *gk2 = nullptr);
 int launch_superlative_pool_bwd(const float *S, const float *rowbase, float *drowbase, const int32_t *row_id,
                                 const int32_t *row_start, const int32_t *row_cnt, int is_min, const float *dpre, float *dS,
-                                int n, int T, int H, hipStream_t s, const int32_t *len = nullptr);
+                                int n, int T, int H, hipStream_t s, const int32_t *len = nullptr, const int32_t *g_row_id = nullptr);
 int launch_scale_rows(float *G, const float *rs, int64_t rows, int H, hipStream_t s);
 int launch_ce_loss(const float *logits, const int32_t *answers, float scale, float *loss, float *dlogits, int n, int A,
                    hipStream_t s);

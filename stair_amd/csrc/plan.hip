@@ -272,6 +272,11 @@ struct Bucket {
     int nrows = 0;      // secondary count (Localize pairs / Superlative action rows)
     std::vector<int32_t> col[8];
     int64_t off[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // offsets into the device idx buffer
+    // training: where the GRADIENT of operand column c goes (same slot numbering; an operand slot that has several consumers at one
+    // level sends all but the first to private staging slots behind the gradient arena, see build_grad_fanin); goff[c] = off[c]
+    // where a column has no redirected copy
+    std::vector<int32_t> gcol[8];
+    int64_t goff[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // float offsets of this bucket's intermediates.  Inference: all buckets share one scratch set;
     // training: private regions, kept until stair_plan_backward has consumed them.
     int64_t svA = 0, svB = 0, svK = 0, svCat = 0, svHid = 0, svRs = 0, svSup = 0, svExtra = 0;
@@ -398,6 +403,14 @@ struct stair_plan {
     std::vector<int32_t> vlen;      // frames per clip [n_vid]
     int n_vec = 0, n_map = 0, n_att = 0, n_aliased = 0;     // n_aliased: nodes that share another node's value (common subexpressions)
     int maxI = 0, maxV = 0, maxK = 0, maxSupRows = 0, n_levels = 0;
+    // deterministic gradient fan-in (training plans): staging slots behind the gradient arenas and, per producer level, the table of
+    // (kind, destination, first staging slot, count, rows) that stair_plan_backward sums in order before it walks that level
+    int n_vec_stage = 0, n_map_stage = 0, n_att_stage = 0;
+    std::vector<int32_t> groots;                 // gradient rows of the program roots (decoder)
+    int64_t off_groots = 0;
+    std::vector<int32_t> fanin;                  // 5 ints per entry
+    std::vector<int> fanin_first, fanin_count;   // per level
+    int64_t off_fanin = 0;
     int64_t coop_bytes = 0;
     // training: weight-gradient products grouped per WEIGHT (WF_* ids).  Every bucket that uses a weight writes its dZ into its
     // block of wg_dz[w]; the matching X operand is the input tiles gathered through wg_off_idx[w] (first-layer weights) or the
@@ -427,6 +440,131 @@ int64_t ctx_weight_floats(const stair_ctx *ctx) {
     int64_t t = 0;
     for (int64_t v : ctx->numel) t += align_up(v, 64);
     return t;
+}
+
+// Deterministic fan-in of the gradient arenas.  A value slot read by several nodes receives one gradient contribution per reader; the
+// readers add with float atomics, so the order inside ONE launch is not defined.  Launches follow each other on the stream, hence an
+// address that gets at most one contribution per launch has a defined sum.  Readers of a slot at different program levels are in
+// different launches; readers at the SAME level may share one (all tile chains of a level are one launch, so are the grouped
+// vector-level problems, and two instances of one bucket share every kernel of the bucket).  So: per (slot, level) the first reader
+// adds into the slot itself, the j-th (j >= 1) into staging slot j - 1 of that slot (staging slots are shared across levels: different
+// launches again), and before the backward pass walks the level that PRODUCED the slot the staging slots are added to it in index
+// order by one small kernel (grad_fanin_kernel).  The columns below replace the operand columns wherever a gradient is scattered.
+struct GEdge { int32_t slot; int level; int bidx, col, pos; int width; };
+enum { FAN_VEC = 0, FAN_MAP = 1, FAN_ATT = 2 };
+
+// vec_fix: where a vec-arena staging index was written with the provisional numbering n_vec + j; the layout pass moves the vec staging
+// rows behind the map staging tiles (the gradient block mirrors [vec arena | map arena]) and adds the difference (fix_vec_staging)
+int build_grad_fanin(stair_plan *pl, int T, std::vector<int32_t *> &vec_fix) {
+    std::vector<GEdge> ev, em, ea;
+    vec_fix.clear();
+    const int top = pl->n_levels;                                         // the decoder reads the roots "above" every level
+    for (int bi = 0; bi < (int)pl->buckets.size(); ++bi) {
+        Bucket &b = pl->buckets[bi];
+        for (int c = 0; c < 8; ++c) b.gcol[c].clear();
+        auto all = [&](std::vector<GEdge> &dst, int c, int width = 1, const std::vector<int32_t> *w = nullptr) {
+            b.gcol[c] = b.col[c];
+            for (int p = 0; p < (int)b.col[c].size(); ++p) dst.push_back({b.col[c][p], b.level, bi, c, p, w ? (*w)[p] : width});
+        };
+        switch (b.op) {
+            case STAIR_OP_AND: case STAIR_OP_XORFRAME:
+                if (b.sub == STAIR_VAL_VEC) { all(ev, 0); all(ev, 1); } else { all(ea, 0); all(ea, 1); }
+                break;
+            case STAIR_OP_ATTNVIDEO: all(em, 0); all(ea, 1); break;
+            case STAIR_OP_CHOOSE: all(ev, 0); all(ev, 1); break;
+            case STAIR_OP_COMPARE: case STAIR_OP_EQUALS: case STAIR_OP_XOR: case STAIR_OP_TOACTION: case STAIR_OP_EXISTS:
+                all(ev, 0); all(ev, 1); break;
+            case STAIR_OP_EXISTSFRAME: all(ev, 0); all(em, 1); break;
+            case STAIR_OP_FILTER: all(em, 0); break;
+            case STAIR_OP_FILTERFRAME: all(em, 0); if (b.variant == 0) all(ev, 1); break;
+            case STAIR_OP_HASITEM: all(em, 0); break;
+            case STAIR_OP_LOCALIZE: all(em, 0); all(ev, 2); break;
+            case STAIR_OP_RELATE: all(ea, 0); break;
+            case STAIR_OP_TEMPORAL: all(em, 0); all(ea, 1, 1, &b.col[2]); break;
+            case STAIR_OP_SUPERLATIVE: {
+                all(em, 0);
+                // action rows (before they are resolved to global row ids): >= 0 a vec row, < 0 row a of map tile -(rid + 1) / T;
+                // a map tile is ONE operand of its instance (edge at its first row)
+                b.gcol[4] = b.col[4];
+                for (int p = 0; p < (int)b.col[4].size(); ++p) {
+                    const int rid = b.col[4][p];
+                    if (rid >= 0) ev.push_back({rid, b.level, bi, 4, p, 1});
+                    else if ((-rid - 1) % T == 0) em.push_back({(-rid - 1) / T, b.level, bi, 4, p, 1});
+                }
+                break;
+            }
+            default: break;
+        }
+    }
+    pl->groots = pl->roots;
+    for (int q = 0; q < (int)pl->roots.size(); ++q) ev.push_back({pl->roots[q], top, -1, 0, q, 1});
+
+    // producer level of every slot (clip tiles and anything not produced by a bucket: 0)
+    std::vector<int> lv(pl->n_vec, 0), lm(pl->n_map, 0), la(std::max(pl->n_att, 1), 0);
+    for (const Node &nd : pl->nodes) {
+        if (nd.bop < 0) continue;
+        if (nd.kind == STAIR_VAL_VEC) lv[nd.slot] = nd.level;
+        else if (nd.kind == STAIR_VAL_MAP) lm[nd.slot] = nd.level;
+        else if (nd.kind == STAIR_VAL_ATT || nd.kind == STAIR_VAL_FRAME) la[nd.slot] = nd.level;
+    }
+    pl->fanin.clear();
+    std::vector<std::vector<int32_t>> per_level(pl->n_levels + 1);
+    auto assign = [&](std::vector<GEdge> &E, int kind, int n_slots, int &n_stage, const std::vector<int> &plevel) {
+        std::sort(E.begin(), E.end(), [](const GEdge &a, const GEdge &b) {
+            return std::tie(a.slot, a.level, a.bidx, a.col, a.pos) < std::tie(b.slot, b.level, b.bidx, b.col, b.pos);
+        });
+        n_stage = 0;
+        for (size_t i = 0; i < E.size();) {
+            size_t e = i;
+            while (e < E.size() && E[e].slot == E[i].slot) ++e;
+            const int width = E[i].width;                                // rows per operand (Localize output read by Temporal: K)
+            int most = 0;
+            for (size_t a = i; a < e;) {                                  // per level: reader j -> staging j - 1
+                size_t z = a;
+                while (z < e && E[z].level == E[a].level) ++z;
+                most = std::max(most, (int)(z - a) - 1);
+                a = z;
+            }
+            const int base = n_slots + n_stage;                          // first staging slot (row, for the att arena) of this slot
+            for (size_t a = i; a < e;) {
+                size_t z = a;
+                while (z < e && E[z].level == E[a].level) ++z;
+                for (size_t k = a + 1; k < z; ++k) {
+                    const GEdge &g = E[k];
+                    const int32_t target = base + (int)(k - a - 1) * width;
+                    if (g.bidx < 0) { pl->groots[g.pos] = target; vec_fix.push_back(&pl->groots[g.pos]); }
+                    else if (g.col == 4 && pl->buckets[g.bidx].op == STAIR_OP_SUPERLATIVE) {
+                        std::vector<int32_t> &gc = pl->buckets[g.bidx].gcol[4];
+                        const std::vector<int32_t> &vc = pl->buckets[g.bidx].col[4];
+                        if (kind == FAN_VEC) { gc[g.pos] = target; vec_fix.push_back(&gc[g.pos]); }
+                        else for (int t = 0; t < T && g.pos + t < (int)vc.size() && vc[g.pos + t] == -(g.slot * T + t) - 1; ++t)
+                            gc[g.pos + t] = -(target * T + t) - 1;                                  // the instance's rows of the tile follow each other
+                    } else {
+                        pl->buckets[g.bidx].gcol[g.col][g.pos] = target;
+                        if (kind == FAN_VEC) vec_fix.push_back(&pl->buckets[g.bidx].gcol[g.col][g.pos]);
+                    }
+                }
+                a = z;
+            }
+            if (most > 0) {
+                const int L = std::min(std::max(plevel[E[i].slot], 0), pl->n_levels);
+                per_level[L].insert(per_level[L].end(), {kind, E[i].slot, base, most, width});
+                n_stage += most * width;
+            }
+            i = e;
+        }
+    };
+    assign(ev, FAN_VEC, pl->n_vec, pl->n_vec_stage, lv);
+    assign(em, FAN_MAP, pl->n_map, pl->n_map_stage, lm);
+    assign(ea, FAN_ATT, pl->n_att, pl->n_att_stage, la);
+    pl->fanin_first.assign(pl->n_levels + 1, 0);
+    pl->fanin_count.assign(pl->n_levels + 1, 0);
+    for (int L = 0; L <= pl->n_levels; ++L) {
+        pl->fanin_first[L] = (int)pl->fanin.size() / 5;
+        pl->fanin_count[L] = (int)per_level[L].size() / 5;
+        pl->fanin.insert(pl->fanin.end(), per_level[L].begin(), per_level[L].end());
+    }
+    return 0;
 }
 
 struct Builder {
@@ -873,10 +1011,15 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
         o += nfloats;
         return r;
     };
+    std::vector<int32_t *> vec_fix;
+    if (pl->train) {
+        if (int rc = build_grad_fanin(pl, T, vec_fix)) return rc;
+    }
     // idx buffer placed first: its size is known only after bucket columns are pushed -> reserve now
     int64_t idx_ints = (int64_t)pl->idx.size();
     for (Bucket &b : pl->buckets)
-        for (int c = 0; c < 8; ++c) idx_ints += align_up((int64_t)b.col[c].size(), 4);
+        for (int c = 0; c < 8; ++c) idx_ints += align_up((int64_t)b.col[c].size(), 4) + align_up((int64_t)b.gcol[c].size(), 4);
+    if (pl->train) idx_ints += align_up((int64_t)pl->groots.size(), 4) + align_up((int64_t)pl->fanin.size(), 4);
     // per-weight gather columns of the deferred weight-gradient products: the input tile of every instance that uses the weight
     // as a first layer, bucket after bucket (Temporal: also the rows of its per-frame scale)
     std::vector<int32_t> wg_idx[WF_COUNT], wg_rs[WF_COUNT];
@@ -894,12 +1037,27 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
     pl->o_vec = take((int64_t)pl->n_vec * H, H);
     pl->o_map = take((int64_t)pl->n_map * T * H, H);
     // resolve Superlative action row ids into global row ids (units of H floats from workspace base)
+    if (pl->train && !vec_fix.empty()) {
+        // vec staging rows live behind the map staging tiles: as vec-row indices relative to the gradient block's vec base
+        const int64_t first = ((pl->o_map - pl->o_vec) + (int64_t)(pl->n_map + pl->n_map_stage) * T * H) / H;
+        STAIR_CHECK(first + pl->n_vec_stage < (1ll << 31), "batch too large for 32-bit row ids");
+        const int32_t delta = (int32_t)(first - pl->n_vec);
+        for (int32_t *v : vec_fix) *v += delta;
+        for (size_t e = 0; e + 4 < pl->fanin.size(); e += 5)
+            if (pl->fanin[e] == FAN_VEC) pl->fanin[e + 2] += delta;
+    }
     for (Bucket &b : pl->buckets)
-        if (b.op == STAIR_OP_SUPERLATIVE)
+        if (b.op == STAIR_OP_SUPERLATIVE) {
             for (int32_t &rid : b.col[4]) rid = rid >= 0 ? (int32_t)(pl->o_vec / H + rid) : (int32_t)(pl->o_map / H + (-rid - 1));
-    STAIR_CHECK((pl->o_map + (int64_t)pl->n_map * T * H) / H < (1ll << 31), "batch too large for 32-bit row ids");
+            for (int32_t &rid : b.gcol[4]) rid = rid >= 0 ? (int32_t)(pl->o_vec / H + rid) : (int32_t)(pl->o_map / H + (-rid - 1));
+        }
+    STAIR_CHECK((pl->o_map + (int64_t)(pl->n_map + pl->n_map_stage) * T * H) / H + pl->n_vec_stage < (1ll << 31), "batch too large for 32-bit row ids");
     for (Bucket &b : pl->buckets)
-        for (int c = 0; c < 8; ++c) b.off[c] = push(b.col[c]);
+        for (int c = 0; c < 8; ++c) {
+            b.off[c] = push(b.col[c]);
+            b.goff[c] = b.gcol[c].empty() ? b.off[c] : push(b.gcol[c]);
+        }
+    if (pl->train) { pl->off_groots = push(pl->groots); pl->off_fanin = push(pl->fanin); }
     if (pl->train)
         for (int w = 0; w < WF_COUNT; ++w) { pl->wg_off_idx[w] = push(wg_idx[w]); pl->wg_off_rs[w] = push(wg_rs[w]); }
     STAIR_CHECK((int64_t)pl->idx.size() == idx_ints, "internal: idx size");
@@ -1042,8 +1200,9 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
         // everything from here to o_zero_end is cleared at the start of every backward pass
         pl->o_zero_beg = align_up(o, 64);
         o = pl->o_zero_beg;
-        pl->o_gblock = take(pl->o_map + (int64_t)pl->n_map * T * H - pl->o_vec, H);   // mirrors [vec arena .. map arena]
-        pl->o_gatt = take((int64_t)std::max(pl->n_att, 1) * T, 64);
+        // mirrors [vec arena .. map arena]; behind it the staging tiles and rows of the deterministic fan-in (build_grad_fanin)
+        pl->o_gblock = take(pl->o_map + (int64_t)(pl->n_map + pl->n_map_stage) * T * H - pl->o_vec + (int64_t)pl->n_vec_stage * H, H);
+        pl->o_gatt = take((int64_t)std::max(pl->n_att + pl->n_att_stage, 1) * T, 64);
         pl->o_gtok = take((int64_t)pl->rows_q * H, 64);
         pl->o_gqfeat = take((int64_t)n * H, 64);
         pl->o_zero_end = align_up(o, 64);
@@ -1083,6 +1242,7 @@ extern "C" int stair_plan_get_info(const stair_plan *pl, stair_plan_info *info) 
     for (const Bucket &b : pl->buckets) launches += b.cnt > 0;
     info->n_launches = launches; info->n_levels = pl->n_levels; info->n_questions = pl->n; info->T = pl->T;
     info->n_aliased = pl->n_aliased;
+    info->n_vec_stage = pl->n_vec_stage; info->n_map_stage = pl->n_map_stage; info->n_att_stage = pl->n_att_stage;
     return 0;
 }
 
@@ -2009,12 +2169,12 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
         return static_cast<const void *>(nullptr);
     };
     auto vg_adj = [&](int rows, const float *a, const int32_t *ia, const float *bmask, int pack, float in_scale, float *in_save, const Lin &l, int nseg,
-                      int adj, const int32_t *fia, const int32_t *fib) {
+                      int adj, const int32_t *fia, const int32_t *fib, const int32_t *gia, const int32_t *gib) {
         VgProblem q = {};
         q.kind = VG_ADJ; q.rows = rows; q.a = a; q.ia = ia; q.lda = H; q.b = bmask; q.ib = ia; q.ldb = H; q.pack = pack; q.in_scale = in_scale; q.kred = 512;
         q.in_save = in_save; q.ld_save = H;
         q.W = B.wt + B.wt_off[l.id]; q.ldw = H; q.N = nseg * H; q.adj = adj; q.wplanes = vslot(l);
-        q.fa = vec; q.fb = vec; q.fia = fia; q.fib = fib; q.ldfa = H; q.ldfb = H; q.ga = g_vec; q.gb = g_vec;
+        q.fa = vec; q.fb = vec; q.fia = fia; q.fib = fib; q.ldfa = H; q.ldfb = H; q.ga = g_vec; q.gb = g_vec; q.gia = gia; q.gib = gib;
         return q;
     };
     if (fused) {
@@ -2052,7 +2212,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
             VgProblem q0 = {};
             q0.kind = VG_ADJ; q0.rows = n; q0.a = gV0; q0.lda = 2 * H; q0.b = gV0 + H; q0.ldb = 2 * H; q0.pack = VG_IN_CAT2; q0.in_scale = 1.0f; q0.kred = 512;
             q0.W = B.wt + B.wt_off[W.dec0.id]; q0.ldw = 2 * H; q0.N = 2 * H; q0.adj = VG_IN_CAT2; q0.wplanes = WFT(WV_DEC0);
-            q0.fia = didx + pl->off_roots; q0.ldfa = H; q0.ldfb = H; q0.ga = g_vec; q0.gb = g_qfeat;
+            q0.fia = didx + pl->off_roots; q0.ldfa = H; q0.ldfb = H; q0.ga = g_vec; q0.gb = g_qfeat; q0.gia = didx + pl->off_groots;
             RUN(launch_vec_group(&q0, 1, s));
         } else {
         RUN(dense_bwd(B, dlogits, n, 1, A, 2 * H, hid, 2 * H, 2 * H, nullptr, W.dec3, gV0, 2 * H, 2 * H, nullptr, 0));
@@ -2072,6 +2232,8 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
         const int32_t *I0 = didx + b.off[0], *I1 = didx + b.off[1], *I2 = didx + b.off[2], *I3 = didx + b.off[3],
                       *I4 = didx + b.off[4], *I5 = didx + b.off[5];
         const int32_t *LEN = pl->ragged ? didx + b.off[6] : nullptr;
+        // where the gradients of the operand columns go: the operand slots themselves, or staging slots (build_grad_fanin)
+        const int32_t *G0 = didx + b.goff[0], *G1 = didx + b.goff[1], *G2 = didx + b.goff[2], *G4 = didx + b.goff[4];
         const float *svA = ws + b.svA, *svB = ws + b.svB, *svK = ws + b.svK, *svCat = ws + b.svCat, *svHid = ws + b.svHid;
         const float *svRs = ws + b.svRs, *svSup = ws + b.svSup;
         // dZ of the bucket's first / second tile layer: its block of the weight's region (the product with X is deferred), else scratch
@@ -2090,7 +2252,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
             a.n_layers = 2;
             a.W[0] = WFT(slot3); a.act[0] = 3; a.act_mask[0] = svA; a.act_scale = inv_keep; a.save[0] = gA;
             a.W[1] = WFT(slot0); a.act[1] = 0;
-            a.tail = STAIR_TILE_ACCUMULATE; a.out = g_map; a.out_gstride = TH; a.out_idx = I0;
+            a.tail = STAIR_TILE_ACCUMULATE; a.out = g_map; a.out_gstride = TH; a.out_idx = G0;
             chain_queue.push_back(a);
             return 0;
         };
@@ -2101,7 +2263,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
             if (relu_second) RUN(launch_mask_relu(gB, gB, TH, nullptr, svB, TH, nullptr, c, (int)TH, s, inv_keep));
             RUN(dense_bwd(B, gB, c, T, H, H, svA, H, TH, nullptr, l3, gA, H, TH, nullptr, 0));
             RUN(launch_mask_relu(gA, gA, TH, nullptr, svA, TH, nullptr, c, (int)TH, s, inv_keep));
-            RUN(dense_bwd(B, gA, c, T, H, H, map, H, TH, I0, l0, g_map, H, TH, I0, 1));
+            RUN(dense_bwd(B, gA, c, T, H, H, map, H, TH, I0, l0, g_map, H, TH, G0, 1));
             return 0;
         };
         switch (b.op) {
@@ -2112,14 +2274,14 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
             case STAIR_OP_XORFRAME: {
                 const bool isvec = b.sub == STAIR_VAL_VEC;
                 RUN(launch_eltwise_bwd(b.op == STAIR_OP_AND ? 0 : 1, isvec ? vec : att, isvec ? g_vec : g_att, I0, I1, I2, c,
-                                       isvec ? H : T, s));
+                                       isvec ? H : T, s, G0, G1));
                 break;
             }
             case STAIR_OP_ATTNVIDEO:
-                RUN(launch_attnvideo_bwd(map, g_map, att, g_att, I0, I1, I2, c, T, H, s));
+                RUN(launch_attnvideo_bwd(map, g_map, att, g_att, I0, I1, I2, c, T, H, s, G0, G1));
                 break;
             case STAIR_OP_CHOOSE:
-                RUN(launch_choose_bwd(vec, g_vec, I0, I1, I2, I3, c, H, s));
+                RUN(launch_choose_bwd(vec, g_vec, I0, I1, I2, I3, c, H, s, G0, G1));
                 break;
             case STAIR_OP_COMPARE:
             case STAIR_OP_EQUALS:
@@ -2129,7 +2291,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
                 const Lin &l = isx ? W.xorl : (b.op == STAIR_OP_COMPARE ? W.compare : W.equals);
                 float *dz0 = ws + b.dzV0;                 // this bucket's rows of the weight's dZ region (its product runs once, at the end)
                 if (grouped) {          // dZ = g[out] * relu'(out) on load (kept), dZ W, the concatenation's adjoint: one work list entry
-                    if (phase == 1) bvg1.push_back(vg_adj(c, g_vec, I2, vec, VG_IN_MASK, 1.0f, dz0, l, isx ? 3 : 2, isx ? VG_IN_XOR : VG_IN_CAT2, I0, I1));
+                    if (phase == 1) bvg1.push_back(vg_adj(c, g_vec, I2, vec, VG_IN_MASK, 1.0f, dz0, l, isx ? 3 : 2, isx ? VG_IN_XOR : VG_IN_CAT2, I0, I1, G0, G1));
                     break;
                 }
                 RUN(launch_mask_relu(dz0, g_vec, H, I2, vec, H, I2, c, H, s));
@@ -2151,7 +2313,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
                     bvg1.push_back(q);
                     // stage 2: dZ0 W0 and the concatenation's adjoint (Exists packs [feat, keyword, feat * keyword] = rows I1, I0)
                     bvg2.push_back(vg_adj(c, dz0, nullptr, nullptr, VG_IN_A, 1.0f, nullptr, ex ? W.exists0 : W.ta0, ex ? 3 : 2, ex ? VG_IN_EXISTS : VG_IN_CAT2,
-                                          ex ? I1 : I0, ex ? I0 : I1));
+                                          ex ? I1 : I0, ex ? I0 : I1, ex ? G1 : G0, ex ? G0 : G1));
                     break;
                 }
                 RUN(launch_mask_relu(dz3, g_vec, H, I2, vec, H, I2, c, H, s, ex ? inv_keep : 1.0f));     // only Exists ends in ReLU . Dropout
@@ -2163,7 +2325,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
                 break;
             }
             case STAIR_OP_EXISTSFRAME:
-                RUN(launch_cosine_attn_bwd(map, TH, I1, vec, I0, g_att, I2, g_map, g_vec, c, T, H, s));
+                RUN(launch_cosine_attn_bwd(map, TH, I1, vec, I0, g_att, I2, g_map, g_vec, c, T, H, s, G1, G0));
                 break;
             case STAIR_OP_FILTER: {
                 const int v = b.variant;
@@ -2199,7 +2361,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
                     a.W[0] = WFT(WF_FFD); a.act[0] = 3; a.act_mask[0] = svB; a.save[0] = gB;
                     a.W[1] = WFT(WF_FF3 + v); a.act[1] = 3; a.act_mask[1] = svA; a.save[1] = gA;
                     a.W[2] = WFT(WF_FF0 + v); a.act[2] = 0;
-                    a.tail = STAIR_TILE_ACCUMULATE; a.out = g_map; a.out_gstride = TH; a.out_idx = I0;
+                    a.tail = STAIR_TILE_ACCUMULATE; a.out = g_map; a.out_gstride = TH; a.out_idx = G0;
                     chain_queue.push_back(a);
                     break;
                 }
@@ -2215,7 +2377,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
                     RUN(launch_weighted_colsum(svB, H, nullptr, gRs2, W.ffatt.dw, c * T, H, s));                  // d w[:H]
                     RUN(launch_weighted_colsum(vec, H, I1, gExtra, W.ffatt.dw + H, c, H, s));                     // d w[H:]
                     RUN(launch_sum_all(gRs2, W.ffatt.db, c * T, s));
-                    RUN(launch_axpy_rows(g_vec, I1, gExtra, W.ffatt.w + H, c, H, s));                             // d keyword
+                    RUN(launch_axpy_rows(g_vec, G1, gExtra, W.ffatt.w + H, c, H, s));                             // d keyword
                 } else {
                     RUN(dense_bwd(B, gA, c, T, H, H, svB, H, TH, nullptr, W.ffdense, gB, H, TH, nullptr, 0));
                 }
@@ -2232,36 +2394,36 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
                     a.cnt = c; a.T = T; a.H = H;
                     a.X = gA; a.x_gstride = TH; a.in_mask = svA; a.in_mask_gstride = TH; a.in_scale = inv_keep; a.save_in = gA;
                     a.n_layers = 1; a.W[0] = WFT(WF_HI0); a.act[0] = 0;
-                    a.tail = STAIR_TILE_ACCUMULATE; a.out = g_map; a.out_gstride = TH; a.out_idx = I0;
+                    a.tail = STAIR_TILE_ACCUMULATE; a.out = g_map; a.out_gstride = TH; a.out_idx = G0;
                     chain_queue.push_back(a);
                     break;
                 }
                 RUN(launch_mask_relu(gA, gA, TH, nullptr, svA, TH, nullptr, c, (int)TH, s, inv_keep));
-                RUN(dense_bwd(B, gA, c, T, H, H, map, H, TH, I0, W.hi0, g_map, H, TH, I0, 1));
+                RUN(dense_bwd(B, gA, c, T, H, H, map, H, TH, I0, W.hi0, g_map, H, TH, G0, 1));
                 break;
             case STAIR_OP_LOCALIZE:
                 if (phase == 2) break;
                 RUN(launch_cosine_attn_bwd_grouped(svB, svK, att, I3, g_att, I3, I4, I5, gB, gK, gRs2, gStats, c, b.nrows, T, H, 2, s));
                 if (grouped) {          // dW_lk stays a reduction over the keyword rows; d(keyword rows) joins the level's grouped launch
                     RUN(dense_bwd(B, gK, b.nrows, 1, H, H, vec, H, H, I2, W.lk, nullptr, H, H, I2, 1));
-                    VgProblem q = vg_fwd(b.nrows, gK, nullptr, H, nullptr, nullptr, 0, VG_IN_A, B.wt + B.wt_off[W.lk.id], H, nullptr, H, 0, g_vec, I2, H);
+                    VgProblem q = vg_fwd(b.nrows, gK, nullptr, H, nullptr, nullptr, 0, VG_IN_A, B.wt + B.wt_off[W.lk.id], H, nullptr, H, 0, g_vec, G2, H);
                     q.accumulate = 1; q.wplanes = vslot(W.lk);
                     bvg1.push_back(q);
                 } else
-                RUN(dense_bwd(B, gK, b.nrows, 1, H, H, vec, H, H, I2, W.lk, g_vec, H, H, I2, 1));
+                RUN(dense_bwd(B, gK, b.nrows, 1, H, H, vec, H, H, I2, W.lk, g_vec, H, H, G2, 1));
                 if (fused) RUN(mlp_tail_fused(W.lv3, W.lv0, WF_LV3, WF_LV0, false, nullptr));
                 else RUN(mlp_tail(W.lv3, W.lv0, false));
                 break;
             case STAIR_OP_RELATE:
-                RUN(launch_relate_softmax_bwd(att, g_att, I0, I1, W.dbeta, b.variant == 0 ? 1.0f : -1.0f, c, T, s, LEN));
+                RUN(launch_relate_softmax_bwd(att, g_att, I0, I1, W.dbeta, b.variant == 0 ? 1.0f : -1.0f, c, T, s, LEN, G0));
                 break;
             case STAIR_OP_SUPERLATIVE:
                 if (phase == 2) break;
                 RUN(launch_mask_relu(gV0, g_vec, H, I3, vec, H, I3, c, H, s));
                 RUN(dense_bwd(B, gV0, c, 1, H, H, svCat, H, H, nullptr, W.supdense, gV1, H, H, nullptr, 0));
-                RUN(launch_superlative_pool_bwd(svSup, ws, gws, I4, I1, I2, b.variant, gV1, gS, c, T, H, s, LEN));
+                RUN(launch_superlative_pool_bwd(svSup, ws, gws, I4, I1, I2, b.variant, gV1, gS, c, T, H, s, LEN, G4));
                 RUN(launch_cosine_attn_bwd_grouped(svB, svK, svSup, nullptr, gS, nullptr, I1, I2, gB, gK, gRs2, gStats, c, b.nrows, T, H, T, s));
-                RUN(dense_bwd(B, gK, b.nrows, 1, H, H, ws, H, H, I4, W.lk, gws, H, H, I4, 1));
+                RUN(dense_bwd(B, gK, b.nrows, 1, H, H, ws, H, H, I4, W.lk, gws, H, H, G4, 1));
                 if (fused) RUN(mlp_tail_fused(W.lv3, W.lv0, WF_LV3, WF_LV0, false, nullptr));
                 else RUN(mlp_tail(W.lv3, W.lv0, false));
                 break;
@@ -2269,9 +2431,9 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
                 const int mode = b.variant;
                 RUN(launch_layernorm_bwd(g_map, TH, I4, svA, c, T, H, W.ln_w, 1e-5f, gA, gStats, W.dln_w, W.dln_b, s, inv_keep));
                 RUN(dense_bwd(B, gA, c, T, H, H, map, H, TH, I0, W.tdense, gB, H, TH, nullptr, 0, att, T, I3));
-                RUN(launch_rowscale_bwd(gB, map, TH, I0, att, T, I3, g_map, g_att, c, T, H, s));
+                RUN(launch_rowscale_bwd(gB, map, TH, I0, att, T, I3, g_map, g_att, c, T, H, s, G0));
                 RUN(launch_temporal_relate_bwd(att, I1, I2, g_att, I3, g_att, c, T, mode, ctx->conv ? 1 : 0, ctx->ksize,
-                                               mode ? W.relate[mode - 1] : nullptr, mode ? W.drelate[mode - 1] : nullptr, s, LEN));
+                                               mode ? W.relate[mode - 1] : nullptr, mode ? W.drelate[mode - 1] : nullptr, s, LEN, G1));
                 break;
             }
             default:
@@ -2279,8 +2441,19 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
         }
         return 0;
     };
+    // deterministic fan-in: before a level's nodes use the gradients of their outputs, the contributions that same-level readers
+    // parked in staging slots are added to those outputs' gradient slots in a fixed order (build_grad_fanin)
+    std::vector<char> fanin_done(pl->n_levels + 2, 0);
+    auto fanin_level = [&](int L) -> int {
+        if (L < 0 || L >= (int)pl->fanin_count.size() || fanin_done[L]) return 0;
+        fanin_done[L] = 1;
+        return launch_grad_fanin(didx + pl->off_fanin + 5 * pl->fanin_first[L], pl->fanin_count[L], g_vec, g_map, g_att, H, T, s);
+    };
     if (!fused) {
-        for (auto it = pl->buckets.rbegin(); it != pl->buckets.rend(); ++it) RUN(bwd_bucket(*it, 0));
+        for (auto it = pl->buckets.rbegin(); it != pl->buckets.rend(); ++it) {
+            RUN(fanin_level(it->level));
+            RUN(bwd_bucket(*it, 0));
+        }
     } else {
         // queue words of the backward chains: status words 18, 19 (zeroed by the forward run, left at zero by every launch)
         unsigned *chain_ctr = reinterpret_cast<unsigned *>(ws + pl->o_status) + 18;
@@ -2290,6 +2463,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
             while (lo_ > 0 && pl->buckets[lo_ - 1].level == pl->buckets[hi_ - 1].level) --lo_;
             chain_queue.clear();
             bvg1.clear(); bvg2.clear();
+            RUN(fanin_level(pl->buckets[hi_ - 1].level));
             for (int64_t k = hi_ - 1; k >= lo_; --k) RUN(bwd_bucket(pl->buckets[k], 1));
             if (!bvg1.empty()) RUN(launch_vec_group(bvg1.data(), (int)bvg1.size(), s));
             if (!bvg2.empty()) RUN(launch_vec_group(bvg2.data(), (int)bvg2.size(), s));
@@ -2301,6 +2475,8 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
             hi_ = lo_;
         }
     }
+
+    for (int L = pl->n_levels; L >= 0; --L) RUN(fanin_level(L));        // levels without a bucket of their own (clip tiles: before BPTT)
 
     // ---- the deferred weight-gradient products: one long reduction per weight -------------------------------
     // They are leaves (nothing downstream reads dW before the optimizer), and what follows on `s` -- BPTT through both encoders,

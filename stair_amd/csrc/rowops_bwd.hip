@@ -109,6 +109,32 @@ int launch_bcast_mask_relu(float *dst, const float *dsum, const float *Y, int gr
     return 0;
 }
 
+// Deterministic fan-in of the gradient arenas (csrc/plan.hip build_grad_fanin): entry = (kind, destination slot, first staging slot,
+// count, rows per slot); destination += staging slot 0 + staging slot 1 + ... in that order.  kind 0: vec rows [H], 1: map tiles [T, H],
+// 2: att rows [rows, T].  One block column per entry, 4096 floats per block.
+__global__ void grad_fanin_kernel(const int32_t *tab, float *gvec, float *gmap, float *gatt, int H, int T) {
+    const int32_t *e = tab + 5 * blockIdx.x;
+    const int kind = e[0], cnt = e[3], width = e[4];
+    float *base = kind == 0 ? gvec : (kind == 1 ? gmap : gatt);
+    const int64_t unit = kind == 0 ? H : (kind == 1 ? (int64_t)T * H : T);
+    const int64_t len = kind == 2 ? (int64_t)width * T : unit;
+    float *dst = base + (int64_t)e[1] * unit;
+    const float *src = base + (int64_t)e[2] * unit;
+    const int64_t step = kind == 2 ? (int64_t)width * T : unit;          // distance between two staging slots
+    for (int64_t i = (int64_t)blockIdx.y * 4096 + threadIdx.x; i < std::min<int64_t>(len, ((int64_t)blockIdx.y + 1) * 4096); i += blockDim.x) {
+        float acc = dst[i];
+        for (int j = 0; j < cnt; ++j) acc += src[(int64_t)j * step + i];
+        dst[i] = acc;
+    }
+}
+int launch_grad_fanin(const int32_t *tab, int n, float *gvec, float *gmap, float *gatt, int H, int T, hipStream_t s) {
+    if (n == 0) return 0;
+    STAIR_ACCT("grad_fanin_kernel", (int64_t)n * T * H * 4);
+    hipLaunchKernelGGL(grad_fanin_kernel, dim3(n, (unsigned)(((int64_t)T * H + 4095) / 4096)), dim3(256), 0, s, tab, gvec, gmap, gatt, H, T);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
 // dst[dst_idx[i]][:] += src[i][:] * scale   (rows of `len` floats, atomic)
 __global__ void scatter_add_rows_kernel(float *dst, const int32_t *dst_idx, const float *src, int n, int len, float scale) {
     const int i = blockIdx.x;
@@ -183,7 +209,7 @@ int launch_span_mean_bwd(float *dtok, int64_t ld, const int32_t *start, const in
 // One block per pair: phase 1 computes per-frame scalars into LDS, phase 2 is column-parallel.
 __global__ void cosine_attn_bwd_kernel(const float *F, int64_t f_gs, const int32_t *f_idx, const float *Kmat,
                                        const int32_t *k_idx, const float *datt, const int32_t *out_idx, float *dF,
-                                       float *dK, int npairs, int T, int H) {
+                                       float *dK, int npairs, int T, int H, const int32_t *gf_idx, const int32_t *gk_idx) {
     extern __shared__ float sm[];       // [3][T]: a_t = dcos/(nf nk), b_t = dcos*cos/nf^2, c_t = dcos*cos
     float *sa = sm, *sb = sm + T, *sc = sm + 2 * T;
     __shared__ float s_nk2;
@@ -210,23 +236,24 @@ __global__ void cosine_attn_bwd_kernel(const float *F, int64_t f_gs, const int32
     }
     __syncthreads();
     const float inv_nk2 = 1.0f / s_nk2;
+    const int gfi = gf_idx ? gf_idx[p] : fi, gki = gk_idx ? gk_idx[p] : ki;        // gradient slots (fan-in staging)
     for (int c = threadIdx.x; c < H; c += blockDim.x) {
         const float kc = k[c];
         float dk = 0.f;
         for (int t = 0; t < T; ++t) {
             const float fc = f[(int64_t)t * H + c];
-            unsafeAtomicAdd(dF + (int64_t)fi * f_gs + (int64_t)t * H + c, sa[t] * kc - sb[t] * fc);
+            unsafeAtomicAdd(dF + (int64_t)gfi * f_gs + (int64_t)t * H + c, sa[t] * kc - sb[t] * fc);
             dk += sa[t] * fc - sc[t] * kc * inv_nk2;
         }
-        unsafeAtomicAdd(dK + (int64_t)ki * H + c, dk);
+        unsafeAtomicAdd(dK + (int64_t)gki * H + c, dk);
     }
 }
 int launch_cosine_attn_bwd(const float *F, int64_t f_gs, const int32_t *f_idx, const float *Kmat, const int32_t *k_idx,
                            const float *datt, const int32_t *out_idx, float *dF, float *dK, int npairs, int T, int H,
-                           hipStream_t s) {
+                           hipStream_t s, const int32_t *gf_idx, const int32_t *gk_idx) {
     if (npairs == 0) return 0;
     hipLaunchKernelGGL(cosine_attn_bwd_kernel, dim3(npairs), dim3(kBlock), 3 * T * sizeof(float), s, F, f_gs, f_idx, Kmat,
-                       k_idx, datt, out_idx, dF, dK, npairs, T, H);
+                       k_idx, datt, out_idx, dF, dK, npairs, T, H, gf_idx, gk_idx);
     STAIR_LAUNCH_CHECK();
     return 0;
 }
@@ -415,7 +442,7 @@ struct RelateWB { const float *w[6]; float *dw[6]; };
 constexpr int kRelateTapStride = 72;      // LDS floats per staged Conv1d filter: up to 71 taps (2 k + 1 with k <= 35) + the bias
 __global__ void temporal_relate_bwd_kernel(const float *att, const int32_t *att_idx, const int32_t *att_k,
                                            const float *drel, const int32_t *rel_idx, float *datt, int n, int T, int mode,
-                                           int conv, int ksize, RelateWB W, const int32_t *len) {
+                                           int conv, int ksize, RelateWB W, const int32_t *len, const int32_t *gatt_idx) {
     extern __shared__ float sm[];   // x0, y1, y2, y3 (post-activation), g (ping), g2 (pong): 6 rows of T; then the conv filters
     float *x0 = sm, *y1 = sm + T, *y2 = sm + 2 * T, *y3 = sm + 3 * T, *ga = sm + 4 * T, *gb = sm + 5 * T;
     // Conv1d nets: the three filters (k, k, 2k + 1 taps) and biases staged in LDS once -- read from global memory inside the tap
@@ -507,12 +534,12 @@ __global__ void temporal_relate_bwd_kernel(const float *att, const int32_t *att_
     // mean over K rows backward
     for (int t = threadIdx.x; t < L; t += blockDim.x) {
         const float v = ga[t] / (float)K;
-        for (int k = 0; k < K; ++k) unsafeAtomicAdd(datt + ((int64_t)att_idx[i] + k) * T + t, v);
+        for (int k = 0; k < K; ++k) unsafeAtomicAdd(datt + ((int64_t)(gatt_idx ? gatt_idx[i] : att_idx[i]) + k) * T + t, v);
     }
 }
 int launch_temporal_relate_bwd(const float *att, const int32_t *att_idx, const int32_t *att_k, const float *drel,
                                const int32_t *rel_idx, float *datt, int n, int T, int mode, int conv, int ksize,
-                               const float *const w[6], float *const dw[6], hipStream_t s, const int32_t *len) {
+                               const float *const w[6], float *const dw[6], hipStream_t s, const int32_t *len, const int32_t *gatt_idx) {
     if (n == 0) return 0;
     // reads: K attention rows in (the mean over K; K <= 2, counted as 2), the relate output's gradient; writes: K attention-row
     // gradients; the three layers' filters / matrices and their gradients are a few hundred floats per launch
@@ -521,7 +548,7 @@ int launch_temporal_relate_bwd(const float *att, const int32_t *att_idx, const i
     for (int i = 0; i < 6; ++i) { W.w[i] = (mode && w) ? w[i] : nullptr; W.dw[i] = (mode && dw) ? dw[i] : nullptr; }
     STAIR_CHECK(!(mode && conv) || 2 * ksize + 1 < kRelateTapStride, "Conv1d relate nets: kernel size <= 35");
     hipLaunchKernelGGL(temporal_relate_bwd_kernel, dim3(n), dim3(64), (6 * T + 3 * kRelateTapStride) * sizeof(float), s, att, att_idx, att_k, drel,
-                       rel_idx, datt, n, T, mode, conv, ksize, W, len);
+                       rel_idx, datt, n, T, mode, conv, ksize, W, len, gatt_idx);
     STAIR_LAUNCH_CHECK();
     return 0;
 }
@@ -673,7 +700,7 @@ int launch_layernorm_bwd(const float *dOut, int64_t g_gs, const int32_t *g_idx, 
 // row-scaled dense backward helper: G = dZ.W already computed for the SCALED input (rs_t * x_t):
 //   dX[xi][t][:] += rs_t * G[g][t][:]   (atomic),   drs[ri][t] += sum_c G[g][t][c] * X[xi][t][c]
 __global__ void rowscale_bwd_kernel(const float *G, const float *X, int64_t x_gs, const int32_t *x_idx, const float *rs,
-                                    int64_t rs_gs, const int32_t *rs_idx, float *dX, float *drs, int n, int T, int H) {
+                                    int64_t rs_gs, const int32_t *rs_idx, float *dX, float *drs, int n, int T, int H, const int32_t *gx_idx) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (row >= (int64_t)n * T) return;
@@ -682,22 +709,23 @@ __global__ void rowscale_bwd_kernel(const float *G, const float *X, int64_t x_gs
     const int64_t ro = (int64_t)idx_or_id(rs_idx, g) * rs_gs + t;
     const float r = rs[ro];
     const float *gr = G + row * H;
+    const int64_t go = gx_idx ? (int64_t)gx_idx[g] * x_gs + (int64_t)t * H : xo;      // where the gradient of the tile goes (fan-in staging)
     float d = 0.f;
     for (int c = lane; c < H; c += 64) {
         const float gv = gr[c];
         d += gv * X[xo + c];
-        if (dX) unsafeAtomicAdd(dX + xo + c, r * gv);
+        if (dX) unsafeAtomicAdd(dX + go + c, r * gv);
     }
     d = wave_sum(d);
     if (lane == 0 && drs) unsafeAtomicAdd(drs + ro, d);
 }
 int launch_rowscale_bwd(const float *G, const float *X, int64_t x_gs, const int32_t *x_idx, const float *rs, int64_t rs_gs,
-                        const int32_t *rs_idx, float *dX, float *drs, int n, int T, int H, hipStream_t s) {
+                        const int32_t *rs_idx, float *dX, float *drs, int n, int T, int H, hipStream_t s, const int32_t *gx_idx) {
     if (n == 0) return 0;
     STAIR_ACCT("rowscale_bwd_kernel", (2ll * n * T * H + (dX ? (int64_t)n * T * H : 0) + (int64_t)n * T) * 4);
     const int64_t rows = (int64_t)n * T;
     hipLaunchKernelGGL(rowscale_bwd_kernel, dim3((unsigned)((rows + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, s,
-                       G, X, x_gs, x_idx, rs, rs_gs, rs_idx, dX, drs, n, T, H);
+                       G, X, x_gs, x_idx, rs, rs_gs, rs_idx, dX, drs, n, T, H, gx_idx);
     STAIR_LAUNCH_CHECK();
     return 0;
 }
@@ -806,7 +834,7 @@ int launch_sum_all(const float *x, float *out, int n, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 // Relate backward: y = softmax(x + sign*beta): dx = y * (dy - sum(dy*y)); datt[in] += dx; dbeta += sign*dx
 __global__ void relate_softmax_bwd_kernel(const float *att, float *datt, const int32_t *in_idx, const int32_t *out_idx,
-                                          float *dbeta, float sign, int n, int T, const int32_t *len) {
+                                          float *dbeta, float sign, int n, int T, const int32_t *len, const int32_t *gin_idx) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (i >= n) return;
@@ -818,22 +846,22 @@ __global__ void relate_softmax_bwd_kernel(const float *att, float *datt, const i
     dot = wave_sum(dot);
     for (int t = lane; t < L; t += 64) {
         const float dx = y[t] * (dy[t] - dot);
-        unsafeAtomicAdd(datt + (int64_t)in_idx[i] * T + t, dx);
+        unsafeAtomicAdd(datt + (int64_t)(gin_idx ? gin_idx[i] : in_idx[i]) * T + t, dx);
         unsafeAtomicAdd(dbeta + t, sign * dx);
     }
 }
 int launch_relate_softmax_bwd(const float *att, float *datt, const int32_t *in_idx, const int32_t *out_idx, float *dbeta,
-                              float sign, int n, int T, hipStream_t s, const int32_t *len) {
+                              float sign, int n, int T, hipStream_t s, const int32_t *len, const int32_t *gin_idx) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(relate_softmax_bwd_kernel, dim3((n + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlock), 0, s, att, datt,
-                       in_idx, out_idx, dbeta, sign, n, T, len);
+                       in_idx, out_idx, dbeta, sign, n, T, len, gin_idx);
     STAIR_LAUNCH_CHECK();
     return 0;
 }
 
 // min / |a-b| backward (torch.minimum splits a tie evenly; sign(0) = 0 for abs)
 __global__ void eltwise_bwd_kernel(int mode, const float *base, float *dbase, const int32_t *ia, const int32_t *ib,
-                                   const int32_t *io, int n, int len) {
+                                   const int32_t *io, int n, int len, const int32_t *gia, const int32_t *gib) {
     const int i = blockIdx.x;
     const int64_t oa = (int64_t)ia[i] * len, ob = (int64_t)ib[i] * len, oo = (int64_t)io[i] * len;
     for (int c = threadIdx.x; c < len; c += blockDim.x) {
@@ -846,50 +874,53 @@ __global__ void eltwise_bwd_kernel(int mode, const float *base, float *dbase, co
             const float sg = sgn(a - b);
             da = sg * g; db = -sg * g;
         }
-        unsafeAtomicAdd(dbase + oa + c, da);
-        unsafeAtomicAdd(dbase + ob + c, db);
+        unsafeAtomicAdd(dbase + (gia ? (int64_t)gia[i] * len : oa) + c, da);
+        unsafeAtomicAdd(dbase + (gib ? (int64_t)gib[i] * len : ob) + c, db);
     }
 }
 int launch_eltwise_bwd(int mode, const float *base, float *dbase, const int32_t *ia, const int32_t *ib, const int32_t *io,
-                       int n, int len, hipStream_t s) {
+                       int n, int len, hipStream_t s, const int32_t *gia, const int32_t *gib) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(eltwise_bwd_kernel, dim3(n), dim3(128), 0, s, mode, base, dbase, ia, ib, io, n, len);
+    hipLaunchKernelGGL(eltwise_bwd_kernel, dim3(n), dim3(128), 0, s, mode, base, dbase, ia, ib, io, n, len, gia, gib);
     STAIR_LAUNCH_CHECK();
     return 0;
 }
 
 // AttnVideo backward: dmap[in][t][:] += att[a][t]*dmap[out][t][:];  datt[a][t] += dmap[out][t].map[in][t]
 __global__ void attnvideo_bwd_kernel(const float *map, float *dmap, const float *att, float *datt, const int32_t *in_idx,
-                                     const int32_t *att_idx, const int32_t *out_idx, int n, int T, int H) {
+                                     const int32_t *att_idx, const int32_t *out_idx, int n, int T, int H, const int32_t *gin_idx,
+                                     const int32_t *gatt_idx) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (row >= (int64_t)n * T) return;
     const int i = (int)(row / T), t = (int)(row - (int64_t)i * T);
     const int64_t xi = ((int64_t)in_idx[i] * T + t) * H, xo = ((int64_t)out_idx[i] * T + t) * H;
+    const int64_t gi = gin_idx ? ((int64_t)gin_idx[i] * T + t) * H : xi;
     const float a = att[(int64_t)att_idx[i] * T + t];
     float d = 0.f;
     for (int c = lane; c < H; c += 64) {
         const float g = dmap[xo + c];
         d += g * map[xi + c];
-        unsafeAtomicAdd(dmap + xi + c, a * g);
+        unsafeAtomicAdd(dmap + gi + c, a * g);
     }
     d = wave_sum(d);
-    if (lane == 0) unsafeAtomicAdd(datt + (int64_t)att_idx[i] * T + t, d);
+    if (lane == 0) unsafeAtomicAdd(datt + (int64_t)(gatt_idx ? gatt_idx[i] : att_idx[i]) * T + t, d);
 }
 int launch_attnvideo_bwd(const float *map, float *dmap, const float *att, float *datt, const int32_t *in_idx,
-                         const int32_t *att_idx, const int32_t *out_idx, int n, int T, int H, hipStream_t s) {
+                         const int32_t *att_idx, const int32_t *out_idx, int n, int T, int H, hipStream_t s, const int32_t *gin_idx,
+                         const int32_t *gatt_idx) {
     if (n == 0) return 0;
     STAIR_ACCT("attnvideo_bwd_kernel", (4ll * n * T * H + 2ll * n * T) * 4);
     const int64_t rows = (int64_t)n * T;
     hipLaunchKernelGGL(attnvideo_bwd_kernel, dim3((unsigned)((rows + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, s,
-                       map, dmap, att, datt, in_idx, att_idx, out_idx, n, T, H);
+                       map, dmap, att, datt, in_idx, att_idx, out_idx, n, T, H, gin_idx, gatt_idx);
     STAIR_LAUNCH_CHECK();
     return 0;
 }
 
 // Choose backward: the output IS one of the two keywords -> route its gradient there (selection recomputed)
 __global__ void choose_bwd_kernel(const float *vec, float *dvec, const int32_t *k1, const int32_t *k2, const int32_t *q,
-                                  const int32_t *out, int n, int H) {
+                                  const int32_t *out, int n, int H, const int32_t *gk1, const int32_t *gk2) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (i >= n) return;
@@ -900,14 +931,14 @@ __global__ void choose_bwd_kernel(const float *vec, float *dvec, const int32_t *
     float da = 0.f, db = 0.f;
     for (int e = lane; e < H; e += 64) { const float cn = c[e] / nc; da += (a[e] / na) * cn; db += (b[e] / nb) * cn; }
     da = wave_sum(da); db = wave_sum(db);
-    const int64_t dst = (int64_t)(da > db ? k1[i] : k2[i]) * H, src = (int64_t)out[i] * H;
+    const int64_t dst = (int64_t)(da > db ? (gk1 ? gk1[i] : k1[i]) : (gk2 ? gk2[i] : k2[i])) * H, src = (int64_t)out[i] * H;
     for (int e = lane; e < H; e += 64) unsafeAtomicAdd(dvec + dst + e, dvec[src + e]);
 }
 int launch_choose_bwd(const float *vec, float *dvec, const int32_t *k1, const int32_t *k2, const int32_t *q,
-                      const int32_t *out, int n, int H, hipStream_t s) {
+                      const int32_t *out, int n, int H, hipStream_t s, const int32_t *gk1, const int32_t *gk2) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(choose_bwd_kernel, dim3((n + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlock), 0, s, vec, dvec, k1, k2,
-                       q, out, n, H);
+                       q, out, n, H, gk1, gk2);
     STAIR_LAUNCH_CHECK();
     return 0;
 }
@@ -916,7 +947,7 @@ int launch_choose_bwd(const float *vec, float *dvec, const int32_t *k1, const in
 //   drows[row_id[a]] += w'_a dpre;   dS[a][t] = w_a (dw_a - sum_b dw_b w_b),  dw_a = +-(dpre . rows[a])
 __global__ void superlative_pool_bwd_kernel(const float *S, const float *rowbase, float *drowbase, const int32_t *row_id,
                                             const int32_t *row_start, const int32_t *row_cnt, int is_min, const float *dpre,
-                                            float *dS, int n, int T, int H, const int32_t *len) {
+                                            float *dS, int n, int T, int H, const int32_t *len, const int32_t *g_row_id) {
     extern __shared__ float sm[];    // w[Ka], dw[Ka], row ids [Ka]
     const int i = blockIdx.x;
     const int r0 = row_start[i], Ka = row_cnt[i];
@@ -967,6 +998,11 @@ __global__ void superlative_pool_bwd_kernel(const float *S, const float *rowbase
         const int a = e / T;
         dS[(int64_t)(r0 + a) * T + (e - a * T)] = (e - a * T) < L ? w[a] * (dw[a] - s_dot) : 0.f;
     }
+    if (g_row_id) {                 // the action rows' GRADIENT rows (fan-in staging, csrc/plan.hip build_grad_fanin)
+        __syncthreads();
+        for (int a = threadIdx.x; a < Ka; a += blockDim.x) rid[a] = g_row_id[r0 + a];
+        __syncthreads();
+    }
     for (int c = threadIdx.x; c < H; c += blockDim.x) {
         const float g = dp[c];
         for (int a = 0; a < Ka; ++a)
@@ -975,13 +1011,13 @@ __global__ void superlative_pool_bwd_kernel(const float *S, const float *rowbase
 }
 int launch_superlative_pool_bwd(const float *S, const float *rowbase, float *drowbase, const int32_t *row_id,
                                 const int32_t *row_start, const int32_t *row_cnt, int is_min, const float *dpre, float *dS,
-                                int n, int T, int H, hipStream_t s, const int32_t *len) {
+                                int n, int T, int H, hipStream_t s, const int32_t *len, const int32_t *g_row_id) {
     if (n == 0) return 0;
     // per instance: scores S [Ka, T] in, dS [Ka, T] out, the Ka action rows [Ka, H] in and their gradient rows out (read-modify-
     // write), the pooled vector's gradient [H] in; Ka = T for the map-valued action lists of the AGQA programs
     STAIR_ACCT("superlative_pool_bwd_kernel", (int64_t)n * ((int64_t)2 * T * T + (int64_t)3 * T * H + H) * 4);
     hipLaunchKernelGGL(superlative_pool_bwd_kernel, dim3(n), dim3(kBlock), (size_t)3 * std::max(T, 2) * sizeof(float), s, S, rowbase,
-                       drowbase, row_id, row_start, row_cnt, is_min, dpre, dS, n, T, H, len);
+                       drowbase, row_id, row_start, row_cnt, is_min, dpre, dS, n, T, H, len, g_row_id);
     STAIR_LAUNCH_CHECK();
     return 0;
 }

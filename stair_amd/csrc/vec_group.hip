@@ -253,6 +253,8 @@ __device__ __forceinline__ void vg_item(const VgProblem &p, const int rt, const 
             const int rw = rt * 32 + erow + 16 * i;
             if (rw >= rows) break;
             const int64_t ra = (int64_t)(p.fia ? p.fia[rw] : rw) * p.ldfa + col, rb = (int64_t)(p.fib ? p.fib[rw] : rw) * p.ldfb + col;
+            // the operands' GRADIENT rows: the same rows unless the plan sends this reader to a staging row (deterministic fan-in)
+            const int64_t gra = p.gia ? (int64_t)p.gia[rw] * p.ldfa + col : ra, grb = p.gib ? (int64_t)p.gib[rw] * p.ldfb + col : rb;
             float da, db;
             if (NOUT == 2) { da = d[0][i]; db = d[J1][i]; }
             else if (p.adj == VG_IN_EXISTS) {       // [a, b, a * b]
@@ -263,8 +265,8 @@ __device__ __forceinline__ void vg_item(const VgProblem &p, const int rt, const 
                 const float sg = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
                 da = d[0][i] * sg + d[J1][i]; db = -d[0][i] * sg + d[J2][i];
             }
-            unsafeAtomicAdd(p.ga + ra, da);
-            unsafeAtomicAdd(p.gb + rb, db);
+            unsafeAtomicAdd(p.ga + gra, da);
+            unsafeAtomicAdd(p.gb + grb, db);
         }
     }
 }

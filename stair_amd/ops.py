@@ -410,6 +410,7 @@ def vec_group(problems):
         q.fa, q.fb, q.fia, q.fib = ptr(d.get('fa')), ptr(d.get('fb')), ptr(d.get('fia')), ptr(d.get('fib'))
         q.ldfa, q.ldfb = int(d.get('ldfa', ld(d.get('ga'), 512))), int(d.get('ldfb', ld(d.get('gb'), 512)))
         q.ga, q.gb = ptr(d.get('ga')), ptr(d.get('gb'))
+        q.gia, q.gib = ptr(d.get('gia')), ptr(d.get('gib'))
     check(lib.stair_vec_group(arr, len(problems), _stream()))
 
 
