@@ -55,6 +55,24 @@ __device__ __forceinline__ float tanh_fast(float x) {
 
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
+// ---- run-to-run reproducible weight gradients -----------------------------------------------------------------------------------
+// Inside stair_plan_backward every kernel that ADDS into a weight-gradient tensor from several workgroups (slab partials of the
+// TN products, the bias sums riding along, LayerNorm / Relate / Conv1d / 1-output-Linear gradients) adds into a 64-bit fixed-point
+// shadow of that tensor instead: integer addition is associative, so the sum does not depend on the order in which the atomics
+// land.  Scale 2^44: a contribution is kept to 5.7e-14 absolute (the sums of a step stay far below 2^19); the shadows are added to
+// the fp32 gradients by one launch at the end of the pass (csrc/plan.hip det_*).  det_shadow(g): the shadow of the gradient
+// element g points at, or NULL outside a backward pass / for a pointer that is not inside a bound gradient tensor / STAIR_DETERMINISTIC=0.
+long long *det_shadow(const float *gptr);
+constexpr float kFxScale = 17592186044416.0f;            // 2^44
+__device__ __forceinline__ void fx_add(long long *p, float v) {
+    atomicAdd(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__float2ll_rn(v * kFxScale));
+}
+// add into the shadow when there is one, else the plain float atomic
+__device__ __forceinline__ void grad_add(float *g, long long *g64, int64_t off, float v) {
+    if (g64) fx_add(g64 + off, v);
+    else unsafeAtomicAdd(g + off, v);
+}
+
 // ---- algorithmic-byte accounting of the HBM-bound row kernels (measurement aid, off unless stair_acct_enable(1)) --------
 // Each row-kernel launcher reports the bytes its launch MUST move (inputs read once + outputs written once, the figure of
 // SURVEY.md section 8d); tools/row_kernels.py divides the per-kernel sums by the rocprofv3 kernel durations of the same run.
@@ -78,6 +96,8 @@ struct TransposeBatch {          // up to 32 matrices transposed by one launch (
 };
 int launch_transpose_many(const TransposeBatch &tb, int total_tiles, hipStream_t s);
 int launch_gemm_tn_tr(const stair_gemm_tn_args &a, hipStream_t s);      // -1: not this kernel's shape
+int launch_gemm_tn_tr_slabs(const stair_gemm_tn_args &a, float *scratch, hipStream_t s);    // slab partials into scratch [8 N K] + queued reduction
+int tn_x3tr_queue(const float *P, float *dst, int nslab, int count4, hipStream_t s);
 // csrc/gemm_tn_x3tr.hip: slab partials of a weight-gradient product into scratch; tn_x3tr_flush adds every queued product's slabs
 // to its destination in fixed order (one launch), on the same stream and thread
 bool tn_x3tr_takes(const stair_gemm_tn_args &a);

@@ -350,7 +350,7 @@ int launch_gemm_tn(const stair_gemm_tn_args &a, hipStream_t s) {
 }
 
 // out[n] += sum_m A[m][n]  (bias gradients; out2, if given, receives the same sums: b_ih and b_hh of an LSTM)
-__global__ void colsum_kernel(const float *A, int64_t lda, float *out, float *out2, int M, int N, int mslab) {
+__global__ void colsum_kernel(const float *A, int64_t lda, float *out, float *out2, int M, int N, int mslab, long long *out64, long long *out2_64) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     const int mbeg = blockIdx.y * mslab, mend = min(M, mbeg + mslab);
@@ -363,13 +363,13 @@ __global__ void colsum_kernel(const float *A, int64_t lda, float *out, float *ou
     }
     for (; m < mend; ++m, p += lda) a0 += *p;
     const float acc = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
-    unsafeAtomicAdd(out + n, acc);
-    if (out2) unsafeAtomicAdd(out2 + n, acc);
+    grad_add(out, out64, n, acc);
+    if (out2) grad_add(out2, out2_64, n, acc);
 }
 int launch_colsum(const float *A, int64_t lda, float *out, int M, int N, hipStream_t s, float *out2) {
     if (M == 0) return 0;
     const int mslab = std::max(64, (M + 511) / 512);
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, (M + mslab - 1) / mslab), dim3(256), 0, s, A, lda, out, out2, M, N, mslab);
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, (M + mslab - 1) / mslab), dim3(256), 0, s, A, lda, out, out2, M, N, mslab, det_shadow(out), out2 ? det_shadow(out2) : nullptr);
     STAIR_LAUNCH_CHECK();
     return 0;
 }

@@ -644,7 +644,9 @@ int launch_gemm_bf16x3(const stair_gemm_args &a, hipStream_t s) {
     if (splitk_on && tiles128 <= 64 && a.K >= 256 && a.K <= 128 * 16) {
         const int kchunk = 128;                         // fixed, so the order of the partial sums does not depend on the batch
         const int ksplit = (a.K + kchunk - 1) / kchunk;
-        const bool direct = a.accumulate && a.act == 0 && !a.bias;
+        // (K pieces that add into the target with atomics land in any order: only when run-to-run reproducibility is switched off)
+        static const bool det = [] { const char *e = getenv("STAIR_DETERMINISTIC"); return !(e && e[0] == '0'); }();
+        const bool direct = a.accumulate && a.act == 0 && !a.bias && !det;
         const bool staged = !a.accumulate && a.splitk_ws && a.splitk_ws_floats >= (int64_t)ksplit * M * a.N;
         if (ksplit > 1 && (direct || staged)) {
             p.ksplit = ksplit; p.kchunk = kchunk;
@@ -697,6 +699,7 @@ struct XTnParams {
     float *C; int64_t ldc;
     float *colsum, *colsum2;
     int M, N, K, mslab, tilesN, tilesK, fast8;
+    long long *C64, *colsum64, *colsum2_64;        // fixed-point shadows of C / colsum / colsum2 (det_shadow), or NULL
 };
 
 // PLAIN: no row scale and every slab holds a multiple of 64 rows, so no element needs a mask or a scale (columns past
@@ -717,6 +720,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16x3_kernel(XTnParams p) {
     const int tile = j % tiles, slab = (j / tiles) * 8 + xcd;
     const int n0 = (tile % p.tilesN) * 128, k0 = (tile / p.tilesN) * 128;
     const int mbeg = min(slab * p.mslab, p.M), mend = min(p.M, mbeg + p.mslab);
+    if (mbeg >= mend) return;                      // a slab without rows (the slab count is a multiple of 8 whatever M is): nothing to add
 
     f32x16 acc00, acc01, acc10, acc11;
 #pragma unroll
@@ -835,8 +839,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16x3_kernel(XTnParams p) {
         for (int c_ = 0; c_ < 4; ++c_) {
             const int n = n0 + 4 * cq + c_;
             if (n < p.N && csum[c_] != 0.0f) {
-                unsafeAtomicAdd(p.colsum + n, csum[c_]);
-                if (p.colsum2) unsafeAtomicAdd(p.colsum2 + n, csum[c_]);
+                grad_add(p.colsum, p.colsum64, n, csum[c_]);
+                if (p.colsum2) grad_add(p.colsum2, p.colsum2_64, n, csum[c_]);
             }
         }
     }
@@ -850,7 +854,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16x3_kernel(XTnParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int n = n0 + wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (n < p.N) unsafeAtomicAdd(p.C + (int64_t)n * p.ldc + k, acc[e]);
+                if (n < p.N) grad_add(p.C, p.C64, (int64_t)n * p.ldc + k, acc[e]);
             }
         }
     }
@@ -970,8 +974,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_bf16x3_t256_kernel(XTnParams p
         for (int c_ = 0; c_ < 4; ++c_) {
             const int n = n0 + 4 * cq + c_;
             if (n < p.N && csum[c_] != 0.0f) {
-                unsafeAtomicAdd(p.colsum + n, csum[c_]);
-                if (p.colsum2) unsafeAtomicAdd(p.colsum2 + n, csum[c_]);
+                grad_add(p.colsum, p.colsum64, n, csum[c_]);
+                if (p.colsum2) grad_add(p.colsum2, p.colsum2_64, n, csum[c_]);
             }
         }
     }
@@ -984,7 +988,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_bf16x3_t256_kernel(XTnParams p
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int n = n0 + wm * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (n < p.N) unsafeAtomicAdd(p.C + (int64_t)n * p.ldc + k, acc[i][j][e]);
+                if (n < p.N) grad_add(p.C, p.C64, (int64_t)n * p.ldc + k, acc[i][j][e]);
             }
         }
     }
@@ -998,6 +1002,7 @@ int launch_gemm_tn_bf16x3(const stair_gemm_tn_args &a, hipStream_t s) {
     p.R = a.rows_per_group; p.row_scale = a.row_scale; p.rs_gstride = a.rs_gstride; p.rs_gidx = a.rs_gidx;
     p.C = a.C; p.ldc = a.ldc; p.M = a.M; p.N = a.N; p.K = a.K;
     p.colsum = a.colsum; p.colsum2 = a.colsum2;
+    p.C64 = det_shadow(a.C); p.colsum64 = a.colsum ? det_shadow(a.colsum) : nullptr; p.colsum2_64 = a.colsum2 ? det_shadow(a.colsum2) : nullptr;
     p.tilesN = (a.N + 127) / 128; p.tilesK = (a.K + 127) / 128;
     p.fast8 = 0;
     const bool bx = a.b_is_bf16 != 0;
@@ -1060,6 +1065,8 @@ int launch_gemm_tn_bf16x3(const stair_gemm_tn_args &a, hipStream_t s) {
     slabs = (slabs + 7) / 8 * 8;                                   // a multiple of the XCD count
     p.mslab = ((a.M + slabs - 1) / slabs + 63) / 64 * 64;
     const size_t shmem = 2 * 2 * 2 * IMG * sizeof(__bf16);
+    if (a.M <= p.mslab) p.C64 = nullptr;           // ONE slab holds every row: one add per element, the float atomic is reproducible as it is
+                                                   // (the bias sums still meet from several threads of a workgroup: they keep their shadow)
     const bool plain = !p.row_scale && a.M % 64 == 0 && p.mslab % 64 == 0;
     STAIR_ACCT_MFMA("gemm_tn_bf16x3", ((int64_t)a.M * a.N * 4 + (int64_t)a.M * a.K * (bx ? 2 : 4) + (int64_t)a.N * a.K * 4), 2ll * a.M * a.N * a.K);
     if (bx) {

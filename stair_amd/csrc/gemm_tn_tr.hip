@@ -42,6 +42,8 @@ struct TrParams {
     const __bf16 *B; int64_t ldb;             // X  [M, ldb], columns k
     float *C; int64_t ldc;                    // dW [N, ldc]
     int M, N, K, mslab, tilesN, tilesK;
+    long long *C64;                           // fixed-point shadow of C (det_shadow): the 8 slabs add in any order, the sum is the same
+    float *P;                                 // or: slab partials [8][N][K], STORED; tn_slab_reduce_kernel adds them to C in slab order
 };
 
 __device__ __forceinline__ int tr_chunk(int row, int ch, int h) { return ch ^ (((row & 3) << 2) | ((row >> 2) & 3)) ^ h; }
@@ -273,13 +275,18 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_tr_kernel(TrParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int n = n0 + 64 * wn + 32 * i + 8 * (e >> 2) + 4 * kg + (e & 3);
-                unsafeAtomicAdd(p.C + (int64_t)n * p.ldc + k, acc[i][t][e]);
+                if (p.P) p.P[((int64_t)slab * p.N + n) * p.K + k] = acc[i][t][e];
+                else grad_add(p.C, p.C64, (int64_t)n * p.ldc + k, acc[i][t][e]);
             }
         }
 }
 
 // Returns -1 when the shape is not this kernel's (the caller falls back to csrc/gemm_bf16x3.hip), 0 on launch, 1 on error.
-int launch_gemm_tn_tr(const stair_gemm_tn_args &a, hipStream_t s) {
+int launch_gemm_tn_tr(const stair_gemm_tn_args &a, hipStream_t s) { return launch_gemm_tn_tr_slabs(a, nullptr, s); }
+
+// scratch (8 * N * K floats, needs ldc == K): the slabs' partial products are stored there and queued for the fixed-order reduction
+// of csrc/gemm_tn_x3tr.hip (tn_x3tr_flush on the same stream adds them to C): no atomics, the same sum every run
+int launch_gemm_tn_tr_slabs(const stair_gemm_tn_args &a, float *scratch, hipStream_t s) {
     static const bool on = [] { const char *e = getenv("STAIR_GEMM_TN_TR"); return !(e && e[0] == '0'); }();
     if (!on || !a.b_is_bf16 || a.row_scale || a.b_gidx || a.colsum || a.colsum2) return -1;
     if (a.rows_per_group != 1 && a.b_gstride != (int64_t)a.rows_per_group * a.ldb) return -1;
@@ -290,6 +297,8 @@ int launch_gemm_tn_tr(const stair_gemm_tn_args &a, hipStream_t s) {
     TrParams p;
     p.A = a.A; p.lda = a.lda; p.B = reinterpret_cast<const __bf16 *>(a.B); p.ldb = a.ldb; p.C = a.C; p.ldc = a.ldc;
     p.M = a.M; p.N = a.N; p.K = a.K;
+    p.P = scratch && a.ldc == a.K ? scratch : nullptr;
+    p.C64 = p.P ? nullptr : det_shadow(a.C);
     p.tilesN = a.N / 256; p.tilesK = a.K / 256;
     p.mslab = a.M / 8;                                             // a multiple of 64: whole stages, an even number of them
     const size_t shmem = (size_t)TR_NST * TR_STAGE;
@@ -309,6 +318,7 @@ int launch_gemm_tn_tr(const stair_gemm_tn_args &a, hipStream_t s) {
     else if (abl == 3) hipLaunchKernelGGL(gemm_tn_tr_kernel<3>, grid, dim3(512), shmem, s, p);
     else hipLaunchKernelGGL(gemm_tn_tr_kernel<0>, grid, dim3(512), shmem, s, p);
     STAIR_LAUNCH_CHECK();
+    if (p.P) return tn_x3tr_queue(p.P, a.C, 8, (int)((int64_t)a.N * a.K / 4), s);
     return 0;
 }
 

@@ -355,6 +355,15 @@ int launch_gemm_tn_x3tr(const stair_gemm_tn_args &a, float *scratch, hipStream_t
 
 void tn_x3tr_discard() { g_pending.n = 0; }
 
+// another kernel's slab partials (csrc/gemm_tn_tr.hip) join the same fixed-order reduction
+int tn_x3tr_queue(const float *P, float *dst, int nslab, int count4, hipStream_t s) {
+    for (int i = 0; i < g_pending.n; ++i)
+        if (g_pending.e[i].dst == dst) { STAIR_CHECK(tn_x3tr_flush(s) == 0, "weight-gradient reduction failed"); break; }
+    if (g_pending.n + 1 > 40) STAIR_CHECK(tn_x3tr_flush(s) == 0, "weight-gradient reduction failed");
+    g_pending.e[g_pending.n++] = {P, dst, nslab, count4};
+    return 0;
+}
+
 int tn_x3tr_flush(hipStream_t s) {
     if (g_pending.n == 0) return 0;
     XtReduceBatch b = g_pending;

@@ -830,6 +830,16 @@ int launch_lstm_bwd_recur(const stair_lstm_bwd_args &a, hipStream_t s) {
 // by the caller's tn_x3tr_flush) when the shape is its and the scratch suffices, the < 32 rows past the last whole stage through the
 // atomic kernel (one add per element: still deterministic); otherwise the atomic kernel.
 static int lstm_weight_product(stair_gemm_tn_args g, float *&scr, int64_t &left, hipStream_t s) {
+    if (g.b_is_bf16 && scr) {               // dW_ih on stored-bf16 rows: the transposed-read kernel with its 8 slabs stored, then added in order
+        const int64_t need = align_up((int64_t)8 * g.N * g.K, 64);
+        if (need <= left) {
+            const int rc = launch_gemm_tn_tr_slabs(g, scr, s);
+            if (rc >= 0) {
+                if (rc == 0) { scr += need; left -= need; }
+                return rc;
+            }
+        }
+    }
     stair_gemm_tn_args h = g;
     h.M = g.M & ~31;
     if (scr && h.M >= 2048 && tn_x3tr_takes(h)) {

@@ -66,6 +66,9 @@ int launch_mask_relu(float *dst, const float *G, int64_t g_gs, const int32_t *g_
                      const int32_t *y_idx, int groups, int rowlen, hipStream_t s, float scale = 1.0f);
 int launch_bcast_mask_relu(float *dst, const float *dsum, const float *Y, int groups, int T, int H, hipStream_t s,
                            float scale = 1.0f, const int32_t *len = nullptr);
+int launch_span_mean_bwd_rows(float *dtok, int64_t ld, int rows, const int32_t *row_ptr, const int32_t *row_span, const int32_t *count,
+                              const float *dvec, const int32_t *out_idx, int H, hipStream_t s);
+int launch_rowsum_small(const float *X, float *out, int n, int T, hipStream_t s);
 int launch_grad_fanin(const int32_t *tab, int n, float *gvec, float *gmap, float *gatt, int H, int T, hipStream_t s);
 int launch_scatter_add_rows(float *dst, const int32_t *dst_idx, const float *src, int n, int len, float scale, hipStream_t s);
 int launch_pack_bwd(int mode, const float *A, const int32_t *ia, const float *B, const int32_t *ib, const float *g,

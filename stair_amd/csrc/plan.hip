@@ -411,6 +411,9 @@ struct stair_plan {
     std::vector<int32_t> fanin;                  // 5 ints per entry
     std::vector<int> fanin_first, fanin_count;   // per level
     int64_t off_fanin = 0;
+    int64_t o_gshadow = 0;
+    std::vector<int32_t> tok_ptr, tok_span;      // training: for every question-token row the span means it belongs to (CSR over the span bucket's instances)
+    int64_t off_tok_ptr = 0, off_tok_span = 0;                       // 64-bit fixed-point shadows of every weight gradient (two floats per element)
     int64_t coop_bytes = 0;
     // training: weight-gradient products grouped per WEIGHT (WF_* ids).  Every bucket that uses a weight writes its dZ into its
     // block of wg_dz[w]; the matching X operand is the input tiles gathered through wg_off_idx[w] (first-layer weights) or the
@@ -1019,7 +1022,23 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
     int64_t idx_ints = (int64_t)pl->idx.size();
     for (Bucket &b : pl->buckets)
         for (int c = 0; c < 8; ++c) idx_ints += align_up((int64_t)b.col[c].size(), 4) + align_up((int64_t)b.gcol[c].size(), 4);
-    if (pl->train) idx_ints += align_up((int64_t)pl->groots.size(), 4) + align_up((int64_t)pl->fanin.size(), 4);
+    if (pl->train) {
+        // token row -> the spans that average over it (their gradient reaches the row by a gather in span order: no atomics)
+        pl->tok_ptr.assign(pl->rows_q + 1, 0);
+        pl->tok_span.clear();
+        for (const Bucket &b : pl->buckets)
+            if (b.op == OP_SPAN) {
+                for (int i = 0; i < b.cnt; ++i)
+                    for (int r = 0; r < b.col[1][i]; ++r) ++pl->tok_ptr[b.col[0][i] + r + 1];
+                for (int r = 0; r < pl->rows_q; ++r) pl->tok_ptr[r + 1] += pl->tok_ptr[r];
+                pl->tok_span.assign(pl->tok_ptr[pl->rows_q], 0);
+                std::vector<int32_t> at(pl->tok_ptr.begin(), pl->tok_ptr.end() - 1);
+                for (int i = 0; i < b.cnt; ++i)
+                    for (int r = 0; r < b.col[1][i]; ++r) pl->tok_span[at[b.col[0][i] + r]++] = i;
+            }
+        idx_ints += align_up((int64_t)pl->groots.size(), 4) + align_up((int64_t)pl->fanin.size(), 4) +
+                    align_up((int64_t)pl->tok_ptr.size(), 4) + align_up((int64_t)pl->tok_span.size(), 4);
+    }
     // per-weight gather columns of the deferred weight-gradient products: the input tile of every instance that uses the weight
     // as a first layer, bucket after bucket (Temporal: also the rows of its per-frame scale)
     std::vector<int32_t> wg_idx[WF_COUNT], wg_rs[WF_COUNT];
@@ -1057,7 +1076,10 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
             b.off[c] = push(b.col[c]);
             b.goff[c] = b.gcol[c].empty() ? b.off[c] : push(b.gcol[c]);
         }
-    if (pl->train) { pl->off_groots = push(pl->groots); pl->off_fanin = push(pl->fanin); }
+    if (pl->train) {
+        pl->off_groots = push(pl->groots); pl->off_fanin = push(pl->fanin);
+        pl->off_tok_ptr = push(pl->tok_ptr); pl->off_tok_span = push(pl->tok_span);
+    }
     if (pl->train)
         for (int w = 0; w < WF_COUNT; ++w) { pl->wg_off_idx[w] = push(wg_idx[w]); pl->wg_off_rs[w] = push(wg_rs[w]); }
     STAIR_CHECK((int64_t)pl->idx.size() == idx_ints, "internal: idx size");
@@ -1207,6 +1229,7 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
         pl->o_gqfeat = take((int64_t)n * H, 64);
         pl->o_zero_end = align_up(o, 64);
         o = pl->o_zero_end;
+        pl->o_gshadow = take(2 * ctx_weight_floats(ctx), 64);     // cleared at the start of every backward pass as well
         // scratch that individual buckets clear themselves before accumulating into it
         pl->o_gK = take((int64_t)std::max(pl->maxK, 1) * H, 64);
         pl->o_gS = take((int64_t)std::max(pl->maxSupRows, 1) * T, 64);
@@ -2007,6 +2030,56 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
 // =============================================================================================
 namespace {
 
+// ---- deterministic weight-gradient accumulation (common.h det_shadow) ----
+struct DetRange { const float *beg, *end; int id; };
+struct DetState {
+    bool active = false;
+    long long *base = nullptr;
+    std::vector<DetRange> ranges;                // the bound gradient tensors, sorted by address
+    std::vector<int64_t> off;                    // per weight id: offset of its shadow
+    std::vector<char> touched;
+};
+thread_local DetState g_det;
+
+bool det_enabled() {
+    static const bool on = [] { const char *e = getenv("STAIR_DETERMINISTIC"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+struct FxFlushBatch { float *dst[128]; long long *src[128]; int count[128]; int n; };
+__global__ void fx_flush_kernel(FxFlushBatch b) {
+    const int t = blockIdx.y;
+    float *d = b.dst[t];
+    long long *sh = b.src[t];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < b.count[t]; i += gridDim.x * blockDim.x)
+        if (sh[i] != 0) { d[i] += (float)((double)sh[i] * (1.0 / 17592186044416.0)); sh[i] = 0; }     // (emptied: a second flush adds nothing twice)
+}
+
+// the shadows of every tensor touched since the last flush -> the fp32 gradients, on stream s
+int det_flush(const stair_ctx *ctx, hipStream_t s) {
+    DetState &d = g_det;
+    if (!d.active) return 0;
+    FxFlushBatch fb;
+    fb.n = 0;
+    int most = 0;
+    auto launch = [&]() -> int {
+        if (fb.n == 0) return 0;
+        for (int i = fb.n; i < 128; ++i) { fb.dst[i] = nullptr; fb.src[i] = nullptr; fb.count[i] = 0; }
+        hipLaunchKernelGGL(fx_flush_kernel, dim3(std::max(1, std::min((most + 255) / 256, 512)), fb.n), dim3(256), 0, s, fb);
+        STAIR_LAUNCH_CHECK();
+        fb.n = 0; most = 0;
+        return 0;
+    };
+    for (size_t i = 0; i < ctx->names.size(); ++i) {
+        if (!d.touched[i]) continue;
+        d.touched[i] = 0;
+        fb.dst[fb.n] = ctx->gptr[i]; fb.src[fb.n] = d.base + d.off[i]; fb.count[fb.n] = (int)ctx->numel[i];
+        most = std::max(most, (int)ctx->numel[i]);
+        if (++fb.n == 128) if (int rc = launch()) return rc;
+    }
+    return launch();
+}
+
 struct BwdCtx {
     hipStream_t s;
     float *wt;                       // transposed weight images
@@ -2066,6 +2139,21 @@ extern "C" int stair_set_tn_slab_min_rows(int32_t rows) {
     return 0;
 }
 
+long long *stair::det_shadow(const float *g) {
+    DetState &d = g_det;
+    if (!d.active || !g) return nullptr;
+    size_t lo = 0, hi = d.ranges.size();
+    while (lo < hi) {                            // the last range that begins at or before g
+        const size_t mid = (lo + hi) / 2;
+        if (d.ranges[mid].beg <= g) lo = mid + 1; else hi = mid;
+    }
+    if (lo == 0) return nullptr;
+    const DetRange &r = d.ranges[lo - 1];
+    if (g >= r.end) return nullptr;
+    d.touched[r.id] = 1;
+    return d.base + d.off[r.id] + (g - r.beg);
+}
+
 extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *video, const float *question,
                                    void *workspace, int64_t workspace_bytes, const int32_t *answers, float loss_scale,
                                    float *loss_out, int32_t flags, stair_stream stream) {
@@ -2105,6 +2193,26 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
     B.s = s; B.wt = ws + pl->o_wt; B.splitk = ws + pl->o_splitk;
     B.tn_ring = pl->o_tnring ? ws + pl->o_tnring : nullptr; B.tn_ring_floats = pl->tnring_floats;
     B.wt_off.assign(ctx->names.size(), 0);
+    // run-to-run reproducible weight gradients: kernels that add into a gradient tensor from several workgroups add into its
+    // fixed-point shadow while this scope is open (common.h det_shadow); the shadows reach the fp32 gradients at the end of the pass
+    struct DetScope {
+        ~DetScope() { g_det.active = false; }
+    } det_scope;
+    if (det_enabled() && pl->o_gshadow > 0) {
+        DetState &d = g_det;
+        d.base = reinterpret_cast<long long *>(ws + pl->o_gshadow);
+        d.off.assign(ctx->names.size(), 0);
+        d.touched.assign(ctx->names.size(), 0);
+        d.ranges.clear();
+        int64_t o64 = 0;
+        for (size_t i = 0; i < ctx->names.size(); ++i) {
+            d.off[i] = o64; o64 += align_up(ctx->numel[i], 64);
+            if (ctx->gptr[i]) d.ranges.push_back({ctx->gptr[i], ctx->gptr[i] + ctx->numel[i], (int)i});
+        }
+        std::sort(d.ranges.begin(), d.ranges.end(), [](const DetRange &a, const DetRange &b) { return a.beg < b.beg; });
+        if (int rcz_ = launch_zero(d.base, o64 * (int64_t)sizeof(long long), s)) return rcz_;
+        d.active = true;
+    }
     // weight-gradient products of the tile-level layers run ONCE per weight, after all buckets (FilterFrame's dense layer keeps
     // its per-bucket product: its X operand carries the attention scale only in the tensor-keyword variant)
     const Lin *lin_of[WF_COUNT] = {&W.f0[0], &W.f0[1], &W.f0[2], &W.f0[3], &W.f3[0], &W.f3[1], &W.f3[2], &W.f3[3], &W.ff0[0], &W.ff0[1], &W.ff0[2],
@@ -2268,7 +2376,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
         };
         switch (b.op) {
             case OP_SPAN:
-                RUN(launch_span_mean_bwd(g_tok, H, I0, I1, g_vec, I2, c, H, s));
+                RUN(launch_span_mean_bwd_rows(g_tok, H, pl->rows_q, didx + pl->off_tok_ptr, didx + pl->off_tok_span, I1, g_vec, I2, H, s));
                 break;
             case STAIR_OP_AND:
             case STAIR_OP_XORFRAME: {
@@ -2373,7 +2481,8 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
                     if (int rcz_ = launch_zero(gExtra, (size_t)c * sizeof(float), s)) return rcz_;
                     RUN(launch_rowscale_bwd(gB, svB, TH, nullptr, svRs, T, nullptr, nullptr, gRs, c, T, H, s));   // da_t = G_t . f_t
                     RUN(launch_scale_rows(gB, svRs, (int64_t)c * T, H, s));                                        // df  = a_t * G_t
-                    RUN(launch_rowdot_sigmoid_bwd(gRs, T, nullptr, svRs, T, nullptr, W.ffatt.w, gB, 1, gRs2, gExtra, c, T, H, s));
+                    RUN(launch_rowdot_sigmoid_bwd(gRs, T, nullptr, svRs, T, nullptr, W.ffatt.w, gB, 1, gRs2, nullptr, c, T, H, s));
+                    RUN(launch_rowsum_small(gRs2, gExtra, c, T, s));          // d(keyword term) = sum_t d(pre-sigmoid), in frame order
                     RUN(launch_weighted_colsum(svB, H, nullptr, gRs2, W.ffatt.dw, c * T, H, s));                  // d w[:H]
                     RUN(launch_weighted_colsum(vec, H, I1, gExtra, W.ffatt.dw + H, c, H, s));                     // d w[H:]
                     RUN(launch_sum_all(gRs2, W.ffatt.db, c * T, s));
@@ -2541,10 +2650,9 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
     if (overlap_tn) STAIR_HIP(hipEventRecord(ctx->ev_join, ctx->side));
     // Every gradient except the two encoders' is final here (decoder, all module levels, their weight-gradient products): a
     // data-parallel trainer starts reducing that part of its bucket now, beside the BPTT below (stair_plan_set_backward_event)
-    if (pl->bwd_event) {
-        if (overlap_tn) STAIR_HIP(hipStreamWaitEvent(s, ctx->ev_join, 0));
-        STAIR_HIP(hipEventRecord(static_cast<hipEvent_t>(pl->bwd_event), s));
-    }
+    if (overlap_tn && (pl->bwd_event || g_det.active)) STAIR_HIP(hipStreamWaitEvent(s, ctx->ev_join, 0));
+    RUN(det_flush(ctx, s));                   // ... including what went through the fixed-point shadows (module levels, decoder)
+    if (pl->bwd_event) STAIR_HIP(hipEventRecord(static_cast<hipEvent_t>(pl->bwd_event), s));
 
     // ---- encoders ------------------------------------------------------------------------------------
     {
@@ -2588,6 +2696,8 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
     }
     RUN(tn_x3tr_flush(s));                   // the encoders' slab-reduced weight gradients
     if (overlap_tn) STAIR_HIP(hipStreamWaitEvent(s, ctx->ev_join, 0));      // the optimizer (next on `s`) sees every dW
+    RUN(det_flush(ctx, s));                  // the encoders' fixed-point shadows -> the fp32 gradients
+    g_det.active = false;
 #undef RUN
     return 0;
 }

@@ -202,6 +202,27 @@ int launch_span_mean_bwd(float *dtok, int64_t ld, const int32_t *start, const in
     return 0;
 }
 
+// The same as a gather per token row (training plans carry the row -> spans lists): dtok[row][:] += sum over the spans that contain
+// the row, in span order, of dvec[out[span]][:] / count[span] -- one writer per element, no atomics, the same sum every run.
+__global__ void span_mean_bwd_rows_kernel(float *dtok, int64_t ld, const int32_t *row_ptr, const int32_t *row_span, const int32_t *count,
+                                          const float *dvec, const int32_t *out_idx, int H) {
+    const int row = blockIdx.x;
+    const int b = row_ptr[row], e = row_ptr[row + 1];
+    if (b == e) return;
+    for (int col = threadIdx.x; col < H; col += blockDim.x) {
+        float acc = 0.f;
+        for (int j = b; j < e; ++j) { const int sp = row_span[j]; acc += dvec[(int64_t)out_idx[sp] * H + col] / (float)count[sp]; }
+        dtok[(int64_t)row * ld + col] += acc;
+    }
+}
+int launch_span_mean_bwd_rows(float *dtok, int64_t ld, int rows, const int32_t *row_ptr, const int32_t *row_span, const int32_t *count,
+                              const float *dvec, const int32_t *out_idx, int H, hipStream_t s) {
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(span_mean_bwd_rows_kernel, dim3(rows), dim3(128), 0, s, dtok, ld, row_ptr, row_span, count, dvec, out_idx, H);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // cosine attention backward.  out = (cos+1)*0.49, cos = f.k / (nf * nk), nf = max(|f|,eps), nk likewise.
 //   dF[fi][t][:] += dcos * (k/(nf nk) - cos f/nf^2)        (atomic: pairs of one Localize share the tile)
@@ -313,8 +334,8 @@ __global__ __launch_bounds__(256) void cosine_attn_bwd_grouped_kernel(const floa
 #pragma unroll
         for (int j = 0; j < 8; ++j) { const int a = a0 + 4 * j; if (a < KP) kt[a * 64 + lane] = v[j]; }
     }
-    float *su = scsum + KP;                 // MF only: u[a][t] = dcos * cos, same [KP][TS] layout as sa
-    int *rowi = reinterpret_cast<int *>(su + (MF ? KP * TS : 0));       // [2][ka_max]: score / dscore row of pair a
+    float *su = scsum + KP;                 // u[a][t] = dcos * cos, same [KP][TS] layout as sa
+    int *rowi = reinterpret_cast<int *>(su + KP * TS);                  // [2][ka_max]: score / dscore row of pair a
     for (int a = threadIdx.x; a < Ka; a += blockDim.x) {
         rowi[a] = score_idx ? score_idx[p0 + a] : p0 + a;
         rowi[ka_max + a] = dscore_idx ? dscore_idx[p0 + a] : p0 + a;
@@ -340,15 +361,12 @@ __global__ __launch_bounds__(256) void cosine_attn_bwd_grouped_kernel(const floa
             const float cosv = sv[j] / 0.49f - 1.0f;
             const float dcos = 0.49f * dv[j];
             sa[a * TS + t] = dcos / (nf[t] * nk[a]);
-            if (MF) su[a * TS + t] = dcos * cosv;
-            else {
-                atomicAdd(&sbsum[t], dcos * cosv / (nf[t] * nf[t]));
-                atomicAdd(&scsum[a], dcos * cosv);
-            }
+            su[a * TS + t] = dcos * cosv;
         }
     }
     __syncthreads();
-    if (MF) {       // the two marginal sums without LDS atomics (Ka * T adds onto T + Ka addresses serialised): column / row walks
+    {               // the two marginal sums as column / row walks: no LDS atomics (Ka * T adds onto T + Ka addresses serialised, and float
+                    // atomics land in any order: the sums would differ from run to run)
         for (int t = threadIdx.x; t < T; t += blockDim.x) {
             float acc = 0.f;
             for (int a = 0; a < Ka; ++a) acc += su[a * TS + t];
@@ -418,7 +436,7 @@ int launch_cosine_attn_bwd_grouped(const float *F, const float *Kmat, const floa
     STAIR_LAUNCH_CHECK();
     const int TP = (T + 31) / 32 * 32, KP = (ka_max + 31) / 32 * 32;
     const size_t shmem_mf = (2 * (size_t)KP * (TP + 1) + (size_t)KP * 64 + (size_t)TP * 64 + TP + KP + 2 * ka_max) * sizeof(float);
-    const size_t shmem_sc = ((size_t)ka_max * T + (size_t)ka_max * 64 + (size_t)T * 64 + T + ka_max + 2 * ka_max) * sizeof(float);
+    const size_t shmem_sc = (2 * (size_t)ka_max * T + (size_t)ka_max * 64 + (size_t)T * 64 + T + ka_max + 2 * ka_max) * sizeof(float);
     const bool mf = ka_max > 8 && shmem_mf <= 80 * 1024;     // many pairs per instance (Superlative); Localize (1-2 pairs) is bound by its F and dF rows, not by the products; at least two blocks per CU
     const size_t shmem = mf ? shmem_mf : shmem_sc;
     STAIR_CHECK(shmem <= 160 * 1024, "cosine backward: Ka*T too large for LDS");
@@ -438,7 +456,7 @@ int launch_cosine_attn_bwd_grouped(const float *F, const float *Kmat, const floa
 
 // ---------------------------------------------------------------------------------------------
 // Temporal relate nets backward (recomputes the three layers in LDS).  dw[6] accumulate with atomics.
-struct RelateWB { const float *w[6]; float *dw[6]; };
+struct RelateWB { const float *w[6]; float *dw[6]; long long *dw64[6]; };      // dw64: fixed-point shadows (det_shadow) or NULL
 constexpr int kRelateTapStride = 72;      // LDS floats per staged Conv1d filter: up to 71 taps (2 k + 1 with k <= 35) + the bias
 __global__ void temporal_relate_bwd_kernel(const float *att, const int32_t *att_idx, const int32_t *att_k,
                                            const float *drel, const int32_t *rel_idx, float *datt, int n, int T, int mode,
@@ -502,12 +520,12 @@ __global__ void temporal_relate_bwd_kernel(const float *att, const int32_t *att_
                 for (int j = threadIdx.x; j < k; j += blockDim.x) {        // dw[j] = sum_t dz[t] x[t+j-left]
                     float acc = 0.f;
                     for (int t = 0; t < L; ++t) { const int u = t + j - left; if (u >= 0 && u < L) acc += gin[t] * x[u]; }
-                    unsafeAtomicAdd(W.dw[2 * layer] + j, acc);
+                    grad_add(W.dw[2 * layer], W.dw64[2 * layer], j, acc);
                 }
                 if (threadIdx.x == 0) {
                     float acc = 0.f;
                     for (int t = 0; t < L; ++t) acc += gin[t];
-                    unsafeAtomicAdd(W.dw[2 * layer + 1], acc);
+                    grad_add(W.dw[2 * layer + 1], W.dw64[2 * layer + 1], 0, acc);
                 }
                 for (int u = threadIdx.x; u < L; u += blockDim.x) {       // dx[u] = sum_j w[j] dz[u-j+left]
                     float acc = 0.f;
@@ -517,9 +535,9 @@ __global__ void temporal_relate_bwd_kernel(const float *att, const int32_t *att_
             } else {
                 for (int e = threadIdx.x; e < T * T; e += blockDim.x) {
                     const int t = e / T, u = e - t * T;
-                    unsafeAtomicAdd(W.dw[2 * layer] + e, gin[t] * x[u]);
+                    grad_add(W.dw[2 * layer], W.dw64[2 * layer], e, gin[t] * x[u]);
                 }
-                for (int t = threadIdx.x; t < T; t += blockDim.x) unsafeAtomicAdd(W.dw[2 * layer + 1] + t, gin[t]);
+                for (int t = threadIdx.x; t < T; t += blockDim.x) grad_add(W.dw[2 * layer + 1], W.dw64[2 * layer + 1], t, gin[t]);
                 for (int u = threadIdx.x; u < T; u += blockDim.x) {
                     float acc = 0.f;
                     for (int t = 0; t < T; ++t) acc += w[(int64_t)t * T + u] * gin[t];
@@ -545,7 +563,10 @@ int launch_temporal_relate_bwd(const float *att, const int32_t *att_idx, const i
     // gradients; the three layers' filters / matrices and their gradients are a few hundred floats per launch
     STAIR_ACCT("temporal_relate_bwd_kernel", (int64_t)n * T * 4 * (2 + 1 + 2));
     RelateWB W;
-    for (int i = 0; i < 6; ++i) { W.w[i] = (mode && w) ? w[i] : nullptr; W.dw[i] = (mode && dw) ? dw[i] : nullptr; }
+    for (int i = 0; i < 6; ++i) {
+        W.w[i] = (mode && w) ? w[i] : nullptr; W.dw[i] = (mode && dw) ? dw[i] : nullptr;
+        W.dw64[i] = W.dw[i] ? det_shadow(W.dw[i]) : nullptr;
+    }
     STAIR_CHECK(!(mode && conv) || 2 * ksize + 1 < kRelateTapStride, "Conv1d relate nets: kernel size <= 35");
     hipLaunchKernelGGL(temporal_relate_bwd_kernel, dim3(n), dim3(64), (6 * T + 3 * kRelateTapStride) * sizeof(float), s, att, att_idx, att_k, drel,
                        rel_idx, datt, n, T, mode, conv, ksize, W, len, gatt_idx);
@@ -585,7 +606,7 @@ __global__ void layernorm_bwd_kernel(const float *dOut, int64_t g_gs, const int3
     if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
 }
 __global__ void layernorm_param_grad_kernel(const float *dOut, int64_t g_gs, const int32_t *g_idx, const float *Y,
-                                            const float *stats, int n, int T, int H, float *dgamma, float *dbeta, int slab) {
+                                            const float *stats, int n, int T, int H, float *dgamma, float *dbeta, int slab, long long *dgamma64, long long *dbeta64) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= H) return;
     const int64_t rbeg = (int64_t)blockIdx.y * slab, rend = min((int64_t)n * T, rbeg + slab);
@@ -596,15 +617,15 @@ __global__ void layernorm_param_grad_kernel(const float *dOut, int64_t g_gs, con
         ag += go * (Y[row * H + c] - stats[2 * row]) * stats[2 * row + 1];
         ab += go;
     }
-    unsafeAtomicAdd(dgamma + c, ag);
-    unsafeAtomicAdd(dbeta + c, ab);
+    grad_add(dgamma, dgamma64, c, ag);
+    grad_add(dbeta, dbeta64, c, ab);
 }
 // One pass for H a multiple of 256: a wave owns a row at a time (16-byte pieces in registers: y and dOut are read ONCE),
 // walks rows grid-stride and keeps the dgamma / dbeta sums of its columns in registers until the end (the two-kernel form
 // above reads Y four times and dOut three times and runs at 1.4 TB/s: profiles/r02_row_kernels.json).
 template <int NV>
 __global__ void layernorm_bwd_fused_kernel(const float *dOut, int64_t g_gs, const int32_t *g_idx, const float *Y, int n, int T,
-                                           const float *gamma, float eps, float *dZ, float *dgamma, float *dbeta, float scale) {
+                                           const float *gamma, float eps, float *dZ, float *dgamma, float *dbeta, float scale, long long *dgamma64, long long *dbeta64) {
     constexpr int H = NV * 256;
     const int lane = threadIdx.x & 63;
     const int64_t rows = (int64_t)n * T, stride = (int64_t)gridDim.x * kWavesPerBlock;
@@ -669,7 +690,7 @@ __global__ void layernorm_bwd_fused_kernel(const float *dOut, int64_t g_gs, cons
         float v = 0.f;
 #pragma unroll
         for (int q = 0; q < kWavesPerBlock; ++q) v += red[which][q][col];
-        unsafeAtomicAdd((which ? dbeta : dgamma) + col, v);
+        grad_add(which ? dbeta : dgamma, which ? dbeta64 : dgamma64, col, v);
     }
 }
 int launch_layernorm_bwd(const float *dOut, int64_t g_gs, const int32_t *g_idx, const float *Y, int n, int T, int H,
@@ -681,8 +702,8 @@ int launch_layernorm_bwd(const float *dOut, int64_t g_gs, const int32_t *g_idx, 
     const bool al = ((reinterpret_cast<uintptr_t>(dOut) | reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(dZ) | reinterpret_cast<uintptr_t>(gamma)) & 15) == 0;
     if (al && (H == 256 || H == 512) && g_gs % 4 == 0) {
         const unsigned blocks = (unsigned)std::min<int64_t>((rows + kWavesPerBlock - 1) / kWavesPerBlock, 256 * 4);
-        if (H == 512) hipLaunchKernelGGL(layernorm_bwd_fused_kernel<2>, dim3(blocks), dim3(kBlock), 0, s, dOut, g_gs, g_idx, Y, n, T, gamma, eps, dZ, dgamma, dbeta, scale);
-        else hipLaunchKernelGGL(layernorm_bwd_fused_kernel<1>, dim3(blocks), dim3(kBlock), 0, s, dOut, g_gs, g_idx, Y, n, T, gamma, eps, dZ, dgamma, dbeta, scale);
+        if (H == 512) hipLaunchKernelGGL(layernorm_bwd_fused_kernel<2>, dim3(blocks), dim3(kBlock), 0, s, dOut, g_gs, g_idx, Y, n, T, gamma, eps, dZ, dgamma, dbeta, scale, det_shadow(dgamma), det_shadow(dbeta));
+        else hipLaunchKernelGGL(layernorm_bwd_fused_kernel<1>, dim3(blocks), dim3(kBlock), 0, s, dOut, g_gs, g_idx, Y, n, T, gamma, eps, dZ, dgamma, dbeta, scale, det_shadow(dgamma), det_shadow(dbeta));
         STAIR_LAUNCH_CHECK();
         return 0;
     }
@@ -691,7 +712,7 @@ int launch_layernorm_bwd(const float *dOut, int64_t g_gs, const int32_t *g_idx, 
     STAIR_LAUNCH_CHECK();
     const int slab = (int)std::max<int64_t>(64, (rows + 255) / 256);
     hipLaunchKernelGGL(layernorm_param_grad_kernel, dim3((H + 255) / 256, (unsigned)((rows + slab - 1) / slab)), dim3(256), 0, s,
-                       dOut, g_gs, g_idx, Y, stats, n, T, H, dgamma, dbeta, slab);
+                       dOut, g_gs, g_idx, Y, stats, n, T, H, dgamma, dbeta, slab, det_shadow(dgamma), det_shadow(dbeta));
     STAIR_LAUNCH_CHECK();
     return 0;
 }
@@ -762,6 +783,20 @@ __global__ void rowdot_sigmoid_bwd_kernel(const float *dOut, int64_t o_gs, const
         if (dextra) unsafeAtomicAdd(dextra + g, dpre);
     }
 }
+// out[g] = sum_t X[g][t] in frame order (the per-instance sum of FilterFrame's pre-sigmoid gradients: one thread per instance, no atomics)
+__global__ void rowsum_small_kernel(const float *X, float *out, int n, int T) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    float acc = 0.f;
+    for (int t = 0; t < T; ++t) acc += X[(int64_t)g * T + t];
+    out[g] = acc;
+}
+int launch_rowsum_small(const float *X, float *out, int n, int T, hipStream_t s) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(rowsum_small_kernel, dim3((n + 127) / 128), dim3(128), 0, s, X, out, n, T);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
 int launch_rowdot_sigmoid_bwd(const float *dOut, int64_t o_gs, const int32_t *o_idx, const float *A, int64_t a_gs,
                               const int32_t *a_idx, const float *w, float *dXdst, int add_mode, float *dpre_out,
                               float *dextra, int n, int T, int H, hipStream_t s, float keep) {
@@ -776,7 +811,7 @@ int launch_rowdot_sigmoid_bwd(const float *dOut, int64_t o_gs, const int32_t *o_
 
 // out[c] += sum_rows scale[row] * X[row][c]   (gradient of a [H] weight used in a row dot; X rows optionally gathered)
 __global__ void weighted_colsum_kernel(const float *X, int64_t ld, const int32_t *x_idx, const float *scale, float *out,
-                                       int rows, int H, int slab) {
+                                       int rows, int H, int slab, long long *out64) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= H) return;
     const int rbeg = blockIdx.y * slab, rend = min(rows, rbeg + slab);
@@ -790,7 +825,7 @@ __global__ void weighted_colsum_kernel(const float *X, int64_t ld, const int32_t
         for (int j = 0; j < 8; ++j) acc += sc[j] * xv[j];
     }
     for (; r < rend; ++r) acc += scale[r] * X[(int64_t)idx_or_id(x_idx, r) * ld + c];
-    unsafeAtomicAdd(out + c, acc);
+    grad_add(out, out64, c, acc);
 }
 int launch_weighted_colsum(const float *X, int64_t ld, const int32_t *x_idx, const float *scale, float *out, int rows, int H,
                            hipStream_t s) {
@@ -798,7 +833,7 @@ int launch_weighted_colsum(const float *X, int64_t ld, const int32_t *x_idx, con
     STAIR_ACCT("weighted_colsum_kernel", ((int64_t)rows * H + rows + H) * 4);
     const int slab = std::max(64, (rows + 255) / 256);
     hipLaunchKernelGGL(weighted_colsum_kernel, dim3((H + 255) / 256, (rows + slab - 1) / slab), dim3(256), 0, s, X, ld, x_idx,
-                       scale, out, rows, H, slab);
+                       scale, out, rows, H, slab, det_shadow(out));
     STAIR_LAUNCH_CHECK();
     return 0;
 }
@@ -818,15 +853,15 @@ int launch_axpy_rows(float *dV, const int32_t *idx, const float *scale, const fl
 }
 
 // sum of a float array into out[0] (bias of a 1-output Linear)
-__global__ void sum_all_kernel(const float *x, float *out, int n) {
+__global__ void sum_all_kernel(const float *x, float *out, int n, long long *out64) {
     float acc = 0.f;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) acc += x[i];
     acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(out, acc);
+    if ((threadIdx.x & 63) == 0) grad_add(out, out64, 0, acc);
 }
 int launch_sum_all(const float *x, float *out, int n, hipStream_t s) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(sum_all_kernel, dim3(std::min((n + 255) / 256, 256)), dim3(256), 0, s, x, out, n);
+    hipLaunchKernelGGL(sum_all_kernel, dim3(std::min((n + 255) / 256, 256)), dim3(256), 0, s, x, out, n, det_shadow(out));
     STAIR_LAUNCH_CHECK();
     return 0;
 }
@@ -834,7 +869,7 @@ int launch_sum_all(const float *x, float *out, int n, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 // Relate backward: y = softmax(x + sign*beta): dx = y * (dy - sum(dy*y)); datt[in] += dx; dbeta += sign*dx
 __global__ void relate_softmax_bwd_kernel(const float *att, float *datt, const int32_t *in_idx, const int32_t *out_idx,
-                                          float *dbeta, float sign, int n, int T, const int32_t *len, const int32_t *gin_idx) {
+                                          float *dbeta, float sign, int n, int T, const int32_t *len, const int32_t *gin_idx, long long *dbeta64) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (i >= n) return;
@@ -847,14 +882,14 @@ __global__ void relate_softmax_bwd_kernel(const float *att, float *datt, const i
     for (int t = lane; t < L; t += 64) {
         const float dx = y[t] * (dy[t] - dot);
         unsafeAtomicAdd(datt + (int64_t)(gin_idx ? gin_idx[i] : in_idx[i]) * T + t, dx);
-        unsafeAtomicAdd(dbeta + t, sign * dx);
+        grad_add(dbeta, dbeta64, t, sign * dx);
     }
 }
 int launch_relate_softmax_bwd(const float *att, float *datt, const int32_t *in_idx, const int32_t *out_idx, float *dbeta,
                               float sign, int n, int T, hipStream_t s, const int32_t *len, const int32_t *gin_idx) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(relate_softmax_bwd_kernel, dim3((n + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlock), 0, s, att, datt,
-                       in_idx, out_idx, dbeta, sign, n, T, len, gin_idx);
+                       in_idx, out_idx, dbeta, sign, n, T, len, gin_idx, det_shadow(dbeta));
     STAIR_LAUNCH_CHECK();
     return 0;
 }

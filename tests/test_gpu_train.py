@@ -745,6 +745,42 @@ def test_contrastive_pools_from_a_class_table_equal_the_pooled_lists(matmul):
         assert float((g - out['table'][1][n]).abs().max()) <= 2e-5 * max(float(g.abs().max()), 1e-3), n
 
 
+@pytest.mark.parametrize('n_q,clips', [(64, 32), (300, 300)])
+def test_training_step_is_bit_reproducible(n_q, clips):
+    """The reference's CPU loop is deterministic (train_module.py:341-412); so is this step: two fresh trainers, the same two
+    windows -- all twelve program forms, full hidden size, stored-bf16 clips, two questions per clip in the first case (shared
+    clips and common subexpressions: several readers per gradient slot) -- must end with bit-identical gradient buckets and
+    bit-identical weights after Adam.  What makes it so: gradient fan-in through staging slots added in a fixed order
+    (stair_plan_info.n_*_stage), weight-gradient partials stored and reduced in slab order, and 64-bit fixed-point shadows
+    under every remaining many-to-one float atomic (csrc/common.h det_shadow)."""
+    from stair_amd.train import Trainer
+    config = dict(spec.DEFAULT_CONFIG)
+    qs = [synth.make_question(config, 21, i, T=64, forms=synth.ALL_FORMS, with_video=False) for i in range(n_q)]
+    g = torch.Generator().manual_seed(9)
+    video = torch.randn(clips, 64, config['video_size'], generator=g).to(torch.bfloat16).to(DEV)
+    vidx = [i % clips for i in range(n_q)] if clips != n_q else None
+    question = torch.cat([torch.as_tensor(q['question']) for q in qs]).to(DEV)
+    q_lens = [q['question'].shape[0] for q in qs]
+    answers = torch.tensor([q['answer'] for q in qs], dtype=torch.int32, device=DEV)
+    progs, spans = [q['nmn_program_list'] for q in qs], [q['prog_str_to_question_tokens'] for q in qs]
+    runs = []
+    for rep in range(2):
+        tr = Trainer(_model(config, 5), dropout=0.0, lr=1e-3)
+        grads = []
+        for it in range(2):
+            _, res = tr.step(progs, spans, video, question, q_lens, answers, video_index=vidx)
+            grads.append(tr.flat_g.clone())
+        tr.check()
+        runs.append((grads, tr.flat_p.clone(), res.info))
+    inf = runs[0][2]
+    if vidx is not None:
+        assert inf.n_aliased > 0 and inf.n_vec_stage > 0 and inf.n_map_stage > 0       # the case is not trivially free of fan-in
+    for it in range(2):
+        assert torch.equal(runs[0][0][it], runs[1][0][it]), 'gradient bucket of step %d differs between two runs' % it
+    assert torch.equal(runs[0][1], runs[1][1])
+    assert float(runs[0][0][0].abs().max()) > 0
+
+
 def test_collated_gold_batch_gives_the_step_of_the_question_dicts():
     """losses.collate_gold (the loader's collate step: the batch's gold intermediates as flat arrays) against the list of question
     dicts: the same index / target arrays reach the same loss kernels -- every criterion value and every parameter gradient bit for
