@@ -88,8 +88,10 @@ def _run(rank, world, supervised, bf16, out, table=False, overlap=None, fail_ran
     torch.save(state, out)
 
 
-def _worker(rank, world, port, supervised, bf16, out_dir, table=False, overlap=None, fail_rank=None, tag='rank'):
+def _worker(rank, world, port, supervised, bf16, out_dir, table=False, overlap=None, fail_rank=None, tag='rank', full_size=False):
     import torch.distributed as dist
+    if full_size:                    # the reference's own sizes: the fused / grouped kernels, whose step is bit-reproducible
+        globals()['CONFIG'] = dict(spec.DEFAULT_CONFIG, max_video_length=40)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
@@ -155,6 +157,23 @@ def test_two_piece_exchange_equals_one_piece_bit_for_bit():
         assert float((dp > 2e-5).float().mean()) < 2e-3 and float(dp.max()) <= 2.1e-3
     for key in ('params', 'grad0', 'grad1', 'touched', 'steps'):
         assert torch.equal(two[0][key], two[1][key]), key       # both ranks of the overlapped job hold the same state, bit for bit
+
+
+def test_two_piece_exchange_is_bit_identical_at_full_size():
+    """The same comparison where the step itself is reproducible (hidden size 512: fused tile operators, grouped vector-level
+    launches, deterministic fan-in): overlapped two-piece exchange against one collective after the pass -- gradients, weights,
+    step counts bit for bit on both ranks.  The module-level shadows must have reached the fp32 gradients before the early piece
+    is reduced (stair_plan_backward flushes them ahead of the 'module gradients final' event)."""
+    import torch.multiprocessing as mp
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(2, _free_port(), False, True, d, False, False, None, 'one', True), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, _free_port(), False, True, d, False, True, None, 'two', True), nprocs=2, join=True)
+        one = [torch.load(os.path.join(d, 'one%d.pt' % r)) for r in range(2)]
+        two = [torch.load(os.path.join(d, 'two%d.pt' % r)) for r in range(2)]
+    for r in range(2):
+        for key in ('params', 'touched', 'steps', 'grad0', 'grad1', 'loss0', 'loss1'):
+            assert torch.equal(one[r][key], two[r][key]), (r, key)
+    assert float(one[0]['grad0'].abs().max()) > 0
 
 
 @pytest.mark.parametrize('overlap', [False, True])
