@@ -540,46 +540,6 @@ def main():
                 sweep.append({'questions_per_step': nq, 'train_ms_per_step': round(dt_t / k * 1e3, 3), 'train_questions_per_s': round(nq * k / dt_t, 1),
                               'infer_ms_per_batch': round(dt_i / k * 1e3, 3), 'infer_questions_per_s': round(nq * k / dt_i, 1)})
             extras['batch_sweep'] = sweep
-            fam = gemm_family_rooflines(lambda: run_step(B, False), device)
-            if fam:
-                extras['roofline_gemm_families'] = fam
-                t = fam.get('tile_mlp_kernel')
-                if t:
-                    # live time of the kernel: HIP events around each of its launches (stair_tile_timing), three steps, no profiler
-                    try:
-                        import ctypes as C
-                        from stair_amd._lib import lib as _lib
-                        from stair_amd import ops as _ops
-                        run_step(B, False); torch.cuda.synchronize()
-                        _lib.stair_tile_timing(1)
-                        with _ops.kernel_accounting() as acct3:
-                            for _ in range(3):
-                                run_step(B, False)
-                            torch.cuda.synchronize()
-                        ms, nl = C.c_double(0.0), C.c_int32(0)
-                        _lib.stair_tile_timing_read(C.byref(ms), C.byref(nl))
-                        _lib.stair_tile_timing(0)
-                        if nl.value > 0 and ms.value > 0 and 'tile_mlp' in acct3.table:
-                            fl = acct3.table['tile_mlp'][2] / 3.0
-                            t = dict(t, ms_per_step=round(ms.value / 3.0, 3), launches_per_step=nl.value // 3,
-                                     algorithmic_TFLOPs=round(fl / (ms.value / 3.0) / 1e9, 1),
-                                     frac_of_bf16_peak=round(fl / (ms.value / 3.0) / 1e9 / BF16_MFMA_PEAK_TFLOPS, 4))
-                            fam['tile_mlp_kernel'] = t
-                    except Exception as e:      # keep the profiler's figure
-                        t = dict(t, timing_error='%s: %s' % (type(e).__name__, str(e)[:80]))
-                if t:       # by SUMMED time per step the fused tile operator (about ten launches) is the largest kernel: its own roofline entry
-                    tile = {'bound': 'mfma', 'kernel': 'tile_mlp_kernel (fused map-level MLP chains, forward and backward, all launches of one step)',
-                            'achieved': t['algorithmic_TFLOPs'], 'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': t['frac_of_bf16_peak'],
-                            'ms_per_step': t['ms_per_step'], 'traffic': None,
-                            'note': 'algorithmic 2MNK of every tile layer of a step / device time of the kernel in the same steps (HIP events around each '
-                                    'launch on its stream, three steps); three executed bf16 MFMAs per algorithmic product'}
-                    try:
-                        pm = json.load(open(os.path.join(ROOT, 'profiles', 'r03_pmc_tile_summary.json')))
-                        tile['traffic'] = pm['per_tile']
-                        tile['traffic_note'] = 'HBM-side bytes PER TILE of a two-layer launch from separate FETCH_SIZE / WRITE_SIZE passes (profiles/r03_pmc_tile_summary.json; reads doubled per the gfx950 correction): algorithmic 131 072 B in, 256 B out in inference, two 131 072 B saves in training'
-                    except (OSError, ValueError, KeyError):
-                        pass
-                    extras['roofline_tile_operator'] = tile
             # ---- configs[4]: the step with per-module intermediate supervision, next to the decoder-only step ----
             if not args.supervision:
                 def host_and_wall(fn, k, warm):
@@ -639,6 +599,48 @@ def main():
             extras['bf16_single_product_mode'] = {'train_questions_per_s': round(3 * B / dtb, 1), 'ms_per_step': round(dtb / 3 * 1e3, 3),
                                                   'note': 'STAIR_MATMUL=bf16: one bf16 MFMA product per operand pair, fp32 accumulate, fp32 features; outside the '
                                                           '1e-4 logit budget by design, so it is reported beside `value`, never as it'}
+            # ---- per-kernel-family rooflines: LAST, because torch's profiler stays hooked into every launch of the process afterwards
+            #      (the legs above would read ~1.3 ms more per step: r03 reported the supervised step that way) ----
+            fam = gemm_family_rooflines(lambda: run_step(B, False), device)
+            if fam:
+                extras['roofline_gemm_families'] = fam
+                t = fam.get('tile_mlp_kernel')
+                if t:
+                    # live time of the kernel: HIP events around each of its launches (stair_tile_timing), three steps, no profiler
+                    try:
+                        import ctypes as C
+                        from stair_amd._lib import lib as _lib
+                        from stair_amd import ops as _ops
+                        run_step(B, False); torch.cuda.synchronize()
+                        _lib.stair_tile_timing(1)
+                        with _ops.kernel_accounting() as acct3:
+                            for _ in range(3):
+                                run_step(B, False)
+                            torch.cuda.synchronize()
+                        ms, nl = C.c_double(0.0), C.c_int32(0)
+                        _lib.stair_tile_timing_read(C.byref(ms), C.byref(nl))
+                        _lib.stair_tile_timing(0)
+                        if nl.value > 0 and ms.value > 0 and 'tile_mlp' in acct3.table:
+                            fl = acct3.table['tile_mlp'][2] / 3.0
+                            t = dict(t, ms_per_step=round(ms.value / 3.0, 3), launches_per_step=nl.value // 3,
+                                     algorithmic_TFLOPs=round(fl / (ms.value / 3.0) / 1e9, 1),
+                                     frac_of_bf16_peak=round(fl / (ms.value / 3.0) / 1e9 / BF16_MFMA_PEAK_TFLOPS, 4))
+                            fam['tile_mlp_kernel'] = t
+                    except Exception as e:      # keep the profiler's figure
+                        t = dict(t, timing_error='%s: %s' % (type(e).__name__, str(e)[:80]))
+                if t:       # by SUMMED time per step the fused tile operator (about ten launches) is the largest kernel: its own roofline entry
+                    tile = {'bound': 'mfma', 'kernel': 'tile_mlp_kernel (fused map-level MLP chains, forward and backward, all launches of one step)',
+                            'achieved': t['algorithmic_TFLOPs'], 'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': t['frac_of_bf16_peak'],
+                            'ms_per_step': t['ms_per_step'], 'traffic': None,
+                            'note': 'algorithmic 2MNK of every tile layer of a step / device time of the kernel in the same steps (HIP events around each '
+                                    'launch on its stream, three steps); three executed bf16 MFMAs per algorithmic product'}
+                    try:
+                        pm = json.load(open(os.path.join(ROOT, 'profiles', 'r03_pmc_tile_summary.json')))
+                        tile['traffic'] = pm['per_tile']
+                        tile['traffic_note'] = 'HBM-side bytes PER TILE of a two-layer launch from separate FETCH_SIZE / WRITE_SIZE passes (profiles/r03_pmc_tile_summary.json; reads doubled per the gfx950 correction): algorithmic 131 072 B in, 256 B out in inference, two 131 072 B saves in training'
+                    except (OSError, ValueError, KeyError):
+                        pass
+                    extras['roofline_tile_operator'] = tile
             del v2, vf
 
     if rank == 0:

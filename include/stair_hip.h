@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STAIR_ABI_VERSION 3
+#define STAIR_ABI_VERSION 4
 
 typedef struct stair_ctx stair_ctx;
 typedef struct stair_plan stair_plan;

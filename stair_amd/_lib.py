@@ -16,7 +16,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('STAIR_LIB_PATH') or os.path.join(_HERE, 'lib', 'libstair_hip.so')   # override: kernel experiments
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)
 

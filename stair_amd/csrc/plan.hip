@@ -55,7 +55,14 @@ struct stair_ctx {
     // backward pass: the per-weight gradient products are leaves of the graph, they run on a second stream beside BPTT
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // 64-bit fixed-point shadows of the weight gradients (common.h det_shadow): owned by the context, all zero between two backward
+    // passes (the flush empties what it adds), so a pass does not start by clearing 8 bytes per parameter; `dirty`: a pass that did not
+    // reach its end left something behind -> the next one clears first
+    void *gshadow = nullptr;
+    int64_t gshadow_elems = 0;
+    bool gshadow_dirty = false;
     ~stair_ctx() {
+        if (gshadow) (void)hipFree(gshadow);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
         if (side) (void)hipStreamDestroy(side);
@@ -1229,7 +1236,7 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
         pl->o_gqfeat = take((int64_t)n * H, 64);
         pl->o_zero_end = align_up(o, 64);
         o = pl->o_zero_end;
-        pl->o_gshadow = take(2 * ctx_weight_floats(ctx), 64);     // cleared at the start of every backward pass as well
+        pl->o_gshadow = 1;            // (training plans use the context's fixed-point gradient shadows, stair_ctx::gshadow)
         // scratch that individual buckets clear themselves before accumulating into it
         pl->o_gK = take((int64_t)std::max(pl->maxK, 1) * H, 64);
         pl->o_gS = take((int64_t)std::max(pl->maxSupRows, 1) * T, 64);
@@ -2200,7 +2207,6 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
     } det_scope;
     if (det_enabled() && pl->o_gshadow > 0) {
         DetState &d = g_det;
-        d.base = reinterpret_cast<long long *>(ws + pl->o_gshadow);
         d.off.assign(ctx->names.size(), 0);
         d.touched.assign(ctx->names.size(), 0);
         d.ranges.clear();
@@ -2210,7 +2216,16 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
             if (ctx->gptr[i]) d.ranges.push_back({ctx->gptr[i], ctx->gptr[i] + ctx->numel[i], (int)i});
         }
         std::sort(d.ranges.begin(), d.ranges.end(), [](const DetRange &a, const DetRange &b) { return a.beg < b.beg; });
-        if (int rcz_ = launch_zero(d.base, o64 * (int64_t)sizeof(long long), s)) return rcz_;
+        if (!ctx->gshadow || ctx->gshadow_elems < o64) {
+            if (ctx->gshadow) { STAIR_HIP(hipStreamSynchronize(s)); STAIR_HIP(hipFree(ctx->gshadow)); ctx->gshadow = nullptr; }
+            STAIR_HIP(hipMalloc(&ctx->gshadow, (size_t)o64 * sizeof(long long)));
+            ctx->gshadow_elems = o64;
+            ctx->gshadow_dirty = true;
+        }
+        d.base = static_cast<long long *>(ctx->gshadow);
+        if (ctx->gshadow_dirty)
+            if (int rcz_ = launch_zero(d.base, o64 * (int64_t)sizeof(long long), s)) return rcz_;
+        ctx->gshadow_dirty = true;                   // until this pass has flushed everything it touched
         d.active = true;
     }
     // weight-gradient products of the tile-level layers run ONCE per weight, after all buckets (FilterFrame's dense layer keeps
@@ -2697,6 +2712,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
     RUN(tn_x3tr_flush(s));                   // the encoders' slab-reduced weight gradients
     if (overlap_tn) STAIR_HIP(hipStreamWaitEvent(s, ctx->ev_join, 0));      // the optimizer (next on `s`) sees every dW
     RUN(det_flush(ctx, s));                  // the encoders' fixed-point shadows -> the fp32 gradients
+    if (g_det.active) ctx->gshadow_dirty = false;    // every touched shadow has been emptied again
     g_det.active = false;
 #undef RUN
     return 0;

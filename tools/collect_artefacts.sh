@@ -2,12 +2,12 @@
 # Runs on the GPU box (gpurun -- 'bash tools/collect_artefacts.sh [prefix]'): the measurement set kept under profiles/ -- default bench
 # line, inference line, graph bench, 2-rank gloo rehearsal of `bench.py --gpus 2` (self-launched) on one card, rocprofv3 kernel stats
 # of the training / inference / 128-question benches, row-kernel byte accounting.  Outputs go to gpurun_out/ under the prefix
-# (default r03_a); copy what is to be judged into profiles/.
+# (default r04_a); copy what is to be judged into profiles/.
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-P=${1:-r03_a}
+P=${1:-r04_a}
 mkdir -p gpurun_out/fin3
 timeout -k 10 900 python bench.py > gpurun_out/${P}_bench_default.json 2> gpurun_out/fin3/bench.err
 echo "bench default done" >> gpurun_out/fin3/progress.txt
@@ -30,5 +30,8 @@ echo "b128 stats done" >> $R/gpurun_out/fin3/progress.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/fin3/rows -o run -- python3 $R/tools/row_kernels.py $R/gpurun_out/fin3/acct.json > $R/gpurun_out/fin3/rows.log 2>&1
 rm -f $R/gpurun_out/fin3/rows/run_kernel_trace.csv
 cd $R
+timeout -k 10 200 python3 tools/supervised_host_time.py > gpurun_out/${P}_supervised_host_time.txt 2>&1 || true
+timeout -k 10 200 python3 tools/determinism_probe.py 64 3 all > gpurun_out/${P}_determinism_probe.txt 2>&1 || true
+timeout -k 10 200 python3 tools/determinism_probe.py 2048 2 paper >> gpurun_out/${P}_determinism_probe.txt 2>&1 || true
 python3 tools/row_kernels.py --merge gpurun_out/fin3/acct.json gpurun_out/fin3/rows/run_kernel_stats.csv gpurun_out/${P}_row_kernels.json
 tail -c 600 gpurun_out/${P}_bench_default.json
