@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STAIR_ABI_VERSION 4
+#define STAIR_ABI_VERSION 5
 
 typedef struct stair_ctx stair_ctx;
 typedef struct stair_plan stair_plan;
@@ -284,7 +284,7 @@ int stair_lstm_bidir_bwd(const stair_lstm_bwd_args *args, stair_stream stream);
  * Rows t >= T of a tile do not exist (nothing is read or written there). */
 enum stair_tile_tail { STAIR_TILE_NONE = 0, STAIR_TILE_STORE = 1, STAIR_TILE_SUM_ROWS = 2, STAIR_TILE_COSINE = 3,
                        STAIR_TILE_ROWDOT_SIGMOID = 4, STAIR_TILE_LAYERNORM = 5, STAIR_TILE_ACCUMULATE = 6,
-                       STAIR_TILE_STORE_ROWS = 7 };
+                       STAIR_TILE_STORE_ROWS = 7, STAIR_TILE_ROWSCALE_ADJ = 8 };
 typedef struct stair_tile_mlp_args {
     const float *X; int64_t x_gstride; const int32_t *x_idx;
     const float *row_scale; const int32_t *rs_idx;
@@ -318,6 +318,28 @@ typedef struct stair_tile_mlp_args {
      *   tail STORE_ROWS  row i of the last layer -> out + out_row_idx[i] * out_gstride */
     int32_t vec_pack; const float *pk_a, *pk_b; const int32_t *pk_a_idx, *pk_b_idx; int32_t vec_cnt;
     float *cat_save; const int32_t *out_row_idx;
+    /* Temporal's backward as ONE chain per tile (autograd of modules.py:310-327, y = LayerNorm(ReLU(Lin(r_t feat_t)))); ABI 5:
+     *   ln_bwd != 0      the input tile is the adjoint of LayerNorm (weight gamma, ln_eps) applied to the incoming gradient rows
+     *                    X (x_idx, x_gstride) at the saved pre-LayerNorm rows in_mask (in_mask_idx, in_mask_gstride), times
+     *                    relu'(in_mask) and in_scale: dZ of the dense layer (kept in save_in for its weight-gradient product);
+     *                    dgamma[H] / dbeta[H] receive the LayerNorm parameter gradients (added; the chains of one launch share them).
+     *                    One layer: W[0] = the planes of W^T, act 0, no bias.  Comes with
+     *   tail ROWSCALE_ADJ  G = the layer's rows = the gradient of the SCALED input: out tile (out_idx) += r_t G_t (fp32 atomics),
+     *                    adj_drs[s][t] += G_t . feat_t with feat = adj_feat + (adj_feat_idx ? adj_feat_idx[i] : i) * adj_feat_gstride,
+     *                    r = adj_rs + s * T, s = adj_rs_idx ? adj_rs_idx[i] : i */
+    int32_t ln_bwd; float *dgamma, *dbeta;
+    const float *adj_feat; int64_t adj_feat_gstride; const int32_t *adj_feat_idx;
+    const float *adj_rs; const int32_t *adj_rs_idx; float *adj_drs;
+    /* acc_exclusive != 0: the caller promises that no two instances of THIS launch add into the same output tile (tails ACCUMULATE,
+     * ROWSCALE_ADJ): the tile is read, added to and written back with plain 16-byte accesses instead of float atomics
+     * (stair_plan_backward: the deterministic fan-in gives every same-level reader of a slot a target of its own) */
+    int32_t acc_exclusive;
+    /* relu' of a saved activation as ONE bit per element (4 KB per tile instead of a 128 KB read in the backward chain):
+     *   save_bits[l]     [cnt][512] 64-bit words, written by a forward launch: word (i, 64 w + c), byte j, bit e = (layer l's
+     *                    activation of tile i, row w + 8 j, column 8 c + e) > 0
+     *   act_bits[l]      what a chain uses instead of act_mask[l] (act[l] == 3, act_mask[l] == NULL);  in_bits instead of in_mask
+     *                    (both indexed by the instance number i, never through in_mask_idx) */
+    unsigned long long *save_bits[3]; const unsigned long long *act_bits[3]; const unsigned long long *in_bits;
 } stair_tile_mlp_args;
 int stair_tile_mlp_fwd(const stair_tile_mlp_args *args, stair_stream stream);
 /* ---- grouped vector-level products (csrc/vec_group.hip) ------------------------------------------------------------------

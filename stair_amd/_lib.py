@@ -16,7 +16,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('STAIR_LIB_PATH') or os.path.join(_HERE, 'lib', 'libstair_hip.so')   # override: kernel experiments
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)
 
@@ -90,7 +90,11 @@ class TileMlpArgs(C.Structure):
                 ('in_mask', C.c_void_p), ('in_mask_gstride', C.c_int64), ('in_mask_idx', C.c_void_p), ('in_scale', C.c_float),
                 ('x_broadcast', C.c_int32), ('save_in', C.c_void_p),
                 ('vec_pack', C.c_int32), ('pk_a', C.c_void_p), ('pk_b', C.c_void_p), ('pk_a_idx', C.c_void_p), ('pk_b_idx', C.c_void_p),
-                ('vec_cnt', C.c_int32), ('cat_save', C.c_void_p), ('out_row_idx', C.c_void_p)]
+                ('vec_cnt', C.c_int32), ('cat_save', C.c_void_p), ('out_row_idx', C.c_void_p),
+                ('ln_bwd', C.c_int32), ('dgamma', C.c_void_p), ('dbeta', C.c_void_p),
+                ('adj_feat', C.c_void_p), ('adj_feat_gstride', C.c_int64), ('adj_feat_idx', C.c_void_p),
+                ('adj_rs', C.c_void_p), ('adj_rs_idx', C.c_void_p), ('adj_drs', C.c_void_p), ('acc_exclusive', C.c_int32),
+                ('save_bits', C.c_void_p * 3), ('act_bits', C.c_void_p * 3), ('in_bits', C.c_void_p)]
 
 
 class VecProblem(C.Structure):

@@ -287,6 +287,9 @@ struct Bucket {
     // float offsets of this bucket's intermediates.  Inference: all buckets share one scratch set;
     // training: private regions, kept until stair_plan_backward has consumed them.
     int64_t svA = 0, svB = 0, svK = 0, svCat = 0, svHid = 0, svRs = 0, svSup = 0, svExtra = 0;
+    // training, fused tile operators: relu' of the first / second / third layer's activation as one bit per element ([cnt][512] 64-bit
+    // words, written by the forward launch, read by the backward chain instead of the 128 KB activation; csrc/tile_mlp.hip save_bits)
+    int64_t bitA = -1, bitB = -1, bitC = -1;
 };
 
 // Vector-level weights whose gradient is ONE product per weight over all buckets that use it (training plans): the dZ rows
@@ -407,6 +410,7 @@ struct stair_plan {
     std::vector<int32_t> idx;       // host image of the device index buffer
     int64_t off_seqv = 0, off_seqt = 0, off_roots = 0, off_lenv = 0;
     bool ragged = false;            // clips of different frame counts in this batch (padded to T; per-instance lengths in col[6])
+    bool bits_written = false;      // the last forward run of this (training) plan went through the fused tile operators: Bucket::bit* are valid
     std::vector<int32_t> vlen;      // frames per clip [n_vid]
     int n_vec = 0, n_map = 0, n_att = 0, n_aliased = 0;     // n_aliased: nodes that share another node's value (common subexpressions)
     int maxI = 0, maxV = 0, maxK = 0, maxSupRows = 0, n_levels = 0;
@@ -1206,6 +1210,13 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
             if (pl->o_wfrag > 0 && b.cnt > 0) {          // the level's backward chains share a launch: no scratch in common
                 if (b.op == STAIR_OP_FILTER) b.gRow = take((int64_t)b.cnt * H, 64);
                 if (b.op == STAIR_OP_FILTERFRAME && b.variant != 0) b.dzC = take((int64_t)b.cnt * T * H, 64);
+                const int64_t words = (int64_t)b.cnt * 512 * 2;          // 64-bit words, counted in floats
+                switch (b.op) {
+                    case STAIR_OP_FILTER: b.bitA = take(words, 64); b.bitB = take(words, 64); break;
+                    case STAIR_OP_FILTERFRAME: b.bitA = take(words, 64); b.bitB = take(words, 64); b.bitC = take(words, 64); break;
+                    case STAIR_OP_HASITEM: case STAIR_OP_LOCALIZE: case STAIR_OP_SUPERLATIVE: b.bitA = take(words, 64); break;
+                    default: break;
+                }
             }
             if (w0 >= 0) { b.dzA = pl->wg_dz[w0] + at[w0] * T * H; at[w0] += b.cnt; }
             if (w3 >= 0) { b.dzB = pl->wg_dz[w3] + at[w3] * T * H; b.svA = pl->wg_sx[w3] + at[w3] * T * H; at[w3] += b.cnt; }
@@ -1635,6 +1646,7 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
 
     // ---- fused per-clip tile operators (csrc/tile_mlp.hip): weights of the buckets that run fused, as fragment-order planes ----
     const bool fused = pl->o_wfrag > 0 && tile_mlp_usable(H, T) && dp <= 0.0f && tile_policy(pl);
+    pl->bits_written = fused && pl->train;
     auto WF = [&](int slot) { return static_cast<const void *>(ws + pl->o_wfrag + (int64_t)slot * H * H); };
     if (fused) {
         const Lin *lin_of[WF_COUNT] = {&W.f0[0], &W.f0[1], &W.f0[2], &W.f0[3], &W.f3[0], &W.f3[1], &W.f3[2], &W.f3[3], &W.ff0[0], &W.ff0[1], &W.ff0[2],
@@ -1724,9 +1736,10 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
         a.X = map; a.x_gstride = TH; a.x_idx = x_idx; a.cnt = cnt_; a.T = T; a.H = H; a.ln_eps = 1e-5f;
         return a;
     };
-    auto tile_layer = [&](stair_tile_mlp_args &a, int slot, const Lin &l, int act, float *save) {
+    auto tile_layer = [&](stair_tile_mlp_args &a, int slot, const Lin &l, int act, float *save, int64_t bits = -1) {
         const int i = a.n_layers++;
         a.W[i] = WF(slot); a.bias[i] = l.b; a.act[i] = act; a.save[i] = pl->train ? save : nullptr;
+        a.save_bits[i] = pl->train && bits >= 0 && act == 1 ? reinterpret_cast<unsigned long long *>(ws + bits) : nullptr;
     };
 
     // ---- program levels ----------------------------------------------------------------------
@@ -1850,8 +1863,8 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
                 if (fused) {            // both layers and the sum over frames on the tile
                     if (phase == 1) {
                         stair_tile_mlp_args a = tile_args(I0, c);
-                        tile_layer(a, WF_F0 + v, W.f0[v], 1, tmpA);
-                        tile_layer(a, WF_F3 + v, W.f3[v], 1, tmpB);
+                        tile_layer(a, WF_F0 + v, W.f0[v], 1, tmpA, b.bitA);
+                        tile_layer(a, WF_F3 + v, W.f3[v], 1, tmpB, b.bitB);
                         a.tail = STAIR_TILE_SUM_ROWS; a.out = cat; a.out_gstride = H; a.len = LEN;
                         tile_queue.push_back(a);
                         if (grouped) {
@@ -1877,9 +1890,9 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
                     if (phase != 1) break;
                     if (v == 0) RUN(launch_vecdot(vec, I1, W.ffatt.w + H, extra, c, H, s));
                     stair_tile_mlp_args a = tile_args(I0, c);
-                    tile_layer(a, WF_FF0 + v, W.ff0[v], 1, tmpA);
-                    tile_layer(a, WF_FF3 + v, W.ff3[v], 1, tmpB);
-                    tile_layer(a, WF_FFD, W.ffdense, 1, nullptr);
+                    tile_layer(a, WF_FF0 + v, W.ff0[v], 1, tmpA, b.bitA);
+                    tile_layer(a, WF_FF3 + v, W.ff3[v], 1, tmpB, b.bitB);
+                    tile_layer(a, WF_FFD, W.ffdense, 1, nullptr, b.bitC);
                     if (v == 0) { a.mid_rowdot = 1; a.vw = W.ffatt.w; a.vb = W.ffatt.b; a.extra = extra; a.rs_out = rsb; }
                     a.tail = STAIR_TILE_STORE; a.out = map; a.out_gstride = TH; a.out_idx = I2;
                     tile_queue.push_back(a);
@@ -1904,7 +1917,7 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
                 if (fused) {
                     if (phase != 1) break;
                     stair_tile_mlp_args a = tile_args(I0, c);
-                    tile_layer(a, WF_HI0, W.hi0, 1, tmpA);
+                    tile_layer(a, WF_HI0, W.hi0, 1, tmpA, b.bitA);
                     a.tail = STAIR_TILE_ROWDOT_SIGMOID; a.vw = W.hi3.w; a.vb = W.hi3.b; a.out = att; a.out_gstride = T; a.out_idx = I1;
                     tile_queue.push_back(a);
                     break;
@@ -1922,7 +1935,7 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
                         vg1.back().wplanes = WF(WV_LK);
                     } else RUN(dense(s, vec, H, H, I2, W.lk, H, kbuf, H, H, nullptr, b.nrows, 1, H, H, 0));
                     stair_tile_mlp_args a = tile_args(I0, c);
-                    tile_layer(a, WF_LV0, W.lv0, 1, tmpA);
+                    tile_layer(a, WF_LV0, W.lv0, 1, tmpA, b.bitA);
                     tile_layer(a, WF_LV3, W.lv3, 0, tmpB);
                     a.tail = STAIR_TILE_COSINE; a.kb = kbuf; a.pair_first = I4; a.pair_cnt = I5; a.att_idx = I3; a.att = att;
                     tile_queue.push_back(a);
@@ -1940,7 +1953,7 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
             case STAIR_OP_SUPERLATIVE:  // modules.py:220-248 (shares Localize's weights, module_net.py:31-32)
                 if (fused && phase == 1) {
                     stair_tile_mlp_args a = tile_args(I0, c);
-                    tile_layer(a, WF_LV0, W.lv0, 1, tmpA);
+                    tile_layer(a, WF_LV0, W.lv0, 1, tmpA, b.bitA);
                     tile_layer(a, WF_LV3, W.lv3, 0, nullptr);
                     a.tail = STAIR_TILE_STORE; a.out = tmpB; a.out_gstride = TH;
                     tile_queue.push_back(a);
@@ -2309,6 +2322,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
                 case STAIR_OP_FILTERFRAME: if (b.variant) need[WF_FF0 + b.variant] = need[WF_FF3 + b.variant] = need[WF_FFD] = true; break;
                 case STAIR_OP_HASITEM: need[WF_HI0] = true; break;
                 case STAIR_OP_LOCALIZE: case STAIR_OP_SUPERLATIVE: need[WF_LV0] = need[WF_LV3] = true; break;
+                case STAIR_OP_TEMPORAL: need[WF_TD] = true; break;
                 default: break;
             }
         }
@@ -2349,6 +2363,14 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
     // phase 0: a bucket's whole adjoint.  With the fused chains a level runs as: phase 1 = everything up to the tile chain (its
     // arguments are queued), ONE launch for the chains of all buckets of the level, phase 2 = what needs the chain's outputs.
     std::vector<stair_tile_mlp_args> chain_queue;
+    // every same-level reader of a gradient slot has a target of its own (build_grad_fanin) and the chains of a level are ONE launch
+    // per kernel form: no two instances of a launch add into the same tile, so the chains add with plain read - add - write
+    // (STAIR_TILE_RMW=0: float atomics)
+    static const int chain_rmw = [] { const char *e = getenv("STAIR_TILE_RMW"); return (e && e[0] == '0') ? 0 : 1; }();
+    // relu' masks as bits (written by the fused forward launches of THIS plan's last run; STAIR_TILE_BITS=0: the fp32 activations)
+    static const bool bits_on = [] { const char *e = getenv("STAIR_TILE_BITS"); return !(e && e[0] == '0'); }();
+    const bool use_bits = bits_on && pl->bits_written;
+    auto BITS = [&](int64_t off) { return reinterpret_cast<const unsigned long long *>(ws + off); };
     auto bwd_bucket = [&](const Bucket &b, const int phase) -> int {
         if (b.cnt == 0) return 0;
         const int c = b.cnt;
@@ -2371,16 +2393,24 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
             a.cnt = c; a.T = T; a.H = H; a.len = LEN;
             if (bcast_row) { a.X = bcast_row; a.x_gstride = H; a.x_broadcast = 1; }
             else { a.X = gB; a.x_gstride = TH; }
-            if (bcast_row || relu_second) { a.in_mask = svB; a.in_mask_gstride = TH; a.in_scale = inv_keep; a.save_in = gB; }
+            if (bcast_row || relu_second) {
+                if (use_bits && b.bitB >= 0) a.in_bits = BITS(b.bitB); else { a.in_mask = svB; a.in_mask_gstride = TH; }
+                a.in_scale = inv_keep; a.save_in = gB;
+            }
             a.n_layers = 2;
-            a.W[0] = WFT(slot3); a.act[0] = 3; a.act_mask[0] = svA; a.act_scale = inv_keep; a.save[0] = gA;
+            a.W[0] = WFT(slot3); a.act[0] = 3; a.act_scale = inv_keep; a.save[0] = gA;
+            if (use_bits && b.bitA >= 0) a.act_bits[0] = BITS(b.bitA); else a.act_mask[0] = svA;
             a.W[1] = WFT(slot0); a.act[1] = 0;
-            a.tail = STAIR_TILE_ACCUMULATE; a.out = g_map; a.out_gstride = TH; a.out_idx = G0;
+            a.tail = STAIR_TILE_ACCUMULATE; a.out = g_map; a.out_gstride = TH; a.out_idx = G0; a.acc_exclusive = chain_rmw;
             chain_queue.push_back(a);
             return 0;
         };
+        // Temporal's backward as a chain of its own kernel form (LayerNorm adjoint in, row-scale adjoint out): STAIR_TILE_TEMPORAL_BWD=0
+        // keeps the four-launch sequence per bucket
+        static const bool temporal_chain_on = [] { const char *e = getenv("STAIR_TILE_TEMPORAL_BWD"); return !(e && e[0] == '0'); }();
+        const bool temporal_chain = fused && temporal_chain_on && b.op == STAIR_OP_TEMPORAL && b.dzA >= 0;
         const bool chain_op = fused && (b.op == STAIR_OP_FILTER || (b.op == STAIR_OP_FILTERFRAME && b.variant != 0) || b.op == STAIR_OP_HASITEM ||
-                                        b.op == STAIR_OP_LOCALIZE || b.op == STAIR_OP_SUPERLATIVE);
+                                        b.op == STAIR_OP_LOCALIZE || b.op == STAIR_OP_SUPERLATIVE || temporal_chain);
         if (phase == 2 && !chain_op) return 0;
         auto mlp_tail = [&](const Lin &l3, const Lin &l0, bool relu_second) -> int {
             if (relu_second) RUN(launch_mask_relu(gB, gB, TH, nullptr, svB, TH, nullptr, c, (int)TH, s, inv_keep));
@@ -2479,12 +2509,15 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
                     stair_tile_mlp_args a = {};
                     a.cnt = c; a.T = T; a.H = H;
                     a.X = g_map; a.x_gstride = TH; a.x_idx = I2;
-                    a.in_mask = map; a.in_mask_gstride = TH; a.in_mask_idx = I2; a.in_scale = inv_keep; a.save_in = gC;
+                    if (use_bits && b.bitC >= 0) a.in_bits = BITS(b.bitC); else { a.in_mask = map; a.in_mask_gstride = TH; a.in_mask_idx = I2; }
+                    a.in_scale = inv_keep; a.save_in = gC;
                     a.n_layers = 3; a.act_scale = inv_keep;
-                    a.W[0] = WFT(WF_FFD); a.act[0] = 3; a.act_mask[0] = svB; a.save[0] = gB;
-                    a.W[1] = WFT(WF_FF3 + v); a.act[1] = 3; a.act_mask[1] = svA; a.save[1] = gA;
+                    a.W[0] = WFT(WF_FFD); a.act[0] = 3; a.save[0] = gB;
+                    a.W[1] = WFT(WF_FF3 + v); a.act[1] = 3; a.save[1] = gA;
+                    if (use_bits && b.bitB >= 0) a.act_bits[0] = BITS(b.bitB); else a.act_mask[0] = svB;
+                    if (use_bits && b.bitA >= 0) a.act_bits[1] = BITS(b.bitA); else a.act_mask[1] = svA;
                     a.W[2] = WFT(WF_FF0 + v); a.act[2] = 0;
-                    a.tail = STAIR_TILE_ACCUMULATE; a.out = g_map; a.out_gstride = TH; a.out_idx = G0;
+                    a.tail = STAIR_TILE_ACCUMULATE; a.out = g_map; a.out_gstride = TH; a.out_idx = G0; a.acc_exclusive = chain_rmw;
                     chain_queue.push_back(a);
                     break;
                 }
@@ -2516,9 +2549,10 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
                 if (fused) {
                     stair_tile_mlp_args a = {};
                     a.cnt = c; a.T = T; a.H = H;
-                    a.X = gA; a.x_gstride = TH; a.in_mask = svA; a.in_mask_gstride = TH; a.in_scale = inv_keep; a.save_in = gA;
+                    a.X = gA; a.x_gstride = TH; a.in_scale = inv_keep; a.save_in = gA;
+                    if (use_bits && b.bitA >= 0) a.in_bits = BITS(b.bitA); else { a.in_mask = svA; a.in_mask_gstride = TH; }
                     a.n_layers = 1; a.W[0] = WFT(WF_HI0); a.act[0] = 0;
-                    a.tail = STAIR_TILE_ACCUMULATE; a.out = g_map; a.out_gstride = TH; a.out_idx = G0;
+                    a.tail = STAIR_TILE_ACCUMULATE; a.out = g_map; a.out_gstride = TH; a.out_idx = G0; a.acc_exclusive = chain_rmw;
                     chain_queue.push_back(a);
                     break;
                 }
@@ -2553,6 +2587,26 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
                 break;
             case STAIR_OP_TEMPORAL: {
                 const int mode = b.variant;
+                if (temporal_chain) {
+                    if (phase == 2) {       // the chain has left d(related attention) in g_att[I3]
+                        RUN(launch_temporal_relate_bwd(att, I1, I2, g_att, I3, g_att, c, T, mode, ctx->conv ? 1 : 0, ctx->ksize,
+                                                       mode ? W.relate[mode - 1] : nullptr, mode ? W.drelate[mode - 1] : nullptr, s, LEN, G1));
+                        break;
+                    }
+                    // d(output tile) -> LayerNorm adjoint * relu' = dZ (kept in the weight's region) -> dZ W -> += r_t . into the
+                    // input's gradient tile, d r_t = (dZ W)_t . feat_t: one chain per tile, all Temporal buckets of the level in one launch
+                    stair_tile_mlp_args a = {};
+                    a.cnt = c; a.T = T; a.H = H; a.ln_eps = 1e-5f;
+                    a.X = g_map; a.x_gstride = TH; a.x_idx = I4;
+                    a.ln_bwd = 1; a.in_mask = svA; a.in_mask_gstride = TH; a.in_scale = inv_keep; a.save_in = gA;
+                    a.gamma = W.ln_w; a.dgamma = W.dln_w; a.dbeta = W.dln_b;
+                    a.n_layers = 1; a.W[0] = WFT(WF_TD); a.act[0] = 0;
+                    a.tail = STAIR_TILE_ROWSCALE_ADJ; a.out = g_map; a.out_gstride = TH; a.out_idx = G0; a.acc_exclusive = chain_rmw;
+                    a.adj_feat = map; a.adj_feat_gstride = TH; a.adj_feat_idx = I0;
+                    a.adj_rs = att; a.adj_rs_idx = I3; a.adj_drs = g_att;
+                    chain_queue.push_back(a);
+                    break;
+                }
                 RUN(launch_layernorm_bwd(g_map, TH, I4, svA, c, T, H, W.ln_w, 1e-5f, gA, gStats, W.dln_w, W.dln_b, s, inv_keep));
                 RUN(dense_bwd(B, gA, c, T, H, H, map, H, TH, I0, W.tdense, gB, H, TH, nullptr, 0, att, T, I3));
                 RUN(launch_rowscale_bwd(gB, map, TH, I0, att, T, I3, g_map, g_att, c, T, H, s, G0));

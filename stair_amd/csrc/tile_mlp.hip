@@ -58,10 +58,65 @@ __device__ __forceinline__ int tm_swz(int R) {
 }
 
 constexpr int TM_MAXB = 8;           // module buckets one launch can carry (the argument block stays under the 4 KB kernarg limit)
+// One bucket's arguments as the kernel sees them: stair_tile_mlp_args with the fields that only ONE kernel form reads overlaid
+// (a launch carries buckets of one form), so that eight buckets still fit the 4 KB argument block.  Same names as the public struct.
+struct TmArg {
+    const float *X; int64_t x_gstride; const int32_t *x_idx;
+    const float *row_scale; const int32_t *rs_idx;
+    const void *W[3]; const float *bias[3]; int32_t act[3]; int32_t n_layers;
+    float *save[3];
+    int32_t mid_rowdot; const float *vw, *vb, *extra; float *rs_out;
+    int32_t tail;
+    float *out; int64_t out_gstride; const int32_t *out_idx;
+    const float *gamma, *beta; float ln_eps;
+    const float *kb; const int32_t *pair_first, *pair_cnt, *att_idx; float *att;
+    const int32_t *len;
+    int32_t cnt, T, H;
+    const float *act_mask[3]; float act_scale;
+    const float *in_mask; int64_t in_mask_gstride; const int32_t *in_mask_idx; float in_scale; int32_t x_broadcast;
+    float *save_in;
+    int32_t acc_exclusive;
+    union {
+        struct {            // KIND 1: vector-level tiles
+            int32_t vec_pack, vec_cnt; const float *pk_a, *pk_b; const int32_t *pk_a_idx, *pk_b_idx; float *cat_save; const int32_t *out_row_idx;
+        };
+        struct {            // KIND 2: Temporal's backward chain
+            float *dgamma, *dbeta; const float *adj_feat; int64_t adj_feat_gstride; const int32_t *adj_feat_idx;
+            const float *adj_rs; const int32_t *adj_rs_idx; float *adj_drs;
+        };
+        struct {            // KIND 0: relu' bit masks of the map-level operators and their chains
+            unsigned long long *save_bits[3]; const unsigned long long *act_bits[3]; const unsigned long long *in_bits;
+        };
+    };
+};
+static TmArg tm_arg(const stair_tile_mlp_args &a, int kind) {
+    TmArg t = {};
+    t.X = a.X; t.x_gstride = a.x_gstride; t.x_idx = a.x_idx; t.row_scale = a.row_scale; t.rs_idx = a.rs_idx;
+    for (int l = 0; l < 3; ++l) { t.W[l] = a.W[l]; t.bias[l] = a.bias[l]; t.act[l] = a.act[l]; t.save[l] = a.save[l]; t.act_mask[l] = a.act_mask[l]; }
+    t.n_layers = a.n_layers; t.mid_rowdot = a.mid_rowdot; t.vw = a.vw; t.vb = a.vb; t.extra = a.extra; t.rs_out = a.rs_out;
+    t.tail = a.tail; t.out = a.out; t.out_gstride = a.out_gstride; t.out_idx = a.out_idx;
+    t.gamma = a.gamma; t.beta = a.beta; t.ln_eps = a.ln_eps;
+    t.kb = a.kb; t.pair_first = a.pair_first; t.pair_cnt = a.pair_cnt; t.att_idx = a.att_idx; t.att = a.att; t.len = a.len;
+    t.cnt = a.cnt; t.T = a.T; t.H = a.H; t.act_scale = a.act_scale;
+    t.in_mask = a.in_mask; t.in_mask_gstride = a.in_mask_gstride; t.in_mask_idx = a.in_mask_idx; t.in_scale = a.in_scale;
+    t.x_broadcast = a.x_broadcast; t.save_in = a.save_in; t.acc_exclusive = a.acc_exclusive;
+    if (kind == 1) {
+        t.vec_pack = a.vec_pack; t.vec_cnt = a.vec_cnt; t.pk_a = a.pk_a; t.pk_b = a.pk_b; t.pk_a_idx = a.pk_a_idx; t.pk_b_idx = a.pk_b_idx;
+        t.cat_save = a.cat_save; t.out_row_idx = a.out_row_idx;
+    } else if (kind == 2) {
+        t.dgamma = a.dgamma; t.dbeta = a.dbeta; t.adj_feat = a.adj_feat; t.adj_feat_gstride = a.adj_feat_gstride; t.adj_feat_idx = a.adj_feat_idx;
+        t.adj_rs = a.adj_rs; t.adj_rs_idx = a.adj_rs_idx; t.adj_drs = a.adj_drs;
+    } else {
+        for (int l = 0; l < 3; ++l) { t.save_bits[l] = a.save_bits[l]; t.act_bits[l] = a.act_bits[l]; }
+        t.in_bits = a.in_bits;
+    }
+    return t;
+}
 struct TmParams {
-    stair_tile_mlp_args a[TM_MAXB];  // the buckets of one program level: independent of each other, so their tiles share one launch
+    TmArg a[TM_MAXB];                // the buckets of one program level: independent of each other, so their tiles share one launch
     int first[TM_MAXB + 1];          // work item w belongs to bucket b with first[b] <= w < first[b + 1]; its tile is w - first[b]
     int nb;
+    long long *fx_g, *fx_b;          // KIND 2: fixed-point shadows of d gamma / d beta (NULL: float atomics into a[0].dgamma / dbeta)
     unsigned *counter;               // work queue: counter[0] = head, counter[1] = workgroups that have left the queue.  Both words are
                                      // zero between launches (the last workgroup to leave puts them back); NULL: tiles are dealt out round robin
 };
@@ -109,15 +164,26 @@ __device__ __forceinline__ int tm_fresh_v(int v) {
 
 #define TM_SYNC() do { __builtin_amdgcn_sched_barrier(0); __syncthreads(); __builtin_amdgcn_sched_barrier(0); } while (0)
 
-template <bool NT, bool VEC>
+// KIND 0: map-level forward operators; 1: vector-level tiles (64 instances per tile); 2: Temporal's backward chain (the LayerNorm
+// adjoint on the way in, the row-scale adjoint on the way out); 3: the map-level backward chains (relu' masks on the way in and
+// between the layers, broadcast input, dZ saves, accumulation).  Kernels of their own: what one form needs in registers and code
+// the others do not pay for (one kernel for everything kept 250+ registers live across the tile loop and spilled).
+template <bool NT, int KIND>
 __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float *F = reinterpret_cast<float *>(lds);
-    const int tid = threadIdx.x, lane0 = tid & 63;
+    // KIND 2: d gamma / d beta of the workgroup's tiles, column tid, as 64-bit fixed point (common.h): integer sums do not depend on
+    // which workgroup the queue gave which tile, so the parameter gradients are bit-identical from run to run
+    __shared__ long long tb_acc[KIND == 2 ? 2 * TM_H : 2];
+    if (KIND == 2) { tb_acc[threadIdx.x] = 0; tb_acc[TM_H + threadIdx.x] = 0; }
+    // the lane id comes from mbcnt wherever it is needed (EXEC is all ones there): threadIdx.x kept alive across the persistent
+    // loop, beside 250+ live registers, went to scratch, and a kernel with ANY scratch pays for its setup at every launch
+#define TM_LANE() ((int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)))
     // the wave index is uniform over the wave: in an SGPR every row address (row = wave + 8 j) is scalar arithmetic and the row-wise
     // accesses take the base-in-SGPR + one shared lane offset form -- as a VGPR it made every row of every array a 64-bit VGPR
     // pointer of its own (hoisted out of the loops: 150 spilled registers once the loads were batched)
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+#define TM_TID() (64 * wave + TM_LANE())
     const int total = pp.first[pp.nb];
     __shared__ int next_work;
     // Work items = tiles of all buckets of the launch, handed out through one atomic counter: a workgroup that finishes a
@@ -127,7 +193,7 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
         int w;
         TM_SYNC();                          // the previous tile's tail has finished reading the staging (and next_work)
         if (pp.counter) {
-            if (tid == 0) next_work = (int)atomicAdd(pp.counter, 1u);
+            if (TM_TID() == 0) next_work = (int)atomicAdd(pp.counter, 1u);
             TM_SYNC();
             w = __builtin_amdgcn_readfirstlane(next_work);       // uniform BY CONSTRUCTION: says so, so that everything derived from it
                                                                  // (argument block, tile pointers) lives in SGPRs, not in 64-bit VGPR pairs
@@ -140,11 +206,11 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
         int bsel = 0;
 #pragma unroll
         for (int j = 1; j < TM_MAXB; ++j) bsel += (j < pp.nb && w >= pp.first[j]) ? 1 : 0;
-        const stair_tile_mlp_args &p = pp.a[bsel];
+        const TmArg &p = pp.a[bsel];
         const int inst = w - pp.first[bsel];
         // the lane id, re-derived per tile from an opaque copy: the dozens of lane-dependent LDS / row offsets below are then computed
         // where they are used instead of being hoisted out of this (persistent) loop and kept alive -- or spilled -- across it
-        const int lane = tm_fresh_v(lane0);
+        const int lane = tm_fresh_v(TM_LANE());
         const int r = lane & 31, h = lane >> 5;
         // B-operand fragment offsets (bytes inside a stage plane, chunk 0) of this lane's two frame tiles
         int offT[2];
@@ -156,15 +222,17 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
 
 
         // rows of this tile: the T frames of a module instance, or (vector-level modules) up to 64 INSTANCES of one row each
-        const int vpack = VEC ? p.vec_pack : 0;          // the vector-level form is a kernel of its own (registers)
+        const int vpack = KIND == 1 ? p.vec_pack : 0;    // the vector-level form is a kernel of its own (registers)
         const int T = vpack ? min(TM_ROWS, p.vec_cnt - TM_ROWS * inst) : p.T;
         const int Ts = vpack ? TM_ROWS : p.T;            // rows between two tiles in the [cnt, T, H] save / mask buffers
         const int nseg = vpack == 0 ? 1 : (vpack == 1 ? 2 : 3);
         // ---- the input tile: fp32 rows -> (row scale) -> bf16 hi / lo image ------------------------------------------
         const float *x = tm_fresh(p.X + (int64_t)(p.x_idx ? __builtin_amdgcn_readfirstlane(p.x_idx[inst]) : inst) * p.x_gstride);
-        const float *rsrow = p.row_scale ? p.row_scale + (int64_t)(p.rs_idx ? __builtin_amdgcn_readfirstlane(p.rs_idx[inst]) : inst) * T : nullptr;
-        const float *imask = tm_fresh(p.in_mask ? p.in_mask + (int64_t)(p.in_mask_idx ? __builtin_amdgcn_readfirstlane(p.in_mask_idx[inst]) : inst) * p.in_mask_gstride : nullptr);
-        const int Lrows = p.x_broadcast ? (p.len ? __builtin_amdgcn_readfirstlane(p.len[inst]) : T) : T;     // a broadcast row fills the clip's own frames only
+        const float *rsrow = KIND == 0 && p.row_scale ? p.row_scale + (int64_t)(p.rs_idx ? __builtin_amdgcn_readfirstlane(p.rs_idx[inst]) : inst) * T : nullptr;
+        // (a NULL must stay a visible NULL: through tm_fresh the forward kernel kept the whole mask path, and its registers)
+        const float *imask = (KIND == 2 || KIND == 3) && p.in_mask ? tm_fresh(p.in_mask + (int64_t)(p.in_mask_idx ? __builtin_amdgcn_readfirstlane(p.in_mask_idx[inst]) : inst) * p.in_mask_gstride) : nullptr;
+        const bool xbc = KIND == 3 && p.x_broadcast;
+        const int Lrows = xbc ? (p.len ? __builtin_amdgcn_readfirstlane(p.len[inst]) : T) : T;     // a broadcast row fills the clip's own frames only
         // vector-level modules: row t of the tile is H-wide block `seg` of the concatenation built from the two operand rows
         // of instance 64 inst + t (never materialised for the GEMM; cat_save keeps it for the weight gradient)
         auto build_vec_image = [&](const int seg) {
@@ -210,11 +278,103 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
             }
         };
         if (vpack) build_vec_image(0);
-        else {
+        else if (KIND == 2) {
+            // Temporal's backward (autograd of modules.py:283,327: y = LayerNorm(a), a = ReLU(Lin(r_t feat_t))): the incoming gradient
+            // rows dY = X go through the adjoint of LayerNorm at the saved rows a = in_mask and through relu'(a) on their way into the
+            // image; what is written there (and kept: save_in) is dZ of the dense layer.  Thread (wave, lane) carries columns
+            // 8 lane .. +7 of rows wave + 8 j, all loads of four rows first (as below).
+            const int c8 = lane;
+            const float *ysv = tm_fresh(imask);
+            const v4f gm0 = *reinterpret_cast<const v4f *>(p.gamma + 8 * c8), gm1 = *reinterpret_cast<const v4f *>(p.gamma + 8 * c8 + 4);
+            v4f ag0 = {0.f, 0.f, 0.f, 0.f}, ag1 = ag0, ab0 = ag0, ab1 = ag0;
+            v4f dz[8][2];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                v4f xa[4], xb[4], ya[4], yb[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int t = wave + 8 * (4 * half + j);
+                    const int ts = t < T ? t : 0;
+                    xa[j] = tm_ld<NT>(x + (int64_t)ts * TM_H + 8 * c8);
+                    xb[j] = tm_ld<NT>(x + (int64_t)ts * TM_H + 8 * c8 + 4);
+                    ya[j] = tm_ld<NT>(ysv + (int64_t)ts * TM_H + 8 * c8);
+                    yb[j] = tm_ld<NT>(ysv + (int64_t)ts * TM_H + 8 * c8 + 4);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int t = wave + 8 * (4 * half + j);
+                    float sum = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sum += ya[j][i] + yb[j][i];
+                    const float mean = wave_sum(sum) / (float)TM_H;
+                    float sq = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { const float a = ya[j][i] - mean, b = yb[j][i] - mean; sq += a * a + b * b; }
+                    const float rstd = rsqrtf(wave_sum(sq) / (float)TM_H + p.ln_eps);
+                    float s1 = 0.f, s2 = 0.f;
+                    v4f ha, hb;                 // the normalised rows
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        ha[i] = (ya[j][i] - mean) * rstd; hb[i] = (yb[j][i] - mean) * rstd;
+                        const float da = xa[j][i] * gm0[i], db = xb[j][i] * gm1[i];
+                        s1 += da + db; s2 += da * ha[i] + db * hb[i];
+                    }
+                    s1 = wave_sum(s1) / (float)TM_H; s2 = wave_sum(s2) / (float)TM_H;
+                    v4f oa = {0.f, 0.f, 0.f, 0.f}, ob = oa;
+                    if (t < T) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            oa[i] = ya[j][i] > 0.f ? rstd * (xa[j][i] * gm0[i] - s1 - ha[i] * s2) * p.in_scale : 0.f;
+                            ob[i] = yb[j][i] > 0.f ? rstd * (xb[j][i] * gm1[i] - s1 - hb[i] * s2) * p.in_scale : 0.f;
+                            ag0[i] += xa[j][i] * ha[i]; ag1[i] += xb[j][i] * hb[i];
+                            ab0[i] += xa[j][i]; ab1[i] += xb[j][i];
+                        }
+                    }
+                    dz[4 * half + j][0] = oa; dz[4 * half + j][1] = ob;
+                }
+            }
+            if (p.save_in) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int t = wave + 8 * j;
+                    if (t < T) {
+                        float *d = p.save_in + ((int64_t)inst * Ts + t) * TM_H + 8 * c8;
+                        tm_st<NT>(d, dz[j][0]); tm_st<NT>(d + 4, dz[j][1]);
+                    }
+                }
+            }
+            // d gamma, d beta: the eight waves' column sums meet in the (not yet written) image area, are added in wave order, and
+            // join the workgroup's fixed-point accumulators
+            float *red = F + (2 * wave) * TM_H + 8 * c8;
+            *reinterpret_cast<v4f *>(red) = ag0; *reinterpret_cast<v4f *>(red + 4) = ag1;
+            *reinterpret_cast<v4f *>(red + TM_H) = ab0; *reinterpret_cast<v4f *>(red + TM_H + 4) = ab1;
+            TM_SYNC();
+            {
+                float g = 0.f, b = 0.f;
+                const int tid = TM_TID();
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { g += F[(2 * q) * TM_H + tid]; b += F[(2 * q + 1) * TM_H + tid]; }
+                tb_acc[tid] += __float2ll_rn(g * kFxScale);
+                tb_acc[TM_H + tid] += __float2ll_rn(b * kFxScale);
+            }
+            TM_SYNC();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int t = wave + 8 * j;
+                bf16x8 hi, lo;
+                tm_split8(dz[j][0], dz[j][1], hi, lo);
+                const int off = (c8 >> 2) * TM_STAGE + (t * 4 + ((c8 & 3) ^ tm_swz(t))) * 16;
+                *reinterpret_cast<bf16x8 *>(lds + off) = hi;
+                *reinterpret_cast<bf16x8 *>(lds + off + 4096) = lo;
+            }
+        } else {
             // thread (wave, lane) carries columns 8 lane .. +7 of rows wave + 8 j.  All global loads of four rows are issued before
             // anything uses them (a load -> use -> store -> load loop runs one memory round trip per row: 8 x ~2 us per tile);
             // rows past the tile's length read row 0 and are zeroed afterwards, so that no load hides behind a branch.
             const int c8 = lane;
+            // relu' of a saved activation as ONE bit per element (8 bytes per thread and tile instead of 256: the forward pass wrote
+            // them in this thread's own (row, column) order, save_bits)
+            const unsigned long long ibits = (KIND == 3 && p.in_bits) ? p.in_bits[(int64_t)inst * TM_H + 64 * wave + c8] : 0ull;
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 v4f xa[4], xb[4], ma[4], mb[4];
@@ -223,7 +383,7 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
                 for (int j = 0; j < 4; ++j) {
                     const int t = wave + 8 * (4 * half + j);
                     const int ts = t < Lrows ? t : 0;
-                    const float *xr = x + (p.x_broadcast ? 0 : (int64_t)ts * TM_H) + 8 * c8;
+                    const float *xr = x + (xbc ? 0 : (int64_t)ts * TM_H) + 8 * c8;
                     xa[j] = tm_ld<NT>(xr);
                     xb[j] = tm_ld<NT>(xr + 4);
                     sc[j] = rsrow ? rsrow[ts] : 1.0f;
@@ -240,6 +400,10 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
                     if (imask) {              // backward chains: the incoming gradient times relu'(saved activation) (x in_scale)
 #pragma unroll
                         for (int i = 0; i < 4; ++i) { a[i] = ma[j][i] > 0.f ? a[i] * p.in_scale : 0.f; b[i] = mb[j][i] > 0.f ? b[i] * p.in_scale : 0.f; }
+                    } else if (KIND == 3 && p.in_bits) {
+                        const unsigned m = (unsigned)(ibits >> (8 * (4 * half + j))) & 0xffu;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { a[i] = (m >> i) & 1u ? a[i] * p.in_scale : 0.f; b[i] = (m >> (4 + i)) & 1u ? b[i] * p.in_scale : 0.f; }
                     }
                     if (t >= Lrows) { a = v4f{0.f, 0.f, 0.f, 0.f}; b = a; }
                     xa[j] = a; xb[j] = b;
@@ -249,7 +413,7 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
                     *reinterpret_cast<bf16x8 *>(lds + off) = hi;
                     *reinterpret_cast<bf16x8 *>(lds + off + 4096) = lo;
                 }
-                if (p.save_in) {
+                if (KIND == 3 && p.save_in) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int t = wave + 8 * (4 * half + j);
@@ -332,10 +496,10 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
             //      n = 64 wave + 32 nt + 8 q + 4 h + i for e = 4 q + i -- then the tile goes to LDS as fp32 rows ---------------
             const int lane_e = tm_fresh_v(lane), r_e = lane_e & 31, h_e = lane_e >> 5;     // offsets of this stage are computed HERE, not before the k loop
             const float *bias = p.bias[ph];
-            const int act = p.act[ph];
+            const int act = (KIND == 3 || p.act[ph] != 3) ? p.act[ph] : 0;          // act 3 (relu' of a saved activation) is the chains' (KIND 3)
             const bool last = ph + 1 == p.n_layers;
             // between two layers of an inference plan nothing touches HBM: the accumulators go straight into the next image
-            const bool direct = !last && !p.save[ph] && act != 3 && !(p.mid_rowdot && ph == 1);
+            const bool direct = !last && !p.save[ph] && !(KIND == 0 && p.save_bits[ph]) && act != 3 && !(KIND == 0 && p.mid_rowdot && ph == 1);
             v4f bvs[2][4];                        // the lane's 32 bias values, loaded together (one round trip, behind the barrier)
             __builtin_amdgcn_sched_barrier(0);    // ... and not earlier: inside the k loop they would cost 32 registers
 #pragma unroll
@@ -377,8 +541,12 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
                 //      need, FilterFrame's attention; then the rows become the next layer's bf16 hi / lo operand image.
                 //      The rows are read into registers first: the image overlays the staging. -----------------------------------
                 float *sv = tm_fresh(p.save[ph]);
-                const float *amask = tm_fresh(act == 3 ? p.act_mask[ph] + (int64_t)inst * Ts * TM_H : nullptr);
-                const bool rowdot = p.mid_rowdot && ph == 1;
+                const float *amask = KIND == 3 && act == 3 && p.act_mask[ph] ? tm_fresh(p.act_mask[ph] + (int64_t)inst * Ts * TM_H) : nullptr;
+                const unsigned long long *abits_p = KIND == 3 && act == 3 && !amask ? p.act_bits[ph] : nullptr;
+                const unsigned long long abits = abits_p ? abits_p[(int64_t)inst * TM_H + 64 * wave + lane_e] : 0ull;
+                unsigned long long *svbits = KIND == 0 ? p.save_bits[ph] : nullptr;
+                unsigned long long obits = 0ull;
+                const bool rowdot = KIND == 0 && p.mid_rowdot && ph == 1;
                 v4f rowv[8][2];
                 // every global load of the stage first (the relu' masks of all eight rows, the row-dot weights): interleaved with
                 // the saves they ran one memory round trip per row
@@ -408,6 +576,16 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
                             if (amask) {
 #pragma unroll
                                 for (int i = 0; i < 4; ++i) { a[i] = mk[jj][0][i] > 0.f ? a[i] * p.act_scale : 0.f; b[i] = mk[jj][1][i] > 0.f ? b[i] * p.act_scale : 0.f; }
+                            } else if (abits_p) {
+                                const unsigned m = (unsigned)(abits >> (8 * j)) & 0xffu;
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) { a[i] = (m >> i) & 1u ? a[i] * p.act_scale : 0.f; b[i] = (m >> (4 + i)) & 1u ? b[i] * p.act_scale : 0.f; }
+                            }
+                            if (svbits) {         // relu' of this activation for the backward chain: one bit per element
+                                unsigned m = 0;
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) m |= (a[i] > 0.f ? 1u << i : 0u) | (b[i] > 0.f ? 1u << (4 + i) : 0u);
+                                obits |= (unsigned long long)m << (8 * j);
                             }
                             if (sv) {
                                 float *d = sv + ((int64_t)inst * Ts + t) * TM_H + 8 * lane_e;
@@ -425,6 +603,7 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
                         rowv[j][0] = a; rowv[j][1] = b;
                     }
                 }
+                if (svbits) svbits[(int64_t)inst * TM_H + 64 * wave + lane_e] = obits;
                 TM_SYNC();                  // every row is in registers: the staging may be overwritten
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -447,8 +626,79 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
                 tm_st<NT>(dst + 4 * lane, *reinterpret_cast<const v4f *>(F + t * TM_FLD + 4 * lane));
                 tm_st<NT>(dst + 256 + 4 * lane, *reinterpret_cast<const v4f *>(F + t * TM_FLD + 256 + 4 * lane));
             }
+        if (KIND == 0 && p.save_bits[p.n_layers - 1]) {     // relu' of the last layer's rows, in the order the chain's input stage reads them
+            unsigned long long obits = 0ull;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int t = wave + 8 * j;
+                const v4f a = *reinterpret_cast<const v4f *>(F + t * TM_FLD + 8 * lane), b = *reinterpret_cast<const v4f *>(F + t * TM_FLD + 8 * lane + 4);
+                unsigned m = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) m |= (a[i] > 0.f ? 1u << i : 0u) | (b[i] > 0.f ? 1u << (4 + i) : 0u);
+                obits |= (unsigned long long)m << (8 * j);
+            }
+            p.save_bits[p.n_layers - 1][(int64_t)inst * TM_H + 64 * wave + lane] = obits;
+        }
         const int64_t oslot = p.out_idx ? __builtin_amdgcn_readfirstlane(p.out_idx[inst]) : inst;
-        switch (p.tail) {
+        if (KIND == 2) {
+            // tail ROWSCALE_ADJ: the staged rows are G = dZ W, the gradient of the SCALED input r_t feat_t of the dense layer:
+            // d feat_t += r_t G_t (one dword per lane, 256 contiguous bytes per wave-instruction), d r_t += G_t . feat_t
+            const float *feat = tm_fresh(p.adj_feat + (int64_t)(p.adj_feat_idx ? __builtin_amdgcn_readfirstlane(p.adj_feat_idx[inst]) : inst) * p.adj_feat_gstride);
+            const int64_t rslot = p.adj_rs_idx ? __builtin_amdgcn_readfirstlane(p.adj_rs_idx[inst]) : inst;
+            const float *rs = p.adj_rs + rslot * T;
+            float *drs = p.adj_drs + rslot * T;
+            float *dst = tm_fresh(p.out + oslot * p.out_gstride);
+            __builtin_amdgcn_sched_barrier(0);      // the loads stay below the epilogue (hoisted, they cost registers there)
+            v4f f0[8], f1[8];
+            float rr[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {           // every global load of the tail first
+                const int t = wave + 8 * j, ts = t < T ? t : 0;
+                f0[j] = tm_ld<NT>(feat + (int64_t)ts * TM_H + 4 * lane);
+                f1[j] = tm_ld<NT>(feat + (int64_t)ts * TM_H + 256 + 4 * lane);
+                rr[j] = rs[ts];
+            }
+            if (p.acc_exclusive) {                  // read - add - write instead of atomics (see ACCUMULATE); a branch of its own:
+                v4f o0[8], o1[8];                   // a condition inside the unrolled loops made every load wait and spill
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int t = wave + 8 * j, ts = t < T ? t : 0;
+                    o0[j] = *reinterpret_cast<const v4f *>(dst + (int64_t)ts * TM_H + 4 * lane);
+                    o1[j] = *reinterpret_cast<const v4f *>(dst + (int64_t)ts * TM_H + 256 + 4 * lane);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int t = wave + 8 * j;
+                    if (t < T) {
+                        const v4f g0 = *reinterpret_cast<const v4f *>(F + t * TM_FLD + 4 * lane), g1 = *reinterpret_cast<const v4f *>(F + t * TM_FLD + 256 + 4 * lane);
+                        float d = 0.f;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) d += g0[i] * f0[j][i] + g1[i] * f1[j][i];
+                        d = wave_sum(d);
+                        if (lane == 0) unsafeAtomicAdd(drs + t, d);
+                        *reinterpret_cast<v4f *>(dst + (int64_t)t * TM_H + 4 * lane) = o0[j] + rr[j] * g0;
+                        *reinterpret_cast<v4f *>(dst + (int64_t)t * TM_H + 256 + 4 * lane) = o1[j] + rr[j] * g1;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int t = wave + 8 * j;
+                    if (t < T) {
+                        const v4f g0 = *reinterpret_cast<const v4f *>(F + t * TM_FLD + 4 * lane), g1 = *reinterpret_cast<const v4f *>(F + t * TM_FLD + 256 + 4 * lane);
+                        float d = 0.f;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) d += g0[i] * f0[j][i] + g1[i] * f1[j][i];
+                        d = wave_sum(d);
+                        if (lane == 0) unsafeAtomicAdd(drs + t, d);
+#pragma unroll
+                        for (int c = 0; c < TM_H / 64; ++c) unsafeAtomicAdd(dst + (int64_t)t * TM_H + 64 * c + lane, rr[j] * F[t * TM_FLD + 64 * c + lane]);
+                    }
+                }
+            }
+        } else
+        switch (KIND == 3 && p.tail != STAIR_TILE_ACCUMULATE ? (p.tail == STAIR_TILE_STORE ? STAIR_TILE_STORE : STAIR_TILE_NONE)
+                                                             : (KIND != 3 && p.tail == STAIR_TILE_ACCUMULATE ? STAIR_TILE_NONE : p.tail)) {
             case STAIR_TILE_STORE:
                 for (int t = wave; t < T; t += 8) {
                     float *dst = p.out + oslot * p.out_gstride + (int64_t)t * TM_H;
@@ -457,6 +707,7 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
                 }
                 break;
             case STAIR_TILE_STORE_ROWS:               // vector-level modules: row t = instance 64 inst + t goes to its own slot
+                if (KIND != 1) break;
                 for (int t = wave; t < T; t += 8) {
                     float *dst = p.out + (int64_t)p.out_row_idx[(int64_t)TM_ROWS * inst + t] * p.out_gstride;
                     *reinterpret_cast<v4f *>(dst + 4 * lane) = *reinterpret_cast<const v4f *>(F + t * TM_FLD + 4 * lane);
@@ -464,8 +715,33 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
                 }
                 break;
             case STAIR_TILE_ACCUMULATE:               // backward chains: dX added into a gradient tile several instances may share
+                if (KIND != 3) break;
                 // one dword per lane, 256 contiguous bytes per wave-instruction: the shape float atomics run at full rate in
                 // (MI355X_MICROARCH.md "Global float atomics"; 16-byte-strided lanes spread an instruction over 1 KB)
+                if (p.acc_exclusive) {
+                    // no other instance of this launch adds into this tile (the caller's promise; stair_plan_backward's fan-in staging
+                    // gives every same-level reader of a slot a target of its own): whole rows read, added and written back, every
+                    // load of the tile's rows in flight at once -- float atomics retire 256 B per ~50 ns and CU (1.3 TB/s chip-wide,
+                    // MI355X_MICROARCH.md "Global float atomics"): 25 us per tile, as long as two layers of the chain
+                    float *dst = tm_fresh(p.out + oslot * p.out_gstride);
+                    __builtin_amdgcn_sched_barrier(0);          // the loads stay below the epilogue (hoisted, they cost registers there)
+                    v4f o0[8], o1[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int t = wave + 8 * j, ts = t < T ? t : 0;
+                        o0[j] = *reinterpret_cast<const v4f *>(dst + (int64_t)ts * TM_H + 4 * lane);
+                        o1[j] = *reinterpret_cast<const v4f *>(dst + (int64_t)ts * TM_H + 256 + 4 * lane);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int t = wave + 8 * j;
+                        if (t < T) {
+                            *reinterpret_cast<v4f *>(dst + (int64_t)t * TM_H + 4 * lane) = o0[j] + *reinterpret_cast<const v4f *>(F + t * TM_FLD + 4 * lane);
+                            *reinterpret_cast<v4f *>(dst + (int64_t)t * TM_H + 256 + 4 * lane) = o1[j] + *reinterpret_cast<const v4f *>(F + t * TM_FLD + 256 + 4 * lane);
+                        }
+                    }
+                    break;
+                }
                 for (int t = wave; t < T; t += 8) {
                     float *dst = p.out + oslot * p.out_gstride + (int64_t)t * TM_H;
 #pragma unroll
@@ -473,13 +749,16 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
                 }
                 break;
             case STAIR_TILE_SUM_ROWS: {               // Filter: sum over the clip's own frames (modules.py:374,376)
+                if (KIND == 3) break;
                 const int L = p.len ? __builtin_amdgcn_readfirstlane(p.len[inst]) : T;
+                const int col = tm_fresh_v(TM_TID());       // (not hoisted out of the tile loop: three values kept that way went to scratch)
                 float s = 0.f;
-                for (int t = 0; t < L; ++t) s += F[t * TM_FLD + tid];
-                p.out[oslot * p.out_gstride + tid] = s;
+                for (int t = 0; t < L; ++t) s += F[t * TM_FLD + col];
+                p.out[oslot * p.out_gstride + col] = s;
                 break;
             }
             case STAIR_TILE_COSINE: {                 // Localize: (cos(f_t, k_j) + 1) * 0.49, nn.CosineSimilarity eps 1e-8
+                if (KIND == 3) break;
                 const int first = __builtin_amdgcn_readfirstlane(p.pair_first[inst]), cn = __builtin_amdgcn_readfirstlane(p.pair_cnt[inst]);
                 // pair-major: a keyword row (and its norm, and its attention slot) is fetched once, not once per frame
                 for (int j = 0; j < cn; ++j) {
@@ -506,6 +785,7 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
                 break;
             }
             case STAIR_TILE_ROWDOT_SIGMOID: {         // HasItem: sigmoid(w . row + b) (modules.py:131-137)
+                if (KIND == 3) break;
                 const v4f w0 = *reinterpret_cast<const v4f *>(p.vw + 4 * lane), w1 = *reinterpret_cast<const v4f *>(p.vw + 256 + 4 * lane);
                 const float off = p.vb[0] + (p.extra ? p.extra[inst] : 0.f);
                 for (int t = wave; t < T; t += 8) {
@@ -519,6 +799,7 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
                 break;
             }
             case STAIR_TILE_LAYERNORM: {              // Temporal: LayerNorm over H, eps 1e-5, biased variance (modules.py:283,327)
+                if (KIND == 3) break;
                 const v4f g0 = *reinterpret_cast<const v4f *>(p.gamma + 4 * lane), g1 = *reinterpret_cast<const v4f *>(p.gamma + 256 + 4 * lane);
                 const v4f b0 = *reinterpret_cast<const v4f *>(p.beta + 4 * lane), b1 = *reinterpret_cast<const v4f *>(p.beta + 256 + 4 * lane);
                 for (int t = wave; t < T; t += 8) {
@@ -546,6 +827,14 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
     // the last one to sign off knows that nobody will touch the head again and zeroes both words, so the next launch on the stream
     // -- eager, or the same kernel node of a replayed hipGraph -- finds them at 0 without any memset in between.
     // (thread 0's last head ticket has RETURNED before it signs off -- it branched on the value -- so no fence is needed between the two)
+    const int tid = TM_TID();
+    if (KIND == 2) {        // column tid of d gamma / d beta: written and read by this thread only, no barrier needed
+        const long long g = tb_acc[tid], b = tb_acc[TM_H + tid];
+        if (pp.fx_g) { if (g) atomicAdd(reinterpret_cast<unsigned long long *>(pp.fx_g + tid), (unsigned long long)g); }
+        else if (g) unsafeAtomicAdd(pp.a[0].dgamma + tid, __ll2float_rn(g) * (1.0f / kFxScale));
+        if (pp.fx_b) { if (b) atomicAdd(reinterpret_cast<unsigned long long *>(pp.fx_b + tid), (unsigned long long)b); }
+        else if (b) unsafeAtomicAdd(pp.a[0].dbeta + tid, __ll2float_rn(b) * (1.0f / kFxScale));
+    }
     if (pp.counter && tid == 0) {
         if (atomicAdd(pp.counter + 1, 1u) == gridDim.x - 1) {
             atomicExch(pp.counter, 0u);
@@ -553,6 +842,9 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
         }
     }
 }
+
+#undef TM_TID
+#undef TM_LANE
 
 // W [N, K] fp32 row-major -> bf16 hi / lo planes in MFMA fragment order: the A operand of v_mfma_f32_32x32x16_bf16 for the
 // 32-row tile nt and the 16-wide k step ks is 64 lanes x 8 bf16, lane (r, h) = W[32 nt + r][16 ks + 8 h + 0..7]; the image is
@@ -635,9 +927,31 @@ static int tile_mlp_check(const stair_tile_mlp_args &a) {
         STAIR_CHECK(a.X && a.cnt >= 0, "null input");
         STAIR_CHECK(a.tail != STAIR_TILE_STORE_ROWS, "STORE_ROWS is the vector-level tail");
     }
+    STAIR_CHECK((a.ln_bwd != 0) == (a.tail == STAIR_TILE_ROWSCALE_ADJ), "ln_bwd and the ROWSCALE_ADJ tail come together (Temporal's backward chain)");
+    if (a.ln_bwd) {
+        STAIR_CHECK(!a.vec_pack && a.n_layers == 1 && a.act[0] == 0 && !a.save[0] && !a.bias[0], "Temporal's backward chain is ONE transposed layer, no bias, no activation");
+        STAIR_CHECK(a.in_mask && a.gamma && a.dgamma && a.dbeta, "ln_bwd: saved pre-LayerNorm rows (in_mask), gamma, dgamma, dbeta");
+        STAIR_CHECK(!a.row_scale && !a.x_broadcast && !a.mid_rowdot, "ln_bwd takes no other input option");
+        STAIR_CHECK(a.adj_feat && a.adj_rs && a.adj_drs && a.out && a.adj_feat_gstride % 4 == 0 && a.out_gstride % 4 == 0 && a.in_mask_gstride % 4 == 0, "ROWSCALE_ADJ: adj_feat, adj_rs, adj_drs, out");
+        STAIR_CHECK(((reinterpret_cast<uintptr_t>(a.adj_feat) | reinterpret_cast<uintptr_t>(a.in_mask) | reinterpret_cast<uintptr_t>(a.gamma) | reinterpret_cast<uintptr_t>(a.save_in)) & 15) == 0, "ln_bwd operands must be 16-byte aligned");
+    }
     for (int l = 0; l < a.n_layers; ++l)
         STAIR_CHECK(a.W[l] && (reinterpret_cast<uintptr_t>(a.W[l]) & 15) == 0, "weight planes (stair_pack_wfrag) missing or unaligned");
-    for (int l = 0; l < a.n_layers; ++l) STAIR_CHECK(a.act[l] != 3 || a.act_mask[l], "act 3 multiplies by relu'(act_mask[l])");
+    for (int l = 0; l < a.n_layers; ++l) STAIR_CHECK(a.act[l] != 3 || a.act_mask[l] || a.act_bits[l], "act 3 multiplies by relu'(act_mask[l]) (or its bits, act_bits[l])");
+    STAIR_CHECK(!(a.in_mask && a.in_bits), "in_mask or in_bits, not both");
+    {   // the backward chains are a kernel of their own: chain options do not mix with the forward operators' options
+        bool chain = a.tail == STAIR_TILE_ACCUMULATE || (!a.ln_bwd && a.in_mask) || a.in_bits || a.x_broadcast || (!a.ln_bwd && a.save_in);
+        for (int l = 0; l < a.n_layers; ++l) chain = chain || a.act[l] == 3;
+        if (chain) {
+            STAIR_CHECK(!a.vec_pack && !a.ln_bwd, "chain options (act 3, in_mask, in_bits, x_broadcast, save_in, ACCUMULATE) are map-level");
+            STAIR_CHECK(a.tail == STAIR_TILE_ACCUMULATE || a.tail == STAIR_TILE_STORE || a.tail == STAIR_TILE_NONE, "a backward chain ends in ACCUMULATE, STORE or NONE");
+            STAIR_CHECK(!a.row_scale && !a.mid_rowdot && !a.save_bits[0] && !a.save_bits[1] && !a.save_bits[2], "a backward chain takes no row_scale / mid_rowdot / save_bits");
+        } else {
+            STAIR_CHECK(!a.act_bits[0] && !a.act_bits[1] && !a.act_bits[2], "act_bits belong to act 3");
+        }
+    }
+    STAIR_CHECK(!((a.vec_pack || a.ln_bwd) && (a.in_bits || a.save_bits[0] || a.save_bits[1] || a.save_bits[2] || a.act_bits[0] || a.act_bits[1] || a.act_bits[2])),
+                "bit masks are a map-level option");
     STAIR_CHECK(!a.x_broadcast || a.x_gstride == a.H, "a broadcast input is one [H] row per instance");
     STAIR_CHECK(!a.mid_rowdot || (a.n_layers == 3 && a.vw && a.vb), "mid_rowdot is FilterFrame's attention between layers 2 and 3");
     STAIR_CHECK(a.vec_pack || (a.x_gstride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.X) & 15) == 0), "input tiles must be 16-byte aligned");
@@ -648,6 +962,7 @@ static int tile_mlp_check(const stair_tile_mlp_args &a) {
         case STAIR_TILE_ROWDOT_SIGMOID: STAIR_CHECK(a.vw && a.vb && a.out, "row-dot tail: vw, vb, out"); break;
         case STAIR_TILE_LAYERNORM: STAIR_CHECK(a.gamma && a.beta && a.out && a.out_gstride % 4 == 0, "LayerNorm tail: gamma, beta, out"); break;
         case STAIR_TILE_STORE_ROWS: STAIR_CHECK(a.out && a.out_row_idx && a.out_gstride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0, "row-scatter tail: out, out_row_idx"); break;
+        case STAIR_TILE_ROWSCALE_ADJ: break;     // checked with ln_bwd above
         case STAIR_TILE_NONE: break;
         default: STAIR_FAIL("unknown tail");
     }
@@ -666,9 +981,13 @@ int launch_tile_mlp_batch(const stair_tile_mlp_args *args, int n, unsigned *coun
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     static int cus[64] = {};
     if (!attr_set[dev]) {
-        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_mlp_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, TM_LDS));
-        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_mlp_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, TM_LDS));
-        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_mlp_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, TM_LDS));
+        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_mlp_kernel<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, TM_LDS));
+        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_mlp_kernel<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, TM_LDS));
+        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_mlp_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, TM_LDS));
+        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_mlp_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, TM_LDS));
+        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_mlp_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, TM_LDS));
+        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_mlp_kernel<true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, TM_LDS));
+        STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_mlp_kernel<false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, TM_LDS));
         int v = 256;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
         cus[dev] = v;
@@ -680,19 +999,33 @@ int launch_tile_mlp_batch(const stair_tile_mlp_args *args, int n, unsigned *coun
     // neutral at 128 questions and in inference.  STAIR_TILE_NT=0 switches them off.
     static const bool nt = [] { const char *e = getenv("STAIR_TILE_NT"); return !(e && e[0] == '0'); }();
     auto rounds = [&](int x) { return args[x].n_layers + (args[x].vec_pack ? (args[x].vec_pack == 1 ? 1 : 2) : 0); };   // k loops per tile
-    // map-level tiles and vector-level tiles are two kernels (the vector form's segment loop costs the other one registers):
-    // two launches when a level has both; stream-ordered, so they share the (self-resetting) queue words
-    for (int vec = 0; vec < 2; ++vec) {
+    // map-level tiles, vector-level tiles and Temporal's backward chains are three kernels (what one form needs in registers the
+    // others do not pay for): one launch per form a level has; stream-ordered, so they share the (self-resetting) queue words
+    auto kind_of = [](const stair_tile_mlp_args &a) {
+        if (a.vec_pack) return 1;
+        if (a.ln_bwd) return 2;
+        bool chain = a.tail == STAIR_TILE_ACCUMULATE || a.in_mask || a.in_bits || a.x_broadcast || a.save_in;
+        for (int l = 0; l < a.n_layers && l < 3; ++l) chain = chain || a.act[l] == 3;
+        return chain ? 3 : 0;
+    };
+    for (int kind = 0; kind < 4; ++kind) {
+        const int vec = kind == 1;
         TmParams pp;
-        pp.nb = 0; pp.counter = counter; pp.first[0] = 0;
+        pp.nb = 0; pp.counter = counter; pp.first[0] = 0; pp.fx_g = pp.fx_b = nullptr;
         int order[TM_MAXB], m = 0;
         for (int i = 0; i < n; ++i)
-            if (args[i].cnt > 0 && (args[i].vec_pack != 0) == (vec != 0)) order[m++] = i;
+            if (args[i].cnt > 0 && kind_of(args[i]) == kind) order[m++] = i;
         if (m == 0) continue;
+        if (kind == 2) {            // one accumulator pair per workgroup: the chains of a launch share their LayerNorm
+            for (int j = 1; j < m; ++j)
+                STAIR_CHECK(args[order[j]].dgamma == args[order[0]].dgamma && args[order[j]].dbeta == args[order[0]].dbeta,
+                            "the Temporal chains of one launch must share dgamma / dbeta");
+            pp.fx_g = det_shadow(args[order[0]].dgamma); pp.fx_b = det_shadow(args[order[0]].dbeta);
+        }
         std::stable_sort(order, order + m, [&](int x, int y) { return rounds(x) > rounds(y); });    // long tiles first
         for (int j = 0; j < m; ++j) {
             const stair_tile_mlp_args &a = args[order[j]];
-            pp.a[j] = a;
+            pp.a[j] = tm_arg(a, kind);
             pp.first[j + 1] = pp.first[j] + a.cnt;
             const int64_t M = a.vec_pack ? a.vec_cnt : (int64_t)a.cnt * a.T;
             const int kl = rounds(order[j]);
@@ -706,9 +1039,13 @@ int launch_tile_mlp_batch(const stair_tile_mlp_args *args, int n, unsigned *coun
             STAIR_HIP(hipEventCreate(&e0)); STAIR_HIP(hipEventCreate(&e1));
             STAIR_HIP(hipEventRecord(e0, s));
         }
-        if (vec) hipLaunchKernelGGL((tile_mlp_kernel<false, true>), dim3(grid), dim3(512), TM_LDS, s, pp);
-        else if (nt) hipLaunchKernelGGL((tile_mlp_kernel<true, false>), dim3(grid), dim3(512), TM_LDS, s, pp);
-        else hipLaunchKernelGGL((tile_mlp_kernel<false, false>), dim3(grid), dim3(512), TM_LDS, s, pp);
+        if (vec) hipLaunchKernelGGL((tile_mlp_kernel<false, 1>), dim3(grid), dim3(512), TM_LDS, s, pp);
+        else if (kind == 2 && nt) hipLaunchKernelGGL((tile_mlp_kernel<true, 2>), dim3(grid), dim3(512), TM_LDS, s, pp);
+        else if (kind == 2) hipLaunchKernelGGL((tile_mlp_kernel<false, 2>), dim3(grid), dim3(512), TM_LDS, s, pp);
+        else if (kind == 3 && nt) hipLaunchKernelGGL((tile_mlp_kernel<true, 3>), dim3(grid), dim3(512), TM_LDS, s, pp);
+        else if (kind == 3) hipLaunchKernelGGL((tile_mlp_kernel<false, 3>), dim3(grid), dim3(512), TM_LDS, s, pp);
+        else if (nt) hipLaunchKernelGGL((tile_mlp_kernel<true, 0>), dim3(grid), dim3(512), TM_LDS, s, pp);
+        else hipLaunchKernelGGL((tile_mlp_kernel<false, 0>), dim3(grid), dim3(512), TM_LDS, s, pp);
         STAIR_LAUNCH_CHECK();
         if (g_tile_timing) {
             STAIR_HIP(hipEventRecord(e1, s));

@@ -374,6 +374,34 @@ def tile_mlp(x, layers, tail, x_idx=None, row_scale=None, rs_idx=None, save=Fals
     return saves, rs_out
 
 
+def tile_temporal_bwd(dy, a_saved, gamma, weight, feat, rs, dfeat, drs, dgamma, dbeta, eps=1e-5, dy_idx=None, feat_idx=None,
+                      rs_idx=None, dfeat_idx=None, exclusive=False):
+    """Temporal's backward as one chain per tile (stair_tile_mlp_args.ln_bwd + tail ROWSCALE_ADJ; autograd of
+    /root/reference/video_nmn/modules.py:310-327, y = LayerNorm(a), a = ReLU(Lin(r_t feat_t))): dy [*, T, 512] gradient tiles of y
+    (tile i = dy[dy_idx[i]]), a_saved [n, T, 512] the saved post-ReLU rows, weight [512, 512] of the dense layer, feat tiles, rs
+    [*, T] the per-frame scales.  ADDS r_t (dZ W)_t into dfeat[dfeat_idx[i]], (dZ W)_t . feat_t into drs[rs_idx[i]], the LayerNorm
+    parameter gradients into dgamma / dbeta; returns dZ [n, T, 512] (the operand of the dense layer's weight-gradient product).
+    exclusive: no two instances share a dfeat tile (plain read - add - write instead of float atomics)."""
+    _req(dy, 'dy')
+    n, T, H = a_saved.shape
+    a = TileMlpArgs()
+    a.X, a.x_gstride, a.x_idx = dy.data_ptr(), T * H, (dy_idx.data_ptr() if dy_idx is not None else None)
+    a.ln_bwd, a.in_mask, a.in_mask_gstride, a.in_scale = 1, a_saved.data_ptr(), T * H, 1.0
+    dz = torch.empty(n, T, H, device=dy.device)
+    a.save_in = dz.data_ptr()
+    a.gamma, a.dgamma, a.dbeta, a.ln_eps = gamma.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), float(eps)
+    planes = pack_wfrag(weight, transpose=True)
+    a.W[0], a.act[0], a.n_layers = planes.data_ptr(), 0, 1
+    a.tail = 8
+    a.out, a.out_gstride, a.out_idx = dfeat.data_ptr(), T * H, (dfeat_idx.data_ptr() if dfeat_idx is not None else None)
+    a.adj_feat, a.adj_feat_gstride, a.adj_feat_idx = feat.data_ptr(), T * H, (feat_idx.data_ptr() if feat_idx is not None else None)
+    a.adj_rs, a.adj_rs_idx, a.adj_drs = rs.data_ptr(), (rs_idx.data_ptr() if rs_idx is not None else None), drs.data_ptr()
+    a.cnt, a.T, a.H = n, T, H
+    a.acc_exclusive = 1 if exclusive else 0
+    check(lib.stair_tile_mlp_fwd(C.byref(a), _stream()))
+    return dz
+
+
 VEC_IN = {'a': 0, 'cat2': 1, 'xor': 2, 'exists': 3, 'mask': 4}
 
 

@@ -26,7 +26,7 @@ def test_header_symbols_are_exported_and_bound():
     assert declared == bound, (declared ^ bound)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.stair_abi_version() == 4
+    assert lib.stair_abi_version() == 5
 
 
 def _ctx(config):

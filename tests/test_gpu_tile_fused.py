@@ -151,3 +151,44 @@ def test_vector_level_module_as_one_tile_launch(kind, n, two_layers):
     out2 = d(out0.clone())
     ops.vec_mlp(kind, d(vec), d(ia), d(vec), d(ib), layers, out2, d(io), save=False)      # inference form: no saves, direct layer boundary
     assert float((out2.cpu().double()[io.long()] - ref).abs().max()) < 3e-5
+
+
+@pytest.mark.parametrize('n,T,exclusive', [(3, 64, False), (300, 64, False), (70, 40, False), (300, 64, True), (9, 33, True)])
+def test_temporal_backward_chain_matches_autograd(n, T, exclusive):
+    """Temporal's backward as one chain per tile (stair_tile_mlp_args.ln_bwd + ROWSCALE_ADJ; /root/reference/video_nmn/modules.py:310-327
+    under autograd: y = LayerNorm(ReLU(Lin(r_t feat_t)))) against fp64 autograd of the same formula: dZ of the dense layer, the
+    gradient of the (shared) feature tiles, of the per-frame scales, of the LayerNorm parameters.  300 tiles: several tiles per
+    workgroup (the fixed-point accumulators), shared input tiles (atomic accumulation)."""
+    from stair_amd import ops
+    H = 512
+    g = torch.Generator().manual_seed(11 * n + T)
+    nf = n + 1 if exclusive else max(2, n // 3)             # feature tiles are shared by several instances (atomic accumulation)
+    feat = torch.randn(nf, T, H, generator=g)               # ... or every instance has its own (read - add - write)
+    fidx = torch.randperm(nf, generator=g)[:n].to(torch.int32) if exclusive else torch.randint(0, nf, (n,), generator=g, dtype=torch.int32)
+    rs = torch.rand(n + 4, T, generator=g)
+    ridx = torch.randperm(n + 4, generator=g)[:n].to(torch.int32)
+    w = torch.randn(H, H, generator=g) / H ** 0.5; b = torch.randn(H, generator=g) * 0.1
+    gamma = 1.0 + 0.1 * torch.randn(H, generator=g); beta = 0.1 * torch.randn(H, generator=g)
+    dy = torch.randn(n + 2, T, H, generator=g)
+    yidx = torch.randperm(n + 2, generator=g)[:n].to(torch.int32)
+    F = feat.double().requires_grad_(True); R = rs.double().requires_grad_(True)
+    G = gamma.double().requires_grad_(True); Bt = beta.double().requires_grad_(True)
+    z = (R[ridx.long()].unsqueeze(-1) * F[fidx.long()]) @ w.double().t() + b.double()
+    z.retain_grad()
+    a = torch.relu(z)
+    y = torch.nn.functional.layer_norm(a, (H,), G, Bt, 1e-5)
+    (y * dy[yidx.long()].double()).sum().backward()
+    d = lambda t: t.to(DEV)
+    dfeat0 = torch.randn(nf, T, H, generator=g); drs0 = torch.randn(n + 4, T, generator=g)
+    dgamma0 = torch.randn(H, generator=g); dbeta0 = torch.randn(H, generator=g)
+    dfeat, drs, dgamma, dbeta = d(dfeat0.clone()), d(drs0.clone()), d(dgamma0.clone()), d(dbeta0.clone())
+    dz = ops.tile_temporal_bwd(d(dy), d(a.detach().float()), d(gamma), d(w), d(feat), d(rs), dfeat, drs, dgamma, dbeta,
+                               dy_idx=d(yidx), feat_idx=d(fidx), rs_idx=d(ridx), dfeat_idx=d(fidx), exclusive=exclusive)
+    def close(got, ref, what):
+        err = float((got.cpu().double() - ref).abs().max())
+        assert err < 3e-5 * max(1.0, float(ref.abs().max())), (what, err)
+    close(dz, z.grad, 'dZ')
+    close(dfeat - d(dfeat0), F.grad, 'dfeat')
+    close(drs - d(drs0), R.grad, 'drs')
+    close(dgamma - d(dgamma0), G.grad, 'dgamma')
+    close(dbeta - d(dbeta0), Bt.grad, 'dbeta')
