@@ -207,7 +207,7 @@ typedef struct stair_lstm_args {
                     configs[1]).  When set, x may be NULL and the input projection runs as a plane GEMM (stair_gemm_planes: A
                     exact in bf16, W_ih split once into hi/lo planes, two MFMA products per pair); needs I % 32 == 0 and a
                     split matmul mode. */
-    void *wih_planes_ws; /* scratch for the W_ih planes when x_bf16 is set: 2 planes x [8*Hh, I] bf16 = 32*Hh*I bytes */
+    void *wih_planes_ws; /* scratch for the W_ih planes when x_bf16 (or x_planes_ws) is set: 2 planes x [8*Hh, I] bf16 = 32*Hh*I bytes */
     void *coop_ws; int64_t coop_ws_bytes; /* optional scratch (>= stair_lstm_coop_ws_bytes(n), 256-byte aligned) for the
                     cooperative recurrence (csrc/lstm_coop.hip: Hh = 256, split matmul modes): hidden units split over groups
                     of 4 co-resident workgroups that exchange h every step, W_hh resident in registers.  NULL = the
@@ -225,6 +225,10 @@ typedef struct stair_lstm_args {
                     the kernel on the current device and otherwise runs the one-workgroup kernel; this word covers what that
                     check cannot see.  stair_plan_run keeps such a word in the plan's workspace (stair_plan_info.status_off);
                     stair_adam_step refuses to update when its `guard` points at a set word. */
+    void *x_planes_ws; /* optional scratch (ABI 5), fp32 input rows only: 2 planes x [rows, Ip] bf16 with Ip = I rounded up to a multiple
+                    of 32 (4 * rows * Ip bytes, 16-byte aligned).  With it AND wih_planes_ws (then 32 * Hh * Ip bytes) the input
+                    projection splits x and W_ih once into zero-padded hi / lo planes and runs as ONE plane GEMM for both
+                    directions (three MFMA products per pair; rows >= 256, split matmul mode) -- the text encoder's E = 300. */
 } stair_lstm_args;
 int64_t stair_lstm_coop_ws_bytes(int32_t n);
 /* Upper bound on the workgroups a cooperative recurrence may use on the current process's devices (default: every CU;

@@ -59,7 +59,7 @@ class LstmArgs(C.Structure):
                 ('xproj_ws', C.c_void_p), ('bias_ws', C.c_void_p), ('whh_pack_ws', C.c_void_p),
                 ('out', C.c_void_p), ('ldo', C.c_int64), ('h_n', C.c_void_p), ('cbuf', C.c_void_p),
                 ('x_bf16', C.c_void_p), ('wih_planes_ws', C.c_void_p), ('coop_ws', C.c_void_p), ('coop_ws_bytes', C.c_int64),
-                ('seq_len', C.c_void_p), ('status', C.c_void_p)]
+                ('seq_len', C.c_void_p), ('status', C.c_void_p), ('x_planes_ws', C.c_void_p)]
 
 
 class LstmBwdArgs(C.Structure):

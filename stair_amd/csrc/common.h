@@ -123,6 +123,7 @@ int launch_gemm_tn_bf16x3(const stair_gemm_tn_args &a, hipStream_t s);
 int matmul_mode();
 int launch_split_planes(const float *x, void *hi, void *lo, int64_t n, hipStream_t s);
 int launch_split_planes_tiled(const float *x, void *hi, void *lo, int rows, int cols, hipStream_t s, int row_off = 0, int total_rows = 0);
+int launch_split_planes_pad(const float *x, int64_t ldx, void *hi, void *lo, int rows, int cols, int Kp, bool tiled, hipStream_t s, int row_off = 0, int total_rows = 0);
 int launch_gemm_planes(const stair_gemm_planes_args &a, hipStream_t s);
 bool gemm_planes_supported(int64_t M, int N, int K);
 int launch_gemm_tn(const stair_gemm_tn_args &a, hipStream_t s);

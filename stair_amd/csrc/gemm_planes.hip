@@ -371,6 +371,43 @@ __global__ void split_planes_tiled_kernel(const float *x, __bf16 *hi, __bf16 *lo
     }
 }
 
+// fp32 [rows, cols] (row stride ldx, cols % 4 == 0) -> hi / lo planes with the columns zero-padded to Kp (a multiple of 32): row-major
+// [rows, Kp] (an A operand of the plane GEMM) or tiled [Kp/32][total_rows][32] (a W operand).  One thread per 8 output elements.
+template <bool TILED>
+__global__ void split_planes_pad_kernel(const float *x, int64_t ldx, __bf16 *hi, __bf16 *lo, int rows, int cols, int Kp, int row_off, int total_rows) {
+    const int c8 = Kp / 8;
+    const int64_t n8 = (int64_t)rows * c8;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / c8), k8 = (int)(i - (int64_t)row * c8);
+        const float *src = x + (int64_t)row * ldx + 8 * k8;
+        const v4f z = {0.f, 0.f, 0.f, 0.f};
+        const v4f a = 8 * k8 < cols ? *reinterpret_cast<const v4f *>(src) : z, b = 8 * k8 + 4 < cols ? *reinterpret_cast<const v4f *>(src + 4) : z;
+        bf16x8 vh, vl;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            vh[j] = (__bf16)a[j]; vl[j] = (__bf16)(a[j] - (float)vh[j]);
+            vh[4 + j] = (__bf16)b[j]; vl[4 + j] = (__bf16)(b[j] - (float)vh[4 + j]);
+        }
+        const int64_t o = TILED ? ((int64_t)(k8 >> 2) * total_rows + row_off + row) * PBK + (k8 & 3) * 8 : (int64_t)row * Kp + 8 * k8;
+        *reinterpret_cast<bf16x8 *>(hi + o) = vh;
+        *reinterpret_cast<bf16x8 *>(lo + o) = vl;
+    }
+}
+
+int launch_split_planes_pad(const float *x, int64_t ldx, void *hi, void *lo, int rows, int cols, int Kp, bool tiled, hipStream_t s, int row_off, int total_rows) {
+    if (total_rows <= 0) total_rows = rows;
+    STAIR_CHECK(x && hi && lo && rows > 0, "null argument");
+    STAIR_CHECK(cols > 0 && cols % 4 == 0 && ldx % 4 == 0 && Kp % PBK == 0 && Kp >= cols, "cols, ldx multiples of 4; Kp a multiple of 32, >= cols");
+    STAIR_CHECK(row_off >= 0 && row_off + rows <= total_rows, "row block outside the plane");
+    STAIR_CHECK(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(hi) | reinterpret_cast<uintptr_t>(lo)) & 15) == 0, "pointers must be 16-byte aligned");
+    const int64_t n8 = (int64_t)rows * (Kp / 8);
+    const int blocks = (int)std::min<int64_t>((n8 + 255) / 256, 8192);
+    if (tiled) hipLaunchKernelGGL(split_planes_pad_kernel<true>, dim3(blocks), dim3(256), 0, s, x, ldx, static_cast<__bf16 *>(hi), static_cast<__bf16 *>(lo), rows, cols, Kp, row_off, total_rows);
+    else hipLaunchKernelGGL(split_planes_pad_kernel<false>, dim3(blocks), dim3(256), 0, s, x, ldx, static_cast<__bf16 *>(hi), static_cast<__bf16 *>(lo), rows, cols, Kp, row_off, total_rows);
+    STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_split_planes_tiled(const float *x, void *hi, void *lo, int rows, int cols, hipStream_t s, int row_off, int total_rows) {
     if (total_rows <= 0) total_rows = rows;
     STAIR_CHECK(row_off >= 0 && row_off + rows <= total_rows, "row block outside the plane");

@@ -909,6 +909,22 @@ int launch_lstm_project(const stair_lstm_args &a, hipStream_t s) {
         g.bias = a.bias_ws; g.C = a.xproj_ws; g.ldc = 8 * (int64_t)Hh;
         g.M = a.rows; g.N = 8 * Hh; g.K = a.I; g.act = 0;
         if (int rc = launch_gemm_planes(g, s)) return rc;
+    } else if (a.x_planes_ws && a.wih_planes_ws && matmul_mode() == STAIR_MATMUL_BF16X3 && gemm_planes_supported(a.rows, 8 * Hh, (a.I + 31) / 32 * 32)) {
+        // fp32 input rows (the text encoder: E = 300): split ONCE into zero-padded hi / lo planes, then the same LDS-DMA plane GEMM
+        // for both directions with three products per operand pair (the register-staged kernel reads and splits every A row once
+        // per column tile and direction)
+        const int Kp = (a.I + 31) / 32 * 32;
+        char *xh = static_cast<char *>(a.x_planes_ws), *xl = xh + (size_t)a.rows * Kp * 2;
+        char *wh = static_cast<char *>(a.wih_planes_ws), *wl = wh + (size_t)8 * Hh * Kp * 2;
+        if (int rc = launch_split_planes_pad(a.x, a.ldx, xh, xl, a.rows, a.I, Kp, false, s)) return rc;
+        for (int dir = 0; dir < 2; ++dir)
+            if (int rc = launch_split_planes_pad(a.w_ih[dir], a.I, wh, wl, 4 * Hh, a.I, Kp, true, s, dir * 4 * Hh, 8 * Hh)) return rc;
+        stair_gemm_planes_args g = {};
+        g.A_hi = xh; g.A_lo = xl; g.lda = Kp;
+        g.W_hi = wh; g.W_lo = wl; g.ldw = 0; g.w_tiled = 1;
+        g.bias = a.bias_ws; g.C = a.xproj_ws; g.ldc = 8 * (int64_t)Hh;
+        g.M = a.rows; g.N = 8 * Hh; g.K = Kp; g.act = 0;
+        if (int rc = launch_gemm_planes(g, s)) return rc;
     } else
     for (int dir = 0; dir < 2; ++dir) {
         stair_gemm_args g = {};

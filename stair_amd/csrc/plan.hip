@@ -435,7 +435,7 @@ struct stair_plan {
     int64_t wg_rows[WF_COUNT] = {}, wg_dz[WF_COUNT] = {}, wg_sx[WF_COUNT] = {}, wg_off_idx[WF_COUNT] = {}, wg_off_rs[WF_COUNT] = {}, wg_part[WF_COUNT] = {};
     // workspace layout (float offsets)
     int64_t o_idx = 0, o_vec = 0, o_map = 0, o_att = 0, o_tok = 0, o_qfeat = 0, o_vhn = 0, o_xpv = 0, o_xpt = 0,
-            o_bias = 0, o_wpack = 0, o_wplanes = 0, o_coop = 0, o_coop2 = 0, o_splitk = 0, o_tmpA = 0, o_tmpB = 0, o_kbuf = 0, o_cat = 0, o_hid = 0, o_rs = 0, o_sup = 0, o_extra = 0,
+            o_bias = 0, o_wpack = 0, o_wplanes = 0, o_wplanes_t = 0, o_xplanes_t = 0, o_coop = 0, o_coop2 = 0, o_splitk = 0, o_tmpA = 0, o_tmpB = 0, o_kbuf = 0, o_cat = 0, o_hid = 0, o_rs = 0, o_sup = 0, o_extra = 0,
             o_logits = 0, o_status = 0, o_wfrag = 0, total = 0;
     // training only
     bool train = false;
@@ -1103,6 +1103,11 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
     pl->o_bias = take(2 * 4 * H, 64);
     pl->o_wpack = take(2 * 2 * H * H, 64);       // 8*Hh*Hh floats per encoder
     pl->o_wplanes = ctx->cfg.video_size % 32 == 0 ? take(4 * H * ctx->cfg.video_size, 64) : 0;   // video W_ih hi/lo planes (bf16 features): 2 x [4H, V] bf16
+    {   // the text encoder's input projection as a plane GEMM: W_ih and the token rows as zero-padded hi / lo planes (counted in floats)
+        const int64_t Ep = (ctx->cfg.text_size + 31) / 32 * 32;
+        pl->o_wplanes_t = take(4 * H * Ep, 64);
+        pl->o_xplanes_t = take((int64_t)std::max(pl->rows_q, 1) * Ep, 64);
+    }
     pl->coop_bytes = std::max(lstm_coop_ws_bytes(pl->n_vid), lstm_coop_ws_bytes(n));
     if (pl->train) pl->coop_bytes = std::max(pl->coop_bytes, std::max(lstm_coop_bwd_ws_bytes(pl->n_vid), lstm_coop_bwd_ws_bytes(n)));
     pl->o_coop = take((pl->coop_bytes + 3) / 4, 64);   // exchange slabs + flags of the cooperative recurrence (video encoder)
@@ -1627,6 +1632,8 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
             t.w_ih[d] = W.enc[1][4 * d]; t.w_hh[d] = W.enc[1][4 * d + 1];
             t.b_ih[d] = W.enc[1][4 * d + 2]; t.b_hh[d] = W.enc[1][4 * d + 3];
         }
+        static const bool text_planes = [] { const char *e = getenv("STAIR_TEXT_PLANES"); return !(e && e[0] == '0'); }();
+        if (text_planes) { t.wih_planes_ws = ws + pl->o_wplanes_t; t.x_planes_ws = ws + pl->o_xplanes_t; }
         t.xproj_ws = ws + pl->o_xpt; t.bias_ws = ws + pl->o_bias + 4 * H; t.whh_pack_ws = ws + pl->o_wpack + 2 * (int64_t)H * H;
         t.out = tok; t.ldo = H; t.h_n = qfeat;
         t.coop_ws = ws + pl->o_coop2; t.coop_ws_bytes = pl->coop_bytes; t.status = status;
@@ -2858,6 +2865,8 @@ extern "C" int stair_plan_regions(stair_plan *pl, const stair_ctx *ctx, const ch
     add("bias", pl->o_bias, 8 * H);
     add("wpack", pl->o_wpack, 4 * H * H);
     if (ctx->cfg.video_size % 32 == 0) add("wplanes", pl->o_wplanes, 4 * H * ctx->cfg.video_size);
+    add("wplanes_t", pl->o_wplanes_t, 4 * H * ((ctx->cfg.text_size + 31) / 32 * 32));
+    add("xplanes_t", pl->o_xplanes_t, (int64_t)std::max(pl->rows_q, 1) * ((ctx->cfg.text_size + 31) / 32 * 32));
     add("coop", pl->o_coop, (pl->coop_bytes + 3) / 4);
     add("coop2", pl->o_coop2, (pl->coop_bytes + 3) / 4);
     add("splitk", pl->o_splitk, kSplitKFloats);

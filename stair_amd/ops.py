@@ -154,12 +154,14 @@ def gemm_tn(A, B, Cmat, M, N, K, rows_per_group=1, b_gstride=None, b_gidx=None, 
     check(lib.stair_gemm_tn_f32(C.byref(a), _stream()))
 
 
-def lstm_bidir(x, seq_off, max_len, weights, save=False, coop=True, seq_len=None):
+def lstm_bidir(x, seq_off, max_len, weights, save=False, coop=True, seq_len=None, x_planes=False):
     """Bidirectional LSTM over packed ragged sequences.
 
     x [rows, I]; seq_off int32 [n+1] (device); weights = (w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r).
     Returns (out [rows, 2*Hh], h_n [n, 2*Hh]); with save=True also (gates, cbuf) for lstm_bidir_bwd.
     seq_len: int32 [n] (device) when the storage is padded -- sequence s holds seq_len[s] data rows of its span.
+    x_planes: fp32 rows only -- the input projection as ONE plane GEMM on zero-padded hi / lo planes of x and W_ih
+    (stair_lstm_args.x_planes_ws: how the plan runs the text encoder, E = 300).
     """
     bf = x.dtype == torch.bfloat16           # stored bf16 input rows (clip features): plane GEMM input projection
     _req(x, 'x', torch.bfloat16 if bf else torch.float32); _req(seq_off, 'seq_off', torch.int32)
@@ -178,6 +180,11 @@ def lstm_bidir(x, seq_off, max_len, weights, save=False, coop=True, seq_len=None
     if bf:
         planes = torch.empty(2 * 8 * Hh * I, device=x.device, dtype=torch.bfloat16)
         a.x_bf16, a.wih_planes_ws = x.data_ptr(), planes.data_ptr()
+    elif x_planes:
+        Ip = (I + 31) // 32 * 32
+        planes = torch.empty(2 * 8 * Hh * Ip, device=x.device, dtype=torch.bfloat16)
+        xpl = torch.empty(2 * rows * Ip, device=x.device, dtype=torch.bfloat16)
+        a.wih_planes_ws, a.x_planes_ws = planes.data_ptr(), xpl.data_ptr()
     a.seq_off = seq_off.data_ptr()
     if seq_len is not None:
         a.seq_len = seq_len.data_ptr()

@@ -198,6 +198,30 @@ def test_lstm_matches_explicit_oracle(Hh, I, lens, matmul):
         assert _maxerr(h_n[s], rh.reshape(-1)) < _tol(matmul, 2e-5, 1e-4), s
 
 
+@pytest.mark.parametrize('I,lens', [(300, [8, 25, 12, 19, 25, 8, 9, 10] * 5), (300, [11] * 47), (64, [30] * 9)])
+def test_lstm_input_projection_on_padded_planes_matches_oracle(I, lens):
+    """The text encoder's form (stair_lstm_args.x_planes_ws): fp32 token rows and W_ih split once into zero-padded bf16 hi / lo
+    planes (E = 300 -> 320 columns), ONE plane GEMM for both directions (/root/reference/video_nmn/module_net.py:44-47,151-158);
+    >= 256 rows take it, against the written-out oracle LSTM, ragged row count."""
+    from stair_amd import ops
+    Hh = 256
+    cfg = dict(spec.DEFAULT_CONFIG, hidden_size=2 * Hh, video_size=I, max_video_length=64)
+    w = oracle_weights(cfg, seed=6)
+    names = ['submodules.video_encoder.' + n + sfx for sfx in ('', '_reverse')
+             for n in ('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0')]
+    g = torch.Generator().manual_seed(I + len(lens))
+    xs = [torch.randn(L, I, generator=g) for L in lens]
+    off = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32)
+    assert int(off[-1]) >= 256
+    with ops.kernel_accounting() as acct:
+        out, h_n = ops.lstm_bidir(torch.cat(xs).to(DEV), off.to(DEV), max(lens), [w[n].to(DEV) for n in names], x_planes=True)
+    assert 'gemm_planes' in acct.table, sorted(acct.table)
+    for s in range(0, len(xs), 3):
+        ro, rh = O.lstm_bidir_explicit(w, 'video_encoder', xs[s])
+        assert _maxerr(out[off[s]:off[s + 1]], ro) < 2e-5, s
+        assert _maxerr(h_n[s], rh.reshape(-1)) < 2e-5, s
+
+
 def test_l2normalize_and_zero_vector():
     from stair_amd import ops
     x = torch.randn(9, 64)
