@@ -18,7 +18,8 @@
  *   - `stream` is a hipStream_t passed as void* (the caller's current torch-ROCm stream).  All
  *     work is enqueued on it; nothing synchronises the device.
  *   - return value 0 = success; non-zero = error, message via stair_last_error() (thread local).
- *   - not thread-safe per ctx; one ctx per GPU / process.
+ *   - one thread at a time per ctx; several contexts per process are supported (one per GPU and thread, or side by side on one
+ *     GPU): policy settings can be overridden per context (stair_ctx_set_option), call-scoped state is thread-local.
  *   - all floating-point data is IEEE fp32, row-major.
  */
 #ifndef STAIR_HIP_H
@@ -113,6 +114,15 @@ int stair_ctx_set_grad(stair_ctx *ctx, int id, float *dev_ptr, int64_t numel);
 #define STAIR_MATMUL_BF16 2
 int stair_set_matmul_mode(int32_t mode);
 int stair_get_matmul_mode(void);
+/* Per-context options (ABI 5).  stair_set_matmul_mode / stair_set_tile_mlp / stair_set_tile_queue / stair_set_tn_slab_min_rows and the
+ * environment set the process-wide DEFAULTS; a context may override each, and its values are in force on the calling thread for the
+ * duration of stair_plan_run[_flags] / stair_plan_backward on that context, so several contexts of one process (one per GPU and
+ * thread, or two configurations side by side) do not see each other's settings.  value < 0: inherit the process default again.
+ * The building-block entry points (stair_gemm_f32, stair_tile_mlp_fwd, ...) take no context and follow the process-wide settings. */
+enum stair_option { STAIR_OPT_MATMUL_MODE = 0, STAIR_OPT_TILE_MLP = 1, STAIR_OPT_TILE_QUEUE = 2, STAIR_OPT_VEC_GROUP = 3,
+                    STAIR_OPT_TN_SLAB_MIN_ROWS = 4, STAIR_OPT_COUNT = 5 };
+int stair_ctx_set_option(stair_ctx *ctx, int32_t option, int32_t value);
+int stair_ctx_get_option(const stair_ctx *ctx, int32_t option, int32_t *value);
 int stair_set_split_min_rows(int32_t rows); /* GEMMs with fewer rows use the exact kernel (default 1 = none) */
 
 /* ---- building blocks (exported for unit tests and reuse; the plan runner calls the same code) */
@@ -228,7 +238,8 @@ typedef struct stair_lstm_args {
     void *x_planes_ws; /* optional scratch (ABI 5), fp32 input rows only: 2 planes x [rows, Ip] bf16 with Ip = I rounded up to a multiple
                     of 32 (4 * rows * Ip bytes, 16-byte aligned).  With it AND wih_planes_ws (then 32 * Hh * Ip bytes) the input
                     projection splits x and W_ih once into zero-padded hi / lo planes and runs as ONE plane GEMM for both
-                    directions (three MFMA products per pair; rows >= 256, split matmul mode) -- the text encoder's E = 300. */
+                    directions (three MFMA products per pair; Hh >= 32, split matmul mode; at every row count, so that a row's
+                    result does not depend on the batch around it) -- the text encoder's E = 300. */
 } stair_lstm_args;
 int64_t stair_lstm_coop_ws_bytes(int32_t n);
 /* Upper bound on the workgroups a cooperative recurrence may use on the current process's devices (default: every CU;

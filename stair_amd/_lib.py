@@ -137,6 +137,8 @@ SIGNATURES = [
     ('stair_lstm_coop_limit', C.c_int, [C.c_int32]),
     ('stair_vec_group', C.c_int, [C.POINTER(VecProblem), C.c_int32, C.c_void_p]),
     ('stair_set_tile_mlp', C.c_int, [C.c_int32]),
+    ('stair_ctx_set_option', C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    ('stair_ctx_get_option', C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     ('stair_set_tile_queue', C.c_int, [C.c_int32]),
     ('stair_tile_mlp_fwd', C.c_int, [C.POINTER(TileMlpArgs), C.c_void_p]),
     ('stair_pack_wfrag', C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

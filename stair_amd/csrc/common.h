@@ -82,6 +82,19 @@ extern bool g_acct_on;
 // the MFMA-bound kernels: which variant a launcher selected, with its algorithmic flops (2MNK) and bytes (operands once + result once)
 #define STAIR_ACCT_MFMA(name, bytes, flops) do { if (::stair::g_acct_on) ::stair::acct_add(name, (int64_t)(bytes), (int64_t)(flops)); } while (0)
 
+// ---- per-context options (stair_ctx_set_option).  The process-wide setters (stair_set_matmul_mode, stair_set_tile_mlp,
+// stair_set_tile_queue, stair_set_tn_slab_min_rows) and the environment give the DEFAULTS; a context may override each of them, and
+// its values are in force on the calling thread for the duration of stair_plan_run / stair_plan_backward on that context (PolicyScope):
+// two contexts of one process -- two GPUs driven from two threads, or two configurations on one GPU -- do not see each other's settings.
+struct Policy { int v[STAIR_OPT_COUNT]; Policy() { for (int &x : v) x = -1; } };       // -1: inherit the process default
+extern thread_local const Policy *tl_policy;
+inline int policy_or(int opt, int dflt) { return tl_policy && tl_policy->v[opt] >= 0 ? tl_policy->v[opt] : dflt; }
+struct PolicyScope {
+    const Policy *prev;
+    explicit PolicyScope(const Policy *p) : prev(tl_policy) { tl_policy = p; }
+    ~PolicyScope() { tl_policy = prev; }
+};
+
 // ---- internal launchers shared between the C ABI and the plan runner ----------------------
 int launch_gemm(const stair_gemm_args &a, hipStream_t s);
 int launch_lstm(const stair_lstm_args &a, hipStream_t s);

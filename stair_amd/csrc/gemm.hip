@@ -194,7 +194,7 @@ int matmul_mode() {
         const char *e = getenv("STAIR_MATMUL");
         g_matmul_mode = (e && std::string(e) == "f32") ? STAIR_MATMUL_F32 : (e && std::string(e) == "bf16") ? STAIR_MATMUL_BF16 : STAIR_MATMUL_BF16X3;
     }
-    return g_matmul_mode;
+    return policy_or(STAIR_OPT_MATMUL_MODE, g_matmul_mode);
 }
 void set_matmul_mode(int m) { g_matmul_mode = m; }
 // Row threshold of the split kernels.  Default 1 = every GEMM: a question's result must not depend on how many

@@ -909,7 +909,9 @@ int launch_lstm_project(const stair_lstm_args &a, hipStream_t s) {
         g.bias = a.bias_ws; g.C = a.xproj_ws; g.ldc = 8 * (int64_t)Hh;
         g.M = a.rows; g.N = 8 * Hh; g.K = a.I; g.act = 0;
         if (int rc = launch_gemm_planes(g, s)) return rc;
-    } else if (a.x_planes_ws && a.wih_planes_ws && matmul_mode() == STAIR_MATMUL_BF16X3 && gemm_planes_supported(a.rows, 8 * Hh, (a.I + 31) / 32 * 32)) {
+    } else if (a.x_planes_ws && a.wih_planes_ws && matmul_mode() == STAIR_MATMUL_BF16X3 && 8 * Hh >= 256) {
+        // (at EVERY row count: a row's result must not depend on how many other rows share the launch -- the kernel's tile is 256 rows,
+        // a short batch fills part of one)
         // fp32 input rows (the text encoder: E = 300): split ONCE into zero-padded hi / lo planes, then the same LDS-DMA plane GEMM
         // for both directions with three products per operand pair (the register-staged kernel reads and splits every A row once
         // per column tile and direction)

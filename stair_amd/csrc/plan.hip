@@ -27,6 +27,7 @@ static thread_local std::string g_err;
 void set_error(const std::string &msg) { g_err = msg; }
 
 bool g_acct_on = false;
+thread_local const Policy *tl_policy = nullptr;
 struct AcctEntry { int64_t launches = 0, bytes = 0, flops = 0; };
 static std::map<std::string, AcctEntry> g_acct;       // kernel -> (launches, algorithmic bytes, algorithmic flops)
 void acct_add(const char *kernel, int64_t bytes, int64_t flops) {
@@ -61,6 +62,7 @@ struct stair_ctx {
     void *gshadow = nullptr;
     int64_t gshadow_elems = 0;
     bool gshadow_dirty = false;
+    Policy policy;                       // stair_ctx_set_option: this context's overrides of the process-wide settings
     ~stair_ctx() {
         if (gshadow) (void)hipFree(gshadow);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -228,7 +230,7 @@ constexpr int64_t kSplitKFloats = 16ll * 64 * 128 * 128;     // split-K scratch:
 int g_tile_queue = -1;
 bool tile_queue_on() {
     static const bool env_on = [] { const char *e = getenv("STAIR_TILE_QUEUE"); return !(e && e[0] == '0'); }();
-    return g_tile_queue >= 0 ? g_tile_queue != 0 : env_on;
+    return policy_or(STAIR_OPT_TILE_QUEUE, g_tile_queue >= 0 ? g_tile_queue : (env_on ? 1 : 0)) != 0;
 }
 
 // Diagnostic twin of the tile operator's work queue (stair_debug_queue_probe): the same ticket protocol, no tile work, every
@@ -1481,7 +1483,7 @@ bool tile_policy(const stair_plan *pl, bool backward = false) {
 }
 
 // dense helper: C[g][r] = act(rs * A[g][r] W^T + b)
-float *g_splitk_ws = nullptr;      // set by stair_plan_run for the duration of the call (one ctx per process, not thread-safe)
+thread_local float *g_splitk_ws = nullptr;      // set by stair_plan_run for the duration of the call, on the calling thread
 
 int dense(hipStream_t s, const float *A, int64_t lda, int64_t a_gs, const int32_t *a_gidx, const Lin &l, int64_t ldw,
           float *C, int64_t ldc, int64_t c_gs, const int32_t *c_gidx, int groups, int R, int N, int K, int act,
@@ -1507,7 +1509,7 @@ VgProblem vg_fwd(int rows, const float *a, const int32_t *ia, int64_t lda, const
 // STAIR_VEC_GROUP=0 keeps the per-module pack -> GEMM -> reduction sequences (and the tile form for large buckets)
 bool vec_group_on() {
     static const bool on = [] { const char *e = getenv("STAIR_VEC_GROUP"); return !(e && e[0] == '0'); }();
-    return on;
+    return policy_or(STAIR_OPT_VEC_GROUP, on ? 1 : 0) != 0;
 }
 
 struct Ptrs {     // workspace views shared by forward and backward
@@ -1567,6 +1569,7 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
                                     void *workspace, int64_t workspace_bytes, float *logits, int32_t *argmax,
                                     int32_t flags, stair_stream stream) {
     STAIR_CHECK(ctx && pl && video && question && workspace, "null argument");
+    PolicyScope policy_scope(&ctx->policy);
     STAIR_CHECK(workspace_bytes >= pl->total * (int64_t)sizeof(float), "workspace too small");
     STAIR_CHECK((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "workspace must be 256-byte aligned");
     STAIR_CHECK(memcmp(&ctx->cfg, &pl->cfg, sizeof(stair_config)) == 0, "plan was built for another configuration");
@@ -2136,7 +2139,7 @@ int dense_bwd(const BwdCtx &B, const float *dZ, int groups, int R, int N, int K,
     t.C = l.dw; t.ldc = K; t.M = M; t.rows_per_group = R; t.N = N; t.K = K;
     t.colsum = l.db;                 // db += colsum(dZ), summed while the TN kernel stages dZ
     if (!(l.id >= 0 && l.id < (int)B.deferred.size() && B.deferred[l.id])) {
-        const int64_t need = M >= g_tn_slab_min_rows && B.tn_ring && tn_x3tr_takes(t) ? align_up(tn_x3tr_scratch_floats(M, N, K), 64) : 0;
+        const int64_t need = M >= policy_or(STAIR_OPT_TN_SLAB_MIN_ROWS, g_tn_slab_min_rows) && B.tn_ring && tn_x3tr_takes(t) ? align_up(tn_x3tr_scratch_floats(M, N, K), 64) : 0;
         if (need && need <= B.tn_ring_floats) {
             if (B.tn_ring_at + need > B.tn_ring_floats) {
                 if (int rc = tn_x3tr_flush(B.s)) return rc;
@@ -2185,6 +2188,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
                                    void *workspace, int64_t workspace_bytes, const int32_t *answers, float loss_scale,
                                    float *loss_out, int32_t flags, stair_stream stream) {
     STAIR_CHECK(ctx && pl && video && question && workspace && answers, "null argument");
+    PolicyScope policy_scope(&ctx->policy);
     STAIR_CHECK(pl->train, "plan was not built with STAIR_PLAN_TRAIN");
     // slab products queued by a pass that failed half-way must not be added into THIS pass's buffers: the queue starts empty and
     // is emptied again however this function returns
@@ -2968,6 +2972,21 @@ extern "C" int stair_debug_queue_probe(void *words, uint32_t *seen, int32_t laun
 }
 
 extern "C" int stair_set_tile_queue(int32_t on) { g_tile_queue = on; return 0; }
+
+extern "C" int stair_ctx_set_option(stair_ctx *ctx, int32_t option, int32_t value) {
+    STAIR_CHECK(ctx, "null context");
+    STAIR_CHECK(option >= 0 && option < STAIR_OPT_COUNT, "unknown option");
+    STAIR_CHECK(option != STAIR_OPT_MATMUL_MODE || value < 0 || value == STAIR_MATMUL_F32 || value == STAIR_MATMUL_BF16X3 || value == STAIR_MATMUL_BF16,
+                "matmul mode must be STAIR_MATMUL_F32, STAIR_MATMUL_BF16X3 or STAIR_MATMUL_BF16");
+    ctx->policy.v[option] = value < 0 ? -1 : value;
+    return 0;
+}
+extern "C" int stair_ctx_get_option(const stair_ctx *ctx, int32_t option, int32_t *value) {
+    STAIR_CHECK(ctx && value, "null argument");
+    STAIR_CHECK(option >= 0 && option < STAIR_OPT_COUNT, "unknown option");
+    *value = ctx->policy.v[option];
+    return 0;
+}
 
 // reset_mode 0 of the probe on its own: a hipMemsetAsync of `bytes` zero bytes on `stream` (which may be capturing) -- which sizes
 // of a captured memset survive a replay?  mode 1: the library's zero-fill kernel instead.

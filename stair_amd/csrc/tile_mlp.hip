@@ -908,7 +908,7 @@ static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_tile_events;
 static int g_tile_on = -1;          // stair_set_tile_mlp; -1 = the environment's STAIR_TILE_MLP (default on)
 bool tile_mlp_usable(int H, int T) {
     static const bool env_on = [] { const char *e = getenv("STAIR_TILE_MLP"); return !(e && e[0] == '0'); }();
-    const bool on = g_tile_on >= 0 ? g_tile_on != 0 : env_on;
+    const bool on = policy_or(STAIR_OPT_TILE_MLP, g_tile_on >= 0 ? g_tile_on : (env_on ? 1 : 0)) != 0;
     return on && H == TM_H && T >= 1 && T <= TM_ROWS && matmul_mode() == STAIR_MATMUL_BF16X3;
 }
 

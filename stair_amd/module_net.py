@@ -322,6 +322,17 @@ class VideoNMN(nn.Module):
             lib.stair_ctx_destroy(ctx)
             self.__dict__['_ctx'] = None        # plain dict write: nn.Module.__setattr__ may be gone at shutdown
 
+    OPTIONS = {'matmul_mode': 0, 'tile_mlp': 1, 'tile_queue': 2, 'vec_group': 3, 'tn_slab_min_rows': 4}
+    MATMUL_MODES = {'f32': 0, 'bf16x3': 1, 'bf16': 2}
+
+    def set_option(self, name, value):
+        """Per-context override of a process-wide library setting (stair_ctx_set_option): 'matmul_mode' ('f32' / 'bf16x3' / 'bf16'),
+        'tile_mlp', 'tile_queue', 'vec_group' (0 / 1), 'tn_slab_min_rows'; None restores the process default.  In force for this
+        model's forward and backward passes only: other models of the process keep their own settings."""
+        if name == 'matmul_mode' and isinstance(value, str):
+            value = self.MATMUL_MODES[value]
+        check(lib.stair_ctx_set_option(self._ctx, self.OPTIONS[name], -1 if value is None else int(value)))
+
     # ---------------------------------------------------------------------------------------
     def _bind_weights(self):
         """(Re)hand the current parameter storage to the ctx; pointers are borrowed by the library."""

@@ -66,6 +66,23 @@ def test_bad_config_is_rejected():
     assert b'hidden_size' in lib.stair_last_error()
 
 
+def test_context_options_are_per_context():
+    """stair_ctx_set_option / stair_ctx_get_option: overrides live in the context (host state only, no GPU needed), -1 = inherit."""
+    cfg = StairConfig(512, 2048, 300, 172, 64, 36, 1)
+    a, b = C.c_void_p(), C.c_void_p()
+    assert lib.stair_ctx_create(C.byref(cfg), C.byref(a)) == 0 and lib.stair_ctx_create(C.byref(cfg), C.byref(b)) == 0
+    v = C.c_int32(7)
+    for opt in range(5):
+        assert lib.stair_ctx_get_option(a, opt, C.byref(v)) == 0 and v.value == -1
+    assert lib.stair_ctx_set_option(a, 0, 0) == 0 and lib.stair_ctx_set_option(a, 1, 0) == 0
+    assert lib.stair_ctx_get_option(a, 0, C.byref(v)) == 0 and v.value == 0
+    assert lib.stair_ctx_get_option(b, 0, C.byref(v)) == 0 and v.value == -1            # the other context is untouched
+    assert lib.stair_ctx_set_option(a, 0, -5) == 0 and lib.stair_ctx_get_option(a, 0, C.byref(v)) == 0 and v.value == -1
+    assert lib.stair_ctx_set_option(a, 0, 9) != 0 and b'matmul mode' in lib.stair_last_error()
+    assert lib.stair_ctx_set_option(a, 5, 1) != 0 and b'unknown option' in lib.stair_last_error()
+    lib.stair_ctx_destroy(a); lib.stair_ctx_destroy(b)
+
+
 @pytest.mark.parametrize('heads', [True, False])
 def test_videonmn_state_dict_layout(heads):
     from stair_amd.module_net import VideoNMN

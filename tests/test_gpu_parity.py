@@ -222,6 +222,31 @@ def test_lstm_input_projection_on_padded_planes_matches_oracle(I, lens):
         assert _maxerr(h_n[s], rh.reshape(-1)) < 2e-5, s
 
 
+def test_two_contexts_keep_their_own_options():
+    """Two models (contexts) in one process with different per-context options, used alternately: each computes exactly what it
+    computes when its setting is the process-wide one (stair_ctx_set_option: the exact-f32 model next to the split-product one, the
+    unfused one next to the fused one)."""
+    from stair_amd._lib import lib
+    config = dict(spec.DEFAULT_CONFIG)
+    qs = [synth.make_question(config, 3, i, form=f) for i, f in enumerate(synth.ALL_FORMS)]
+    ref = {}
+    for mode in (0, 1):
+        assert lib.stair_set_matmul_mode(mode) == 0
+        ref[mode] = _model(config, 5).forward_batch(qs).logits.cpu().clone()
+    lib.stair_set_tile_mlp(0)
+    ref['unfused'] = _model(config, 5).forward_batch(qs).logits.cpu().clone()
+    lib.stair_set_tile_mlp(-1)
+    assert not torch.equal(ref[0], ref[1]) and not torch.equal(ref[1], ref['unfused'])
+    a, b, c = _model(config, 5), _model(config, 5), _model(config, 5)
+    a.set_option('matmul_mode', 'f32'); c.set_option('tile_mlp', 0)
+    for _ in range(2):                            # interleaved: no model inherits another's setting
+        assert torch.equal(a.forward_batch(qs).logits.cpu(), ref[0])
+        assert torch.equal(b.forward_batch(qs).logits.cpu(), ref[1])
+        assert torch.equal(c.forward_batch(qs).logits.cpu(), ref['unfused'])
+    a.set_option('matmul_mode', None)
+    assert torch.equal(a.forward_batch(qs).logits.cpu(), ref[1])            # (the process-wide mode is 1 = bf16x3 again: the loop's last value)
+
+
 def test_l2normalize_and_zero_vector():
     from stair_amd import ops
     x = torch.randn(9, 64)
