@@ -631,6 +631,20 @@ int stair_plan_zero_grads(stair_plan *plan, void *workspace, stair_stream stream
  * The gradient pointers (d_att / d_vec / dW / db) may be NULL: the call then only evaluates the losses, which is how the
  * validation loop (train_module.py:219-270) scores an inference plan. */
 
+/* Reproducible criteria (ABI 5; the supervised step, BASELINE configs[4], bit-identical from run to run like the decoder-only step):
+ *   stair_loss_groups        the NEXT stair_loss_* call on this thread takes its n items in groups: items order[grp_off[g]] ..
+ *                            order[grp_off[g+1] - 1] (indices into that call's item arrays) add into the same gradient slot -- the
+ *                            caller has sorted them (supervised nodes that alias one slot) -- and ONE workgroup evaluates them
+ *                            one after the other, adding with plain read - add - write instead of float atomics.  Device arrays
+ *                            order [n], grp_off [n_groups + 1]; consumed by that call; n_groups = 0 cancels.
+ *   stair_grad_shadows_begin opens the fixed-point accumulation scope of stair_plan_backward EARLY on this thread: kernels launched
+ *                            from here on that add into a bound gradient tensor of `ctx` from several workgroups (the head weights
+ *                            of stair_loss_head / stair_loss_filterframe) add into its 64-bit fixed-point shadow, where the order
+ *                            of the adds cannot matter; the next stair_plan_backward(ctx, ...) on this thread adds the shadows to
+ *                            the gradients and closes the scope.  A no-op under STAIR_DETERMINISTIC=0. */
+int stair_loss_groups(const int32_t *order, const int32_t *grp_off, int32_t n_groups);
+int stair_grad_shadows_begin(stair_ctx *ctx, stair_stream stream);
+
 /* attention_score_criterion (:83-90) on att rows slot[i] .. slot[i]+K[i]-1 against the soft interval masks of
  * span_to_attention (:67-81); intervals[2*(iv_off[i]+r)] = (start, end) of row r in frames (double, like the
  * reference).  Localize (:173-182, K rows, mean over K*T), Temporal / ExistsFrame (:157-164, :184-191, K = 1). */

@@ -180,6 +180,8 @@ SIGNATURES = [
     ('stair_comm_destroy', None, [C.c_void_p]),
     ('stair_comm_info', C.c_int, [C.c_void_p, c_int32_p, c_int32_p]),
     ('stair_allreduce_grads', C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    ('stair_loss_groups', C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    ('stair_grad_shadows_begin', C.c_int, [C.c_void_p, C.c_void_p]),
     ('stair_loss_decoder_ce', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     ('stair_score_cosine_to_mean', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     ('stair_loss_attention_len', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,

@@ -5,9 +5,26 @@
 #include "ops.h"
 
 namespace stair {
+// stair_loss_groups: the NEXT stair_loss_* launch of this thread evaluates its items group by group (items that add into the same
+// gradient slot, sorted by the caller): one workgroup (one wave for the head criterion) walks a group's items in order and adds their
+// gradients with plain read - add - write, so the arena sums do not depend on the order in which float atomics land.  Consumed by
+// that launch.
+struct LossGroups { const int32_t *order = nullptr, *grp_off = nullptr; int n_groups = 0; };
+static thread_local LossGroups tl_groups;
+static LossGroups take_groups(int n_items) {
+    LossGroups g = tl_groups;
+    tl_groups = LossGroups();
+    if (g.n_groups <= 0 || g.n_groups > n_items) g = LossGroups();
+    return g;
+}
 namespace {
 constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = kBlock / 64;
+// add into a gradient arena element: plain when the launch is grouped (one workgroup owns the slot), else a float atomic
+__device__ __forceinline__ void arena_add(float *p, float v, bool owned) {
+    if (owned) *p += v;
+    else unsafeAtomicAdd(p, v);
+}
 
 // span_to_attention, train_module.py:67-81, evaluated per frame t (double arithmetic like the reference)
 __device__ __forceinline__ float span_gold(double g0, double g1, int L, int t) {
@@ -30,8 +47,10 @@ __device__ __forceinline__ float span_gold(double g0, double g1, int L, int t) {
 // `len` (optional): frames of item i's clip; the attention rows keep the stride T, criterion and gold mask see L frames
 __global__ void loss_attention_kernel(const float *att, float *d_att, const int32_t *slot, const int32_t *K,
                                       const int32_t *iv_off, const double *intervals, int n, int T, float scale, float *loss,
-                                      const int32_t *len) {
-    const int i = blockIdx.x;
+                                      const int32_t *len, const int32_t *order, const int32_t *grp_off) {
+  const int q0 = grp_off ? grp_off[blockIdx.x] : blockIdx.x, q1 = grp_off ? grp_off[blockIdx.x + 1] : blockIdx.x + 1;
+  for (int q = q0; q < q1; ++q) {            // (a group's items share the slot, hence K and the clip: element e is the same thread's every time)
+    const int i = order ? order[q] : q;
     const int k = K[i];
     const int L = len ? len[i] : T;
     const float inv = 1.0f / (float)(k * L);
@@ -43,15 +62,18 @@ __global__ void loss_attention_kernel(const float *att, float *d_att, const int3
         const int64_t o = ((int64_t)slot[i] + r) * T + t;
         const float p = att[o];
         acc += -(g * logf(p) + (1.f - g) * logf(1.f - p));
-        if (d_att) unsafeAtomicAdd(d_att + o, scale * inv * (-g / p + (1.f - g) / (1.f - p)));
+        if (d_att) arena_add(d_att + o, scale * inv * (-g / p + (1.f - g) / (1.f - p)), grp_off != nullptr);
     }
     acc = wave_sum(acc);
     if (threadIdx.x == 0) loss[i] = acc * inv;       // blockDim == 64: one wave
+  }
 }
 int launch_loss_attention(const float *att, float *d_att, const int32_t *slot, const int32_t *K, const int32_t *iv_off,
                           const double *intervals, int n, int T, float scale, float *loss, hipStream_t s, const int32_t *len = nullptr) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(loss_attention_kernel, dim3(n), dim3(64), 0, s, att, d_att, slot, K, iv_off, intervals, n, T, scale, loss, len);
+    const LossGroups G = take_groups(n);
+    hipLaunchKernelGGL(loss_attention_kernel, dim3(G.n_groups ? G.n_groups : n), dim3(64), 0, s, att, d_att, slot, K, iv_off, intervals, n, T, scale, loss, len,
+                       G.order, G.grp_off);
     STAIR_LAUNCH_CHECK();
     return 0;
 }
@@ -60,10 +82,14 @@ int launch_loss_attention(const float *att, float *d_att, const int32_t *slot, c
 // NOUT == 1: mean squared error against 0/1 (Equals, :101-107).
 template <int NOUT>
 __global__ void loss_head_kernel(const float *vec, float *d_vec, const int32_t *slot, const int32_t *label, const float *W,
-                                 const float *b, float *dW, float *db, int n, int H, float scale, float *loss) {
+                                 const float *b, float *dW, float *db, int n, int H, float scale, float *loss,
+                                 const int32_t *order, const int32_t *grp_off, int n_groups, long long *dW64, long long *db64) {
     const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    if (i >= n) return;
+    const int gq = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);          // ungrouped: the item; grouped: the group (a wave walks it)
+    if (gq >= (grp_off ? n_groups : n)) return;
+  const int q0 = grp_off ? grp_off[gq] : gq, q1 = grp_off ? grp_off[gq + 1] : gq + 1;
+  for (int q = q0; q < q1; ++q) {
+    const int i = order ? order[q] : q;
     const float *x = vec + (int64_t)slot[i] * H;
     float z[NOUT];
 #pragma unroll
@@ -91,24 +117,28 @@ __global__ void loss_head_kernel(const float *vec, float *d_vec, const int32_t *
 #pragma unroll
         for (int j = 0; j < NOUT; ++j) {
             dx += dz[j] * W[(int64_t)j * H + c];
-            if (dW) unsafeAtomicAdd(dW + (int64_t)j * H + c, dz[j] * x[c]);
+            if (dW) grad_add(dW, dW64, (int64_t)j * H + c, dz[j] * x[c]);
         }
-        if (d_vec) unsafeAtomicAdd(d_vec + (int64_t)slot[i] * H + c, dx);
+        if (d_vec) arena_add(d_vec + (int64_t)slot[i] * H + c, dx, grp_off != nullptr);
     }
     if (lane == 0) {
 #pragma unroll
         for (int j = 0; j < NOUT; ++j)
-            if (db) unsafeAtomicAdd(db + j, dz[j]);
+            if (db) grad_add(db, db64, j, dz[j]);
         loss[i] = l;
     }
+  }
 }
 int launch_loss_head(int nout, const float *vec, float *d_vec, const int32_t *slot, const int32_t *label, const float *W,
                      const float *b, float *dW, float *db, int n, int H, float scale, float *loss, hipStream_t s) {
     if (n == 0) return 0;
     STAIR_CHECK(nout == 1 || nout == 2, "head width must be 1 (Equals) or 2 (Exists/Xor)");
-    const dim3 grid((n + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlock);
-    if (nout == 2) hipLaunchKernelGGL(loss_head_kernel<2>, grid, block, 0, s, vec, d_vec, slot, label, W, b, dW, db, n, H, scale, loss);
-    else hipLaunchKernelGGL(loss_head_kernel<1>, grid, block, 0, s, vec, d_vec, slot, label, W, b, dW, db, n, H, scale, loss);
+    const LossGroups G = take_groups(n);
+    const int units = G.n_groups ? G.n_groups : n;
+    const dim3 grid((units + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlock);
+    long long *dW64 = dW ? det_shadow(dW) : nullptr, *db64 = db ? det_shadow(db) : nullptr;       // inside a fixed-point scope (stair_grad_shadows_begin)
+    if (nout == 2) hipLaunchKernelGGL(loss_head_kernel<2>, grid, block, 0, s, vec, d_vec, slot, label, W, b, dW, db, n, H, scale, loss, G.order, G.grp_off, G.n_groups, dW64, db64);
+    else hipLaunchKernelGGL(loss_head_kernel<1>, grid, block, 0, s, vec, d_vec, slot, label, W, b, dW, db, n, H, scale, loss, G.order, G.grp_off, G.n_groups, dW64, db64);
     STAIR_LAUNCH_CHECK();
     return 0;
 }
@@ -121,13 +151,16 @@ int launch_loss_head(int nout, const float *vec, float *d_vec, const int32_t *sl
 // others' class lists on the host), pos[i] the positive CLASS id; absent classes take no part in the softmax.
 __global__ void loss_contrastive_kernel(const float *vec, float *d_vec, const int32_t *slot, const int32_t *pos,
                                         const int32_t *win_start, const int32_t *win_cnt, const float *G, int n, int H,
-                                        float scale, float *loss, const float *presence, const int32_t *win_row, int n_cls) {
+                                        float scale, float *loss, const float *presence, const int32_t *win_row, int n_cls,
+                                        const int32_t *order, const int32_t *grp_off) {
     extern __shared__ float sm[];      // [C] logits -> softmax probs, then [H] dpred
-    const int i = blockIdx.x;
+    __shared__ float s_nrm, s_part[kWavesPerBlock];
+  const int q0 = grp_off ? grp_off[blockIdx.x] : blockIdx.x, q1 = grp_off ? grp_off[blockIdx.x + 1] : blockIdx.x + 1;
+  for (int q = q0; q < q1; ++q) {
+    const int i = order ? order[q] : q;
     const int c0 = presence ? 0 : win_start[i], C = presence ? n_cls : win_cnt[i];
     const float *mask = presence ? presence + (int64_t)win_row[i] * n_cls : nullptr;
     float *prob = sm, *dpred = sm + C;
-    __shared__ float s_nrm, s_dot;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float *x = vec + (int64_t)slot[i] * H;
     if (wave == 0) {
@@ -166,21 +199,24 @@ __global__ void loss_contrastive_kernel(const float *vec, float *d_vec, const in
         part += d * x[h] * inv;
     }
     part = wave_sum(part);
-    if (threadIdx.x == 0) s_dot = 0.f;
+    if (lane == 0) s_part[wave] = part;
     __syncthreads();
-    if (lane == 0) atomicAdd(&s_dot, part);
-    __syncthreads();
-    const float dot = s_dot;       // pred . dpred
+    float dot = 0.f;               // pred . dpred, the waves' parts in wave order (an LDS float atomic summed them in arrival order)
+#pragma unroll
+    for (int w = 0; w < kWavesPerBlock; ++w) dot += s_part[w];
     if (d_vec)
         for (int h = threadIdx.x; h < H; h += blockDim.x)
-            unsafeAtomicAdd(d_vec + (int64_t)slot[i] * H + h, (dpred[h] - x[h] * inv * dot) * inv);
+            arena_add(d_vec + (int64_t)slot[i] * H + h, (dpred[h] - x[h] * inv * dot) * inv, grp_off != nullptr);
+    __syncthreads();               // the next item of the group reuses the LDS
+  }
 }
 int launch_loss_contrastive(const float *vec, float *d_vec, const int32_t *slot, const int32_t *pos, const int32_t *win_start,
                             const int32_t *win_cnt, const float *G, int n, int H, int max_classes, float scale, float *loss,
                             hipStream_t s) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(loss_contrastive_kernel, dim3(n), dim3(kBlock), (size_t)(max_classes + H) * sizeof(float), s, vec, d_vec,
-                       slot, pos, win_start, win_cnt, G, n, H, scale, loss, (const float *)nullptr, (const int32_t *)nullptr, 0);
+    const LossGroups Gr = take_groups(n);
+    hipLaunchKernelGGL(loss_contrastive_kernel, dim3(Gr.n_groups ? Gr.n_groups : n), dim3(kBlock), (size_t)(max_classes + H) * sizeof(float), s, vec, d_vec,
+                       slot, pos, win_start, win_cnt, G, n, H, scale, loss, (const float *)nullptr, (const int32_t *)nullptr, 0, Gr.order, Gr.grp_off);
     STAIR_LAUNCH_CHECK();
     return 0;
 }
@@ -188,8 +224,9 @@ int launch_loss_contrastive_table(const float *vec, float *d_vec, const int32_t 
                                   const float *presence, const float *reps, int n, int n_cls, int H, float scale, float *loss, hipStream_t s) {
     if (n == 0) return 0;
     STAIR_CHECK(n_cls > 0 && (size_t)(n_cls + H) * sizeof(float) <= 60 * 1024, "class table too large for the loss kernel's LDS (n_cls + H floats)");
-    hipLaunchKernelGGL(loss_contrastive_kernel, dim3(n), dim3(kBlock), (size_t)(n_cls + H) * sizeof(float), s, vec, d_vec,
-                       slot, pos_class, (const int32_t *)nullptr, (const int32_t *)nullptr, reps, n, H, scale, loss, presence, win_row, n_cls);
+    const LossGroups Gr = take_groups(n);
+    hipLaunchKernelGGL(loss_contrastive_kernel, dim3(Gr.n_groups ? Gr.n_groups : n), dim3(kBlock), (size_t)(n_cls + H) * sizeof(float), s, vec, d_vec,
+                       slot, pos_class, (const int32_t *)nullptr, (const int32_t *)nullptr, reps, n, H, scale, loss, presence, win_row, n_cls, Gr.order, Gr.grp_off);
     STAIR_LAUNCH_CHECK();
     return 0;
 }
@@ -205,15 +242,18 @@ int launch_loss_contrastive_table(const float *vec, float *d_vec, const int32_t 
 __global__ __launch_bounds__(256) void loss_filterframe_kernel(const float *map, float *d_map, const int32_t *slot,
                                                                const float *gold, const float *W, const float *b, float *dW,
                                                                float *db, int T, int H, int O, float scale, float *loss,
-                                                               const int32_t *len) {
+                                                               const int32_t *len, const int32_t *order, const int32_t *grp_off,
+                                                               long long *dW64, long long *db64) {
     extern __shared__ float z[];                 // [T][O]
-    __shared__ float s_loss;
-    const int i = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ float s_part[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q0 = grp_off ? grp_off[blockIdx.x] : blockIdx.x, q1 = grp_off ? grp_off[blockIdx.x + 1] : blockIdx.x + 1;
+  for (int q = q0; q < q1; ++q) {
+    const int i = order ? order[q] : q;
     const float *x = map + (int64_t)slot[i] * T * H;
     const float *g = gold + (int64_t)i * T * O;
     const int nh = H >> 6;                       // floats per lane (H % 64 == 0, H <= 512)
     const int L = len ? len[i] : T;
-    if (threadIdx.x == 0) s_loss = 0.f;
     for (int e = threadIdx.x + L * O; e < T * O; e += blockDim.x) z[e] = 0.f;       // frames past the clip: no gradient
     for (int t = wave; t < L; t += 4) {
         float xr[8];
@@ -248,9 +288,9 @@ __global__ __launch_bounds__(256) void loss_filterframe_kernel(const float *map,
         }
     }
     part = wave_sum(part);
-    if (lane == 0 && part != 0.f) atomicAdd(&s_loss, part);
+    if (lane == 0) s_part[wave] = part;
     __syncthreads();
-    if (threadIdx.x == 0) loss[i] = s_loss * inv;
+    if (threadIdx.x == 0) loss[i] = (s_part[0] + s_part[1] + s_part[2] + s_part[3]) * inv;      // in wave order
     if (d_map) {
         float *dx = d_map + (int64_t)slot[i] * T * H;
         for (int t = wave; t < T; t += 4) {
@@ -263,7 +303,7 @@ __global__ __launch_bounds__(256) void loss_filterframe_kernel(const float *map,
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                if (j < nh) unsafeAtomicAdd(dx + (int64_t)t * H + j * 64 + lane, acc[j]);
+                if (j < nh) arena_add(dx + (int64_t)t * H + j * 64 + lane, acc[j], grp_off != nullptr);
         }
     }
     if (dW) {
@@ -277,23 +317,26 @@ __global__ __launch_bounds__(256) void loss_filterframe_kernel(const float *map,
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                if (j < nh) unsafeAtomicAdd(dW + (int64_t)o * H + j * 64 + lane, acc[j]);
+                if (j < nh) grad_add(dW, dW64, (int64_t)o * H + j * 64 + lane, acc[j]);
         }
     }
     if (db)
         for (int o = threadIdx.x; o < O; o += blockDim.x) {
             float sdz = 0.f;
             for (int t = 0; t < T; ++t) sdz += z[t * O + o];
-            unsafeAtomicAdd(db + o, sdz);
+            grad_add(db, db64, o, sdz);
         }
+    __syncthreads();               // the next item of the group reuses z
+  }
 }
 int launch_loss_filterframe(const float *map, float *d_map, const int32_t *slot, const float *gold, const float *W, const float *b,
                             float *dW, float *db, int n, int T, int H, int O, float scale, float *loss, hipStream_t s, const int32_t *len) {
     STAIR_CHECK(H % 64 == 0 && H <= 512, "hidden size must be a multiple of 64, at most 512");
     STAIR_CHECK(T > 0 && O > 0 && (int64_t)T * O * 4 <= 60 * 1024, "T * object_types too large for the LDS tile");
     if (n == 0) return 0;
-    hipLaunchKernelGGL(loss_filterframe_kernel, dim3(n), dim3(256), (size_t)T * O * sizeof(float), s, map, d_map, slot, gold, W, b,
-                       dW, db, T, H, O, scale, loss, len);
+    const LossGroups G = take_groups(n);
+    hipLaunchKernelGGL(loss_filterframe_kernel, dim3(G.n_groups ? G.n_groups : n), dim3(256), (size_t)T * O * sizeof(float), s, map, d_map, slot, gold, W, b,
+                       dW, db, T, H, O, scale, loss, len, G.order, G.grp_off, dW ? det_shadow(dW) : nullptr, db ? det_shadow(db) : nullptr);
     STAIR_LAUNCH_CHECK();
     return 0;
 }
@@ -336,6 +379,11 @@ int launch_cosine_to_mean(const float *vec, const int32_t *slot, const float *re
 
 }  // namespace stair
 
+extern "C" int stair_loss_groups(const int32_t *order, const int32_t *grp_off, int32_t n_groups) {
+    STAIR_CHECK((order && grp_off && n_groups > 0) || n_groups == 0, "order, grp_off and n_groups > 0 (or n_groups == 0: no grouping)");
+    stair::tl_groups.order = n_groups ? order : nullptr; stair::tl_groups.grp_off = n_groups ? grp_off : nullptr; stair::tl_groups.n_groups = n_groups;
+    return 0;
+}
 extern "C" int stair_loss_attention(const float *att, float *d_att, const int32_t *slot, const int32_t *K,
                                     const int32_t *iv_off, const double *intervals, int32_t n, int32_t T, float scale,
                                     float *loss, stair_stream stream) {

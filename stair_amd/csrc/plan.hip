@@ -2064,6 +2064,7 @@ namespace {
 struct DetRange { const float *beg, *end; int id; };
 struct DetState {
     bool active = false;
+    const stair_ctx *early_ctx = nullptr;       // the scope was opened by stair_grad_shadows_begin for this context (the next backward pass keeps it)
     long long *base = nullptr;
     std::vector<DetRange> ranges;                // the bound gradient tensors, sorted by address
     std::vector<int64_t> off;                    // per weight id: offset of its shadow
@@ -2108,6 +2109,39 @@ int det_flush(const stair_ctx *ctx, hipStream_t s) {
         if (++fb.n == 128) if (int rc = launch()) return rc;
     }
     return launch();
+}
+
+// opens the fixed-point accumulation scope on this thread: shadow layout of the context's gradient tensors, shadows zeroed if a pass
+// left them dirty
+// which gradient tensors are bound where (they may have been bound since the scope was opened): offsets depend on the sizes only
+static int64_t det_layout(const stair_ctx *ctx) {
+    DetState &d = g_det;
+    d.off.assign(ctx->names.size(), 0);
+    d.ranges.clear();
+    int64_t o64 = 0;
+    for (size_t i = 0; i < ctx->names.size(); ++i) {
+        d.off[i] = o64; o64 += align_up(ctx->numel[i], 64);
+        if (ctx->gptr[i]) d.ranges.push_back({ctx->gptr[i], ctx->gptr[i] + ctx->numel[i], (int)i});
+    }
+    std::sort(d.ranges.begin(), d.ranges.end(), [](const DetRange &a, const DetRange &b) { return a.beg < b.beg; });
+    return o64;
+}
+int det_begin(stair_ctx *ctx, hipStream_t s) {
+    DetState &d = g_det;
+    d.touched.assign(ctx->names.size(), 0);
+    const int64_t o64 = det_layout(ctx);
+    if (!ctx->gshadow || ctx->gshadow_elems < o64) {
+        if (ctx->gshadow) { STAIR_HIP(hipStreamSynchronize(s)); STAIR_HIP(hipFree(ctx->gshadow)); ctx->gshadow = nullptr; }
+        STAIR_HIP(hipMalloc(&ctx->gshadow, (size_t)o64 * sizeof(long long)));
+        ctx->gshadow_elems = o64;
+        ctx->gshadow_dirty = true;
+    }
+    d.base = static_cast<long long *>(ctx->gshadow);
+    if (ctx->gshadow_dirty)
+        if (int rcz_ = launch_zero(d.base, o64 * (int64_t)sizeof(long long), s)) return rcz_;
+    ctx->gshadow_dirty = true;                   // until a pass has flushed everything it touched
+    d.active = true;
+    return 0;
 }
 
 struct BwdCtx {
@@ -2225,32 +2259,21 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
     B.tn_ring = pl->o_tnring ? ws + pl->o_tnring : nullptr; B.tn_ring_floats = pl->tnring_floats;
     B.wt_off.assign(ctx->names.size(), 0);
     // run-to-run reproducible weight gradients: kernels that add into a gradient tensor from several workgroups add into its
-    // fixed-point shadow while this scope is open (common.h det_shadow); the shadows reach the fp32 gradients at the end of the pass
+    // fixed-point shadow while this scope is open (common.h det_shadow); the shadows reach the fp32 gradients at the end of the pass.
+    // stair_grad_shadows_begin may have opened the scope already (the criteria of csrc/losses.hip add their head-weight gradients
+    // through it before this pass starts): then it is kept as it is, with what it has recorded as touched.
     struct DetScope {
-        ~DetScope() { g_det.active = false; }
+        ~DetScope() { g_det.active = false; g_det.early_ctx = nullptr; }
     } det_scope;
     if (det_enabled() && pl->o_gshadow > 0) {
-        DetState &d = g_det;
-        d.off.assign(ctx->names.size(), 0);
-        d.touched.assign(ctx->names.size(), 0);
-        d.ranges.clear();
-        int64_t o64 = 0;
-        for (size_t i = 0; i < ctx->names.size(); ++i) {
-            d.off[i] = o64; o64 += align_up(ctx->numel[i], 64);
-            if (ctx->gptr[i]) d.ranges.push_back({ctx->gptr[i], ctx->gptr[i] + ctx->numel[i], (int)i});
+        if (!(g_det.active && g_det.early_ctx == ctx)) {
+            if (int rc_ = det_begin(ctx, s)) return rc_;
+        } else {
+            det_layout(ctx);                 // (gradient buffers bound since then are found now; what was touched stays touched)
         }
-        std::sort(d.ranges.begin(), d.ranges.end(), [](const DetRange &a, const DetRange &b) { return a.beg < b.beg; });
-        if (!ctx->gshadow || ctx->gshadow_elems < o64) {
-            if (ctx->gshadow) { STAIR_HIP(hipStreamSynchronize(s)); STAIR_HIP(hipFree(ctx->gshadow)); ctx->gshadow = nullptr; }
-            STAIR_HIP(hipMalloc(&ctx->gshadow, (size_t)o64 * sizeof(long long)));
-            ctx->gshadow_elems = o64;
-            ctx->gshadow_dirty = true;
-        }
-        d.base = static_cast<long long *>(ctx->gshadow);
-        if (ctx->gshadow_dirty)
-            if (int rcz_ = launch_zero(d.base, o64 * (int64_t)sizeof(long long), s)) return rcz_;
-        ctx->gshadow_dirty = true;                   // until this pass has flushed everything it touched
-        d.active = true;
+        g_det.early_ctx = nullptr;
+    } else {
+        g_det.active = false;
     }
     // weight-gradient products of the tile-level layers run ONCE per weight, after all buckets (FilterFrame's dense layer keeps
     // its per-bucket product: its X operand carries the attention scale only in the tensor-keyword variant)
@@ -2972,6 +2995,14 @@ extern "C" int stair_debug_queue_probe(void *words, uint32_t *seen, int32_t laun
 }
 
 extern "C" int stair_set_tile_queue(int32_t on) { g_tile_queue = on; return 0; }
+
+extern "C" int stair_grad_shadows_begin(stair_ctx *ctx, stair_stream stream) {
+    STAIR_CHECK(ctx, "null context");
+    if (!det_enabled()) return 0;                // STAIR_DETERMINISTIC=0: float atomics everywhere
+    if (int rc = det_begin(ctx, static_cast<hipStream_t>(stream))) return rc;
+    g_det.early_ctx = ctx;
+    return 0;
+}
 
 extern "C" int stair_ctx_set_option(stair_ctx *ctx, int32_t option, int32_t value) {
     STAIR_CHECK(ctx, "null context");

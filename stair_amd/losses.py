@@ -62,6 +62,16 @@ def filterframe_target(gold, T, O, word2index):
     return g
 
 
+def slot_groups(slot):
+    """Items that add into the same gradient slot, for stair_loss_groups: (order int32 [n], grp_off int32 [groups + 1]); order
+    is a stable sort by slot, so inside a group the items keep their batch order (the order the sums are formed in)."""
+    slot = np.asarray(slot, dtype=np.int64)
+    order = np.argsort(slot, kind='stable')
+    ss = slot[order]
+    starts = np.flatnonzero(np.concatenate([[True], ss[1:] != ss[:-1]])) if len(ss) else np.zeros(0, dtype=np.int64)
+    return np.ascontiguousarray(order, dtype=np.int32), np.ascontiguousarray(np.concatenate([starts, [len(ss)]]), dtype=np.int32)
+
+
 def _filterframe_launch(model, res, items, scale, grads):
     """items: [(map slot, gold dict)] or [(map slot, gold dict, frames of the item's clip)] when the batch mixes clip
     lengths.  Returns the per-item losses (device tensor)."""
@@ -87,6 +97,10 @@ def _filterframe_launch(model, res, items, scale, grads):
     mp = res._ws[inf.map_off: inf.map_off + inf.n_map * T * H]
     gmap = res.grad_arena('map') if grads else None
     p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    if grads:                           # reproducible sums: items of one tile evaluated by one workgroup, in order
+        order, goff = slot_groups([a[0] for a in items])
+        order_d, goff_d = torch.from_numpy(order).to(dev), torch.from_numpy(goff).to(dev)
+        check(lib.stair_loss_groups(p(order_d), p(goff_d), len(goff) - 1))
     check(lib.stair_loss_filterframe_len(p(mp), p(gmap), p(slot), p(gold), p(head.weight), p(head.bias),
                                          p(head.weight.grad) if grads else None, p(head.bias.grad) if grads else None, p(len_d),
                                          len(items), T, H, O, C.c_float(scale), p(out),
@@ -384,7 +398,8 @@ def prepare_module_losses(model, res, questions, pretrain_modules=CRITERION_MODU
         keep = np.arange(2)[None, :] < K[:, None]
         qf = res.question_frames
         att_len = i32(np.asarray(qf)[gb.att_q]) if qf is not None else np.zeros(0, np.int32)
-        stage('att', i32(slot), i32(K), i32(np.concatenate([[0], np.cumsum(K)])), np.ascontiguousarray(iv[keep], dtype=np.float64), att_len)
+        stage('att', i32(slot), i32(K), i32(np.concatenate([[0], np.cumsum(K)])), np.ascontiguousarray(iv[keep], dtype=np.float64), att_len,
+              *slot_groups(slot))
     # ---- linear heads (Exists / Xor / Equals) ----
     n_head = {}
     for module in ('Exists', 'Xor', 'Equals'):
@@ -397,7 +412,7 @@ def prepare_module_losses(model, res, questions, pretrain_modules=CRITERION_MODU
         hq, hpos, hlab = gb.head[module]
         tok = hpos + base[hq]
         n_head[module] = len(tok)
-        stage(module, i32(slot_t[tok]), i32(hlab))
+        stage(module, i32(slot_t[tok]), i32(hlab), *slot_groups(slot_t[tok]))
     # ---- contrastive (Filter / ToAction / Superlative) ----
     n_cg = int(gb.cg_q.size)
     c_slot = slot_t[base[gb.cg_q] + gb.cg_pos] if n_cg else np.zeros(0, dtype=np.int64)
@@ -419,7 +434,7 @@ def prepare_module_losses(model, res, questions, pretrain_modules=CRITERION_MODU
                 raise KeyError('class %s is not in the ClassTable (build it from the whole dataset: ClassTable.from_questions)' % e)
         if n_cg:
             presence[c_wid - wid0, c_cls] = 1.0
-        stage('cont', i32(c_slot), i32(c_cls), i32(c_wid - wid0), presence.reshape(-1))
+        stage('cont', i32(c_slot), i32(c_cls), i32(c_wid - wid0), presence.reshape(-1), *slot_groups(c_slot))
     entries = [] if table_mode else [(int(g), n, e) for g, n, e in zip(c_gpos, c_name, gb.cg_emb)]
     c_slot, c_wid = (c_slot, c_wid) if table_mode else (c_slot.tolist(), c_wid.tolist())
     cw = contrastive_windows(entries, window, world) if ((n_cg or world > 1) and not table_mode) else None
@@ -431,7 +446,7 @@ def prepare_module_losses(model, res, questions, pretrain_modules=CRITERION_MODU
         max_classes = max(r[1] for r in win_range.values())
         stage('cont', i32(c_slot), i32([slot_of[(w, n)] for w, n in zip(c_wid, c_name)]),
               i32([win_range[w][0] for w in c_wid]), i32([win_range[w][1] for w in c_wid]), rows,
-              i32(np.concatenate([[0], np.cumsum(lens)])), np.ascontiguousarray(np.concatenate(embs)))
+              i32(np.concatenate([[0], np.cumsum(lens)])), np.ascontiguousarray(np.concatenate(embs)), *slot_groups(c_slot))
     qf_ = res.question_frames
     ff_items = [(int(slot_t[base[qi] + pos]), gold, int(qf_[qi]) if qf_ is not None else T) for qi, pos, gold in gb.ff]
     # ---- ONE upload ----
@@ -441,7 +456,8 @@ def prepare_module_losses(model, res, questions, pretrain_modules=CRITERION_MODU
     prep = {'n_att': n_att, 'n_head': n_head, 'n_cont': n_cg, 'ff_items': ff_items, 'max_classes': max_classes,
             'att': got('att') if n_att else None, 'head': {m: got(m) for m in n_head}}
     if table_mode:
-        slot_d, cls_d, win_d, pres_d = got('cont')
+        slot_d, cls_d, win_d, pres_d, c_order_d, c_goff_d = got('cont')
+        prep['cont_groups'] = (c_order_d, c_goff_d)
         if world > 1:                       # the pools of the GLOBAL windows: one small device all-reduce, no host round trip
             import torch.distributed as dist
             dist.all_reduce(pres_d, op=dist.ReduceOp.SUM)
@@ -452,7 +468,8 @@ def prepare_module_losses(model, res, questions, pretrain_modules=CRITERION_MODU
     elif n_cg:
         # class representations: text encoder without gradient + L2Normalize (module_net.py:78-89); they depend on the weights
         # only, so they are encoded here, ahead of the forward pass, on the same stream
-        slot_d, pos_d, ws_d, wc_d, rows_d, seq_off, x = got('cont')
+        slot_d, pos_d, ws_d, wc_d, rows_d, seq_off, x, c_order_d, c_goff_d = got('cont')
+        prep['cont_groups'] = (c_order_d, c_goff_d)
         x = x.view(-1, model.config['text_size'])
         _, h_n = ops.lstm_bidir(x, seq_off, max(lens), [w.detach() for w in model._lstm_weights('text_encoder')])
         prep['cont'] = (slot_d, pos_d, ws_d, wc_d, ops.l2normalize(h_n).index_select(0, rows_d.long()))    # every window's classes, window after window
@@ -469,16 +486,23 @@ def launch_module_losses(model, res, prep, scale):
     vec, gvec = res._arena(res.info.vec_off, res.info.n_vec, H), res.grad_arena('vec')
     att, gatt = res._arena(res.info.att_off, res.info.n_att, T), res.grad_arena('att')
     P = lambda t: C.c_void_p(t.data_ptr())
+    # reproducible sums (like the decoder-only step): head-weight gradients through the context's fixed-point shadows, which the
+    # backward pass that follows adds to the gradients; arena gradients group by group (stair_loss_groups)
+    model._bind_grads()                 # the shadows are found through the bound gradient buffers
+    check(lib.stair_grad_shadows_begin(model._ctx, stream))
+    groups = lambda order_d, goff_d: check(lib.stair_loss_groups(P(order_d), P(goff_d), goff_d.numel() - 1))
     if prep['n_att']:
-        slot_d, K_d, off_d, iv_d, len_d = prep['att']
+        slot_d, K_d, off_d, iv_d, len_d, order_d, goff_d = prep['att']
         out = torch.empty(prep['n_att'], device=dev)
+        groups(order_d, goff_d)
         check(lib.stair_loss_attention_len(P(att), P(gatt), P(slot_d), P(K_d), P(off_d), P(iv_d), P(len_d) if len_d.numel() else None,
                                            prep['n_att'], T, C.c_float(scale), P(out), stream))
         losses['attention'] = out
     for module, n_items in prep['n_head'].items():
         head = model.submodules[module].pretrain_head
-        slot_d, lab_d = prep['head'][module]
+        slot_d, lab_d, order_d, goff_d = prep['head'][module]
         out = torch.empty(n_items, device=dev)
+        groups(order_d, goff_d)
         check(lib.stair_loss_head(head.weight.shape[0], P(vec), P(gvec), P(slot_d), P(lab_d), P(head.weight), P(head.bias),
                                   P(head.weight.grad), P(head.bias.grad), n_items, H, C.c_float(scale), P(out), stream))
         losses[module] = out
@@ -490,12 +514,14 @@ def launch_module_losses(model, res, prep, scale):
     if prep['n_cont'] and 'cont_table' in prep:
         slot_d, cls_d, win_d, pres_d, reps, n_cls = prep['cont_table']
         out = torch.empty(prep['n_cont'], device=dev)
+        groups(*prep['cont_groups'])
         check(lib.stair_loss_contrastive_table(P(vec), P(gvec), P(slot_d), P(cls_d), P(win_d), P(pres_d), P(reps), prep['n_cont'],
                                                n_cls, H, C.c_float(scale), P(out), stream))
         losses['contrastive'] = out
     elif prep['n_cont']:
         slot_d, pos_d, ws_d, wc_d, G = prep['cont']
         out = torch.empty(prep['n_cont'], device=dev)
+        groups(*prep['cont_groups'])
         check(lib.stair_loss_contrastive(P(vec), P(gvec), P(slot_d), P(pos_d), P(ws_d), P(wc_d), P(G), prep['n_cont'], H,
                                          prep['max_classes'], C.c_float(scale), P(out), stream))
         losses['contrastive'] = out

@@ -781,6 +781,40 @@ def test_training_step_is_bit_reproducible(n_q, clips):
     assert float(runs[0][0][0].abs().max()) > 0
 
 
+def test_supervised_step_is_bit_reproducible():
+    """BASELINE configs[4]: the step with every per-module criterion (train_module.py:33-194, 351-406) is bit-identical from run to
+    run as well -- 64 questions on 32 shared clips (aliased supervised nodes: several criteria items per gradient slot).  The criteria
+    add into the arenas group by group (stair_loss_groups) and into the head weights through the fixed-point shadows
+    (stair_grad_shadows_begin), the LDS sums of the criteria run in wave order."""
+    from stair_amd.train import Trainer
+    config = dict(spec.DEFAULT_CONFIG)
+    n_q, clips = 64, 32
+    qs = [synth.make_question(config, 23, i, T=64, forms=synth.ALL_FORMS, with_video=False) for i in range(n_q)]
+    qs = _with_gold(config, 23, qs, 64)
+    g = torch.Generator().manual_seed(10)
+    video = torch.randn(clips, 64, config['video_size'], generator=g).to(torch.bfloat16).to(DEV)
+    vidx = [i % clips for i in range(n_q)]
+    question = torch.cat([torch.as_tensor(q['question']) for q in qs]).to(DEV)
+    q_lens = [q['question'].shape[0] for q in qs]
+    answers = torch.tensor([q['answer'] for q in qs], dtype=torch.int32, device=DEV)
+    progs, spans = [q['nmn_program_list'] for q in qs], [q['prog_str_to_question_tokens'] for q in qs]
+    runs = []
+    for rep in range(2):
+        tr = Trainer(_model(config, 5), dropout=0.0, lr=1e-3)
+        grads = []
+        for it in range(2):
+            tr.step(progs, spans, video, question, q_lens, answers, questions=qs, video_index=vidx)
+            grads.append(tr.flat_g.clone())
+        tr.check()
+        runs.append((grads, tr.flat_p.clone(), {k: v.clone() for k, v in tr.module_losses.items()}))
+    for it in range(2):
+        assert torch.equal(runs[0][0][it], runs[1][0][it]), 'gradient bucket of supervised step %d differs between two runs' % it
+    assert torch.equal(runs[0][1], runs[1][1])
+    assert set(runs[0][2]) >= {'attention', 'contrastive'} and any(k in runs[0][2] for k in ('Exists', 'Xor', 'Equals'))    # every criterion family ran
+    for k, v in runs[0][2].items():
+        assert torch.equal(v, runs[1][2][k]), k
+
+
 def test_collated_gold_batch_gives_the_step_of_the_question_dicts():
     """losses.collate_gold (the loader's collate step: the batch's gold intermediates as flat arrays) against the list of question
     dicts: the same index / target arrays reach the same loss kernels -- every criterion value and every parameter gradient bit for
