@@ -679,6 +679,23 @@ def main():
             'path_tflops': round(ALGO_FLOP_PER_QUESTION * (3.0 if args.mode == 'train' else 1.0) * qps / world / 1e12, 2),
         }
         line.update(extras)
+        # what the matrix pipes of THIS device sustain on random operands (back-to-back MFMAs from registers, no memory): the chip
+        # holds its clock well under 2.4 GHz under such a load, so this -- not the datasheet's 2.5 PFLOP/s -- is the ceiling of a
+        # kernel's EXECUTED flop rate here; `roofline.peak` stays the datasheet figure
+        try:
+            import ctypes as C
+            from stair_amd._lib import lib as _lib, check as _check
+            tf = C.c_double(0.0)
+            _check(_lib.stair_mfma_probe(20000, 3, C.byref(tf), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            ex = nprod * achieved
+            line['roofline']['sustained_mfma_probe'] = {
+                'TFLOP/s': round(tf.value, 1), 'frac_of_datasheet_peak': round(tf.value / BF16_MFMA_PEAK_TFLOPS, 4),
+                'kernel_executed_over_sustained': round(ex / tf.value, 4),
+                'note': 'stair_mfma_probe: v_mfma_f32_32x32x16_bf16 back to back from registers on every CU (2 waves per SIMD), random '
+                        'operands, 3 launches of ~5 ms after a warm-up, same process and device as the line; the dominant kernel executes '
+                        '%.0f TFLOP/s of MFMAs = %.2f of what the pipes sustain' % (ex, ex / tf.value)}
+        except Exception as e:
+            line['roofline']['sustained_mfma_probe'] = {'error': '%s: %s' % (type(e).__name__, str(e)[:120])}
         if not args.no_cpu_baseline and world == 1:        # the CPU leg runs on rank 0 at N=1 only
             # the box gives one GPU a 16-core CPU share; more ATen threads than that only thrash
             ncores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))

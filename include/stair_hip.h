@@ -198,6 +198,12 @@ typedef struct stair_gemm_planes_args {
     int32_t w_tiled; /* 0: W planes row-major [N, ldw]; 1: tiled [K/32][N][32] (stair_split_planes_tiled; ldw ignored) */
 } stair_gemm_planes_args;
 int stair_gemm_planes(const stair_gemm_planes_args *args, stair_stream stream);
+/* Measurement aid (ABI 5): the bf16 MFMA rate this device SUSTAINS on random operands -- a full grid (one 512-thread workgroup per CU)
+ * of v_mfma_f32_32x32x16_bf16 issued back to back from registers, no memory traffic, `repeats` launches of `iters` x 8 MFMAs per wave
+ * after one warm-up launch, timed with events on `stream` (the call waits for them).  Under such a load the chip holds its clock
+ * well below 2.4 GHz, so the result lies well under the 2.5 PFLOP/s dense peak: it is the ceiling of the EXECUTED flop rate of any
+ * bf16 MFMA kernel on this device (bench.py reports it beside `roofline`, whose `peak` stays the datasheet's). */
+int stair_mfma_probe(int32_t iters, int32_t repeats, double *tflops, stair_stream stream);
 
 /* Bidirectional single-layer LSTM over n ragged sequences (nn.LSTM as used at
  * module_net.py:39-47,151-163).  x [rows, I] with sequence s at rows seq_off[s]..seq_off[s+1]-1

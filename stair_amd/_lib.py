@@ -180,6 +180,7 @@ SIGNATURES = [
     ('stair_comm_destroy', None, [C.c_void_p]),
     ('stair_comm_info', C.c_int, [C.c_void_p, c_int32_p, c_int32_p]),
     ('stair_allreduce_grads', C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    ('stair_mfma_probe', C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_double), C.c_void_p]),
     ('stair_loss_groups', C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     ('stair_grad_shadows_begin', C.c_int, [C.c_void_p, C.c_void_p]),
     ('stair_loss_decoder_ce', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),

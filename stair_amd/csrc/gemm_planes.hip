@@ -18,6 +18,7 @@
 // the ds_read_b128 fragment reads (32 consecutive rows of one chunk) are bank-conflict free.
 #include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 #include "common.h"
 
@@ -518,6 +519,78 @@ int launch_gemm_planes(const stair_gemm_planes_args &a, hipStream_t s) {
     return 0;
 }
 
+// Measurement aid (bench.py's roofline): what the matrix pipes of THIS device sustain on random operands.  Every wave of a full grid
+// (one 512-thread workgroup per CU, two waves per SIMD -- the residency of the plane GEMMs) issues v_mfma_f32_32x32x16_bf16 back to
+// back from registers: no memory, no LDS, no barrier in the loop.  The chip lowers its clock under such a load
+// (MI355X_MICROARCH.md "DVFS give-back"), so the rate is well under the 2.5 PFLOP/s the 2.4 GHz figure gives: this is the ceiling any
+// bf16 MFMA kernel can reach here, and the number to read a kernel's EXECUTED flop rate against.
+__global__ __launch_bounds__(512, 1) void mfma_probe_kernel(const __bf16 *seed, float *sink, int iters) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    bf16x8 a[4], b[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8 *>(seed + ((wave * 6 + i) * 64 + lane) * 8);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8 *>(seed + ((wave * 6 + 4 + j) * 64 + lane) * 8);
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) t += acc[i][j][e];
+    if (t == 123.456f) sink[blockIdx.x * 512 + threadIdx.x] = t;      // never true for this data: keeps the loop alive
+}
+
+}  // namespace stair
+
+extern "C" int stair_mfma_probe(int32_t iters, int32_t repeats, double *tflops, stair_stream stream) {
+    using namespace stair;
+    STAIR_CHECK(iters > 0 && repeats > 0 && tflops, "iters, repeats > 0 and a result pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    const size_t seed_elems = (size_t)8 * 6 * 64 * 8;
+    __bf16 *seed = nullptr;
+    float *sink = nullptr;
+    STAIR_HIP(hipMalloc(&seed, seed_elems * sizeof(__bf16)));
+    STAIR_HIP(hipMalloc(&sink, (size_t)cus * 512 * sizeof(float)));
+    std::vector<unsigned short> host(seed_elems);
+    unsigned x = 12345u;
+    for (size_t i = 0; i < seed_elems; ++i) {              // random bf16 values in (-2, 2): sign, exponent 125..127, 7 random mantissa bits
+        x = x * 1664525u + 1013904223u;
+        host[i] = (unsigned short)(((x >> 31) << 15) | ((125u + ((x >> 8) % 3u)) << 7) | ((x >> 16) & 0x7f));
+    }
+    STAIR_HIP(hipMemcpy(seed, host.data(), seed_elems * sizeof(__bf16), hipMemcpyHostToDevice));
+    hipEvent_t e0, e1;
+    STAIR_HIP(hipEventCreate(&e0)); STAIR_HIP(hipEventCreate(&e1));
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(cus), dim3(512), 0, s, seed, sink, iters);       // warm-up (clocks settle under load)
+    STAIR_HIP(hipEventRecord(e0, s));
+    for (int r = 0; r < repeats; ++r) hipLaunchKernelGGL(mfma_probe_kernel, dim3(cus), dim3(512), 0, s, seed, sink, iters);
+    STAIR_HIP(hipEventRecord(e1, s));
+    STAIR_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    STAIR_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(seed); (void)hipFree(sink);
+    const double flops = (double)repeats * cus * 8.0 * iters * 8.0 * 2.0 * 32 * 32 * 16;
+    *tflops = flops / ((double)ms * 1e-3) / 1e12;
+    return 0;
+}
+
+namespace stair {
 }  // namespace stair
 
 extern "C" int stair_split_planes(const float *x, void *hi, void *lo, int64_t n, stair_stream stream) {
