@@ -43,6 +43,7 @@ struct PlParams {
     int64_t ldc;
     int M, N, K, tilesM, tilesN;
     int nt_store;             // 1: the output tile is stored with the non-temporal hint (it is a stream; the A panels and W planes are re-read from L2)
+    int stagger;              // 1: waves 4..7 issue their LDS-DMA half a stage after waves 0..3 (MF == 0 form)
 };
 
 __device__ __forceinline__ void glds16(const __bf16 *src, __attribute__((address_space(3))) char *dst) {
@@ -85,9 +86,10 @@ __global__ __launch_bounds__(512, 1) void gemm_planes_kernel(PlParams p) {
     constexpr int NST = NPA == 1 ? 3 : 2;                // ring depth (144 KB / 128 KB)
     constexpr int STAGE_BYTES = NPL * PLANE_BYTES;
     constexpr int LPS = NPL * 2;                         // LDS-DMA instructions per wave and stage
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (uniform: the role branches below are scalar)
     const int wm = wave >> 2, wn = wave & 3;
     const int K = p.K;
+    const bool stagger = p.stagger != 0;
 
     // XCD-aware renumbering: workgroups with equal blockIdx % 8 share an XCD (speed only), and at any moment they hold
     // consecutive tiles, i.e. all tilesN column tiles of the same A panels: the panel leaves HBM once, W stays in L2.
@@ -184,6 +186,23 @@ __global__ __launch_bounds__(512, 1) void gemm_planes_kernel(PlParams p) {
             acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s_][i_], fwl[s_][j_], acc[i_][j_], 0, 0, 0);    \
             acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s_][i_], fwh[s_][j_], acc[i_][j_], 0, 0, 0);    \
         }
+        // one (i, j) block of PL_MUL, and the rest: the first half of a step multiplies ONE block before it issues its reads -- the
+        // fragments of k step 0 come out of the previous iteration, and hipcc's wait-count pass, which cannot count across the loop's
+        // back edge, puts an lgkmcnt(0) in front of their first use: placed after the reads it waited for all eight of them
+#define PL_MUL_ONE(s_)                                                                                               \
+    {                                                                                                                \
+        if (NPA == 2) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[s_][0], fwh[s_][0], acc[0][0], 0, 0, 0); \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s_][0], fwl[s_][0], acc[0][0], 0, 0, 0);              \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s_][0], fwh[s_][0], acc[0][0], 0, 0, 0);              \
+    }
+#define PL_MUL_REST(s_)                                                                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                                 \
+        _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                           \
+            if (i_ == 0 && j_ == 0) continue;                                                                        \
+            if (NPA == 2) acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[s_][i_], fwh[s_][j_], acc[i_][j_], 0, 0, 0);   \
+            acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s_][i_], fwl[s_][j_], acc[i_][j_], 0, 0, 0);    \
+            acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s_][i_], fwh[s_][j_], acc[i_][j_], 0, 0, 0);    \
+        }
         // Ring: at the top of a step, its stage is in LDS and visible to every wave, its k-step-0 fragments are already in
         // registers, and the next NST-2 stages are in flight.  The step
         //   issues the stage NST-1 ahead (into the buffer whose last reader was the previous step: every wave finished
@@ -197,25 +216,40 @@ __global__ __launch_bounds__(512, 1) void gemm_planes_kernel(PlParams p) {
         wait_vm<(NST - 2) * LPS>();
         __builtin_amdgcn_s_barrier();
         int sbuf = 0, ibuf = (NST - 1) * STAGE_BYTES;
-        if (ABL != 2) PL_READ(sbuf, 0);
+        if (ABL != 2) PL_READ(sbuf, 0);         // (the MFMA-only ablations multiply these fragments over and over)
+        // STAGGER: the two waves of a SIMD (w and w + 4) run this same program in lockstep, so they used to issue their LDS-DMA -- six
+        // instructions of ~100 cycles of issue each, as long as half a wave's MFMAs of the stage -- at the same moment, with the SIMD's
+        // matrix pipe idle meanwhile.  Waves 4..7 now issue theirs HALF a stage later (after the barrier, before k step 1), beside their
+        // partners' MFMAs, and wait for all of it (vmcnt(0)) before the next barrier: it has had a whole stage of MFMAs to land.
+        const bool late = stagger && wave >= 4;
         for (int ord = 0; ord < my_tiles; ++ord) {
             for (int t = 0; t < nt; ++t) {
-                if (ABL != 1) PL_STAGE(ibuf, i_k);
-                if (ABL != 2) {
-                    PL_READ(sbuf, 1);
-                    PL_MUL(0);
+                // ABL (measurements): 1 no LDS-DMA; 2 no reads, no MFMAs; 3 MFMAs only (no DMA, reads, barrier); 4 MFMAs + barrier;
+                // 5 MFMAs + reads, no barrier (and no DMA); 6 everything but the epilogue's stores
+                constexpr bool PIN = ABL != 7;          // (7: the reads unpinned, as before)
+                constexpr bool DMA = ABL == 0 || ABL == 2 || ABL == 6 || ABL == 7, RD = ABL == 0 || ABL == 1 || ABL == 5 || ABL == 6 || ABL == 7, MM = ABL != 2,
+                               BAR = ABL != 3 && ABL != 5;
+                if (DMA && !late) PL_STAGE(ibuf, i_k);
+                if (MM && PIN) { PL_MUL_ONE(0); __builtin_amdgcn_sched_barrier(0); }
+                if (RD) PL_READ(sbuf, 1);
+                // the reads stay ABOVE the MFMAs they hide behind: hipcc otherwise sinks all eight to the END of the block (shorter live
+                // ranges), right in front of the lgkmcnt(0) below, and every half stage waits out an LDS round trip with the matrix pipe idle
+                if (PIN) __builtin_amdgcn_sched_barrier(0);
+                if (MM) { if (PIN) { PL_MUL_REST(0); } else { PL_MUL(0); } }
+                __builtin_amdgcn_sched_barrier(0);
+                if (BAR) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (late) wait_vm<0>(); else wait_vm<(NST - 2) * LPS>();
+                    __builtin_amdgcn_s_barrier();
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                wait_vm<(NST - 2) * LPS>();
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
+                if (DMA && late) PL_STAGE(ibuf, i_k);
                 sbuf = sbuf + STAGE_BYTES == NST * STAGE_BYTES ? 0 : sbuf + STAGE_BYTES;
                 ibuf = ibuf + STAGE_BYTES == NST * STAGE_BYTES ? 0 : ibuf + STAGE_BYTES;
-                if (ABL != 2) {
-                    PL_READ(sbuf, 0);
-                    PL_MUL(1);
-                }
+                if (MM && PIN) { PL_MUL_ONE(1); __builtin_amdgcn_sched_barrier(0); }     // (as above: the compiler's own wait for k step 1's fragments lands here, where it is free)
+                if (RD) PL_READ(sbuf, 0);
+                if (PIN) __builtin_amdgcn_sched_barrier(0);
+                if (MM) { if (PIN) { PL_MUL_REST(1); } else { PL_MUL(1); } }
                 advance();                  // (the branches of the cursor sit at the end: the blocks above stay straight-line)
             }
             const int tile = first + ord * G;
@@ -239,7 +273,7 @@ __global__ __launch_bounds__(512, 1) void gemm_planes_kernel(PlParams p) {
                         if (ACT == 2) v = sigmoid_acc(v);
                         __attribute__((address_space(1))) float *rowp =
                             (__attribute__((address_space(1))) float *)(ctile + (int64_t)rl * p.ldc + j * 32);
-                        if (full || (n < p.N && m0 + wm * 128 + 4 * h + rl < p.M)) {
+                        if (ABL != 6 && (full || (n < p.N && m0 + wm * 128 + 4 * h + rl < p.M))) {
                             if (p.nt_store) __builtin_nontemporal_store(v, rowp + loff);
                             else rowp[loff] = v;
                         }
@@ -250,6 +284,8 @@ __global__ __launch_bounds__(512, 1) void gemm_planes_kernel(PlParams p) {
         }
 #undef PL_READ
 #undef PL_MUL
+#undef PL_MUL_ONE
+#undef PL_MUL_REST
     } else {
         // ---- 16 x 16 x 32: lane l holds A[row l & 15][k = 8 (l >> 4) + j], the whole 32-wide stage is ONE k step ----
         const int r16 = lane & 15, c4 = lane >> 4;
@@ -455,6 +491,8 @@ int launch_gemm_planes(const stair_gemm_planes_args &a, hipStream_t s) {
     {   // measured: 1.985 -> 1.969 ms per launch at the bench shape (two A/B pairs on one box); STAIR_PLANES_NT_STORE=0 switches it off
         static const int nts = [] { const char *e = getenv("STAIR_PLANES_NT_STORE"); return (e && e[0] == '0') ? 0 : 1; }();
         p.nt_store = nts;
+        static const int stg = [] { const char *e = getenv("STAIR_PLANES_STAGGER"); return (e && e[0] == '0') ? 0 : 1; }();
+        p.stagger = stg;
     }
     p.M = a.M; p.N = a.N; p.K = a.K;
     p.tilesM = (a.M + 255) / 256; p.tilesN = (a.N + 255) / 256;
@@ -484,7 +522,7 @@ int launch_gemm_planes(const stair_gemm_planes_args &a, hipStream_t s) {
         P_FOREACH(P_ATTR)
 #undef P_ATTR
 #define P_ATTR_A(MF_, ABL_) STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_planes_kernel<1, 0, true, MF_, ABL_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh1));
-        P_ATTR_A(0, 1) P_ATTR_A(0, 2) P_ATTR_A(1, 1) P_ATTR_A(1, 2)
+        P_ATTR_A(0, 1) P_ATTR_A(0, 2) P_ATTR_A(1, 1) P_ATTR_A(1, 2) P_ATTR_A(0, 3) P_ATTR_A(0, 4) P_ATTR_A(0, 5) P_ATTR_A(0, 6) P_ATTR_A(0, 7)
 #undef P_ATTR_A
         attr_set = true;
     }
@@ -495,7 +533,12 @@ int launch_gemm_planes(const stair_gemm_planes_args &a, hipStream_t s) {
     }
 #define P_LAUNCH(ACT_, WT_) { if (mf_env) P_LAUNCH2(ACT_, WT_, 1) else P_LAUNCH2(ACT_, WT_, 0) }
     if (ablate && a.act == 0 && a.w_tiled && !a.A_lo) {
-        if (mf_env == 0 && ablate == 1) hipLaunchKernelGGL((gemm_planes_kernel<1, 0, true, 0, 1>), grid, block, sh1, s, p);
+        if (mf_env == 0 && ablate == 3) hipLaunchKernelGGL((gemm_planes_kernel<1, 0, true, 0, 3>), grid, block, sh1, s, p);
+        else if (mf_env == 0 && ablate == 4) hipLaunchKernelGGL((gemm_planes_kernel<1, 0, true, 0, 4>), grid, block, sh1, s, p);
+        else if (mf_env == 0 && ablate == 5) hipLaunchKernelGGL((gemm_planes_kernel<1, 0, true, 0, 5>), grid, block, sh1, s, p);
+        else if (mf_env == 0 && ablate == 6) hipLaunchKernelGGL((gemm_planes_kernel<1, 0, true, 0, 6>), grid, block, sh1, s, p);
+        else if (mf_env == 0 && ablate == 7) hipLaunchKernelGGL((gemm_planes_kernel<1, 0, true, 0, 7>), grid, block, sh1, s, p);
+        else if (mf_env == 0 && ablate == 1) hipLaunchKernelGGL((gemm_planes_kernel<1, 0, true, 0, 1>), grid, block, sh1, s, p);
         else if (mf_env == 0) hipLaunchKernelGGL((gemm_planes_kernel<1, 0, true, 0, 2>), grid, block, sh1, s, p);
         else if (ablate == 1) hipLaunchKernelGGL((gemm_planes_kernel<1, 0, true, 1, 1>), grid, block, sh1, s, p);
         else hipLaunchKernelGGL((gemm_planes_kernel<1, 0, true, 1, 2>), grid, block, sh1, s, p);
