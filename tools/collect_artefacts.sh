@@ -33,5 +33,7 @@ cd $R
 timeout -k 10 200 python3 tools/supervised_host_time.py > gpurun_out/${P}_supervised_host_time.txt 2>&1 || true
 timeout -k 10 200 python3 tools/determinism_probe.py 64 3 all > gpurun_out/${P}_determinism_probe.txt 2>&1 || true
 timeout -k 10 200 python3 tools/determinism_probe.py 2048 2 paper >> gpurun_out/${P}_determinism_probe.txt 2>&1 || true
+timeout -k 10 200 python3 tools/determinism_probe.py 64 4 all 1 >> gpurun_out/${P}_determinism_probe.txt 2>&1 || true      # the supervised step (configs[4])
+timeout -k 10 200 python3 tools/chain_bench.py > gpurun_out/${P}_chain_bench.txt 2>&1 || true
 python3 tools/row_kernels.py --merge gpurun_out/fin3/acct.json gpurun_out/fin3/rows/run_kernel_stats.csv gpurun_out/${P}_row_kernels.json
 tail -c 600 gpurun_out/${P}_bench_default.json
