@@ -140,6 +140,7 @@ int launch_split_planes_pad(const float *x, int64_t ldx, void *hi, void *lo, int
 int launch_gemm_planes(const stair_gemm_planes_args &a, hipStream_t s);
 bool gemm_planes_supported(int64_t M, int N, int K);
 int launch_gemm_tn(const stair_gemm_tn_args &a, hipStream_t s);
+int launch_gemm_tn_batch(const stair_gemm_tn_args *a, int n, hipStream_t s);
 int launch_tile_mlp(const stair_tile_mlp_args &a, hipStream_t s);          // csrc/tile_mlp.hip
 int launch_tile_mlp_batch(const stair_tile_mlp_args *args, int n, unsigned *counter, hipStream_t s);   // <= 8 buckets, one launch
 bool tile_mlp_usable(int H, int T);

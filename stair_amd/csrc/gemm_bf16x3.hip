@@ -707,7 +707,7 @@ struct XTnParams {
 // BX: B holds bf16 values (stored clip features, exact): rows are read as 8-byte quads, no lo image of B is written and the
 // ah * bl product is dropped (NP == 3 -> two products per pair); plain row matrices only (fast8 == 1 or 2).
 template <bool PLAIN, int NP, bool BX = false>
-__global__ __launch_bounds__(256, 2) void gemm_tn_bf16x3_kernel(XTnParams p) {
+__device__ __forceinline__ void gemm_tn_bf16x3_body(const XTnParams &p, const int bid) {
     extern __shared__ __attribute__((aligned(16))) __bf16 xlds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -716,7 +716,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16x3_kernel(XTnParams p) {
     // 8*(j / tiles) + xcd run on one L2 and walk the slab's rows together: A/B rows leave HBM ~once per slab
     // instead of once per tile (the plain (n,k,slab) grid re-fetched them 8-16x: 16 GB per dW_ih launch).
     const int tiles = p.tilesN * p.tilesK;
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int xcd = bid & 7, j = bid >> 3;
     const int tile = j % tiles, slab = (j / tiles) * 8 + xcd;
     const int n0 = (tile % p.tilesN) * 128, k0 = (tile / p.tilesN) * 128;
     const int mbeg = min(slab * p.mslab, p.M), mend = min(p.M, mbeg + p.mslab);
@@ -860,6 +860,25 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16x3_kernel(XTnParams p) {
     }
 }
 
+
+template <bool PLAIN, int NP, bool BX = false>
+__global__ __launch_bounds__(256, 2) void gemm_tn_bf16x3_kernel(XTnParams p) {
+    gemm_tn_bf16x3_body<PLAIN, NP, BX>(p, (int)blockIdx.x);
+}
+// EXPERIMENT (off unless STAIR_TN_BATCH=1): several small weight-gradient products in one launch of the same body over a
+// problem table.  With three or more problems per launch the results are not reproducible from run to run while two working workgroups
+// share a CU (reproducible with one per CU: STAIR_TN_BATCH_LDS=98304); cause open, so stair_plan_backward keeps its sequence of launches.
+constexpr int XTN_BATCH = 20;
+struct XTnBatch { XTnParams p[XTN_BATCH]; int first[XTN_BATCH + 1]; int n; };
+static_assert(sizeof(XTnBatch) <= 4096, "kernarg limit");
+__global__ __launch_bounds__(256, 2) void gemm_tn_bf16x3_batch_kernel(XTnBatch b) {
+    int q = 0;
+#pragma unroll
+    for (int i = 1; i < XTN_BATCH; ++i) q += (i < b.n && (int)blockIdx.x >= b.first[i]) ? 1 : 0;
+    q = __builtin_amdgcn_readfirstlane(q);
+    const XTnParams p = b.p[q];
+    gemm_tn_bf16x3_body<false, 3, false>(p, (int)blockIdx.x - b.first[q]);
+}
 
 // 256 x 256 tile form of the TN kernel for the largest weight gradient (dW_ih of the video encoder: N = 1024, K = 2048,
 // 32 tiles): PLAIN launches whose B rows come in groups of 8 (fast8 == 1).  Waves 0-3 stage A (256 columns of dZ),
@@ -1078,6 +1097,58 @@ int launch_gemm_tn_bf16x3(const stair_gemm_tn_args &a, hipStream_t s) {
     else if (one) hipLaunchKernelGGL((gemm_tn_bf16x3_kernel<false, 1>), dim3(tiles * slabs), dim3(256), shmem, s, p);
     else hipLaunchKernelGGL((gemm_tn_bf16x3_kernel<false, 3>), dim3(tiles * slabs), dim3(256), shmem, s, p);
     STAIR_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_gemm_tn_batch(const stair_gemm_tn_args *a, int n, hipStream_t s) {
+    static const bool on = [] { const char *e = getenv("STAIR_TN_BATCH"); return e && e[0] == '1'; }();      // EXPERIMENT: off unless asked for
+    bool ok = on && n >= 2 && matmul_mode() == STAIR_MATMUL_BF16X3;
+    for (int i = 0; i < n && ok; ++i)
+        ok = a[i].M > 0 && a[i].M < 16384 && !a[i].b_is_bf16 && a[i].N % 4 == 0 && a[i].K % 4 == 0 && a[i].lda % 4 == 0 && a[i].ldb % 4 == 0 &&
+             a[i].b_gstride % 4 == 0 && a[i].rows_per_group > 0;
+    if (!ok) {
+        for (int i = 0; i < n; ++i)
+            if (a[i].M > 0)
+                if (int rc = launch_gemm_tn(a[i], s)) return rc;
+        return 0;
+    }
+    static const int lds_req = [] { const char *e = getenv("STAIR_TN_BATCH_LDS"); return e ? atoi(e) : 0; }();
+    const size_t shmem = lds_req > 0 ? (size_t)lds_req : 2 * 2 * 2 * IMG * sizeof(__bf16);
+    if (lds_req > 65536) {
+        static bool set_ = false;
+        if (!set_) { STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tn_bf16x3_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_req)); set_ = true; }
+    }
+    static const int bmax = [] { const char *e = getenv("STAIR_TN_BATCH_MAX"); return e ? std::max(1, std::min(XTN_BATCH, atoi(e))) : XTN_BATCH; }();
+    for (int i0 = 0; i0 < n; i0 += bmax) {
+        XTnBatch b;
+        b.n = std::min(bmax, n - i0);
+        b.first[0] = 0;
+        for (int i = 0; i < XTN_BATCH; ++i) {
+            if (i >= b.n) { b.p[i] = b.p[0]; b.first[i + 1] = b.first[b.n]; continue; }
+            const stair_gemm_tn_args &g = a[i0 + i];
+            XTnParams &p = b.p[i];
+            p.A = g.A; p.lda = g.lda; p.B = g.B; p.ldb = g.ldb; p.b_gstride = g.b_gstride; p.b_gidx = g.b_gidx;
+            p.R = g.rows_per_group; p.row_scale = g.row_scale; p.rs_gstride = g.rs_gstride; p.rs_gidx = g.rs_gidx;
+            p.C = g.C; p.ldc = g.ldc; p.M = g.M; p.N = g.N; p.K = g.K;
+            p.colsum = g.colsum; p.colsum2 = g.colsum2;
+            p.C64 = det_shadow(g.C); p.colsum64 = g.colsum ? det_shadow(g.colsum) : nullptr; p.colsum2_64 = g.colsum2 ? det_shadow(g.colsum2) : nullptr;
+            p.tilesN = (g.N + 127) / 128; p.tilesK = (g.K + 127) / 128;
+            p.fast8 = 0;
+            const bool plain_matrix = !p.b_gidx && !p.rs_gidx && p.b_gstride == (int64_t)p.R * p.ldb && (!p.row_scale || p.rs_gstride == p.R);
+            if (g.M % 8 == 0 && g.M >= 8) {
+                if (p.R % 8 == 0) p.fast8 = 1;
+                else if (plain_matrix) { p.R = 8; p.b_gstride = 8 * p.ldb; p.rs_gstride = 8; p.fast8 = 1; }
+            } else if (plain_matrix) p.fast8 = 2;
+            const int tiles = p.tilesN * p.tilesK;
+            int slabs = std::max(1, std::min((g.M + 255) / 256, (512 + tiles - 1) / tiles));
+            slabs = (slabs + 7) / 8 * 8;
+            p.mslab = ((g.M + slabs - 1) / slabs + 63) / 64 * 64;
+            if (g.M <= p.mslab) p.C64 = nullptr;
+            b.first[i + 1] = b.first[i] + tiles * slabs;
+        }
+        hipLaunchKernelGGL(gemm_tn_bf16x3_batch_kernel, dim3(b.first[b.n]), dim3(256), shmem, s, b);
+        STAIR_LAUNCH_CHECK();
+    }
     return 0;
 }
 

@@ -2728,6 +2728,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
     // the vector-level weights (and Filter's dense layer on the pooled rows): one product per weight over the rows of all its
     // buckets; from 2048 rows on through the slab kernel (whole 32-row stages; the < 32 rows left over by the atomic kernel, one
     // add per element), below that the atomic kernel's single pass is shorter
+    std::vector<stair_gemm_tn_args> small_tn;
     for (int w = 0; w < VD_COUNT; ++w) {
         if (pl->vd_rows[w] == 0) continue;
         const Lin &l = *vlin_of[w];
@@ -2747,8 +2748,9 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
             if (t.M == h.M) continue;
             t.A += (int64_t)h.M * t.lda; t.B += (int64_t)h.M * t.ldb; t.M -= h.M;
         }
-        RUN(launch_gemm_tn(t, s_tn));
+        small_tn.push_back(t);
     }
+    if (!small_tn.empty()) RUN(launch_gemm_tn_batch(small_tn.data(), (int)small_tn.size(), s_tn));
     RUN(tn_x3tr_flush(s_tn));                 // dW, db += the slabs of every product above, in slab order: one launch
     if (overlap_tn) STAIR_HIP(hipEventRecord(ctx->ev_join, ctx->side));
     // Every gradient except the two encoders' is final here (decoder, all module levels, their weight-gradient products): a
