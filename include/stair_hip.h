@@ -195,7 +195,9 @@ typedef struct stair_gemm_planes_args {
     const float *bias;
     float *C; int64_t ldc;
     int32_t M, N, K, act;
-    int32_t w_tiled; /* 0: W planes row-major [N, ldw]; 1: tiled [K/32][N][32] (stair_split_planes_tiled; ldw ignored) */
+    int32_t w_tiled; /* 0: W planes row-major [N, ldw]; 1: tiled [K/32][N][32] (stair_split_planes_tiled; ldw ignored);
+                        2: W_hi = ONE image in MFMA fragment order, [N/32][K/16][hi, lo][64 lanes][8] (stair_pack_wfrag), W_lo unused
+                           but non-NULL: W never enters LDS, each wave loads its own fragments (A_lo NULL, act 0, N % 32, K % 64) */
 } stair_gemm_planes_args;
 int stair_gemm_planes(const stair_gemm_planes_args *args, stair_stream stream);
 /* Measurement aid (ABI 5): the bf16 MFMA rate this device SUSTAINS on random operands -- a full grid (one 512-thread workgroup per CU)

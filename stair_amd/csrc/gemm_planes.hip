@@ -374,6 +374,198 @@ __global__ __launch_bounds__(512, 1) void gemm_planes_kernel(PlParams p) {
 #undef PL_STAGE
 }
 
+// ---- W from registers (round 4 experiment -> product where it wins; w_tiled == 2) ------------------------------------------------
+// The ablations of the kernel above say it is co-limited by what it STAGES: 48 KB per 256 x 256 x 32 stage through LDS-DMA (A 16 KB,
+// W hi + lo 32 KB), 12.9 GB per launch, and by the fragment reads that bring all of it back out of LDS.  Two thirds of those bytes are W,
+// and a wave needs only ITS 64 columns of W: here W never enters LDS.  It is stored in MFMA fragment order (stair_pack_wfrag:
+// [N/32][K/16][hi, lo][64 lanes][8 bf16], 1 KB per fragment) and each wave loads its own fragments global -> VGPR one stage ahead (the two
+// waves that share a column block load the same lines: L1 hits); LDS-DMA stages A alone (16 KB per stage, ring of 4).  NPA == 1, act 0.
+template <int ABL = 0>
+__global__ __launch_bounds__(512, 1) void gemm_planes_wr_kernel(PlParams p) {
+    extern __shared__ __attribute__((aligned(16))) char plds[];
+    constexpr int NSTA = 4;                              // A stages in the ring (64 KB)
+    constexpr int STAGE_BYTES = PLANE_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int K = p.K, KS = K / 16;
+    const int nb = p.tilesM * p.tilesN, G = gridDim.x;
+    const int bid = blockIdx.x;
+    const int qd = G >> 3, rm = G & 7, xcd = bid & 7, loc = bid >> 3;
+    const int first = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
+    const int my_tiles = (nb - first + G - 1) / G;
+
+    const int u0 = 2 * wave * 64 + lane;
+    const int srow[2] = {u0 >> 2, (u0 + 64) >> 2};
+    const int scol = ((u0 & 3) ^ pl_swz(u0 >> 2)) * 8;
+    const int dst_off[2] = {2 * wave * 1024, (2 * wave + 1) * 1024};
+    const __bf16 *srcA[2];
+    auto set_src = [&](int tile) {
+        const int tm = tile / p.tilesN;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) srcA[i] = p.A[0] + (int64_t)min(tm * 256 + srow[i], p.M - 1) * p.lda + scol;
+    };
+    __attribute__((address_space(3))) char *lbase = (__attribute__((address_space(3))) char *)plds;
+#define WR_STAGE(buf, k0)                                                                                   \
+    {                                                                                                       \
+        __attribute__((address_space(3))) char *sb_ = lbase + (buf);                                        \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) glds16(srcA[i_] + (k0), sb_ + dst_off[i_]);        \
+    }
+    // A cursor (NSTA - 1 stages ahead of the multiply) and W cursor (one stage ahead): both cross into the next tile on their own
+    int i_ord = 0, i_k = 0;
+    set_src(first);
+    auto advance = [&]() {
+        i_k += PBK;
+        if (i_k == K) {
+            if (i_ord + 1 < my_tiles) { ++i_ord; i_k = 0; set_src(first + i_ord * G); }
+            else i_k = K - PBK;
+        }
+    };
+    int w_ord = 0, w_s = 0;                              // the stage the W cursor points at
+    const __bf16 *wq0;                                   // fragment image of this wave's first column block of tile w_ord (uniform)
+    auto set_w = [&](int tile) {
+        const int tn = tile - (tile / p.tilesN) * p.tilesN;
+        const int nt0 = min((tn * 256 + wn * 64) >> 5, (p.N >> 5) - 2);
+        wq0 = p.W[0] + (int64_t)nt0 * KS * 2 * 512;
+    };
+    set_w(first);
+    auto advance_w = [&]() {
+        ++w_s;
+        if (w_s == K / PBK) {
+            if (w_ord + 1 < my_tiles) { ++w_ord; w_s = 0; set_w(first + w_ord * G); }
+            else w_s = K / PBK - 1;
+        }
+    };
+    const int nt = K / PBK;
+    const int r = lane & 31, h = lane >> 5;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    int offA[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int R = wm * 128 + 32 * i + r;
+        offA[i] = (R * 4 + pl_swz(R)) * 16;
+    }
+    bf16x8 fa[2][4];
+    bf16x8 wf[2][2][2][2];                               // [ring slot][k step][column block][hi, lo]
+    // The loads are inline asm: a load hipcc can see gets a wait-count it chooses -- across this loop's back edge a vmcnt(0) right
+    // behind the issue, i.e. no prefetch at all.  Base in SGPRs (uniform: block nt0 + j, stage w_s), lane offset in one VGPR, the
+    // four fragments of a column block (k step 0 / 1 x hi / lo) 1 KB apart through the immediate offset.
+    const unsigned lane16 = (unsigned)lane * 16u;
+#define WR_LOAD1(dst_, base_, off_) asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #off_ : "=v"(dst_) : "v"(lane16), "s"(base_) : "memory")
+#define WR_LOADW(slot_)                                                                                      \
+    {                                                                                                        \
+        const char *b0_ = reinterpret_cast<const char *>(wq0) + (int64_t)w_s * 4096;                         \
+        const char *b1_ = b0_ + (int64_t)KS * 2048;                                                          \
+        WR_LOAD1(wf[slot_][0][0][0], b0_, 0); WR_LOAD1(wf[slot_][0][0][1], b0_, 1024);                       \
+        WR_LOAD1(wf[slot_][1][0][0], b0_, 2048); WR_LOAD1(wf[slot_][1][0][1], b0_, 3072);                    \
+        WR_LOAD1(wf[slot_][0][1][0], b1_, 0); WR_LOAD1(wf[slot_][0][1][1], b1_, 1024);                       \
+        WR_LOAD1(wf[slot_][1][1][0], b1_, 2048); WR_LOAD1(wf[slot_][1][1][1], b1_, 3072);                    \
+    }
+    // every fragment of ring slot `slot_` has landed (all but the N newest vector-memory operations are done); the registers are
+    // operands of the statement, so nothing that reads them can be scheduled above it
+#define WR_WAITW(slot_, N_)                                                                                  \
+    asm volatile("s_waitcnt vmcnt(" #N_ ")"                                                                  \
+                 : "+v"(wf[slot_][0][0][0]), "+v"(wf[slot_][0][0][1]), "+v"(wf[slot_][1][0][0]), "+v"(wf[slot_][1][0][1]),   \
+                   "+v"(wf[slot_][0][1][0]), "+v"(wf[slot_][0][1][1]), "+v"(wf[slot_][1][1][0]), "+v"(wf[slot_][1][1][1]) :: "memory")
+#define WR_READ(buf, s_)                                                                                     \
+    {                                                                                                        \
+        const char *sb_ = plds + (buf);                                                                      \
+        const int cx_ = (2 * (s_) + h) << 4;                                                                 \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) fa[s_][i_] = *reinterpret_cast<const bf16x8 *>(sb_ + (offA[i_] ^ cx_));   \
+    }
+#define WR_MUL_ONE(s_, slot_)                                                                                \
+    {                                                                                                        \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s_][0], wf[slot_][s_][0][1], acc[0][0], 0, 0, 0);   \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s_][0], wf[slot_][s_][0][0], acc[0][0], 0, 0, 0);   \
+    }
+#define WR_MUL_REST(s_, slot_)                                                                               \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                         \
+        _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                   \
+            if (i_ == 0 && j_ == 0) continue;                                                                \
+            acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s_][i_], wf[slot_][s_][j_][1], acc[i_][j_], 0, 0, 0);   \
+            acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s_][i_], wf[slot_][s_][j_][0], acc[i_][j_], 0, 0, 0);   \
+        }
+    // prologue: A stages 0 .. NSTA-2 and the W fragments of stage 0
+#pragma unroll
+    for (int q = 0; q < NSTA - 1; ++q) { WR_STAGE(q * STAGE_BYTES, i_k); advance(); }
+    WR_LOADW(0)
+    advance_w();
+    WR_WAITW(0, 0);                                      // A stages 0 .. 2 and the fragments of stage 0 have landed
+    __builtin_amdgcn_s_barrier();
+    int sbuf = 0, ibuf = (NSTA - 1) * STAGE_BYTES;
+    WR_READ(sbuf, 0);
+    int done = 0;                                        // stages multiplied since the start (the first two wait differently)
+#define WR_STEP(slot_)                                                                                       \
+    {                                                                                                        \
+        /* this stage's fragments were requested one step ago; behind them only that step's two LDS-DMA: vmcnt(2) (first step: 0) */ \
+        if (done > 0) { WR_WAITW(slot_, 2); } else { WR_WAITW(slot_, 0); }                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        WR_LOADW(1 - (slot_))                            /* W of the NEXT stage: 8 ops */                     \
+        if (ABL != 1) WR_STAGE(ibuf, i_k);               /* then A of the stage NSTA-1 ahead: 2 ops */       \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        WR_MUL_ONE(0, slot_); __builtin_amdgcn_sched_barrier(0);                                             \
+        WR_READ(sbuf, 1); __builtin_amdgcn_sched_barrier(0);                                                 \
+        WR_MUL_REST(0, slot_);                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
+        /* (the NEXT stage's A was requested two steps ago: the wait at the top of THIS step has already seen it land) */ \
+        __builtin_amdgcn_s_barrier();                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        sbuf = sbuf + STAGE_BYTES == NSTA * STAGE_BYTES ? 0 : sbuf + STAGE_BYTES;                            \
+        ibuf = ibuf + STAGE_BYTES == NSTA * STAGE_BYTES ? 0 : ibuf + STAGE_BYTES;                            \
+        WR_MUL_ONE(1, slot_); __builtin_amdgcn_sched_barrier(0);                                             \
+        WR_READ(sbuf, 0); __builtin_amdgcn_sched_barrier(0);                                                 \
+        WR_MUL_REST(1, slot_);                                                                               \
+        advance(); advance_w(); ++done;                                                                      \
+    }
+    for (int ord = 0; ord < my_tiles; ++ord) {
+        for (int t = 0; t < nt; t += 2) {                // nt is even (K % 64 == 0, launcher): the ring slot of a step is static
+            WR_STEP(0)
+            WR_STEP(1)
+        }
+        const int tile = first + ord * G;
+        const int tm = tile / p.tilesN, tn = tile - tm * p.tilesN;
+        const int m0 = tm * 256, n0 = tn * 256;
+        float *ctile = p.C + (int64_t)m0 * p.ldc + n0;
+        const unsigned loff = (unsigned)((wm * 128 + 4 * h) * (int)p.ldc + wn * 64 + r);
+        const bool full = m0 + 256 <= p.M && n0 + 256 <= p.N;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + r;
+            const float b = (p.bias && n < p.N) ? p.bias[n] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int rl = i * 32 + (e & 3) + 8 * (e >> 2);
+                    const float v = acc[i][j][e] + b;
+                    __attribute__((address_space(1))) float *rowp =
+                        (__attribute__((address_space(1))) float *)(ctile + (int64_t)rl * p.ldc + j * 32);
+                    if (full || (n < p.N && m0 + wm * 128 + 4 * h + rl < p.M)) {
+                        if (p.nt_store) __builtin_nontemporal_store(v, rowp + loff);
+                        else rowp[loff] = v;
+                    }
+                    acc[i][j][e] = 0.0f;
+                }
+            }
+        }
+    }
+    wait_vm<0>();
+#undef WR_STEP
+#undef WR_MUL_REST
+#undef WR_MUL_ONE
+#undef WR_READ
+#undef WR_LOADW
+#undef WR_LOAD1
+#undef WR_WAITW
+#undef WR_STAGE
+}
+
 // x -> hi = bf16(x), lo = bf16(x - hi); 8 elements per thread (two 16-byte loads, two 16-byte stores)
 __global__ void split_planes_kernel(const float *x, __bf16 *hi, __bf16 *lo, int64_t n8) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
@@ -505,6 +697,15 @@ int launch_gemm_planes(const stair_gemm_planes_args &a, hipStream_t s) {
     }();
     static const int ablate = [] { const char *e = getenv("STAIR_PLANES_ABLATE"); return e ? atoi(e) : 0; }();   // measurements only
     const dim3 grid(std::min(nb, ncu)), block(512);
+    if (a.w_tiled == 2) {               // W in fragment order, loaded global -> VGPR by the wave that multiplies it (gemm_planes_wr_kernel)
+        STAIR_CHECK(!a.A_lo && a.act == 0, "fragment-order W: exact-bf16 A, no activation");
+        STAIR_CHECK(a.N % 32 == 0 && a.N >= 64 && a.K % 64 == 0, "fragment-order W: N % 32 == 0, N >= 64, K % 64 == 0");
+        const size_t shw = 4 * PLANE_BYTES;
+        if (ablate == 1) hipLaunchKernelGGL((gemm_planes_wr_kernel<1>), grid, block, shw, s, p);
+        else hipLaunchKernelGGL((gemm_planes_wr_kernel<0>), grid, block, shw, s, p);
+        STAIR_LAUNCH_CHECK();
+        return 0;
+    }
     const size_t sh1 = 3 * 3 * PLANE_BYTES, sh2 = 2 * 4 * PLANE_BYTES;
     static bool attr_set = false;       // one device per process (one ctx per GPU / process, see stair_hip.h)
     // MFMA shape: measured equal for two products (0.95 ms either way on the dominant shape); with three the 16x16x32 form

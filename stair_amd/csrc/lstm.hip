@@ -901,11 +901,20 @@ int launch_lstm_project(const stair_lstm_args &a, hipStream_t s) {
         STAIR_CHECK(a.I % 32 == 0 && a.ldx % 8 == 0, "bf16 input rows need I % 32 == 0 and ldx % 8 == 0");
         STAIR_CHECK(a.wih_planes_ws != nullptr, "wih_planes_ws missing");
         char *hi = static_cast<char *>(a.wih_planes_ws), *lo = hi + (size_t)8 * Hh * a.I * 2;
-        for (int dir = 0; dir < 2; ++dir)
-            if (int rc = launch_split_planes_tiled(a.w_ih[dir], hi, lo, 4 * Hh, a.I, s, dir * 4 * Hh, 8 * Hh)) return rc;
+        // W_ih in MFMA fragment order, read global -> VGPR by the waves that multiply it (LDS-DMA stages the rows alone): STAIR_PLANES_WR=1
+        static const bool wr = [] { const char *e = getenv("STAIR_PLANES_WR"); return e && e[0] == '1'; }();
+        const bool use_wr = wr && a.I % 64 == 0 && Hh % 8 == 0;
         stair_gemm_planes_args g = {};
+        if (use_wr) {
+            const float *src[2] = {a.w_ih[0], a.w_ih[1]};
+            void *dst[2] = {hi, hi + (size_t)4 * Hh * a.I * 2 * 2};
+            if (int rc = launch_pack_wfrag_many(src, dst, 2, 4 * Hh, a.I, s)) return rc;
+        } else {
+            for (int dir = 0; dir < 2; ++dir)
+                if (int rc = launch_split_planes_tiled(a.w_ih[dir], hi, lo, 4 * Hh, a.I, s, dir * 4 * Hh, 8 * Hh)) return rc;
+        }
         g.A_hi = a.x_bf16; g.A_lo = nullptr; g.lda = a.ldx;
-        g.W_hi = hi; g.W_lo = lo; g.ldw = 0; g.w_tiled = 1;
+        g.W_hi = hi; g.W_lo = lo; g.ldw = 0; g.w_tiled = use_wr ? 2 : 1;
         g.bias = a.bias_ws; g.C = a.xproj_ws; g.ldc = 8 * (int64_t)Hh;
         g.M = a.rows; g.N = 8 * Hh; g.K = a.I; g.act = 0;
         if (int rc = launch_gemm_planes(g, s)) return rc;

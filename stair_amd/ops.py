@@ -109,13 +109,28 @@ def split_planes_tiled(w):
     return hi, lo
 
 
-def gemm_planes(a_hi, a_lo, w_hi, w_lo, bias=None, act=None, out=None):
+def gemm_planes(a_hi, a_lo, w_hi, w_lo, bias=None, act=None, out=None, w_frag_rows=None):
     """act((a_hi + a_lo) @ (w_hi + w_lo).T + bias) on bf16 planes staged by LDS-DMA (stair_gemm_planes).
-    a_hi [M,K] bf16, a_lo None (A exact in bf16: two MFMA products per pair) or [M,K]; w_hi, w_lo [N,K]."""
+    a_hi [M,K] bf16, a_lo None (A exact in bf16: two MFMA products per pair) or [M,K]; w_hi, w_lo [N,K].
+    w_frag_rows = N: w_hi is ONE fragment-order image of the [N, K] weight (ops.pack_wfrag), w_lo is ignored (pass w_hi): the
+    waves load their own W fragments global -> VGPR (stair_gemm_planes_args.w_tiled == 2; a_lo None, no activation)."""
     _req(a_hi, 'a_hi', torch.bfloat16); _req(w_hi, 'w_hi', torch.bfloat16); _req(w_lo, 'w_lo', torch.bfloat16)
     if a_lo is not None:
         _req(a_lo, 'a_lo', torch.bfloat16)
     M, K = a_hi.shape
+    if w_frag_rows is not None:
+        N = int(w_frag_rows)
+        assert w_hi.numel() == 2 * N * K
+        if out is None:
+            out = torch.empty(M, N, device=a_hi.device, dtype=torch.float32)
+        a = GemmPlanesArgs()
+        a.A_hi, a.A_lo, a.lda = a_hi.data_ptr(), None, K
+        a.W_hi, a.W_lo, a.ldw = w_hi.data_ptr(), w_hi.data_ptr(), K
+        a.bias = bias.data_ptr() if bias is not None else None
+        a.C, a.ldc = out.data_ptr(), out.stride(0)
+        a.M, a.N, a.K, a.act, a.w_tiled = M, N, K, ACT[act], 2
+        check(lib.stair_gemm_planes(C.byref(a), _stream()))
+        return out
     tiled = w_hi.dim() == 3
     N = w_hi.shape[1] if tiled else w_hi.shape[0]
     assert w_hi.shape == w_lo.shape == ((K // 32, N, 32) if tiled else (N, K))

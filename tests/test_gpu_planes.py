@@ -61,6 +61,25 @@ def test_gemm_planes_matches_fp64(M, N, K, act, a_lo, tiled):
     assert err < 2e-5 * max(1.0, float(ref.abs().max())), err
 
 
+@pytest.mark.parametrize('M,N,K', [(256, 256, 64), (300, 256, 128), (1000, 1024, 2048), (256 * 5 + 7, 512, 512), (4096, 320, 320 + 64),
+                                   (70000, 2048, 256)])
+def test_gemm_planes_with_w_in_fragment_order_matches_fp64(M, N, K):
+    """stair_gemm_planes_args.w_tiled == 2 (gemm_planes_wr_kernel): W as ONE fragment-order image (stair_pack_wfrag) that never enters
+    LDS -- each wave loads its own fragments global -> VGPR with hand-counted waits, LDS-DMA stages A alone.  Ragged M and N tails,
+    several tiles per workgroup (the stage stream crosses tile boundaries), bias; against fp64 of the stored bf16 A."""
+    from stair_amd import ops
+    g = torch.Generator().manual_seed(M * 5 + N + K)
+    x = torch.randn(M, K, generator=g).to(DEV).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    wf = ops.pack_wfrag(w)
+    y = ops.gemm_planes(x, None, wf, wf, b, None, w_frag_rows=N)
+    for lo, hi in ((0, min(M, 600)), (max(0, M - 600), M)):
+        ref = x[lo:hi].double() @ w.double().T + b.double()
+        err = float((y[lo:hi].double() - ref).abs().max())
+        assert err < 2e-5 * max(1.0, float(ref.abs().max())), (M, N, K, lo, err)
+
+
 def test_split_planes_tiled_is_a_relayout_of_the_plain_split():
     from stair_amd import ops
     w = torch.randn(300, 96, generator=torch.Generator().manual_seed(5)).to(DEV)
