@@ -706,7 +706,10 @@ struct XTnParams {
 // N or K are computed from clamped addresses and never written).
 // BX: B holds bf16 values (stored clip features, exact): rows are read as 8-byte quads, no lo image of B is written and the
 // ah * bl product is dropped (NP == 3 -> two products per pair); plain row matrices only (fast8 == 1 or 2).
-template <bool PLAIN, int NP, bool BX = false>
+// RS: a row scale is present (its 8 values per register set are loaded with the rows and carry the row mask); without it the mask of a
+// row is recomputed from the chunk index when the set is split, so no scale registers are live across the MFMA phase (with them the
+// non-PLAIN kernels spilled 12-32 bytes per lane).
+template <bool PLAIN, int NP, bool BX = false, bool RS = true>
 __device__ __forceinline__ void gemm_tn_bf16x3_body(const XTnParams &p, const int bid) {
     extern __shared__ __attribute__((aligned(16))) __bf16 xlds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -734,7 +737,7 @@ __device__ __forceinline__ void gemm_tn_bf16x3_body(const XTnParams &p, const in
     const float cmask = col0 + 4 * cq < ncols ? 1.0f : 0.0f;
 
     v4f v[3][8];              // three register sets: the loads of chunks c+1, c+2, c+3 are in flight while chunk c multiplies
-    float sc[3][8];
+    float sc[RS ? 3 : 1][8];
     // bias gradient riding along: the workgroups of the first K tile already stage every dZ element of their (slab, N tile)
     // once, so waves 0,1 add them up per column while splitting (colsum_kernel re-read all of dZ for this)
     const bool do_colsum = p.colsum != nullptr && !isB && k0 == 0;
@@ -749,7 +752,7 @@ __device__ __forceinline__ void gemm_tn_bf16x3_body(const XTnParams &p, const in
             const bool full_ = mfirst + 7 < p.M;          /* all 8 rows exist: constant stride from one base */ \
             const float *base_ = p.A + (int64_t)(full_ ? mfirst : 0) * p.lda + cc;                          \
             _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) {                                              \
-                sc[set][j_] = mfirst + j_ < mend ? cmask : 0.0f;                                            \
+                if (RS) sc[set][j_] = mfirst + j_ < mend ? cmask : 0.0f;                                    \
                 const int64_t ro_ = full_ ? (int64_t)j_ * p.lda : (int64_t)max(0, min(mfirst + j_, p.M - 1)) * p.lda;   \
                 v[set][j_] = *(gv4p)(base_ + ro_);                                                          \
             }                                                                                               \
@@ -760,8 +763,8 @@ __device__ __forceinline__ void gemm_tn_bf16x3_body(const XTnParams &p, const in
             const float *rsb_ = p.row_scale ? p.row_scale + (p.rs_gidx ? (int64_t)p.rs_gidx[g_] : (int64_t)g_) * p.rs_gstride + rr_ : nullptr;   \
             const bool in_ = mfirst <= p.M - 8;                                                             \
             _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) {                                              \
-                sc[set][j_] = (in_ && mfirst + j_ < mend) ? cmask : 0.0f;                                   \
-                if (rsb_) sc[set][j_] *= rsb_[j_];                                                          \
+                if (RS) sc[set][j_] = (in_ && mfirst + j_ < mend) ? cmask : 0.0f;                           \
+                if (RS && rsb_) sc[set][j_] *= rsb_[j_];                                                    \
                 if (BX) v[set][j_] = load4_bf16(p.B, boff_ + (int64_t)j_ * p.ldb);                          \
                 else v[set][j_] = *(gv4p)(p.B + boff_ + (int64_t)j_ * p.ldb);                               \
             }                                                                                               \
@@ -769,8 +772,8 @@ __device__ __forceinline__ void gemm_tn_bf16x3_body(const XTnParams &p, const in
             _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) {                                              \
                 const int mraw_ = mfirst + j_;                                                              \
                 const int m_ = max(0, min(mraw_, p.M - 1));                                                 \
-                sc[set][j_] = mraw_ < mend ? cmask : 0.0f;                                                  \
-                if (p.row_scale) sc[set][j_] *= p.row_scale[m_];                                            \
+                if (RS) sc[set][j_] = mraw_ < mend ? cmask : 0.0f;                                          \
+                if (RS && p.row_scale) sc[set][j_] *= p.row_scale[m_];                                      \
                 if (BX) v[set][j_] = load4_bf16(p.B, (int64_t)m_ * p.ldb + cc);                             \
                 else v[set][j_] = *(gv4p)(p.B + (int64_t)m_ * p.ldb + cc);                                  \
             }                                                                                               \
@@ -779,8 +782,8 @@ __device__ __forceinline__ void gemm_tn_bf16x3_body(const XTnParams &p, const in
                 const int mraw_ = mfirst + j_;                                                              \
                 const int m_ = max(0, min(mraw_, p.M - 1));                                                 \
                 const int g_ = m_ / p.R, rr_ = m_ - g_ * p.R;                                               \
-                sc[set][j_] = mraw_ < mend ? cmask : 0.0f;                                                  \
-                if (p.row_scale) sc[set][j_] *= p.row_scale[(p.rs_gidx ? p.rs_gidx[g_] : g_) * p.rs_gstride + rr_];   \
+                if (RS) sc[set][j_] = mraw_ < mend ? cmask : 0.0f;                                          \
+                if (RS && p.row_scale) sc[set][j_] *= p.row_scale[(p.rs_gidx ? p.rs_gidx[g_] : g_) * p.rs_gstride + rr_];   \
                 v[set][j_] = *(gv4p)(p.B + (p.b_gidx ? (int64_t)p.b_gidx[g_] : (int64_t)g_) * p.b_gstride + (int64_t)rr_ * p.ldb + cc);   \
             }                                                                                               \
         }                                                                                                   \
@@ -789,10 +792,11 @@ __device__ __forceinline__ void gemm_tn_bf16x3_body(const XTnParams &p, const in
     {                                                                                                       \
         const int operand_ = isB ? 1 : 0;                                                                   \
         const bool sum_ = do_colsum && (chunk_) < nchunks;   /* a chunk past the slab is staged but belongs to nobody */ \
+        const int mrow_ = mbeg + (chunk_) * XBK + 8 * mq;    /* first of this thread's 8 rows of the chunk */ \
         _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) {                                                  \
             bf16x8 hi_, lo_;                                                                                \
             _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) {                                              \
-                const float x_ = PLAIN ? v[set][j_][c_] : v[set][j_][c_] * sc[set][j_];                     \
+                const float x_ = PLAIN ? v[set][j_][c_] : v[set][j_][c_] * (RS ? sc[RS ? set : 0][j_] : (mrow_ + j_ < mend ? cmask : 0.0f));   \
                 if (sum_) csum[c_] += x_;                                                                   \
                 hi_[j_] = (__bf16)x_;                                                                       \
                 lo_[j_] = (__bf16)(x_ - (float)hi_[j_]);                                                    \
@@ -861,13 +865,15 @@ __device__ __forceinline__ void gemm_tn_bf16x3_body(const XTnParams &p, const in
 }
 
 
-template <bool PLAIN, int NP, bool BX = false>
-__global__ __launch_bounds__(256, 2) void gemm_tn_bf16x3_kernel(XTnParams p) {
-    gemm_tn_bf16x3_body<PLAIN, NP, BX>(p, (int)blockIdx.x);
+// (the row-scale forms are built for one workgroup per CU: with two per CU they need 12-32 bytes of scratch per lane, and a kernel that
+// spills while two of its workgroups share a CU has returned wrong sums on MI355X -- DESIGN.md "scratch and co-resident workgroups")
+template <bool PLAIN, int NP, bool BX = false, bool RS = true>
+__global__ __launch_bounds__(256, (RS && !PLAIN) ? 1 : 2) void gemm_tn_bf16x3_kernel(XTnParams p) {
+    gemm_tn_bf16x3_body<PLAIN, NP, BX, RS>(p, (int)blockIdx.x);
 }
-// EXPERIMENT (off unless STAIR_TN_BATCH=1): several small weight-gradient products in one launch of the same body over a
-// problem table.  With three or more problems per launch the results are not reproducible from run to run while two working workgroups
-// share a CU (reproducible with one per CU: STAIR_TN_BATCH_LDS=98304); cause open, so stair_plan_backward keeps its sequence of launches.
+// Several small weight-gradient products in one launch of the same body over a problem table (STAIR_TN_BATCH=0: one launch each).  The body is
+// the form without scale registers: the form with them spilled, and a spilling kernel with two workgroups on a CU is what made this launch
+// irreproducible when it was first tried ("scratch and co-resident workgroups").
 constexpr int XTN_BATCH = 20;
 struct XTnBatch { XTnParams p[XTN_BATCH]; int first[XTN_BATCH + 1]; int n; };
 static_assert(sizeof(XTnBatch) <= 4096, "kernarg limit");
@@ -877,7 +883,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16x3_batch_kernel(XTnBatch b
     for (int i = 1; i < XTN_BATCH; ++i) q += (i < b.n && (int)blockIdx.x >= b.first[i]) ? 1 : 0;
     q = __builtin_amdgcn_readfirstlane(q);
     const XTnParams p = b.p[q];
-    gemm_tn_bf16x3_body<false, 3, false>(p, (int)blockIdx.x - b.first[q]);
+    gemm_tn_bf16x3_body<false, 3, false, false>(p, (int)blockIdx.x - b.first[q]);
 }
 
 // 256 x 256 tile form of the TN kernel for the largest weight gradient (dW_ih of the video encoder: N = 1024, K = 2048,
@@ -1088,23 +1094,43 @@ int launch_gemm_tn_bf16x3(const stair_gemm_tn_args &a, hipStream_t s) {
                                                    // (the bias sums still meet from several threads of a workgroup: they keep their shadow)
     const bool plain = !p.row_scale && a.M % 64 == 0 && p.mslab % 64 == 0;
     STAIR_ACCT_MFMA("gemm_tn_bf16x3", ((int64_t)a.M * a.N * 4 + (int64_t)a.M * a.K * (bx ? 2 : 4) + (int64_t)a.N * a.K * 4), 2ll * a.M * a.N * a.K);
+    // non-PLAIN launches without a row scale take the kernels that keep no scale registers (RS = false)
+    static const bool rs_always = [] { const char *e = getenv("STAIR_TN_RS_ALWAYS"); return e && e[0] == '1'; }();   // diagnostics
+    static const size_t lds_force = [] { const char *e = getenv("STAIR_TN_LDS"); return e ? (size_t)atol(e) : (size_t)0; }();   // diagnostics: 98304 = one workgroup per CU
+    const bool rs = p.row_scale != nullptr || rs_always;
+    size_t lds = shmem;
+    if (lds_force > shmem) {
+        lds = lds_force;
+        static bool attr_set = false;
+        if (!attr_set) {
+#define TN_ATTR(...) STAIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tn_bf16x3_kernel<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
+            TN_ATTR(true, 3, true); TN_ATTR(false, 3, true, false); TN_ATTR(false, 3, true, true); TN_ATTR(true, 1); TN_ATTR(true, 3);
+            TN_ATTR(false, 1, false, true); TN_ATTR(false, 1, false, false); TN_ATTR(false, 3, false, true); TN_ATTR(false, 3, false, false);
+#undef TN_ATTR
+            attr_set = true;
+        }
+    }
+    const dim3 grid(tiles * slabs), block(256);
     if (bx) {
         STAIR_CHECK(p.fast8 != 0, "internal: bf16 B rows need a plain row matrix");
-        if (plain) hipLaunchKernelGGL((gemm_tn_bf16x3_kernel<true, 3, true>), dim3(tiles * slabs), dim3(256), shmem, s, p);
-        else hipLaunchKernelGGL((gemm_tn_bf16x3_kernel<false, 3, true>), dim3(tiles * slabs), dim3(256), shmem, s, p);
-    } else if (plain && one) hipLaunchKernelGGL((gemm_tn_bf16x3_kernel<true, 1>), dim3(tiles * slabs), dim3(256), shmem, s, p);
-    else if (plain) hipLaunchKernelGGL((gemm_tn_bf16x3_kernel<true, 3>), dim3(tiles * slabs), dim3(256), shmem, s, p);
-    else if (one) hipLaunchKernelGGL((gemm_tn_bf16x3_kernel<false, 1>), dim3(tiles * slabs), dim3(256), shmem, s, p);
-    else hipLaunchKernelGGL((gemm_tn_bf16x3_kernel<false, 3>), dim3(tiles * slabs), dim3(256), shmem, s, p);
+        if (plain) hipLaunchKernelGGL((gemm_tn_bf16x3_kernel<true, 3, true>), grid, block, lds, s, p);
+        else if (rs) hipLaunchKernelGGL((gemm_tn_bf16x3_kernel<false, 3, true, true>), grid, block, lds, s, p);
+        else hipLaunchKernelGGL((gemm_tn_bf16x3_kernel<false, 3, true, false>), grid, block, lds, s, p);
+    } else if (plain && one) hipLaunchKernelGGL((gemm_tn_bf16x3_kernel<true, 1>), grid, block, lds, s, p);
+    else if (plain) hipLaunchKernelGGL((gemm_tn_bf16x3_kernel<true, 3>), grid, block, lds, s, p);
+    else if (one && rs) hipLaunchKernelGGL((gemm_tn_bf16x3_kernel<false, 1, false, true>), grid, block, lds, s, p);
+    else if (one) hipLaunchKernelGGL((gemm_tn_bf16x3_kernel<false, 1, false, false>), grid, block, lds, s, p);
+    else if (rs) hipLaunchKernelGGL((gemm_tn_bf16x3_kernel<false, 3, false, true>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((gemm_tn_bf16x3_kernel<false, 3, false, false>), grid, block, lds, s, p);
     STAIR_LAUNCH_CHECK();
     return 0;
 }
 
 int launch_gemm_tn_batch(const stair_gemm_tn_args *a, int n, hipStream_t s) {
-    static const bool on = [] { const char *e = getenv("STAIR_TN_BATCH"); return e && e[0] == '1'; }();      // EXPERIMENT: off unless asked for
+    static const bool on = [] { const char *e = getenv("STAIR_TN_BATCH"); return !(e && e[0] == '0'); }();
     bool ok = on && n >= 2 && matmul_mode() == STAIR_MATMUL_BF16X3;
     for (int i = 0; i < n && ok; ++i)
-        ok = a[i].M > 0 && a[i].M < 16384 && !a[i].b_is_bf16 && a[i].N % 4 == 0 && a[i].K % 4 == 0 && a[i].lda % 4 == 0 && a[i].ldb % 4 == 0 &&
+        ok = a[i].M > 0 && a[i].M < 16384 && !a[i].b_is_bf16 && !a[i].row_scale && a[i].N % 4 == 0 && a[i].K % 4 == 0 && a[i].lda % 4 == 0 && a[i].ldb % 4 == 0 &&
              a[i].b_gstride % 4 == 0 && a[i].rows_per_group > 0;
     if (!ok) {
         for (int i = 0; i < n; ++i)

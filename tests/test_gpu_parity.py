@@ -737,6 +737,29 @@ def test_gemm_tn_bias_gradient_rides_along(M, N, K, matmul):
     assert _maxerr(Cm, refw) < _tol(matmul, 1e-4, 4e-4) * max(1.0, (M / 1000) ** 0.5 * 3)
 
 
+@pytest.mark.parametrize('M', [6700, 6704])
+def test_gemm_tn_is_stable_with_two_workgroups_per_cu(M):
+    """Regression: a ragged product whose grid puts two WORKING workgroups on every CU (16 tiles x 32 slabs), launched back to back.  The
+    form of the kernel that kept its row masks in registers spilled 12 bytes per lane, and with the spill a third of such launches returned
+    sums that were wrong by O(|dW|) (dW_hh of the text encoder in tests/test_gpu_lstm_coop.py was where it showed); see
+    tests/test_kernel_resources.py for the static side of the same rule."""
+    from stair_amd import ops
+    N, K = 1024, 256
+    g = torch.Generator(device=DEV).manual_seed(M)
+    dZ = torch.randn(M, N, device=DEV, generator=g)
+    X = torch.randn(M, K, device=DEV, generator=g)
+    ref = (dZ.double().t() @ X.double()).float()
+    tol = 2e-5 * float(ref.abs().max())
+    outs = []
+    for _ in range(60):
+        Cm = torch.zeros(N, K, device=DEV)
+        ops.gemm_tn(dZ, X, Cm, M, N, K)
+        outs.append(Cm)
+    torch.cuda.synchronize()
+    worst = max(float((c - ref).abs().max()) for c in outs)
+    assert worst < tol, (worst, tol)
+
+
 def test_gemm_accumulate_scatter_add(matmul):
     """dX products: two groups writing the same output slot must add up (atomic epilogue)."""
     from stair_amd import ops
