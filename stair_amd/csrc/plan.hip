@@ -56,6 +56,7 @@ struct stair_ctx {
     // backward pass: the per-weight gradient products are leaves of the graph, they run on a second stream beside BPTT
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork_enc = nullptr, ev_join_enc = nullptr;     // the text encoder's backward beside the video encoder's
     // 64-bit fixed-point shadows of the weight gradients (common.h det_shadow): owned by the context, all zero between two backward
     // passes (the flush empties what it adds), so a pass does not start by clearing 8 bytes per parameter; `dirty`: a pass that did not
     // reach its end left something behind -> the next one clears first
@@ -67,6 +68,8 @@ struct stair_ctx {
         if (gshadow) (void)hipFree(gshadow);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
+        if (ev_fork_enc) (void)hipEventDestroy(ev_fork_enc);
+        if (ev_join_enc) (void)hipEventDestroy(ev_join_enc);
         if (side) (void)hipStreamDestroy(side);
     }
 
@@ -1231,7 +1234,7 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
         const int64_t I = std::max(pl->maxI, 1), Vv = pl->maxV;
         pl->o_cv = take((int64_t)pl->n_vid * T * H, 64);
         pl->o_ct = take((int64_t)pl->rows_q * H, 64);
-        pl->o_hprev = take((int64_t)std::max(pl->n_vid * T, pl->rows_q) * H, 64);
+        pl->o_hprev = take(((int64_t)pl->n_vid * T + pl->rows_q) * H, 64);        // video rows, then text rows: the two backward passes may run side by side
         pl->o_wt = take(ctx_weight_floats(ctx), 64);
         pl->o_gA = take(I * T * H, 64);
         pl->o_gB = take(I * T * H, 64);
@@ -2699,8 +2702,8 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
     hipStream_t s_tn = s;
     if (overlap_tn) {
         RUN(tn_x3tr_flush(s));               // sums queued on `s` by the buckets stay on `s`
-        if (!ctx->side) {
-            STAIR_HIP(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+        if (!ctx->side) STAIR_HIP(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+        if (!ctx->ev_fork) {
             STAIR_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
             STAIR_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
         }
@@ -2777,7 +2780,8 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
                 a.whh_pack_ws = ws + pl->o_wpack + 2 * (int64_t)H * H;
                 a.coop_ws = ws + pl->o_coop2;
             }
-            a.n = e == 0 ? pl->n_vid : n; a.Hh = Hh; a.ldo = H; a.ldd = H; a.hprev_ws = ws + pl->o_hprev;
+            a.n = e == 0 ? pl->n_vid : n; a.Hh = Hh; a.ldo = H; a.ldd = H;
+            a.hprev_ws = ws + pl->o_hprev + (e == 0 ? 0 : (int64_t)pl->n_vid * T * H);
             a.coop_ws_bytes = pl->coop_bytes;
             a.status = reinterpret_cast<uint32_t *>(ws + pl->o_status);
             if (pl->o_tnenc[e]) { a.tn_ws = ws + pl->o_tnenc[e]; a.tn_ws_floats = pl->tnenc_floats[e]; }
@@ -2792,8 +2796,29 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
         if (lstm_bwd_takes_coop(enc[0]) && lstm_bwd_takes_coop(enc[1])) rc_pair = launch_lstm_bwd_coop_pair(enc[1], enc[0], s);
         if (rc_pair > 0) return rc_pair;
         if (rc_pair < 0) {
-            RUN(launch_lstm_bwd(enc[1], s));
-            RUN(launch_lstm_bwd(enc[0], s));
+            // Two independent passes (disjoint inputs, workspaces and gradient buffers; their slab partials are added after the join), so the
+            // text encoder's backward CAN run beside the video encoder's on a second stream (STAIR_ENC_OVERLAP=1).  Measured: nothing to gain
+            // at 512 or 2048 questions (6.13 vs 6.12 ms; 16.4-16.7 vs 15.9-16.8) -- the one-workgroup reverse recurrence takes 256 registers x
+            // 512 threads, so from 1024 sequences on either pass fills every CU by itself.  Off by default.
+            static const bool enc_overlap = [] { const char *e = getenv("STAIR_ENC_OVERLAP"); return e && e[0] == '1'; }();
+            if (enc_overlap) {
+                if (!ctx->side) STAIR_HIP(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+                if (!ctx->ev_fork_enc) {
+                    STAIR_HIP(hipEventCreateWithFlags(&ctx->ev_fork_enc, hipEventDisableTiming));
+                    STAIR_HIP(hipEventCreateWithFlags(&ctx->ev_join_enc, hipEventDisableTiming));
+                }
+                STAIR_HIP(hipEventRecord(ctx->ev_fork_enc, s));
+                STAIR_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_fork_enc, 0));
+                const int rc_t = launch_lstm_bwd(enc[1], ctx->side);
+                const int rc_v = rc_t ? 0 : launch_lstm_bwd(enc[0], s);
+                STAIR_HIP(hipEventRecord(ctx->ev_join_enc, ctx->side));       // joined on every path: nothing of this pass is left running on the side stream
+                STAIR_HIP(hipStreamWaitEvent(s, ctx->ev_join_enc, 0));
+                if (rc_t) return rc_t;
+                if (rc_v) return rc_v;
+            } else {
+                RUN(launch_lstm_bwd(enc[1], s));
+                RUN(launch_lstm_bwd(enc[0], s));
+            }
         } else {
             RUN(launch_lstm_bwd_weights(enc[1], s));
             RUN(launch_lstm_bwd_weights(enc[0], s));
@@ -2931,7 +2956,7 @@ extern "C" int stair_plan_regions(stair_plan *pl, const stair_ctx *ctx, const ch
         const int64_t I = std::max(pl->maxI, 1), Vv = pl->maxV;
         add("cv", pl->o_cv, (int64_t)pl->n_vid * T * H);
         add("ct", pl->o_ct, (int64_t)pl->rows_q * H);
-        add("hprev", pl->o_hprev, (int64_t)std::max<int64_t>((int64_t)pl->n_vid * T, pl->rows_q) * H);
+        add("hprev", pl->o_hprev, ((int64_t)pl->n_vid * T + pl->rows_q) * H);
         add("wt", pl->o_wt, ctx_weight_floats(ctx));
         add("gA", pl->o_gA, I * T * H);
         add("gB", pl->o_gB, I * T * H);
