@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define STAIR_ABI_VERSION 5
+#define STAIR_ABI_VERSION 6
 
 typedef struct stair_ctx stair_ctx;
 typedef struct stair_plan stair_plan;
@@ -497,6 +497,11 @@ int stair_cosine_topk(const float *queries, int64_t ldq, const int32_t *q_idx, c
                                again in the same program -- aliases its slot (same value; gradients of all users add up in it).
                                Filter's tensor keyword does not enter the comparison: its attention is identically 1
                                (modules.py:354,373).  Env STAIR_PLAN_CSE=0 has the same effect. */
+#define STAIR_PLAN_EXT_PROJECTION 4 /* flags (ABI 6): the regions of the encoders' input projections (x W_ih^T + biases of every clip frame and
+                               token row: the gates of a training plan; bias sums; W_ih / token-row planes) are NOT laid out in the plan's
+                               workspace but live in a caller-owned buffer of stair_projection_floats floats, handed over with
+                               stair_plan_set_projection before the first pass.  Their layout depends on the batch SHAPE alone, so
+                               stair_encoders_project can fill the buffer before the plan exists (see there). */
 int stair_plan_build(stair_ctx *ctx, int32_t n, const int32_t *prog_off, const int32_t *tokens,
                      const int32_t *span_lo, const int32_t *span_hi, const int32_t *q_off, int32_t T,
                      int32_t flags, stair_plan **out);
@@ -614,7 +619,25 @@ int stair_dropout_fwd(float *x, int64_t gstride, const int32_t *gidx, int32_t gr
 #define STAIR_RUN_VIDEO_BF16 2 /* `video` points to bf16 [n_videos, T, V] (V % 32 == 0): the stored clip-feature format of
                                   BASELINE.json configs[1]; results equal the fp32 path fed the same (rounded) values up to
                                   the split-product error.  Also a flag of stair_plan_backward. */
+#define STAIR_RUN_PROJECTED 4 /* (ABI 6) a STAIR_PLAN_EXT_PROJECTION plan whose buffer already holds the projections of THESE inputs
+                                 (stair_encoders_project on the same stream, same weights): the pass starts at the recurrences.  Without the
+                                 flag the pass computes the projections into the buffer itself (a captured plan's replay does). */
 int stair_plan_upload(stair_plan *plan, void *workspace, int64_t workspace_bytes, stair_stream stream);
+/* The encoders' input projections ahead of the plan.  module_net.py:74-75 encodes the clip and the question before the interpreter
+ * looks at the program; here the encoders' FIRST half (the projection GEMMs: 0.60 of the 0.86 GFLOP of a question, ~2.2 ms of device
+ * time at 2048 questions) depends on nothing but the batch's inputs, while packing the programs and building the plan is 3-4 ms of
+ * host work: a caller that enqueues the projections first lets the device work through them meanwhile (a loop that reads the loss
+ * after every step otherwise idles the device for that long at every step entry).
+ *   stair_projection_floats   size of the buffer for n_videos clips of T frames and question_rows token rows (floats; -1 on bad input)
+ *   stair_encoders_project    enqueue both projections into buf (256-byte aligned, device); video is fp32 [n_videos, T, V] or, with
+ *                             video_is_bf16, bf16 (V % 32 == 0); reads the bound weights (stair_ctx_set_weight) at execution time
+ *   stair_plan_set_projection attach the buffer to a plan built with STAIR_PLAN_EXT_PROJECTION for the same batch shape; it must stay
+ *                             alive and unmodified until the plan's last pass has executed (stair_plan_backward reads the gates there)
+ * then stair_plan_run_flags(..., STAIR_RUN_PROJECTED | ...).  Results are bit-identical to the plan computing the projections itself. */
+int64_t stair_projection_floats(const stair_ctx *ctx, int32_t n_videos, int32_t T, int64_t question_rows);
+int stair_encoders_project(stair_ctx *ctx, const void *video, int32_t video_is_bf16, int32_t n_videos, int32_t T,
+                           const float *question, int64_t question_rows, float *buf, int64_t buf_floats, stair_stream stream);
+int stair_plan_set_projection(const stair_ctx *ctx, stair_plan *plan, float *buf, int64_t buf_floats);
 int stair_plan_run_flags(stair_ctx *ctx, stair_plan *plan, const float *video, const float *question,
                          void *workspace, int64_t workspace_bytes, float *logits, int32_t *argmax, int32_t flags,
                          stair_stream stream);

@@ -16,7 +16,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('STAIR_LIB_PATH') or os.path.join(_HERE, 'lib', 'libstair_hip.so')   # override: kernel experiments
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)
 
@@ -220,6 +220,10 @@ SIGNATURES = [
     ('stair_plan_set_dropout', C.c_int, [C.c_void_p, C.c_float, C.c_uint64]),
     ('stair_plan_set_backward_event', C.c_int, [C.c_void_p, C.c_void_p]),
     ('stair_plan_upload', C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    ('stair_projection_floats', C.c_int64, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64]),
+    ('stair_encoders_project', C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                          C.c_void_p]),
+    ('stair_plan_set_projection', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     ('stair_plan_run_flags', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                        C.c_void_p, C.c_int32, C.c_void_p]),
 ]

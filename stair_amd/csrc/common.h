@@ -127,6 +127,7 @@ int launch_lstm_rec_coop_pair(const stair_lstm_args &a, const stair_lstm_args &b
 int launch_lstm_bwd_coop_pair(const stair_lstm_bwd_args &a, const stair_lstm_bwd_args &b, hipStream_t s);  // -1: not applicable
 int launch_lstm_project(const stair_lstm_args &a, hipStream_t s);
 int launch_lstm_recur(const stair_lstm_args &a, hipStream_t s);
+int launch_lstm_zero_tail(const stair_lstm_args &a, hipStream_t s);
 int launch_lstm_bwd_recur(const stair_lstm_bwd_args &a, hipStream_t s);
 int launch_lstm_bwd_weights(const stair_lstm_bwd_args &a, hipStream_t s);
 bool lstm_bwd_takes_coop(const stair_lstm_bwd_args &a);

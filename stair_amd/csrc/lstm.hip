@@ -883,6 +883,8 @@ int launch_lstm_bwd(const stair_lstm_bwd_args &a, hipStream_t s) {
     return launch_lstm_bwd_weights(a, s);
 }
 
+int launch_lstm_zero_tail(const stair_lstm_args &a, hipStream_t s);
+
 // input projection (+ bias sums, tail zeroing) of a layer: everything of launch_lstm before the recurrence
 int launch_lstm_project(const stair_lstm_args &a, hipStream_t s) {
     STAIR_CHECK(a.n >= 0 && a.rows >= 0 && a.I > 0 && a.Hh > 0, "bad shape");
@@ -945,17 +947,23 @@ int launch_lstm_project(const stair_lstm_args &a, hipStream_t s) {
         g.groups = a.rows; g.rows_per_group = 1; g.N = 4 * Hh; g.K = a.I; g.act = 0;
         if (int rc = launch_gemm(g, s)) return rc;
     }
-    STAIR_CHECK(a.whh_pack_ws != nullptr, "whh_pack_ws missing");
-    if (a.seq_len) {                  // padded storage: rows past each sequence's length read as zero downstream
-        hipLaunchKernelGGL(lstm_zero_tail_kernel, dim3(a.n), dim3(256), 0, s, a.out, a.ldo, a.seq_off, a.seq_len, Hh);
-        STAIR_LAUNCH_CHECK();
-    }
+    if (a.out) return launch_lstm_zero_tail(a, s);       // (no output rows yet: projections enqueued ahead of their plan, stair_encoders_project)
+    return 0;
+}
+
+// padded storage: rows past each sequence's length read as zero downstream
+int launch_lstm_zero_tail(const stair_lstm_args &a, hipStream_t s) {
+    if (a.n == 0 || a.rows == 0 || !a.seq_len) return 0;
+    STAIR_CHECK(a.out, "null output rows");
+    hipLaunchKernelGGL(lstm_zero_tail_kernel, dim3(a.n), dim3(256), 0, s, a.out, a.ldo, a.seq_off, a.seq_len, a.Hh);
+    STAIR_LAUNCH_CHECK();
     return 0;
 }
 
 // the recurrence over projected inputs (a.xproj_ws)
 int launch_lstm_recur(const stair_lstm_args &a, hipStream_t s) {
     if (a.n == 0 || a.rows == 0) return 0;
+    STAIR_CHECK(a.whh_pack_ws != nullptr, "whh_pack_ws missing");
     const int Hh = a.Hh;
     if (a.coop_ws && lstm_coop_usable(Hh)) {          // hidden units split over co-resident workgroups
         const int rc = launch_lstm_rec_coop(a, s);

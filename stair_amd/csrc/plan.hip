@@ -339,6 +339,25 @@ namespace {
 struct PinnedBuf { int32_t *p = nullptr; size_t cap = 0; };
 std::mutex g_pin_mu;
 std::vector<PinnedBuf> g_pin_pool;
+// Regions of the encoders' input projections, as offsets in floats from a base: [xproj video | xproj text | bias sums | video W_ih planes |
+// text W_ih planes | text row planes].  A function of the batch SHAPE only (clips, frames, token rows): the same layout inside a plan's
+// workspace and in a caller-owned buffer filled by stair_encoders_project before the plan is built.
+struct ProjLayout { int64_t xpv, xpt, bias, wplanes, wplanes_t, xplanes_t, total; };
+static ProjLayout proj_layout(const stair_config &g, int64_t n_vid, int64_t T, int64_t rows_q) {
+    const int64_t H = g.hidden_size, Ep = (g.text_size + 31) / 32 * 32;
+    ProjLayout L;
+    int64_t at = 0;
+    auto take = [&](int64_t len) { const int64_t o = at; at += (len + 63) / 64 * 64; return o; };
+    L.xpv = take(n_vid * T * 4 * H);
+    L.xpt = take(rows_q * 4 * H);
+    L.bias = take(2 * 4 * H);
+    L.wplanes = g.video_size % 32 == 0 ? take(4 * H * g.video_size) : 0;
+    L.wplanes_t = take(4 * H * Ep);
+    L.xplanes_t = take(std::max<int64_t>(rows_q, 1) * Ep);
+    L.total = at;
+    return L;
+}
+
 PinnedBuf pinned_take(size_t ints) {
     {
         std::lock_guard<std::mutex> lk(g_pin_mu);
@@ -439,6 +458,10 @@ struct stair_plan {
     int64_t o_tnring = 0, tnring_floats = 0, o_tnenc[2] = {0, 0}, tnenc_floats[2] = {0, 0};
     int64_t wg_rows[WF_COUNT] = {}, wg_dz[WF_COUNT] = {}, wg_sx[WF_COUNT] = {}, wg_off_idx[WF_COUNT] = {}, wg_off_rs[WF_COUNT] = {}, wg_part[WF_COUNT] = {};
     // workspace layout (float offsets)
+    // STAIR_PLAN_EXT_PROJECTION: the encoders' input-projection regions live in a caller-owned buffer (stair_plan_set_projection) whose
+    // layout depends on the batch shape alone (proj_layout), so that the projections can be enqueued BEFORE the plan exists
+    bool ext_proj = false;
+    float *proj = nullptr;
     int64_t o_idx = 0, o_vec = 0, o_map = 0, o_att = 0, o_tok = 0, o_qfeat = 0, o_vhn = 0, o_xpv = 0, o_xpt = 0,
             o_bias = 0, o_wpack = 0, o_wplanes = 0, o_wplanes_t = 0, o_xplanes_t = 0, o_coop = 0, o_coop2 = 0, o_splitk = 0, o_tmpA = 0, o_tmpB = 0, o_kbuf = 0, o_cat = 0, o_hid = 0, o_rs = 0, o_sup = 0, o_extra = 0,
             o_logits = 0, o_status = 0, o_wfrag = 0, total = 0;
@@ -642,6 +665,7 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
     pl->n = n;
     pl->T = T;
     pl->train = (flags & STAIR_PLAN_TRAIN) != 0;
+    pl->ext_proj = (flags & STAIR_PLAN_EXT_PROJECTION) != 0;
     const int ntok = prog_off[n];
     pl->nodes.assign(ntok, Node());
     pl->roots.assign(n, -1);
@@ -1103,16 +1127,16 @@ extern "C" int stair_plan_build_ragged(stair_ctx *ctx, int32_t n, const int32_t 
     pl->o_tok = take((int64_t)pl->rows_q * H, 64);
     pl->o_qfeat = take((int64_t)n * H, 64);
     pl->o_vhn = take((int64_t)pl->n_vid * H, 64);
-    pl->o_xpv = take((int64_t)pl->n_vid * T * 4 * H, 64);
-    pl->o_xpt = take((int64_t)pl->rows_q * 4 * H, 64);
-    pl->o_bias = take(2 * 4 * H, 64);
-    pl->o_wpack = take(2 * 2 * H * H, 64);       // 8*Hh*Hh floats per encoder
-    pl->o_wplanes = ctx->cfg.video_size % 32 == 0 ? take(4 * H * ctx->cfg.video_size, 64) : 0;   // video W_ih hi/lo planes (bf16 features): 2 x [4H, V] bf16
-    {   // the text encoder's input projection as a plane GEMM: W_ih and the token rows as zero-padded hi / lo planes (counted in floats)
-        const int64_t Ep = (ctx->cfg.text_size + 31) / 32 * 32;
-        pl->o_wplanes_t = take(4 * H * Ep, 64);
-        pl->o_xplanes_t = take((int64_t)std::max(pl->rows_q, 1) * Ep, 64);
+    {   // input projections of the two encoders: xproj (the gates of a training plan), bias sums, W_ih planes of the video encoder (bf16
+        // features: 2 x [4H, V] bf16), and the text encoder's projection as a plane GEMM (W_ih and the token rows as zero-padded hi / lo
+        // planes, counted in floats) -- one block with the layout of proj_layout, here or in the caller's buffer (ext_proj)
+        const ProjLayout L = proj_layout(ctx->cfg, pl->n_vid, T, pl->rows_q);
+        const int64_t base = pl->ext_proj ? 0 : take(L.total, 64);
+        pl->o_xpv = base + L.xpv; pl->o_xpt = base + L.xpt; pl->o_bias = base + L.bias;
+        pl->o_wplanes = ctx->cfg.video_size % 32 == 0 ? base + L.wplanes : 0;
+        pl->o_wplanes_t = base + L.wplanes_t; pl->o_xplanes_t = base + L.xplanes_t;
     }
+    pl->o_wpack = take(2 * 2 * H * H, 64);       // 8*Hh*Hh floats per encoder
     pl->coop_bytes = std::max(lstm_coop_ws_bytes(pl->n_vid), lstm_coop_ws_bytes(n));
     if (pl->train) pl->coop_bytes = std::max(pl->coop_bytes, std::max(lstm_coop_bwd_ws_bytes(pl->n_vid), lstm_coop_bwd_ws_bytes(n)));
     pl->o_coop = take((pl->coop_bytes + 3) / 4, 64);   // exchange slabs + flags of the cooperative recurrence (video encoder)
@@ -1562,6 +1586,58 @@ extern "C" int stair_plan_upload(stair_plan *pl, void *workspace, int64_t worksp
     return upload_index_image(pl, didx, static_cast<hipStream_t>(stream));
 }
 
+extern "C" int64_t stair_projection_floats(const stair_ctx *ctx, int32_t n_videos, int32_t T, int64_t question_rows) {
+    if (!ctx || n_videos < 0 || T < 0 || question_rows < 0) return -1;
+    return proj_layout(ctx->cfg, n_videos, T, question_rows).total;
+}
+
+// The input projections of both encoders (x W_ih^T + b_ih + b_hh for every clip frame and every token row) into a caller-owned buffer,
+// from the batch's inputs alone -- no plan needed, so the ~2 ms of GPU work they are at 2048 questions can be enqueued before the host
+// packs the programs and builds the plan (3-4 ms during which the GPU would otherwise idle whenever it is not already a step behind).
+extern "C" int stair_encoders_project(stair_ctx *ctx, const void *video, int32_t video_is_bf16, int32_t n_videos, int32_t T,
+                                      const float *question, int64_t question_rows, float *buf, int64_t buf_floats,
+                                      stair_stream stream) {
+    STAIR_CHECK(ctx && video && question && buf, "null argument");
+    STAIR_CHECK(n_videos >= 0 && T >= 1 && question_rows >= 0, "bad shape");
+    STAIR_CHECK((reinterpret_cast<uintptr_t>(buf) & 255) == 0, "projection buffer must be 256-byte aligned");
+    PolicyScope policy_scope(&ctx->policy);
+    const stair_config &g = ctx->cfg;
+    const ProjLayout L = proj_layout(g, n_videos, T, question_rows);
+    STAIR_CHECK(buf_floats >= L.total, "projection buffer too small (stair_projection_floats)");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Weights W;
+    if (resolve(ctx, W, false)) return 1;
+    const int H = g.hidden_size, Hh = H / 2, V = g.video_size, E = g.text_size;
+    stair_lstm_args a = {}, t = {};
+    a.x = static_cast<const float *>(video); a.ldx = V; a.rows = n_videos * T; a.n = n_videos; a.max_len = T; a.I = V; a.Hh = Hh;
+    if (video_is_bf16) {
+        STAIR_CHECK(V % 32 == 0, "bf16 clip features need video_size % 32 == 0");
+        a.x = nullptr; a.x_bf16 = video; a.wih_planes_ws = buf + L.wplanes;
+    }
+    for (int d = 0; d < 2; ++d) {
+        a.w_ih[d] = W.enc[0][4 * d]; a.b_ih[d] = W.enc[0][4 * d + 2]; a.b_hh[d] = W.enc[0][4 * d + 3];
+        t.w_ih[d] = W.enc[1][4 * d]; t.b_ih[d] = W.enc[1][4 * d + 2]; t.b_hh[d] = W.enc[1][4 * d + 3];
+    }
+    a.xproj_ws = buf + L.xpv; a.bias_ws = buf + L.bias;
+    t.x = question; t.ldx = E; t.rows = (int32_t)question_rows; t.n = 1; t.max_len = (int32_t)question_rows; t.I = E; t.Hh = Hh;
+    static const bool text_planes = [] { const char *e = getenv("STAIR_TEXT_PLANES"); return !(e && e[0] == '0'); }();
+    if (text_planes) { t.wih_planes_ws = buf + L.wplanes_t; t.x_planes_ws = buf + L.xplanes_t; }
+    t.xproj_ws = buf + L.xpt; t.bias_ws = buf + L.bias + 4 * H;
+    if (int rc = launch_lstm_project(a, s)) return rc;
+    return launch_lstm_project(t, s);
+}
+
+// The buffer of a STAIR_PLAN_EXT_PROJECTION plan (>= stair_projection_floats of the plan's batch shape); it must stay alive and untouched
+// until the last pass of the plan that reads it has run (a training plan's backward pass reads the gates there).
+extern "C" int stair_plan_set_projection(const stair_ctx *ctx, stair_plan *pl, float *buf, int64_t buf_floats) {
+    STAIR_CHECK(ctx && pl && buf, "null argument");
+    STAIR_CHECK(pl->ext_proj, "plan was not built with STAIR_PLAN_EXT_PROJECTION");
+    STAIR_CHECK((reinterpret_cast<uintptr_t>(buf) & 255) == 0, "projection buffer must be 256-byte aligned");
+    STAIR_CHECK(buf_floats >= proj_layout(pl->cfg, pl->n_vid, pl->T, pl->rows_q).total, "projection buffer too small (stair_projection_floats)");
+    pl->proj = buf;
+    return 0;
+}
+
 extern "C" int stair_plan_run(stair_ctx *ctx, stair_plan *pl, const float *video, const float *question,
                               void *workspace, int64_t workspace_bytes, float *logits, int32_t *argmax,
                               stair_stream stream) {
@@ -1616,10 +1692,15 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
     // ---- encoders (module_net.py:74-75) ------------------------------------------------------
     {
         stair_lstm_args a = {}, t = {};
+        // the projections' regions: in the workspace, or in the caller's buffer (STAIR_PLAN_EXT_PROJECTION), where STAIR_RUN_PROJECTED
+        // says they already hold this batch's projections (stair_encoders_project, enqueued before the plan was built)
+        STAIR_CHECK(!pl->ext_proj || pl->proj, "plan built with STAIR_PLAN_EXT_PROJECTION: call stair_plan_set_projection first");
+        STAIR_CHECK(!(flags & STAIR_RUN_PROJECTED) || pl->ext_proj, "STAIR_RUN_PROJECTED needs a STAIR_PLAN_EXT_PROJECTION plan");
+        float *pb = pl->ext_proj ? pl->proj : ws;
         a.x = video; a.ldx = V; a.rows = pl->n_vid * T; a.n = pl->n_vid; a.max_len = T; a.I = V; a.Hh = Hh;
         if (flags & STAIR_RUN_VIDEO_BF16) {
             STAIR_CHECK(V % 32 == 0, "bf16 clip features need video_size % 32 == 0");
-            a.x = nullptr; a.x_bf16 = video; a.wih_planes_ws = ws + pl->o_wplanes;
+            a.x = nullptr; a.x_bf16 = video; a.wih_planes_ws = pb + pl->o_wplanes;
         }
         a.seq_off = didx + pl->off_seqv;
         if (pl->ragged) a.seq_len = didx + pl->off_lenv;
@@ -1627,7 +1708,7 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
             a.w_ih[d] = W.enc[0][4 * d]; a.w_hh[d] = W.enc[0][4 * d + 1];
             a.b_ih[d] = W.enc[0][4 * d + 2]; a.b_hh[d] = W.enc[0][4 * d + 3];
         }
-        a.xproj_ws = ws + pl->o_xpv; a.bias_ws = ws + pl->o_bias; a.whh_pack_ws = ws + pl->o_wpack;
+        a.xproj_ws = pb + pl->o_xpv; a.bias_ws = pb + pl->o_bias; a.whh_pack_ws = ws + pl->o_wpack;
         a.out = map; a.ldo = H; a.h_n = ws + pl->o_vhn;
         a.coop_ws = ws + pl->o_coop; a.coop_ws_bytes = pl->coop_bytes; a.status = status;
         a.cbuf = pl->train ? ws + pl->o_cv : nullptr;
@@ -1639,16 +1720,20 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
             t.b_ih[d] = W.enc[1][4 * d + 2]; t.b_hh[d] = W.enc[1][4 * d + 3];
         }
         static const bool text_planes = [] { const char *e = getenv("STAIR_TEXT_PLANES"); return !(e && e[0] == '0'); }();
-        if (text_planes) { t.wih_planes_ws = ws + pl->o_wplanes_t; t.x_planes_ws = ws + pl->o_xplanes_t; }
-        t.xproj_ws = ws + pl->o_xpt; t.bias_ws = ws + pl->o_bias + 4 * H; t.whh_pack_ws = ws + pl->o_wpack + 2 * (int64_t)H * H;
+        if (text_planes) { t.wih_planes_ws = pb + pl->o_wplanes_t; t.x_planes_ws = pb + pl->o_xplanes_t; }
+        t.xproj_ws = pb + pl->o_xpt; t.bias_ws = pb + pl->o_bias + 4 * H; t.whh_pack_ws = ws + pl->o_wpack + 2 * (int64_t)H * H;
         t.out = tok; t.ldo = H; t.h_n = qfeat;
         t.coop_ws = ws + pl->o_coop2; t.coop_ws_bytes = pl->coop_bytes; t.status = status;
         t.cbuf = pl->train ? ws + pl->o_ct : nullptr;
 
         // both input projections, then the two recurrences -- in ONE launch while all their workgroups fit on the chip
         // (csrc/lstm_coop.hip, lstm_rec_coop_pair_kernel), else one after the other
-        RUN(launch_lstm_project(a, s));
-        RUN(launch_lstm_project(t, s));
+        if (flags & STAIR_RUN_PROJECTED) {
+            RUN(launch_lstm_zero_tail(a, s));        // (the part of the projection step that writes the plan's own arena)
+        } else {
+            RUN(launch_lstm_project(a, s));
+            RUN(launch_lstm_project(t, s));
+        }
         const int rc_pair = launch_lstm_rec_coop_pair(a, t, s);
         if (rc_pair > 0) return rc_pair;
         if (rc_pair < 0) {
@@ -2771,12 +2856,12 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
                 a.x = video; a.ldx = V; a.rows = pl->n_vid * T; a.max_len = T; a.I = V; a.seq_off = didx + pl->off_seqv;
                 if (pl->ragged) a.seq_len = didx + pl->off_lenv;
                 if (flags & STAIR_RUN_VIDEO_BF16) { a.x = nullptr; a.x_bf16 = video; }
-                a.gates = ws + pl->o_xpv; a.cbuf = ws + pl->o_cv; a.out = map; a.d_out = g_map; a.d_hn = nullptr;
+                a.gates = (pl->ext_proj ? pl->proj : ws) + pl->o_xpv; a.cbuf = ws + pl->o_cv; a.out = map; a.d_out = g_map; a.d_hn = nullptr;
                 a.whh_pack_ws = ws + pl->o_wpack;
                 a.coop_ws = ws + pl->o_coop;
             } else {
                 a.x = question; a.ldx = E; a.rows = pl->rows_q; a.max_len = pl->max_q; a.I = E; a.seq_off = didx + pl->off_seqt;
-                a.gates = ws + pl->o_xpt; a.cbuf = ws + pl->o_ct; a.out = ws + pl->o_tok; a.d_out = g_tok; a.d_hn = g_qfeat;
+                a.gates = (pl->ext_proj ? pl->proj : ws) + pl->o_xpt; a.cbuf = ws + pl->o_ct; a.out = ws + pl->o_tok; a.d_out = g_tok; a.d_hn = g_qfeat;
                 a.whh_pack_ws = ws + pl->o_wpack + 2 * (int64_t)H * H;
                 a.coop_ws = ws + pl->o_coop2;
             }
@@ -2914,13 +2999,17 @@ extern "C" int stair_plan_regions(stair_plan *pl, const stair_ctx *ctx, const ch
     add("tok", pl->o_tok, (int64_t)pl->rows_q * H);
     add("qfeat", pl->o_qfeat, n * H);
     add("vhn", pl->o_vhn, (int64_t)pl->n_vid * H);
+    if (!pl->ext_proj) {
     add("xpv", pl->o_xpv, (int64_t)pl->n_vid * T * 4 * H);
     add("xpt", pl->o_xpt, (int64_t)pl->rows_q * 4 * H);
-    add("bias", pl->o_bias, 8 * H);
+    }
+    if (!pl->ext_proj) add("bias", pl->o_bias, 8 * H);
     add("wpack", pl->o_wpack, 4 * H * H);
+    if (!pl->ext_proj) {
     if (ctx->cfg.video_size % 32 == 0) add("wplanes", pl->o_wplanes, 4 * H * ctx->cfg.video_size);
     add("wplanes_t", pl->o_wplanes_t, 4 * H * ((ctx->cfg.text_size + 31) / 32 * 32));
     add("xplanes_t", pl->o_xplanes_t, (int64_t)std::max(pl->rows_q, 1) * ((ctx->cfg.text_size + 31) / 32 * 32));
+    }
     add("coop", pl->o_coop, (pl->coop_bytes + 3) / 4);
     add("coop2", pl->o_coop2, (pl->coop_bytes + 3) / 4);
     add("splitk", pl->o_splitk, kSplitKFloats);

@@ -16,6 +16,7 @@ torch is plumbing here (device memory, streams, Parameter containers); the arith
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 
 import numpy as np
@@ -26,7 +27,8 @@ from . import frontend, ops, spec
 from ._lib import PlanInfo, StairConfig, StairError, check, lib
 
 VAL_STR, VAL_VEC, VAL_MAP, VAL_ATT, VAL_FRAME, VAL_PAIR = range(6)
-RUN_INDEX_RESIDENT, RUN_VIDEO_BF16 = 1, 2          # stair_plan_run_flags / stair_plan_backward flags (include/stair_hip.h)
+RUN_INDEX_RESIDENT, RUN_VIDEO_BF16, RUN_PROJECTED = 1, 2, 4          # stair_plan_run_flags / stair_plan_backward flags (include/stair_hip.h)
+PLAN_EXT_PROJECTION = 4                                              # stair_plan_build* flag
 
 
 class L2Normalize(nn.Module):
@@ -242,6 +244,10 @@ class CapturedPlan:
         model, info = res._model, res.info
         dev = res._video.device
         self._ws = torch.empty((info.workspace_bytes + 3) // 4, dtype=torch.float32, device=dev)
+        self._proj = None
+        if getattr(res, '_proj', None) is not None:       # the plan keeps its projections outside the workspace: a private buffer too
+            self._proj = torch.empty(res._proj.numel(), dtype=torch.float32, device=dev)     # (the replay recomputes them: no RUN_PROJECTED)
+            check(lib.stair_plan_set_projection(model._ctx, res._plan, C.c_void_p(self._proj.data_ptr()), self._proj.numel()))
         self.logits, self.pred = res.logits, res.pred
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -314,6 +320,9 @@ class VideoNMN(nn.Module):
         self._bound = {}
         self._gbound = {}
         self._ws = None
+        self._proj = None
+        # run_programs: enqueue the encoders' input projections before the plan is built (STAIR_EARLY_PROJECTION=0: inside the plan's pass)
+        self.early_projection = os.environ.get('STAIR_EARLY_PROJECTION', '1') != '0'
         self._programs = frontend.ProgramCache()
 
     def __del__(self):
@@ -355,6 +364,12 @@ class VideoNMN(nn.Module):
             if self._gbound.get(name) != g.data_ptr():
                 check(lib.stair_ctx_set_grad(self._ctx, i, C.c_void_p(g.data_ptr()), g.numel()))
                 self._gbound[name] = g.data_ptr()
+
+    def _projection(self, nfloats, device):
+        """The shared buffer of the encoders' input projections (same lifetime rules as the shared workspace: the next batch rewrites it)."""
+        if self._proj is None or self._proj.numel() < nfloats or self._proj.device != device:
+            self._proj = torch.empty(int(nfloats * 1.25), dtype=torch.float32, device=device)
+        return self._proj
 
     def _workspace(self, nbytes, device):
         n = (nbytes + 3) // 4
@@ -403,6 +418,15 @@ class VideoNMN(nn.Module):
             raise ValueError('bf16 clip features need video_size % 32 == 0')
         T = video.shape[1]
         self._bind_weights()
+        # The encoders' input projections need the inputs only: enqueue them BEFORE packing the programs and building the plan (3-4 ms
+        # of host work at 2048 questions), so the device is busy meanwhile (stair_encoders_project; results bit-identical)
+        proj = None
+        if self.early_projection and n > 0 and video.shape[0] > 0 and question.shape[0] > 0:
+            nf = int(lib.stair_projection_floats(self._ctx, video.shape[0], T, question.shape[0]))
+            proj = self._projection(nf, video.device)
+            check(lib.stair_encoders_project(self._ctx, C.c_void_p(video.data_ptr()), 1 if video.dtype == torch.bfloat16 else 0,
+                                             video.shape[0], T, C.c_void_p(question.data_ptr()), question.shape[0],
+                                             C.c_void_p(proj.data_ptr()), proj.numel(), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         cache = self._programs
         compiled = [cache.get(p, sp) for p, sp in zip(programs, spans)]       # packed once per distinct (program, spans)
         prog_off, tokens, lo, hi, q_off = frontend.pack_batch(compiled, q_lens)
@@ -422,7 +446,8 @@ class VideoNMN(nn.Module):
                 video_len = None
         check(lib.stair_plan_build_ragged(self._ctx, n, ip(prog_off), ip(tokens), ip(lo), ip(hi), ip(q_off), video.shape[0],
                                           ip(video_index) if video_index is not None else None,
-                                          ip(video_len) if video_len is not None else None, T, (1 if train else 0) | (0 if cse and not drop_on else 2),
+                                          ip(video_len) if video_len is not None else None, T,
+                                          (1 if train else 0) | (0 if cse and not drop_on else 2) | (PLAN_EXT_PROJECTION if proj is not None else 0),
                                           C.byref(plan)))
         try:
             info = PlanInfo()
@@ -432,6 +457,8 @@ class VideoNMN(nn.Module):
                     raise ValueError('dropout is a training-mode operation (train=True)')
                 check(lib.stair_plan_set_dropout(plan, C.c_float(float(dropout[0])), C.c_uint64(int(dropout[1]) & (2 ** 64 - 1))))
             ws = self._workspace(info.workspace_bytes, video.device)
+            if proj is not None:
+                check(lib.stair_plan_set_projection(self._ctx, plan, C.c_void_p(proj.data_ptr()), proj.numel()))
             A = self.config['answer_vocab_length']
             logits = torch.empty(n, A, dtype=torch.float32, device=video.device)
             pred = torch.empty(n, dtype=torch.int32, device=video.device)
@@ -439,13 +466,15 @@ class VideoNMN(nn.Module):
             lib.stair_plan_destroy(plan)
             raise
         res = BatchResult(self, plan, info, ws, logits, pred, prog_off, programs, video, question)     # owns the plan from here on
+        res._proj = proj
         if video_len is not None:       # frames of every question's clip (the loss driver masks its criteria with them)
             res.question_frames = video_len[video_index] if video_index is not None else video_len
         if before_run is not None:
             before_run(res)
         check(lib.stair_plan_run_flags(self._ctx, plan, C.c_void_p(video.data_ptr()), C.c_void_p(question.data_ptr()),
                                        C.c_void_p(ws.data_ptr()), ws.numel() * 4, C.c_void_p(logits.data_ptr()),
-                                       C.c_void_p(pred.data_ptr()), RUN_VIDEO_BF16 if video.dtype == torch.bfloat16 else 0,
+                                       C.c_void_p(pred.data_ptr()),
+                                       (RUN_VIDEO_BF16 if video.dtype == torch.bfloat16 else 0) | (RUN_PROJECTED if proj is not None else 0),
                                        C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         if train:       # a training plan keeps its logits inside the workspace for the backward pass; hand the caller a copy
             res.logits = ws[info.logits_off: info.logits_off + n * A].view(n, A).clone()    # (n x A floats) that survives the next step

@@ -26,7 +26,7 @@ def test_header_symbols_are_exported_and_bound():
     assert declared == bound, (declared ^ bound)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.stair_abi_version() == 5
+    assert lib.stair_abi_version() == 6
 
 
 def _ctx(config):
@@ -205,6 +205,57 @@ def test_workspace_regions_are_disjoint(train):
     check(lib.stair_plan_get_info(plan, C.byref(info)))
     assert regs[-1][2] == 'END' and regs[-1][0] * 4 == info.workspace_bytes
     lib.stair_plan_destroy(plan)
+    lib.stair_ctx_destroy(h)
+
+
+@pytest.mark.parametrize('train', [False, True])
+def test_external_projection_plan_leaves_the_projection_regions_out(train):
+    """STAIR_PLAN_EXT_PROJECTION (ABI 6): the encoders' input-projection regions move to a caller-owned buffer whose size depends on the
+    batch shape alone (stair_projection_floats) -- the workspace shrinks by exactly that much, the remaining regions stay disjoint, and a
+    buffer that is too small, or a plan built without the flag, is refused."""
+    config = dict(spec.DEFAULT_CONFIG)
+    qs = [synth.make_question(config, 0, i, form=name, with_video=False) for i, name in enumerate(sorted(synth.CORPUS))]
+    programs = [q['nmn_program_list'] for q in qs]
+    h = _ctx(config)
+    enc = [np.asarray(spec.encode_program(p), dtype=np.int32) for p in programs]
+    n = len(qs)
+    prog_off = np.zeros(n + 1, np.int32); np.cumsum([len(e) for e in enc], out=prog_off[1:])
+    tokens = np.concatenate(enc)
+    lo = np.zeros(len(tokens), np.int32); hi = np.zeros(len(tokens), np.int32)
+    for q in range(n):
+        for i, c in enumerate(enc[q]):
+            if c == spec.TOK_SPAN:
+                lo[prog_off[q] + i], hi[prog_off[q] + i] = qs[q]['prog_str_to_question_tokens'][i]
+    q_off = np.zeros(n + 1, np.int32); np.cumsum([q['question'].shape[0] for q in qs], out=q_off[1:])
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    sizes = {}
+    for ext in (0, 4):
+        plan = C.c_void_p()
+        check(lib.stair_plan_build(h, n, ip(prog_off), ip(tokens), ip(lo), ip(hi), ip(q_off), 64, (1 if train else 0) | ext, C.byref(plan)))
+        info = PlanInfo()
+        check(lib.stair_plan_get_info(plan, C.byref(info)))
+        sizes[ext] = info.workspace_bytes
+        cap = 8192
+        nm = (C.c_char_p * cap)(); beg = (C.c_int64 * cap)(); end = (C.c_int64 * cap)()
+        k = lib.stair_plan_regions(plan, h, nm, beg, end, cap)
+        regs = sorted((beg[i], end[i], nm[i].decode()) for i in range(k))
+        for a, b in zip(regs, regs[1:]):
+            assert a[1] <= b[0], ('overlap', a, b)
+        assert ('xpv' in {r[2] for r in regs}) == (ext == 0)
+        nf = lib.stair_projection_floats(h, n, 64, int(q_off[-1]))
+        assert nf > n * 64 * 4 * config['hidden_size']
+        dummy = C.c_void_p(256)               # an aligned non-null address: the setter only records it (nothing is launched here)
+        if ext:
+            with pytest.raises(StairError, match='too small'):
+                check(lib.stair_plan_set_projection(h, plan, dummy, nf - 1))
+            check(lib.stair_plan_set_projection(h, plan, dummy, nf))
+        else:
+            with pytest.raises(StairError, match='EXT_PROJECTION'):
+                check(lib.stair_plan_set_projection(h, plan, dummy, nf))
+        lib.stair_plan_destroy(plan)
+    saved = sizes[0] - sizes[4] - 4 * lib.stair_projection_floats(h, n, 64, int(q_off[-1]))
+    assert 0 <= saved < 16384            # (alignment of the regions laid out behind them)
+    assert lib.stair_projection_floats(h, -1, 64, 10) == -1
     lib.stair_ctx_destroy(h)
 
 
