@@ -664,6 +664,7 @@ def main():
             'dtype': ('%s clip features; f32 storage/accumulate elsewhere; products on bf16 MFMA as split hi/lo pairs (~4e-6 rel. error): '
                       '2 per operand pair where an operand is the stored bf16 clip, else 3' % args.features),
             'config': {'workload': mode_txt, 'questions_per_gpu_per_step': B, 'mode': args.mode, 'dropout': args.dropout,
+                       'encoder_projections_ahead_of_plan': bool(model.early_projection),
                        'parallelism': ('dp%d (questions sharded round-robin, one flat fp32 gradient all-reduce per step, touched mask in the same bucket)'
                                        if args.mode == 'train' else 'dp%d (questions sharded, no collective)') % world},
             'roofline': {'bound': 'mfma', 'kernel': '%s, M=%d N=%d K=%d' % (kname, Mg, Ng, Kg),
