@@ -171,12 +171,26 @@ __global__ void loss_contrastive_kernel(const float *vec, float *d_vec, const in
     }
     __syncthreads();
     const float inv = 1.0f / s_nrm;
+    float xr[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xr[j] = 64 * j + lane < H ? x[64 * j + lane] : 0.f;
+    // (a class that is absent from the item's window is never multiplied: its logit is -inf whatever the product, its softmax term
+    // and its gradient term are exactly zero -- with a table of 214 classes and windows of 32 questions four classes in five are absent)
     for (int c = wave; c < C; c += kWavesPerBlock) {
+        if (mask && !(mask[c] > 0.f)) {             // wave-uniform
+            if (lane == 0) prob[c] = -INFINITY;
+            continue;
+        }
         const float *g = G + (int64_t)(c0 + c) * H;
+        float gr[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gr[j] = 64 * j + lane < H ? g[64 * j + lane] : 0.f;       // the row's loads together (H <= 512)
         float d = 0.f;
-        for (int h = lane; h < H; h += 64) d += g[h] * x[h];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (64 * j + lane < H) d += gr[j] * xr[j];
         d = wave_sum(d);
-        if (lane == 0) prob[c] = (mask && !(mask[c] > 0.f)) ? -INFINITY : d * inv;
+        if (lane == 0) prob[c] = d * inv;
     }
     __syncthreads();
     if (wave == 0) {
@@ -194,7 +208,10 @@ __global__ void loss_contrastive_kernel(const float *vec, float *d_vec, const in
     float part = 0.f;
     for (int h = threadIdx.x; h < H; h += blockDim.x) {
         float d = 0.f;
-        for (int c = 0; c < C; ++c) d += prob[c] * G[(int64_t)(c0 + c) * H + h];
+        for (int c = 0; c < C; ++c) {
+            const float pc = prob[c];               // the same LDS word for every thread: a uniform branch
+            if (pc != 0.f) d += pc * G[(int64_t)(c0 + c) * H + h];      // (skipping an exact zero term leaves the sum bit-identical)
+        }
         dpred[h] = d;
         part += d * x[h] * inv;
     }
@@ -214,6 +231,7 @@ int launch_loss_contrastive(const float *vec, float *d_vec, const int32_t *slot,
                             const int32_t *win_cnt, const float *G, int n, int H, int max_classes, float scale, float *loss,
                             hipStream_t s) {
     if (n == 0) return 0;
+    STAIR_CHECK(H <= 512, "hidden size above 512");
     const LossGroups Gr = take_groups(n);
     hipLaunchKernelGGL(loss_contrastive_kernel, dim3(Gr.n_groups ? Gr.n_groups : n), dim3(kBlock), (size_t)(max_classes + H) * sizeof(float), s, vec, d_vec,
                        slot, pos, win_start, win_cnt, G, n, H, scale, loss, (const float *)nullptr, (const int32_t *)nullptr, 0, Gr.order, Gr.grp_off);
@@ -223,6 +241,7 @@ int launch_loss_contrastive(const float *vec, float *d_vec, const int32_t *slot,
 int launch_loss_contrastive_table(const float *vec, float *d_vec, const int32_t *slot, const int32_t *pos_class, const int32_t *win_row,
                                   const float *presence, const float *reps, int n, int n_cls, int H, float scale, float *loss, hipStream_t s) {
     if (n == 0) return 0;
+    STAIR_CHECK(H <= 512, "hidden size above 512");
     STAIR_CHECK(n_cls > 0 && (size_t)(n_cls + H) * sizeof(float) <= 60 * 1024, "class table too large for the loss kernel's LDS (n_cls + H floats)");
     const LossGroups Gr = take_groups(n);
     hipLaunchKernelGGL(loss_contrastive_kernel, dim3(Gr.n_groups ? Gr.n_groups : n), dim3(kBlock), (size_t)(n_cls + H) * sizeof(float), s, vec, d_vec,
