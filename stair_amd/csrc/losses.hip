@@ -153,14 +153,16 @@ __global__ void loss_contrastive_kernel(const float *vec, float *d_vec, const in
                                         const int32_t *win_start, const int32_t *win_cnt, const float *G, int n, int H,
                                         float scale, float *loss, const float *presence, const int32_t *win_row, int n_cls,
                                         const int32_t *order, const int32_t *grp_off) {
-    extern __shared__ float sm[];      // [C] logits -> softmax probs, then [H] dpred
+    extern __shared__ float sm[];      // [C] logits -> softmax probs, [H] dpred, [C] classes with a non-zero gradient term, [C] their coefficients
     __shared__ float s_nrm, s_part[kWavesPerBlock];
+    __shared__ int s_nact;
   const int q0 = grp_off ? grp_off[blockIdx.x] : blockIdx.x, q1 = grp_off ? grp_off[blockIdx.x + 1] : blockIdx.x + 1;
   for (int q = q0; q < q1; ++q) {
     const int i = order ? order[q] : q;
     const int c0 = presence ? 0 : win_start[i], C = presence ? n_cls : win_cnt[i];
     const float *mask = presence ? presence + (int64_t)win_row[i] * n_cls : nullptr;
-    float *prob = sm, *dpred = sm + C;
+    float *prob = sm, *dpred = sm + C, *acoef = sm + C + H + C;
+    int *act = reinterpret_cast<int *>(sm + C + H);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float *x = vec + (int64_t)slot[i] * H;
     if (wave == 0) {
@@ -202,16 +204,34 @@ __global__ void loss_contrastive_kernel(const float *vec, float *d_vec, const in
         sum = wave_sum(sum);
         const int p = pos[i] - c0;
         if (lane == 0) loss[i] = logf(sum) + m - prob[p];
-        for (int c = lane; c < C; c += 64) prob[c] = scale * (expf(prob[c] - m) / sum - (c == p ? 1.f : 0.f));   // dlogits
+        // dlogits; the classes whose term is not an exact zero, compacted in class order (skipping a zero term leaves every sum below
+        // bit-identical; a list instead of a test inside the loop lets the loads of several classes be in flight together)
+        int base = 0;
+        for (int cb = 0; cb < C; cb += 64) {
+            const int c = cb + lane;
+            const float dl = c < C ? scale * (expf(prob[c] - m) / sum - (c == p ? 1.f : 0.f)) : 0.f;
+            const bool on = dl != 0.f;
+            const unsigned long long bal = __ballot(on);
+            if (on) {
+                const int at = base + __popcll(bal & ((1ull << lane) - 1ull));
+                act[at] = c; acoef[at] = dl;
+            }
+            base += __popcll(bal);
+        }
+        if (lane == 0) s_nact = base;
     }
     __syncthreads();
+    const int nact = s_nact;
     float part = 0.f;
     for (int h = threadIdx.x; h < H; h += blockDim.x) {
+        const float *gh = G + (int64_t)c0 * H + h;
         float d = 0.f;
-        for (int c = 0; c < C; ++c) {
-            const float pc = prob[c];               // the same LDS word for every thread: a uniform branch
-            if (pc != 0.f) d += pc * G[(int64_t)(c0 + c) * H + h];      // (skipping an exact zero term leaves the sum bit-identical)
+        int k = 0;
+        for (; k + 4 <= nact; k += 4) {
+            const float g0 = gh[(int64_t)act[k] * H], g1 = gh[(int64_t)act[k + 1] * H], g2 = gh[(int64_t)act[k + 2] * H], g3 = gh[(int64_t)act[k + 3] * H];
+            d += acoef[k] * g0; d += acoef[k + 1] * g1; d += acoef[k + 2] * g2; d += acoef[k + 3] * g3;
         }
+        for (; k < nact; ++k) d += acoef[k] * gh[(int64_t)act[k] * H];
         dpred[h] = d;
         part += d * x[h] * inv;
     }
@@ -233,7 +253,7 @@ int launch_loss_contrastive(const float *vec, float *d_vec, const int32_t *slot,
     if (n == 0) return 0;
     STAIR_CHECK(H <= 512, "hidden size above 512");
     const LossGroups Gr = take_groups(n);
-    hipLaunchKernelGGL(loss_contrastive_kernel, dim3(Gr.n_groups ? Gr.n_groups : n), dim3(kBlock), (size_t)(max_classes + H) * sizeof(float), s, vec, d_vec,
+    hipLaunchKernelGGL(loss_contrastive_kernel, dim3(Gr.n_groups ? Gr.n_groups : n), dim3(kBlock), (size_t)(3 * max_classes + H) * sizeof(float), s, vec, d_vec,
                        slot, pos, win_start, win_cnt, G, n, H, scale, loss, (const float *)nullptr, (const int32_t *)nullptr, 0, Gr.order, Gr.grp_off);
     STAIR_LAUNCH_CHECK();
     return 0;
@@ -242,9 +262,9 @@ int launch_loss_contrastive_table(const float *vec, float *d_vec, const int32_t 
                                   const float *presence, const float *reps, int n, int n_cls, int H, float scale, float *loss, hipStream_t s) {
     if (n == 0) return 0;
     STAIR_CHECK(H <= 512, "hidden size above 512");
-    STAIR_CHECK(n_cls > 0 && (size_t)(n_cls + H) * sizeof(float) <= 60 * 1024, "class table too large for the loss kernel's LDS (n_cls + H floats)");
+    STAIR_CHECK(n_cls > 0 && (size_t)(3 * n_cls + H) * sizeof(float) <= 60 * 1024, "class table too large for the loss kernel's LDS (3 n_cls + H floats)");
     const LossGroups Gr = take_groups(n);
-    hipLaunchKernelGGL(loss_contrastive_kernel, dim3(Gr.n_groups ? Gr.n_groups : n), dim3(kBlock), (size_t)(n_cls + H) * sizeof(float), s, vec, d_vec,
+    hipLaunchKernelGGL(loss_contrastive_kernel, dim3(Gr.n_groups ? Gr.n_groups : n), dim3(kBlock), (size_t)(3 * n_cls + H) * sizeof(float), s, vec, d_vec,
                        slot, pos_class, (const int32_t *)nullptr, (const int32_t *)nullptr, reps, n, H, scale, loss, presence, win_row, n_cls, Gr.order, Gr.grp_off);
     STAIR_LAUNCH_CHECK();
     return 0;
