@@ -363,6 +363,12 @@ typedef struct stair_tile_mlp_args {
      *   act_bits[l]      what a chain uses instead of act_mask[l] (act[l] == 3, act_mask[l] == NULL);  in_bits instead of in_mask
      *                    (both indexed by the instance number i, never through in_mask_idx) */
     unsigned long long *save_bits[3]; const unsigned long long *act_bits[3]; const unsigned long long *in_bits;
+    /* nn.Dropout behind layer l's activation (the `D` positions of modules.py), forward launches, ABI 6: drop_site[l] = 1 + the site of
+     * stair_dropout_fwd (0: none); element e = (instance * T + row) * H + column of the launch draws the same bit as stair_dropout_fwd on
+     * the [cnt, T, H] rows would, so the fused and the launch-per-layer forms of a plan drop the same elements.  One probability and seed
+     * per LAUNCH (the first bucket's are taken).  The saved activations / bits are those AFTER the dropout: a backward chain needs only the
+     * factor 1 / (1 - p) beside its relu' masks (act_scale, in_scale). */
+    uint32_t drop_site[3]; float drop_p; uint64_t drop_seed;
 } stair_tile_mlp_args;
 int stair_tile_mlp_fwd(const stair_tile_mlp_args *args, stair_stream stream);
 /* ---- grouped vector-level products (csrc/vec_group.hip) ------------------------------------------------------------------

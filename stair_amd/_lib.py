@@ -94,7 +94,8 @@ class TileMlpArgs(C.Structure):
                 ('ln_bwd', C.c_int32), ('dgamma', C.c_void_p), ('dbeta', C.c_void_p),
                 ('adj_feat', C.c_void_p), ('adj_feat_gstride', C.c_int64), ('adj_feat_idx', C.c_void_p),
                 ('adj_rs', C.c_void_p), ('adj_rs_idx', C.c_void_p), ('adj_drs', C.c_void_p), ('acc_exclusive', C.c_int32),
-                ('save_bits', C.c_void_p * 3), ('act_bits', C.c_void_p * 3), ('in_bits', C.c_void_p)]
+                ('save_bits', C.c_void_p * 3), ('act_bits', C.c_void_p * 3), ('in_bits', C.c_void_p),
+                ('drop_site', C.c_uint32 * 3), ('drop_p', C.c_float), ('drop_seed', C.c_uint64)]
 
 
 class VecProblem(C.Structure):

@@ -1534,6 +1534,10 @@ VgProblem vg_fwd(int rows, const float *a, const int32_t *ia, int64_t lda, const
     return p;
 }
 // STAIR_VEC_GROUP=0 keeps the per-module pack -> GEMM -> reduction sequences (and the tile form for large buckets)
+static bool tile_dropout_on() {
+    static const bool on = [] { const char *e = getenv("STAIR_TILE_DROPOUT"); return !(e && e[0] == '0'); }();
+    return on;
+}
 bool vec_group_on() {
     static const bool on = [] { const char *e = getenv("STAIR_VEC_GROUP"); return !(e && e[0] == '0'); }();
     return policy_or(STAIR_OPT_VEC_GROUP, on ? 1 : 0) != 0;
@@ -1743,7 +1747,9 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
     }
 
     // ---- fused per-clip tile operators (csrc/tile_mlp.hip): weights of the buckets that run fused, as fragment-order planes ----
-    const bool fused = pl->o_wfrag > 0 && tile_mlp_usable(H, T) && dp <= 0.0f && tile_policy(pl);
+    // (under dropout the map-level tile operators stay fused -- the kernel draws stair_dropout_fwd's bits in its epilogues -- while the
+    // vector-level modules and the decoder take their launch-per-layer forms; STAIR_TILE_DROPOUT=0: everything unfused, as before ABI 6)
+    const bool fused = pl->o_wfrag > 0 && tile_mlp_usable(H, T) && (dp <= 0.0f || tile_dropout_on()) && tile_policy(pl);
     pl->bits_written = fused && pl->train;
     auto WF = [&](int slot) { return static_cast<const void *>(ws + pl->o_wfrag + (int64_t)slot * H * H); };
     if (fused) {
@@ -1777,7 +1783,7 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
     // The row-wise Linear layers of a level -- vector-level modules, Filter's dense layer, Localize's keyword rows, the decoder -- as
     // problems of ONE launch before the level's tile operators (first layers, keyword rows) and ONE after them (second layers, the
     // dense layers on the pooled rows): csrc/vec_group.hip.  Takes precedence over the tile form of the vector-level modules.
-    const bool grouped = fused && vec_group_usable(H) && vec_group_on();
+    const bool grouped = fused && dp <= 0.0f && vec_group_usable(H) && vec_group_on();
     std::vector<VgProblem> vg1, vg2;
     // [512 x 512] blocks of a row-wise weight as planes: slot + (output block) * nseg + (input segment); blocks of a [N, nseg * 512] matrix
     struct VgW { int slot, nblk, nseg; const Lin *l; int op; };
@@ -1800,8 +1806,8 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
                     }
         if (cnt_w) RUN(launch_pack_wfrag_many(src, dst, cnt_w, H, H, s, false, ld));
     }
-    auto fused_vec_for = [&](const Bucket &b) { return !grouped && fused && vec_min > 0 && b.cnt >= vec_min; };
-    const bool fused_vec = !grouped && fused && vec_min > 0;
+    auto fused_vec_for = [&](const Bucket &b) { return !grouped && fused && dp <= 0.0f && vec_min > 0 && b.cnt >= vec_min; };
+    const bool fused_vec = !grouped && fused && dp <= 0.0f && vec_min > 0;
     if (fused_vec) {
         struct { int slot, nseg; const Lin *l; int op; } vw[7] = {{WV_CMP, 2, &W.compare, STAIR_OP_COMPARE}, {WV_EQ, 2, &W.equals, STAIR_OP_EQUALS},
             {WV_XOR, 3, &W.xorl, STAIR_OP_XOR}, {WV_TA0, 2, &W.ta0, STAIR_OP_TOACTION}, {WV_TA3, 1, &W.ta3, STAIR_OP_TOACTION},
@@ -1834,10 +1840,12 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
         a.X = map; a.x_gstride = TH; a.x_idx = x_idx; a.cnt = cnt_; a.T = T; a.H = H; a.ln_eps = 1e-5f;
         return a;
     };
-    auto tile_layer = [&](stair_tile_mlp_args &a, int slot, const Lin &l, int act, float *save, int64_t bits = -1) {
+    // drop_pos: the layer's activation is followed by nn.Dropout, position `drop_pos` of the bucket (the `pos` of drop() below)
+    auto tile_layer = [&](stair_tile_mlp_args &a, int slot, const Lin &l, int act, float *save, int64_t bits = -1, int drop_pos = -1) {
         const int i = a.n_layers++;
         a.W[i] = WF(slot); a.bias[i] = l.b; a.act[i] = act; a.save[i] = pl->train ? save : nullptr;
         a.save_bits[i] = pl->train && bits >= 0 && act == 1 ? reinterpret_cast<unsigned long long *>(ws + bits) : nullptr;
+        if (dp > 0.0f && drop_pos >= 0) { a.drop_site[i] = (uint32_t)(bucket_no * 8 + drop_pos) + 1u; a.drop_p = dp; a.drop_seed = pl->drop_seed; }
     };
 
     // ---- program levels ----------------------------------------------------------------------
@@ -1961,8 +1969,8 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
                 if (fused) {            // both layers and the sum over frames on the tile
                     if (phase == 1) {
                         stair_tile_mlp_args a = tile_args(I0, c);
-                        tile_layer(a, WF_F0 + v, W.f0[v], 1, tmpA, b.bitA);
-                        tile_layer(a, WF_F3 + v, W.f3[v], 1, tmpB, b.bitB);
+                        tile_layer(a, WF_F0 + v, W.f0[v], 1, tmpA, b.bitA, 0);
+                        tile_layer(a, WF_F3 + v, W.f3[v], 1, tmpB, b.bitB, 1);
                         a.tail = STAIR_TILE_SUM_ROWS; a.out = cat; a.out_gstride = H; a.len = LEN;
                         tile_queue.push_back(a);
                         if (grouped) {
@@ -1988,9 +1996,9 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
                     if (phase != 1) break;
                     if (v == 0) RUN(launch_vecdot(vec, I1, W.ffatt.w + H, extra, c, H, s));
                     stair_tile_mlp_args a = tile_args(I0, c);
-                    tile_layer(a, WF_FF0 + v, W.ff0[v], 1, tmpA, b.bitA);
-                    tile_layer(a, WF_FF3 + v, W.ff3[v], 1, tmpB, b.bitB);
-                    tile_layer(a, WF_FFD, W.ffdense, 1, nullptr, b.bitC);
+                    tile_layer(a, WF_FF0 + v, W.ff0[v], 1, tmpA, b.bitA, 0);
+                    tile_layer(a, WF_FF3 + v, W.ff3[v], 1, tmpB, b.bitB, 1);
+                    tile_layer(a, WF_FFD, W.ffdense, 1, nullptr, b.bitC, 2);
                     if (v == 0) { a.mid_rowdot = 1; a.vw = W.ffatt.w; a.vb = W.ffatt.b; a.extra = extra; a.rs_out = rsb; }
                     a.tail = STAIR_TILE_STORE; a.out = map; a.out_gstride = TH; a.out_idx = I2;
                     tile_queue.push_back(a);
@@ -2013,9 +2021,10 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
             }
             case STAIR_OP_HASITEM:      // modules.py:123-138
                 if (fused) {
+                    if (phase == 2) RUN(drop(att, T, I1, c, T, 1));        // (the D behind HasItem's sigmoid: after the level's tile launch)
                     if (phase != 1) break;
                     stair_tile_mlp_args a = tile_args(I0, c);
-                    tile_layer(a, WF_HI0, W.hi0, 1, tmpA, b.bitA);
+                    tile_layer(a, WF_HI0, W.hi0, 1, tmpA, b.bitA, 0);
                     a.tail = STAIR_TILE_ROWDOT_SIGMOID; a.vw = W.hi3.w; a.vb = W.hi3.b; a.out = att; a.out_gstride = T; a.out_idx = I1;
                     tile_queue.push_back(a);
                     break;
@@ -2033,7 +2042,7 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
                         vg1.back().wplanes = WF(WV_LK);
                     } else RUN(dense(s, vec, H, H, I2, W.lk, H, kbuf, H, H, nullptr, b.nrows, 1, H, H, 0));
                     stair_tile_mlp_args a = tile_args(I0, c);
-                    tile_layer(a, WF_LV0, W.lv0, 1, tmpA, b.bitA);
+                    tile_layer(a, WF_LV0, W.lv0, 1, tmpA, b.bitA, 0);
                     tile_layer(a, WF_LV3, W.lv3, 0, tmpB);
                     a.tail = STAIR_TILE_COSINE; a.kb = kbuf; a.pair_first = I4; a.pair_cnt = I5; a.att_idx = I3; a.att = att;
                     tile_queue.push_back(a);
@@ -2051,7 +2060,7 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
             case STAIR_OP_SUPERLATIVE:  // modules.py:220-248 (shares Localize's weights, module_net.py:31-32)
                 if (fused && phase == 1) {
                     stair_tile_mlp_args a = tile_args(I0, c);
-                    tile_layer(a, WF_LV0, W.lv0, 1, tmpA, b.bitA);
+                    tile_layer(a, WF_LV0, W.lv0, 1, tmpA, b.bitA, 0);
                     tile_layer(a, WF_LV3, W.lv3, 0, nullptr);
                     a.tail = STAIR_TILE_STORE; a.out = tmpB; a.out_gstride = TH;
                     tile_queue.push_back(a);
@@ -2079,7 +2088,7 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
                 if (fused) {            // r_t feat_t -> Lin . ReLU -> LayerNorm on the tile
                     if (phase != 1) break;
                     stair_tile_mlp_args a = tile_args(I0, c);
-                    tile_layer(a, WF_TD, W.tdense, 1, tmpA);
+                    tile_layer(a, WF_TD, W.tdense, 1, tmpA, -1, 0);
                     a.row_scale = att; a.rs_idx = I3;
                     a.tail = STAIR_TILE_LAYERNORM; a.gamma = W.ln_w; a.beta = W.ln_b; a.out = map; a.out_gstride = TH; a.out_idx = I4;
                     tile_queue.push_back(a);
@@ -2394,11 +2403,11 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
         RUN(launch_transpose_many(tb, tiles, s));       // one launch for all 31 images
     }
     // ---- backward chains of the fused tile operators (csrc/tile_mlp.hip): dX = (dZ2 W2 * relu'(Z1)) W1 stays on the tile ----
-    const bool fused = pl->o_wfragT > 0 && tile_mlp_usable(H, T) && pl->drop_p <= 0.0f && tile_policy(pl, true);
+    const bool fused = pl->o_wfragT > 0 && tile_mlp_usable(H, T) && (pl->drop_p <= 0.0f || tile_dropout_on()) && tile_policy(pl, true);
     auto WFT = [&](int slot) { return static_cast<const void *>(ws + pl->o_wfragT + (int64_t)slot * H * H); };
     // the row-wise layers' backward as grouped launches (csrc/vec_group.hip): per level one launch for everything that starts from a
     // gradient row of the arena (relu' on load, kept as dZ), one for the second stage of the two-layer modules
-    const bool grouped = fused && vec_group_usable(H) && vec_group_on();
+    const bool grouped = fused && pl->drop_p <= 0.0f && vec_group_usable(H) && vec_group_on();
     std::vector<VgProblem> bvg1, bvg2;
     if (grouped) {      // planes of the transposed images (already there as fp32): block (j, s) of W^T = slot + j * nin + s
         struct VgWT { int slot, nblk, nin; const Lin *l; int op; };        // W^T is [nblk * 512, nin * 512]

@@ -595,12 +595,7 @@ int launch_l2norm(const float *x, float *out, int n, int H, hipStream_t s) {
 // element), i.e. a pure function: the backward pass needs no stored mask (a dropped element is an exact zero of the
 // saved activation) and a step can be replayed.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t drop_hash(uint64_t seed, uint32_t site, uint64_t e) {
-    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (e + 1) + ((uint64_t)site << 40);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return (uint32_t)((z ^ (z >> 31)) >> 40);          // 24 uniform bits
-}
+// (drop_hash: csrc/common.h -- the fused tile operator draws the same bits)
 __global__ void dropout_rows_kernel(float *X, int64_t gstride, const int32_t *gidx, int groups, int64_t rowlen, uint32_t thresh,
                                     float inv_keep, uint64_t seed, uint32_t site) {
     const int64_t total = (int64_t)groups * rowlen;

@@ -86,6 +86,7 @@ struct TmArg {
         };
         struct {            // KIND 0: relu' bit masks of the map-level operators and their chains
             unsigned long long *save_bits[3]; const unsigned long long *act_bits[3]; const unsigned long long *in_bits;
+            uint16_t drop_site[3];       // forward launches: 1 + dropout site behind layer l's activation (0: none)
         };
     };
 };
@@ -109,6 +110,7 @@ static TmArg tm_arg(const stair_tile_mlp_args &a, int kind) {
     } else {
         for (int l = 0; l < 3; ++l) { t.save_bits[l] = a.save_bits[l]; t.act_bits[l] = a.act_bits[l]; }
         t.in_bits = a.in_bits;
+        for (int l = 0; l < 3; ++l) t.drop_site[l] = (uint16_t)a.drop_site[l];
     }
     return t;
 }
@@ -117,6 +119,7 @@ struct TmParams {
     int first[TM_MAXB + 1];          // work item w belongs to bucket b with first[b] <= w < first[b + 1]; its tile is w - first[b]
     int nb;
     long long *fx_g, *fx_b;          // KIND 2: fixed-point shadows of d gamma / d beta (NULL: float atomics into a[0].dgamma / dbeta)
+    unsigned drop_thresh; float drop_inv_keep; unsigned long long drop_seed;    // forward launches under dropout (drop_thresh 0: none)
     unsigned *counter;               // work queue: counter[0] = head, counter[1] = workgroups that have left the queue.  Both words are
                                      // zero between launches (the last workgroup to leave puts them back); NULL: tiles are dealt out round robin
 };
@@ -498,6 +501,7 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
             const float *bias = p.bias[ph];
             const int act = (KIND == 3 || p.act[ph] != 3) ? p.act[ph] : 0;          // act 3 (relu' of a saved activation) is the chains' (KIND 3)
             const bool last = ph + 1 == p.n_layers;
+            const unsigned dsite = (KIND == 0 && pp.drop_thresh) ? p.drop_site[ph] : 0u;
             // between two layers of an inference plan nothing touches HBM: the accumulators go straight into the next image
             const bool direct = !last && !p.save[ph] && !(KIND == 0 && p.save_bits[ph]) && act != 3 && !(KIND == 0 && p.mid_rowdot && ph == 1);
             v4f bvs[2][4];                        // the lane's 32 bias values, loaded together (one round trip, behind the barrier)
@@ -521,6 +525,12 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
                         for (int i = 0; i < 4; ++i) {
                             z[i] = acc[nt][tt][4 * q + i] + bv[i];
                             if (act == 1) z[i] = fmaxf(z[i], 0.0f);
+                        }
+                        if (KIND == 0 && dsite) {       // nn.Dropout behind this activation: the bits stair_dropout_fwd draws for the [cnt, T, H] rows
+                            const unsigned long long e0 = ((unsigned long long)inst * p.T + t) * p.H + (64 * wave + 32 * nt + 8 * q + 4 * h_e);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                z[i] = drop_hash(pp.drop_seed, dsite - 1u, e0 + i) >= pp.drop_thresh ? z[i] * pp.drop_inv_keep : 0.0f;
                         }
                         if (direct) {             // 4 consecutive columns of frame t = 8 bytes of the next operand row
                             bf16x4 zh4, zl4;
@@ -1012,6 +1022,7 @@ int launch_tile_mlp_batch(const stair_tile_mlp_args *args, int n, unsigned *coun
         const int vec = kind == 1;
         TmParams pp;
         pp.nb = 0; pp.counter = counter; pp.first[0] = 0; pp.fx_g = pp.fx_b = nullptr;
+        pp.drop_thresh = 0; pp.drop_inv_keep = 1.0f; pp.drop_seed = 0;
         int order[TM_MAXB], m = 0;
         for (int i = 0; i < n; ++i)
             if (args[i].cnt > 0 && kind_of(args[i]) == kind) order[m++] = i;
@@ -1021,6 +1032,17 @@ int launch_tile_mlp_batch(const stair_tile_mlp_args *args, int n, unsigned *coun
                 STAIR_CHECK(args[order[j]].dgamma == args[order[0]].dgamma && args[order[j]].dbeta == args[order[0]].dbeta,
                             "the Temporal chains of one launch must share dgamma / dbeta");
             pp.fx_g = det_shadow(args[order[0]].dgamma); pp.fx_b = det_shadow(args[order[0]].dbeta);
+        }
+        if (kind == 0) {            // dropout behind the activations of a forward launch: one probability and seed per launch
+            for (int j = 0; j < m; ++j) {
+                const stair_tile_mlp_args &a = args[order[j]];
+                if (!(a.drop_p > 0.0f) || !(a.drop_site[0] | a.drop_site[1] | a.drop_site[2])) continue;
+                STAIR_CHECK(a.drop_p < 1.0f, "dropout probability must be below 1");
+                STAIR_CHECK(a.drop_site[0] < 65536u && a.drop_site[1] < 65536u && a.drop_site[2] < 65536u, "dropout site above 65534");
+                const unsigned th = (unsigned)(a.drop_p * 16777216.0f);
+                STAIR_CHECK(pp.drop_thresh == 0 || (pp.drop_thresh == th && pp.drop_seed == a.drop_seed), "the buckets of one launch must share dropout probability and seed");
+                pp.drop_thresh = th; pp.drop_inv_keep = 1.0f / (1.0f - a.drop_p); pp.drop_seed = a.drop_seed;
+            }
         }
         std::stable_sort(order, order + m, [&](int x, int y) { return rounds(x) > rounds(y); });    // long tiles first
         for (int j = 0; j < m; ++j) {
