@@ -608,7 +608,7 @@ int stair_plan_set_dropout(stair_plan *plan, float p, uint64_t seed);
  * gradient bucket beside the rest of the pass (stair_amd/train.py; the reference is single-process, train_module.py:408). */
 int stair_plan_set_backward_event(stair_plan *plan, void *event);
 /* The mask generator on its own (building block / test hook): in place on `groups` rows of `rowlen` floats, row g at
- * x + (gidx ? gidx[g] : g) * gstride; element e of the launch is kept iff hash24(seed, site, e) >= p * 2^24 and then
+ * x + (gidx ? gidx[g] : g) * gstride; element e of the launch is kept iff its 16 bits of hash64(seed, site, e / 4) (bits 16 (e % 4) .. +15) are >= p * 2^16 and then
  * divided by (1 - p). */
 int stair_dropout_fwd(float *x, int64_t gstride, const int32_t *gidx, int32_t groups, int64_t rowlen, float p,
                       uint64_t seed, uint32_t site, stair_stream stream);

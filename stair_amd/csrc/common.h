@@ -125,14 +125,16 @@ int64_t lstm_coop_ws_bytes(int n);
 int launch_lstm_bwd_coop(const stair_lstm_bwd_args &a, hipStream_t s);
 int launch_lstm_rec_coop_pair(const stair_lstm_args &a, const stair_lstm_args &b, hipStream_t s);          // -1: not applicable
 int launch_lstm_bwd_coop_pair(const stair_lstm_bwd_args &a, const stair_lstm_bwd_args &b, hipStream_t s);  // -1: not applicable
-// Dropout mask bits: a counter-based hash of (seed, site, element), 24 uniform bits; an element is DROPPED when the value is below
-// p * 2^24 (csrc/rowops.hip dropout_rows_kernel, and the epilogue of the fused tile operator, csrc/tile_mlp.hip)
-__device__ __forceinline__ uint32_t drop_hash(uint64_t seed, uint32_t site, uint64_t e) {
-    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (e + 1) + ((uint64_t)site << 40);
+// Dropout mask bits: a counter-based hash of (seed, site, element / 4) gives 64 mixed bits, 16 per element of an aligned group of four
+// consecutive elements; an element is DROPPED when its 16 bits are below p * 2^16 (csrc/rowops.hip dropout_rows_kernel, and the
+// epilogue of the fused tile operator, csrc/tile_mlp.hip, whose lanes hold such groups: one hash per four elements)
+__device__ __forceinline__ uint64_t drop_hash4(uint64_t seed, uint32_t site, uint64_t e4) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (e4 + 1) + ((uint64_t)site << 40);
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return (uint32_t)((z ^ (z >> 31)) >> 40);
+    return z ^ (z >> 31);
 }
+__device__ __forceinline__ bool drop_keep(uint64_t bits4, int i, uint32_t thresh16) { return (uint32_t)((bits4 >> (16 * i)) & 0xffffu) >= thresh16; }
 int launch_lstm_project(const stair_lstm_args &a, hipStream_t s);
 int launch_lstm_recur(const stair_lstm_args &a, hipStream_t s);
 int launch_lstm_zero_tail(const stair_lstm_args &a, hipStream_t s);

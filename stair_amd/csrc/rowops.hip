@@ -595,7 +595,7 @@ int launch_l2norm(const float *x, float *out, int n, int H, hipStream_t s) {
 // element), i.e. a pure function: the backward pass needs no stored mask (a dropped element is an exact zero of the
 // saved activation) and a step can be replayed.
 // ---------------------------------------------------------------------------------------------
-// (drop_hash: csrc/common.h -- the fused tile operator draws the same bits)
+// (drop_hash4 / drop_keep: csrc/common.h -- the fused tile operator draws the same bits)
 __global__ void dropout_rows_kernel(float *X, int64_t gstride, const int32_t *gidx, int groups, int64_t rowlen, uint32_t thresh,
                                     float inv_keep, uint64_t seed, uint32_t site) {
     const int64_t total = (int64_t)groups * rowlen;
@@ -603,7 +603,7 @@ __global__ void dropout_rows_kernel(float *X, int64_t gstride, const int32_t *gi
         const int g = (int)(e / rowlen);
         const int64_t r = e - (int64_t)g * rowlen;
         float *x = X + (int64_t)idx_or_id(gidx, g) * gstride + r;
-        *x = drop_hash(seed, site, (uint64_t)e) >= thresh ? *x * inv_keep : 0.0f;
+        *x = drop_keep(drop_hash4(seed, site, (uint64_t)e >> 2), (int)(e & 3), thresh) ? *x * inv_keep : 0.0f;
     }
 }
 int launch_dropout_rows(float *X, int64_t gstride, const int32_t *gidx, int groups, int64_t rowlen, float p, uint64_t seed,
@@ -611,7 +611,7 @@ int launch_dropout_rows(float *X, int64_t gstride, const int32_t *gidx, int grou
     if (groups == 0 || rowlen == 0 || p <= 0.0f) return 0;
     STAIR_CHECK(p < 1.0f, "dropout probability must be below 1");
     const int64_t total = (int64_t)groups * rowlen;
-    const uint32_t thresh = (uint32_t)(p * 16777216.0f);         // drop when the 24-bit hash is below p * 2^24
+    const uint32_t thresh = (uint32_t)(p * 65536.0f);            // drop when the element's 16 hash bits are below p * 2^16
     hipLaunchKernelGGL(dropout_rows_kernel, dim3((unsigned)std::min<int64_t>((total + kBlock - 1) / kBlock, 8192)), dim3(kBlock), 0,
                        s, X, gstride, gidx, groups, rowlen, thresh, 1.0f / (1.0f - p), seed, site);
     STAIR_LAUNCH_CHECK();

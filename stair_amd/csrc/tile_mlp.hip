@@ -528,9 +528,9 @@ __global__ __launch_bounds__(512, 1) void tile_mlp_kernel(TmParams pp) {
                         }
                         if (KIND == 0 && dsite) {       // nn.Dropout behind this activation: the bits stair_dropout_fwd draws for the [cnt, T, H] rows
                             const unsigned long long e0 = ((unsigned long long)inst * p.T + t) * p.H + (64 * wave + 32 * nt + 8 * q + 4 * h_e);
+                            const unsigned long long bits4 = drop_hash4(pp.drop_seed, dsite - 1u, e0 >> 2);      // e0 % 4 == 0 (H % 4 == 0)
 #pragma unroll
-                            for (int i = 0; i < 4; ++i)
-                                z[i] = drop_hash(pp.drop_seed, dsite - 1u, e0 + i) >= pp.drop_thresh ? z[i] * pp.drop_inv_keep : 0.0f;
+                            for (int i = 0; i < 4; ++i) z[i] = drop_keep(bits4, i, pp.drop_thresh) ? z[i] * pp.drop_inv_keep : 0.0f;
                         }
                         if (direct) {             // 4 consecutive columns of frame t = 8 bytes of the next operand row
                             bf16x4 zh4, zl4;
@@ -1039,7 +1039,7 @@ int launch_tile_mlp_batch(const stair_tile_mlp_args *args, int n, unsigned *coun
                 if (!(a.drop_p > 0.0f) || !(a.drop_site[0] | a.drop_site[1] | a.drop_site[2])) continue;
                 STAIR_CHECK(a.drop_p < 1.0f, "dropout probability must be below 1");
                 STAIR_CHECK(a.drop_site[0] < 65536u && a.drop_site[1] < 65536u && a.drop_site[2] < 65536u, "dropout site above 65534");
-                const unsigned th = (unsigned)(a.drop_p * 16777216.0f);
+                const unsigned th = (unsigned)(a.drop_p * 65536.0f);
                 STAIR_CHECK(pp.drop_thresh == 0 || (pp.drop_thresh == th && pp.drop_seed == a.drop_seed), "the buckets of one launch must share dropout probability and seed");
                 pp.drop_thresh = th; pp.drop_inv_keep = 1.0f / (1.0f - a.drop_p); pp.drop_seed = a.drop_seed;
             }
