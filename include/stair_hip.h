@@ -405,6 +405,9 @@ typedef struct stair_vec_problem {
     const int32_t *gia, *gib; /* optional: the gradient rows ga + gia[i] * ldfa, gb + gib[i] * ldfb when they are not the rows fia / fib
                                  (a plan sends all but one same-level reader of a shared operand to private staging rows, so that every
                                  address receives at most one atomic add per launch: stair_plan_backward's deterministic fan-in) */
+    uint32_t drop_site; float drop_p; uint64_t drop_seed; /* ABI 6, forward problems with act 1: nn.Dropout behind the ReLU -- drop_site = 1 + the
+                                 site of stair_dropout_fwd (0: none); element e = row * N + column draws the bits stair_dropout_fwd draws
+                                 for the [rows, N] matrix */
 } stair_vec_problem;
 int stair_vec_group(const stair_vec_problem *problems, int32_t count, stair_stream stream);
 

@@ -107,7 +107,8 @@ class VecProblem(C.Structure):
                 ('out', C.c_void_p), ('io', C.c_void_p), ('ldo', C.c_int64), ('accumulate', C.c_int32),
                 ('in_save', C.c_void_p), ('ld_save', C.c_int64),
                 ('adj', C.c_int32), ('fa', C.c_void_p), ('fb', C.c_void_p), ('fia', C.c_void_p), ('fib', C.c_void_p),
-                ('ldfa', C.c_int64), ('ldfb', C.c_int64), ('ga', C.c_void_p), ('gb', C.c_void_p), ('gia', C.c_void_p), ('gib', C.c_void_p)]
+                ('ldfa', C.c_int64), ('ldfb', C.c_int64), ('ga', C.c_void_p), ('gb', C.c_void_p), ('gia', C.c_void_p), ('gib', C.c_void_p),
+                ('drop_site', C.c_uint32), ('drop_p', C.c_float), ('drop_seed', C.c_uint64)]
 
 
 class PlanInfo(C.Structure):

@@ -1747,8 +1747,8 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
     }
 
     // ---- fused per-clip tile operators (csrc/tile_mlp.hip): weights of the buckets that run fused, as fragment-order planes ----
-    // (under dropout the map-level tile operators stay fused -- the kernel draws stair_dropout_fwd's bits in its epilogues -- while the
-    // vector-level modules and the decoder take their launch-per-layer forms; STAIR_TILE_DROPOUT=0: everything unfused, as before ABI 6)
+    // (under dropout the tile operators and the grouped vector-level launches stay on: their kernels draw stair_dropout_fwd's bits in their
+    // epilogues; STAIR_TILE_DROPOUT=0: launch-per-layer forms everywhere, as before ABI 6)
     const bool fused = pl->o_wfrag > 0 && tile_mlp_usable(H, T) && (dp <= 0.0f || tile_dropout_on()) && tile_policy(pl);
     pl->bits_written = fused && pl->train;
     auto WF = [&](int slot) { return static_cast<const void *>(ws + pl->o_wfrag + (int64_t)slot * H * H); };
@@ -1783,7 +1783,7 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
     // The row-wise Linear layers of a level -- vector-level modules, Filter's dense layer, Localize's keyword rows, the decoder -- as
     // problems of ONE launch before the level's tile operators (first layers, keyword rows) and ONE after them (second layers, the
     // dense layers on the pooled rows): csrc/vec_group.hip.  Takes precedence over the tile form of the vector-level modules.
-    const bool grouped = fused && dp <= 0.0f && vec_group_usable(H) && vec_group_on();
+    const bool grouped = fused && vec_group_usable(H) && vec_group_on();
     std::vector<VgProblem> vg1, vg2;
     // [512 x 512] blocks of a row-wise weight as planes: slot + (output block) * nseg + (input segment); blocks of a [N, nseg * 512] matrix
     struct VgW { int slot, nblk, nseg; const Lin *l; int op; };
@@ -1846,6 +1846,11 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
         a.W[i] = WF(slot); a.bias[i] = l.b; a.act[i] = act; a.save[i] = pl->train ? save : nullptr;
         a.save_bits[i] = pl->train && bits >= 0 && act == 1 ? reinterpret_cast<unsigned long long *>(ws + bits) : nullptr;
         if (dp > 0.0f && drop_pos >= 0) { a.drop_site[i] = (uint32_t)(bucket_no * 8 + drop_pos) + 1u; a.drop_p = dp; a.drop_seed = pl->drop_seed; }
+    };
+
+    // nn.Dropout behind a grouped forward problem's ReLU (position `pos` of the current bucket): the bits of drop() on the problem's [rows, N] output
+    auto vg_drop = [&](VgProblem &q, int pos) {
+        if (dp > 0.0f) { q.drop_site = (uint32_t)(bucket_no * 8 + pos) + 1u; q.drop_p = dp; q.drop_seed = pl->drop_seed; }
     };
 
     // ---- program levels ----------------------------------------------------------------------
@@ -1926,6 +1931,7 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
                     VgProblem q = vg_fwd(c, vec, I0, H, vec, I1, H, VG_IN_CAT2, W.ta0.w, 2 * H, W.ta0.b, H, 1, hid, nullptr, H);
                     q.wplanes = WF(WV_TA0);
                     if (pl->train) { q.in_save = cat; q.ld_save = 2 * H; }
+                    vg_drop(q, 0);
                     vg1.push_back(q);
                     vg2.push_back(vg_fwd(c, hid, nullptr, H, nullptr, nullptr, 0, VG_IN_A, W.ta3.w, H, W.ta3.b, H, 1, vec, I2, H));
                     vg2.back().wplanes = WF(WV_TA3);
@@ -1946,9 +1952,11 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
                     VgProblem q = vg_fwd(c, vec, I1, H, vec, I0, H, VG_IN_EXISTS, W.exists0.w, 3 * H, W.exists0.b, H, 1, hid, nullptr, H);
                     q.wplanes = WF(WV_EX0);
                     if (pl->train) { q.in_save = cat; q.ld_save = 3 * H; }
+                    vg_drop(q, 0);
                     vg1.push_back(q);
                     vg2.push_back(vg_fwd(c, hid, nullptr, H, nullptr, nullptr, 0, VG_IN_A, W.exists3.w, H, W.exists3.b, H, 1, vec, I2, H));
                     vg2.back().wplanes = WF(WV_EX3);
+                    vg_drop(vg2.back(), 1);
                     break;
                 }
                 if (fused_vec_for(b)) {
@@ -2137,6 +2145,8 @@ extern "C" int stair_plan_run_flags(stair_ctx *ctx, stair_plan *pl, const float 
         VgProblem q = vg_fwd(n, vec, didx + pl->off_roots, H, qfeat, nullptr, H, VG_IN_CAT2, W.dec0.w, 2 * H, W.dec0.b, 2 * H, 1, hid, nullptr, 2 * H);
         q.wplanes = WF(WV_DEC0);
         if (pl->train) { q.in_save = cat; q.ld_save = 2 * H; }
+        bucket_no = 0x1fff;
+        vg_drop(q, 7);
         RUN(launch_vec_group(&q, 1, s));
         VgProblem q3 = vg_fwd(n, hid, nullptr, 2 * H, hid + H, nullptr, 2 * H, VG_IN_CAT2, W.dec3.w, 2 * H, W.dec3.b, A, 0, logits, nullptr, A);
         RUN(launch_vec_group(&q3, 1, s));
@@ -2407,7 +2417,7 @@ extern "C" int stair_plan_backward(stair_ctx *ctx, stair_plan *pl, const float *
     auto WFT = [&](int slot) { return static_cast<const void *>(ws + pl->o_wfragT + (int64_t)slot * H * H); };
     // the row-wise layers' backward as grouped launches (csrc/vec_group.hip): per level one launch for everything that starts from a
     // gradient row of the arena (relu' on load, kept as dZ), one for the second stage of the two-layer modules
-    const bool grouped = fused && pl->drop_p <= 0.0f && vec_group_usable(H) && vec_group_on();
+    const bool grouped = fused && vec_group_usable(H) && vec_group_on();
     std::vector<VgProblem> bvg1, bvg2;
     if (grouped) {      // planes of the transposed images (already there as fp32): block (j, s) of W^T = slot + j * nin + s
         struct VgWT { int slot, nblk, nin; const Lin *l; int op; };        // W^T is [nblk * 512, nin * 512]

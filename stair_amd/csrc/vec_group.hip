@@ -239,7 +239,13 @@ __device__ __forceinline__ void vg_item(const VgProblem &p, const int rt, const 
             const int rw = rt * 32 + erow + 16 * i;
             if (rw >= rows) break;
             float v = d[0][i] + bias;
-            if (p.act == 1) v = fmaxf(v, 0.f);
+            if (p.act == 1) {
+                v = fmaxf(v, 0.f);
+                if (p.drop_site) {             // nn.Dropout behind the ReLU: stair_dropout_fwd's bits for element rw * N + col of the [rows, N] matrix
+                    const unsigned long long e = (unsigned long long)rw * p.N + col;
+                    v = drop_keep(drop_hash4(p.drop_seed, p.drop_site - 1u, e >> 2), (int)(e & 3), (unsigned)(p.drop_p * 65536.0f)) ? v * (1.0f / (1.0f - p.drop_p)) : 0.f;
+                }
+            }
             else if (p.act == 2) v = p.emask[(int64_t)rw * p.ldm + col] > 0.f ? v * p.escale : 0.f;
             float *dst = p.out + (int64_t)(p.io ? p.io[rw] : rw) * p.ldo + col;
             if (p.accumulate) unsafeAtomicAdd(dst, v);
