@@ -569,7 +569,7 @@ def main():
                 dt_d, _ = timed(lambda: run_step(B, False), 6, 3)
                 trainer.dropout = 0.0
                 extras['dropout_0.25_step'] = {'train_questions_per_s': round(6 * B / dt_d, 1), 'ms_per_step': round(dt_d / 6 * 1e3, 3),
-                                               'note': 'counter-based masks (stair_plan_set_dropout), backward without stored masks'}
+                                               'note': 'the recipe the reference trains with (args.py:31): counter-based masks (stair_plan_set_dropout) drawn inside the fused operators, backward without stored masks'}
             # ---- clips of their own lengths in one launch batch (dataset.py:137-143 keeps every clip's frame count): T uniform
             # in 16..64 (mean 40), padded to 64; the same questions, the frames past a clip's length are padding ----
             rng = np.random.RandomState(0)
