@@ -781,6 +781,39 @@ def test_training_step_is_bit_reproducible(n_q, clips):
     assert float(runs[0][0][0].abs().max()) > 0
 
 
+def test_dropout_step_is_bit_reproducible_and_runs_fused():
+    """The recipe the reference trains with (nn.Dropout(0.25), args.py:31): the masks are a pure function of (seed, site, element) drawn
+    inside the fused tile operators and the grouped vector-level launches, so the step replays bit for bit on two fresh trainers -- and it
+    must really be running fused (the launch-per-layer forms were the only ones a dropout plan could take before ABI 6)."""
+    from stair_amd import ops
+    from stair_amd.train import Trainer
+    config = dict(spec.DEFAULT_CONFIG)
+    n_q = 96
+    qs = [synth.make_question(config, 22, i, T=64, forms=synth.ALL_FORMS, with_video=False) for i in range(n_q)]
+    g = torch.Generator().manual_seed(11)
+    video = torch.randn(n_q, 64, config['video_size'], generator=g).to(torch.bfloat16).to(DEV)
+    question = torch.cat([torch.as_tensor(q['question']) for q in qs]).to(DEV)
+    q_lens = [q['question'].shape[0] for q in qs]
+    answers = torch.tensor([q['answer'] for q in qs], dtype=torch.int32, device=DEV)
+    progs, spans = [q['nmn_program_list'] for q in qs], [q['prog_str_to_question_tokens'] for q in qs]
+    runs = []
+    for rep in range(2):
+        tr = Trainer(_model(config, 5), dropout=0.25, lr=1e-3)
+        with ops.kernel_accounting() as acct:
+            for it in range(2):
+                tr.step(progs, spans, video, question, q_lens, answers)
+        tr.check()
+        runs.append((tr.flat_g.clone(), tr.flat_p.clone(), dict(acct.table)))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    assert float(runs[0][0].abs().max()) > 0
+    assert 'tile_mlp' in runs[0][2] and 'vec_group' in runs[0][2], sorted(runs[0][2])
+    # another step draws other masks: the second step's gradients differ from a trainer that repeats the first seed
+    plain = Trainer(_model(config, 5), dropout=0.0, lr=1e-3)
+    plain.step(progs, spans, video, question, q_lens, answers)
+    plain.step(progs, spans, video, question, q_lens, answers)
+    assert not torch.equal(plain.flat_g, runs[0][0])
+
+
 def test_supervised_step_is_bit_reproducible():
     """BASELINE configs[4]: the step with every per-module criterion (train_module.py:33-194, 351-406) is bit-identical from run to
     run as well -- 64 questions on 32 shared clips (aliased supervised nodes: several criteria items per gradient slot).  The criteria
