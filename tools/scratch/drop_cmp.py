@@ -8,7 +8,8 @@ from stair_amd.module_net import VideoNMN
 from stair_amd._lib import lib
 DEV = 'cuda:0'
 config = dict(spec.DEFAULT_CONFIG)
-qs = [synth.make_question(config, 4, i, form=f) for i, f in enumerate(synth.ALL_FORMS * 2)]
+NQ = int(os.environ.get('NQ', '24'))
+qs = [synth.make_question(config, 4, i, form=synth.ALL_FORMS[i % len(synth.ALL_FORMS)], T=(64 if os.environ.get('RAGGED') != '1' else [64, 17, 40, 33, 8, 51][i % 6])) for i in range(NQ)]
 out = {}
 for mode in (1, 0):
     lib.stair_set_tile_mlp(mode)
@@ -23,8 +24,12 @@ for mode in (1, 0):
     out[mode] = {n: p.grad.detach().cpu().clone() for n, p in m.named_parameters()}
 lib.stair_set_tile_mlp(-1)
 gmax = max(float(g.abs().max()) for g in out[0].values())
+worst = 0.0
 for n, g in out[0].items():
+    worst = max(worst, float((out[1][n] - g).norm()) / max(float(g.norm()), 1e-3 * gmax))
     d = float((out[1][n] - g).abs().max()); mx = float(g.abs().max())
     flag = '  <<<' if d > 4e-4 * max(mx, 1e-3 * gmax) else ''
     if flag or d > 1e-5 * max(mx, 1e-3 * gmax):
         print('%-55s max|g| %.3e  max diff %.3e  rel %.2e%s' % (n, mx, d, d / max(mx, 1e-12), flag))
+
+print('worst relative L2 error over all parameters: %.3e' % worst)
