@@ -411,7 +411,7 @@ typedef struct stair_vec_problem {
 } stair_vec_problem;
 int stair_vec_group(const stair_vec_problem *problems, int32_t count, stair_stream stream);
 
-/* stair_plan_run uses the fused operators where they apply (hidden_size 512, T <= 64, split matmul mode, no dropout);
+/* stair_plan_run uses the fused operators where they apply (hidden_size 512, T <= 64, split matmul mode; with dropout too since ABI 6);
  * on = 0 keeps the GEMM / row-kernel sequences everywhere, on < 0 restores the default (env STAIR_TILE_MLP, default on). */
 int stair_set_tile_mlp(int32_t on);
 /* Tiles of a fused launch are dealt out through a self-resetting atomic work queue in the plan workspace (on != 0, default; two
