@@ -208,7 +208,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_x3tr_kernel(XtParams p) {
     write(0, g0);
     int s = 0;
     // (Tried: the two waves of a SIMD running a stage's two phases in opposite order -- 5 % slower; s_setprio(1) around the MFMA
-    // clusters -- 3-5 % slower (tools/scratch/build_variant.sh, one box).  Parts compiled out at
+    // clusters -- 3-5 % slower; __builtin_amdgcn_iglp_opt(0) in the multiply phase -- within noise, (1) -- 6 % slower
+    // (tools/scratch/build_variant.sh, one box each).  Parts compiled out at
     // M = 109 056: loads + split + writes alone 0.52 of the full time, loads + multiplies alone 0.76: the phases add up.)
     for (; s + 4 <= S; s += 2) {                                     // steady state: both halves have a stage to load, no branches
         __syncthreads();
